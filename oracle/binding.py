@@ -1,0 +1,315 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes bindings of
+
+* oracle/_ref/libptref.so  (class ``Ref``):    the compiled reference (oracle/ref_harness.cpp);
+* oracle/libptoracle.so    (class ``Oracle``): our plain-C restatement (oracle/pt_oracle.c).
+
+Both expose the same methods so a test can run one comparison against either.  Imported only
+from tests/, tests/golden/make_golden.py, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Product code (pathtracer_amd/) never imports this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "libptref.so")
+ORACLE_LIB_PATH = os.path.join(_HERE, "libptoracle.so")
+
+
+def ref_available() -> bool:
+    return os.path.exists(REF_LIB_PATH)
+
+
+def oracle_available() -> bool:
+    return os.path.exists(ORACLE_LIB_PATH)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+_f = C.c_float
+_i = C.c_int
+
+
+def light_intensity(R, scale=1.0):
+    """Scene::intensite_lumiere: 1e9*4pi/(4pi*R*R*pi) (Raytracer.cpp:1270) times the GUI slider
+    factor (mainApp.cpp:775), evaluated in double and narrowed to the float member."""
+    R = float(np.float32(R))
+    return float(np.float32(scale * 1000000000 * 4. * np.pi / (4. * np.pi * R * R * np.pi)))
+
+
+class _Prefixed:
+    """Resolves ``self.lib.ref_xxx`` to ``<prefix>xxx`` of the loaded library."""
+
+    def __init__(self, cdll, prefix):
+        self._cdll, self._prefix = cdll, prefix
+
+    def __getattr__(self, name):
+        assert name.startswith("ref_")
+        return getattr(self._cdll, self._prefix + name[4:])
+
+
+class _Base:
+    """One `Raytracer` instance (after loadScene())."""
+    PREFIX = "ref_"
+    PATH = REF_LIB_PATH
+
+    def __init__(self):
+        self.cdll = C.CDLL(self.PATH)
+        self.lib = _Prefixed(self.cdll, self.PREFIX)
+        L = self.lib
+        L.ref_create.restype = C.c_void_p
+        self.ctx = C.c_void_p(L.ref_create())
+        self.W = self.H = self.spp = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def close(self):
+        if self.ctx:
+            self.lib.ref_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- setup
+    def set_render(self, W, H, spp, nb_bounces, sigma_filter=0.5):
+        self.W, self.H, self.spp = W, H, spp
+        self.lib.ref_set_render(self.ctx, W, H, spp, nb_bounces, _f(sigma_filter))
+
+    def set_camera(self, pos, direction, up, fov, focus, aperture):
+        a = lambda v: (_f * 3)(*v)
+        self.lib.ref_set_camera(self.ctx, a(pos), a(direction), a(up), _f(fov), _f(focus), _f(aperture))
+
+    def get_camera(self):
+        out = np.zeros(12, np.float32)
+        self.lib.ref_get_camera(self.ctx, _p(out, _f))
+        return out
+
+    def set_light(self, center, R, scale=1.0):
+        self.lib.ref_set_light(self.ctx, (_f * 3)(*center), _f(R), _f(light_intensity(R, scale)))
+
+    def set_envmap_intensity(self, v):
+        self.lib.ref_set_envmap_intensity(self.ctx, _f(v))
+
+    def set_object_flags(self, obj, miroir=False, flip_normals=False):
+        self.lib.ref_set_object_flags(self.ctx, obj, int(miroir), int(flip_normals))
+
+    def set_group_material(self, obj, grp, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
+        a = lambda v: (_f * 3)(*v)
+        self.lib.ref_set_group_material(self.ctx, obj, grp, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))
+
+    def add_group_material(self, obj, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
+        a = lambda v: (_f * 3)(*v)
+        self.lib.ref_add_group_material(self.ctx, obj, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))
+
+    def apply_config(self, cfg):
+        self.set_render(cfg.W, cfg.H, cfg.spp, cfg.nb_bounces, cfg.sigma_filter)
+        self.set_camera(cfg.cam_pos, cfg.cam_dir, cfg.cam_up, cfg.fov, cfg.focus, cfg.aperture)
+        self.set_light(cfg.light_center, cfg.light_radius, cfg.light_scale)
+        self.set_envmap_intensity(cfg.envmap_intensity)
+
+    def prepare(self):
+        self.lib.ref_prepare(self.ctx)
+
+    # ---- dumps
+    def light(self):
+        out = np.zeros(5, np.float32)
+        self.lib.ref_get_light(self.ctx, _p(out, _f))
+        return out
+
+    def tables(self):
+        rpp = np.zeros((self.H * self.W, 2), np.float32)
+        s2d = np.zeros((self.spp, 2), np.float32)
+        fi = np.zeros(64 * 64, np.float32)
+        fs = _i(0)
+        self.lib.ref_get_tables(self.ctx, _p(rpp, _f), _p(s2d, _f), _p(fi, _f), C.byref(fs))
+        w = 2 * fs.value + 1
+        return rpp, s2d, fi[: w * w].copy(), fs.value
+
+    def object_matrices(self, obj):
+        t, inv, r = np.zeros(12, np.float32), np.zeros(12, np.float32), np.zeros(9, np.float32)
+        self.lib.ref_get_object_matrices(self.ctx, obj, _p(t, _f), _p(inv, _f), _p(r, _f))
+        return t, inv, r
+
+    def mesh_dump(self, obj):
+        c = [_i(0) for _ in range(5)]
+        self.lib.ref_mesh_counts(self.ctx, obj, *[C.byref(x) for x in c])
+        ntri, nnodes = c[0].value, c[1].value
+        perm = np.zeros(ntri, np.int32)
+        nodes_i = np.zeros((nnodes, 3), np.int32)
+        nodes_bb = np.zeros((nnodes, 6), np.float32)
+        soup = np.zeros((ntri, 31), np.float32)
+        groups = np.zeros(ntri, np.int32)
+        root = np.zeros(6, np.float32)
+        self.lib.ref_mesh_dump(self.ctx, obj, _p(perm, _i), _p(nodes_i, _i), _p(nodes_bb, _f), _p(soup, _f),
+                               _p(groups, _i), _p(root, _f))
+        return dict(perm=perm, nodes_i=nodes_i, nodes_bb=nodes_bb, soup=soup, groups=groups, root_bb=root,
+                    nverts=c[2].value, nnormals=c[3].value, nuvs=c[4].value)
+
+    # ---- leaf functions
+    def pcg32(self, seed, n):
+        out = np.zeros(n, np.uint32)
+        self.lib.ref_pcg32(C.c_uint64(seed), n, _p(out, C.c_uint32))
+        return out
+
+    def lattice(self, n):
+        out = np.zeros((n, 2), np.float32)
+        self.lib.ref_lattice(n, _p(out, _f))
+        return out
+
+    def invsqroot(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(x)
+        self.lib.ref_invsqroot(x.size, _p(x, _f), _p(out, _f))
+        return out
+
+    def fast_normalize(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.zeros_like(v)
+        self.lib.ref_fast_normalize(v.shape[0], _p(v, _f), _p(out, _f))
+        return out
+
+    def fast_exp(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(x)
+        self.lib.ref_fast_exp(x.size, _p(x, C.c_double), _p(out, C.c_double))
+        return out
+
+    def random_cos(self, N, r12):
+        N = np.ascontiguousarray(N, np.float32)
+        r12 = np.ascontiguousarray(r12, np.float32)
+        out = np.zeros_like(N)
+        self.lib.ref_random_cos(N.shape[0], _p(N, _f), _p(r12, _f), _p(out, _f))
+        return out
+
+    def camera_rays(self, ij, jit4):
+        ij = np.ascontiguousarray(ij, np.int32)
+        jit4 = np.ascontiguousarray(jit4, np.float32)
+        out = np.zeros((ij.shape[0], 6), np.float32)
+        self.lib.ref_camera_rays(self.ctx, ij.shape[0], _p(ij, _i), _p(jit4, _f), _p(out, _f))
+        return out
+
+    def intersect(self, rays6):
+        rays6 = np.ascontiguousarray(rays6, np.float32)
+        n = rays6.shape[0]
+        oi = np.zeros((n, 3), np.int32)
+        of = np.zeros((n, 20), np.float32)
+        self.lib.ref_intersect(self.ctx, n, _p(rays6, _f), _p(oi, _i), _p(of, _f))
+        return oi, of
+
+    def intersect_shadow(self, rays6, dist):
+        rays6 = np.ascontiguousarray(rays6, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        out = np.zeros(rays6.shape[0], np.int32)
+        self.lib.ref_intersect_shadow(self.ctx, rays6.shape[0], _p(rays6, _f), _p(dist, _f), _p(out, _i))
+        return out
+
+    def phong_sample(self, mat9, wo, N, r12, seeds):
+        mat9 = np.ascontiguousarray(mat9, np.float32); wo = np.ascontiguousarray(wo, np.float32)
+        N = np.ascontiguousarray(N, np.float32); r12 = np.ascontiguousarray(r12, np.float32)
+        seeds = np.ascontiguousarray(seeds, np.uint64)
+        out = np.zeros((mat9.shape[0], 5), np.float32)
+        self.lib.ref_phong_sample(mat9.shape[0], _p(mat9, _f), _p(wo, _f), _p(N, _f), _p(r12, _f),
+                                  _p(seeds, C.c_uint64), _p(out, _f))
+        return out
+
+    def phong_eval(self, mat9, wi, wo, N):
+        mat9 = np.ascontiguousarray(mat9, np.float32); wi = np.ascontiguousarray(wi, np.float32)
+        wo = np.ascontiguousarray(wo, np.float32); N = np.ascontiguousarray(N, np.float32)
+        out = np.zeros((mat9.shape[0], 3), np.float32)
+        self.lib.ref_phong_eval(mat9.shape[0], _p(mat9, _f), _p(wi, _f), _p(wo, _f), _p(N, _f), _p(out, _f))
+        return out
+
+    # ---- radiance
+    def getcolor_samples(self, ij, k0, k1):
+        ij = np.ascontiguousarray(ij, np.int32)
+        n = ij.shape[0]
+        rgb = np.zeros((n, k1 - k0, 3), np.float32)
+        dxdy = np.zeros((n, k1 - k0, 2), np.float32)
+        self.lib.ref_getcolor_samples(self.ctx, n, _p(ij, _i), k0, k1, _p(rgb, _f), _p(dxdy, _f))
+        return rgb, dxdy
+
+    def render_seeded(self):
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        self.lib.ref_render_seeded(self.ctx, _p(img, _f), _p(cnt, _f))
+        return img, cnt
+
+    def max_threads(self):
+        return self.lib.ref_max_threads()
+
+
+class Ref(_Base):
+    """The compiled reference (oracle/_ref/libptref.so)."""
+    PREFIX = "ref_"
+    PATH = REF_LIB_PATH
+
+    def __init__(self):
+        super().__init__()
+        self.cdll.ref_time_render_nopreviz.restype = C.c_double
+        self.cdll.ref_time_render_image.restype = C.c_double
+
+    def add_mesh(self, mesh, scale=30.0, center=True, tmpdir=None):
+        """Writes the mesh as OBJ text and lets the reference's own readOBJ parse it."""
+        import tempfile
+        from pathtracer_amd import scenes
+        d = tmpdir or tempfile.mkdtemp(prefix="ptref_obj_")
+        path = os.path.join(d, mesh.name + ".obj")
+        scenes.write_obj(mesh, path)
+        return self.lib.ref_add_mesh(self.ctx, path.encode(), _f(scale), 1 if center else 0)
+
+    def time_render_nopreviz(self, threads):
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        t = self.lib.ref_time_render_nopreviz(self.ctx, threads, _p(img, _f))
+        return t, img
+
+    def time_render_image(self, threads):
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        t = self.lib.ref_time_render_image(self.ctx, threads, _p(img, _f), _p(cnt, _f))
+        return t, img, cnt
+
+
+
+class Oracle(_Base):
+    """Our plain-C restatement (oracle/libptoracle.so)."""
+    PREFIX = "o_"
+    PATH = ORACLE_LIB_PATH
+
+    def __init__(self):
+        super().__init__()
+        self.cdll.o_render_omp.restype = C.c_double
+
+    def add_mesh(self, mesh, scale=30.0, center=True, tmpdir=None):
+        v = np.ascontiguousarray(mesh.vertices, np.float32)
+        n = np.ascontiguousarray(mesh.normals, np.float32)
+        fv = np.ascontiguousarray(mesh.faces_v, np.int32)
+        fn = np.ascontiguousarray(mesh.faces_n, np.int32)
+        if mesh.uvs is not None:
+            uv = np.ascontiguousarray(mesh.uvs, np.float32)
+            ft = np.ascontiguousarray(mesh.faces_t, np.int32)
+            uvp, ftp, nt = _p(uv, _f), _p(ft, _i), uv.shape[0]
+        else:
+            uvp, ftp, nt = None, None, 0
+        return self.lib.ref_add_mesh(self.ctx, v.shape[0], _p(v, _f), n.shape[0], _p(n, _f), nt, uvp,
+                                     fv.shape[0], _p(fv, _i), _p(fn, _i), ftp, _f(scale), 1 if center else 0)
+
+    def render_omp(self, threads):
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        rays = np.zeros(2, np.uint64)
+        t = self.cdll.o_render_omp(self.ctx, threads, _p(img, _f), _p(cnt, _f), _p(rays, C.c_uint64))
+        return t, img, cnt, rays
+
+    def counters_reset(self):
+        self.cdll.o_counters_reset()
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        self.cdll.o_counters_get(_p(out, C.c_uint64))
+        return out

@@ -1,0 +1,171 @@
+"""Synthetic scenes for the hot path (SURVEY.md §8d "Synthetic inputs").
+
+The reference ships no scenes, so every mesh here is procedural:
+
+* ``cornell_mesh()``  – 12-triangle inward-normal open box + one floating panel (config C0).
+* ``blob_mesh(n)``    – displaced UV-sphere with analytic normals (n=258 -> 133 128 triangles,
+  config C1; n=1120 -> 2 508 800 triangles, configs C2/C3; n=3444 -> 23.7 M, config C4).
+
+A mesh is a ``MeshData`` of float32 / int32 arrays laid out exactly like what the reference's
+``TriMesh::readOBJ`` (TriangleMesh.cpp:240-458) produces from the equivalent OBJ text, and
+``write_obj`` writes that text with ``%.9g`` so that ``sscanf("%f")`` recovers the same float32
+bit patterns: the reference (through oracle/_ref), the oracle and the HIP path all start from
+identical inputs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+
+@dataclass
+class MeshData:
+    vertices: np.ndarray            # (nv,3) float32, OBJ order (before the reference's axis swap)
+    normals: np.ndarray             # (nn,3) float32
+    uvs: Optional[np.ndarray]       # (nt,2) float32 or None
+    faces_v: np.ndarray             # (nf,3) int32, 0-based
+    faces_n: np.ndarray             # (nf,3) int32
+    faces_t: Optional[np.ndarray]   # (nf,3) int32 or None
+    name: str = "mesh"
+
+    @property
+    def ntri(self) -> int:
+        return int(self.faces_v.shape[0])
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+
+
+def cornell_mesh() -> MeshData:
+    """Open box (floor, ceiling, back, left, right: 10 triangles, normals pointing inward)
+    plus one floating quad (2 triangles, normal up) — 12 triangles.  Shading in the reference
+    is one-sided (Raytracer.cpp:510-511, 593), hence the inward normals."""
+    # box corners, unit cube centred at origin; opening towards +x in OBJ space
+    # (the reference maps OBJ (x,y,z) -> (-z,y,x), TriangleMesh.cpp:742-751, so OBJ +x = world +z,
+    # which faces the default camera at z=+50 looking down -z).
+    v = [
+        (-0.5, -0.5, -0.5), (0.5, -0.5, -0.5), (0.5, -0.5, 0.5), (-0.5, -0.5, 0.5),   # floor 0-3
+        (-0.5, 0.5, -0.5), (0.5, 0.5, -0.5), (0.5, 0.5, 0.5), (-0.5, 0.5, 0.5),       # ceiling 4-7
+        (-0.15, -0.2, -0.25), (0.2, -0.2, -0.2), (0.25, -0.15, 0.2), (-0.2, -0.15, 0.25),  # panel 8-11
+    ]
+    n = [(0, 1, 0), (0, -1, 0), (1, 0, 0), (0, 0, 1), (0, 0, -1), (0.05, 1, 0.02)]
+    nn = np.asarray(n, dtype=np.float64)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    quads = [
+        ((0, 3, 2, 1), 0),   # floor, normal +y
+        ((4, 5, 6, 7), 1),   # ceiling, normal -y
+        ((0, 4, 7, 3), 2),   # back wall x=-0.5, normal +x
+        ((0, 1, 5, 4), 3),   # wall z=-0.5, normal +z
+        ((3, 7, 6, 2), 4),   # wall z=+0.5, normal -z
+        ((8, 11, 10, 9), 5),  # floating panel, normal ~+y
+    ]
+    fv, fn = [], []
+    for (a, b, c, d), ni in quads:
+        fv += [(a, b, c), (a, c, d)]
+        fn += [(ni, ni, ni), (ni, ni, ni)]
+    return MeshData(_f32(v), _f32(nn), None, np.asarray(fv, np.int32), np.asarray(fn, np.int32), None, "cornell12")
+
+
+def blob_mesh(n: int, fine_detail: bool = False, with_uv: bool = False) -> MeshData:
+    """Displaced UV sphere r(θ,φ)=1+0.15 sin5θ cos7φ+0.05 sin(23θ+3φ)[+0.01 sin131θ sin97φ],
+    θ∈[0.02,π−0.02], n×n quads -> 2n² triangles, analytic vertex normals."""
+    th = np.linspace(0.02, np.pi - 0.02, n + 1)
+    ph = np.linspace(0.0, 2.0 * np.pi, n + 1)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    r = 1 + 0.15 * np.sin(5 * T) * np.cos(7 * P) + 0.05 * np.sin(23 * T + 3 * P)
+    rt = 0.75 * np.cos(5 * T) * np.cos(7 * P) + 1.15 * np.cos(23 * T + 3 * P)
+    rp = -1.05 * np.sin(5 * T) * np.sin(7 * P) + 0.15 * np.cos(23 * T + 3 * P)
+    if fine_detail:
+        r = r + 0.01 * np.sin(131 * T) * np.sin(97 * P)
+        rt = rt + 1.31 * np.cos(131 * T) * np.sin(97 * P)
+        rp = rp + 0.97 * np.sin(131 * T) * np.cos(97 * P)
+    st, ct, sp, cp = np.sin(T), np.cos(T), np.sin(P), np.cos(P)
+    d = np.stack([st * cp, ct, st * sp], -1)
+    dT = np.stack([ct * cp, -st, ct * sp], -1)
+    dP = np.stack([-st * sp, np.zeros_like(T), st * cp], -1)
+    pos = r[..., None] * d
+    pT = rt[..., None] * d + r[..., None] * dT
+    pP = rp[..., None] * d + r[..., None] * dP
+    nrm = np.cross(pP, pT)   # outward for this parametrisation
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-30)
+    verts = _f32(pos.reshape(-1, 3))
+    norms = _f32(nrm.reshape(-1, 3))
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a = (ii * (n + 1) + jj).ravel()
+    b = a + 1
+    c = a + (n + 1)
+    e = c + 1
+    # two triangles per quad, counter-clockwise seen from outside
+    f = np.empty((2 * n * n, 3), np.int32)
+    f[0::2] = np.stack([a, b, e], -1)
+    f[1::2] = np.stack([a, e, c], -1)
+    uvs = None
+    ft = None
+    if with_uv:
+        uvs = _f32(np.stack([P / (2 * np.pi), T / np.pi], -1).reshape(-1, 2))
+        ft = f.copy()
+    return MeshData(verts, norms, uvs, f, f.copy(), ft, f"blob{n}" + ("f" if fine_detail else ""))
+
+
+def write_obj(mesh: MeshData, path: str) -> None:
+    """OBJ text with ``vn`` and ``f a//a`` (or ``a/t/n``) faces.  SURVEY.md §4 pitfall 1: an OBJ
+    without ``vn`` renders black in the reference, so normals are always written."""
+    with open(path, "w") as f:
+        np.savetxt(f, mesh.vertices, fmt="v %.9g %.9g %.9g")
+        np.savetxt(f, mesh.normals, fmt="vn %.9g %.9g %.9g")
+        if mesh.uvs is not None:
+            np.savetxt(f, mesh.uvs, fmt="vt %.9g %.9g")
+            cols = np.stack([mesh.faces_v[:, 0], mesh.faces_t[:, 0], mesh.faces_n[:, 0],
+                             mesh.faces_v[:, 1], mesh.faces_t[:, 1], mesh.faces_n[:, 1],
+                             mesh.faces_v[:, 2], mesh.faces_t[:, 2], mesh.faces_n[:, 2]], -1) + 1
+            np.savetxt(f, cols, fmt="f %d/%d/%d %d/%d/%d %d/%d/%d")
+        else:
+            cols = np.stack([mesh.faces_v[:, 0], mesh.faces_n[:, 0], mesh.faces_v[:, 1], mesh.faces_n[:, 1],
+                             mesh.faces_v[:, 2], mesh.faces_n[:, 2]], -1) + 1
+            np.savetxt(f, cols, fmt="f %d//%d %d//%d %d//%d")
+
+
+@dataclass
+class RenderConfig:
+    """Mirror of the Raytracer fields the hot path reads (Raytracer.h:73-111)."""
+    W: int = 256
+    H: int = 256
+    spp: int = 64
+    nb_bounces: int = 4
+    sigma_filter: float = 0.5
+    cam_pos: tuple = (0.0, 0.0, 50.0)
+    cam_dir: tuple = (0.0, 0.0, -1.0)
+    cam_up: tuple = (0.0, 1.0, 0.0)
+    fov: float = float(np.float32(35 * np.pi / 180))
+    focus: float = 50.0
+    aperture: float = 0.1
+    light_center: tuple = (10.0, 23.0, 15.0)
+    light_radius: float = 10.0
+    light_scale: float = 1.0
+    envmap_intensity: float = 1.0
+    mesh_scale: float = 30.0
+
+
+def default_camera_rotated():
+    """The reference's loadScene() camera after cam.rotate(0, -22 deg, 1) (Raytracer.cpp:1250,1273;
+    Vector.h:725-750).  The float32 values are the ones the compiled reference produces (libm
+    cosf/sinf of float(-22*pi/180)); tests/test_oracle_vs_reference.py checks them against it."""
+    c = float.fromhex("0x1.dab7d8p-1")   # cosf(22 deg)
+    s = float.fromhex("0x1.7f98dep-2")   # sinf(22 deg)
+    return (0.0, -s, -c), (0.0, c, -s)
+
+
+def config_c0() -> RenderConfig:
+    """BASELINE.json configs[0]: 12-triangle Cornell-style scene, 256x256, 64 spp, depth 4."""
+    return RenderConfig(W=256, H=256, spp=64, nb_bounces=4, cam_pos=(0.0, -12.3, 55.0), aperture=0.01,
+                        light_center=(0.0, -3.0, 0.0), light_radius=3.0, light_scale=0.04)
+
+
+def config_c1(W=1920, H=1080, spp=256) -> RenderConfig:
+    """BASELINE.json configs[1]: 133k-triangle diffuse blob, 1080p, 256 spp, depth 4, default
+    loadScene() light and camera."""
+    d, u = default_camera_rotated()
+    return RenderConfig(W=W, H=H, spp=spp, nb_bounces=4, cam_dir=d, cam_up=u)

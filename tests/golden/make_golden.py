@@ -1,0 +1,135 @@
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libptref.so).
+
+Run in the build container only (needs /root/reference to have been compiled by
+`make -f oracle/Makefile ref`):   python tests/golden/make_golden.py
+
+The files hold data only — inputs and the reference's outputs (SURVEY.md §8c list i–viii) — so that
+the oracle and the HIP path can be checked on the GPU box, where the reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.binding import Ref  # noqa: E402
+from pathtracer_amd import scenes  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def golden_scene(name):
+    """(mesh, cfg, materials) of the named golden scene; shared with the tests."""
+    if name == "cornell":
+        cfg = scenes.config_c0()
+        cfg.W, cfg.H, cfg.spp = 64, 64, 16
+        return scenes.cornell_mesh(), cfg, None
+    if name == "blob32":
+        cfg = scenes.config_c1(96, 54, 8)
+        return scenes.blob_mesh(32), cfg, None
+    if name == "glossy":   # Phong lobe + mirror-ish plane material
+        cfg = scenes.config_c1(64, 36, 8)
+        return scenes.blob_mesh(24), cfg, dict(Kd=(0.4, 0.3, 0.2), Ks=(0.5, 0.5, 0.4), Ne=(40.0, 60.0, 80.0))
+    if name == "glass":    # Fresnel dielectric, deep paths
+        cfg = scenes.config_c1(64, 36, 8)
+        cfg.nb_bounces = 8
+        return scenes.blob_mesh(24), cfg, dict(Kd=(0.5, 0.5, 0.5), Ks=(0, 0, 0), Ne=(0, 0, 0), transp=0.0, refr=1.3)
+    if name == "c0full":
+        return scenes.cornell_mesh(), scenes.config_c0(), None
+    raise KeyError(name)
+
+
+def setup(X, name):
+    mesh, cfg, mat = golden_scene(name)
+    X.apply_config(cfg)
+    oid = X.add_mesh(mesh)
+    if mat is not None:
+        X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"], mat.get("transp", 1.0), mat.get("refr", 1.3))
+    X.prepare()
+    return mesh, cfg, oid
+
+
+def all_pixels(cfg):
+    return np.stack(np.meshgrid(np.arange(cfg.H), np.arange(cfg.W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+
+
+def main():
+    rng = np.random.default_rng(20261002)
+    R = Ref()
+    g = {}
+    # (i) pcg32, (ii) lattice, helpers
+    for s in (0, 1, 42, 123456789012345):
+        g[f"pcg32_{s}"] = R.pcg32(s, 16)
+    g["lattice"] = R.lattice(64)
+    x = np.concatenate([rng.uniform(0, 1e4, 500), 10.0 ** rng.uniform(-30, 30, 500), [0.0, 1.0]]).astype(np.float32)
+    g["invsqroot_in"], g["invsqroot_out"] = x, R.invsqroot(x)
+    y = rng.uniform(-20, 1, 1000)
+    g["fast_exp_in"], g["fast_exp_out"] = y, R.fast_exp(y)
+    v = rng.normal(size=(1000, 3)).astype(np.float32)
+    N = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    r12 = rng.uniform(0, 1, (1000, 2)).astype(np.float32)
+    g["random_cos_N"], g["random_cos_r"], g["random_cos_out"] = N, r12, R.random_cos(N, r12)
+    # (vi) Phong sample / eval on random tuples
+    n = 256
+    mat9 = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0, 0.9, (n, 3)), rng.uniform(0, 200, (n, 3))], 1).astype(np.float32)
+    mat9[: n // 4, 3:6] = 0      # pure diffuse
+    mat9[: n // 8, 6:9] = 0      # Ne = 0 (OBJ default)
+    Nn = N[:n]
+    wo = rng.normal(size=(n, 3)); wo /= np.linalg.norm(wo, axis=1, keepdims=True); wo = np.where((wo * Nn).sum(1, keepdims=True) < 0, -wo, wo).astype(np.float32)
+    wi = rng.normal(size=(n, 3)); wi /= np.linalg.norm(wi, axis=1, keepdims=True); wi = np.where((wi * Nn).sum(1, keepdims=True) < 0, -wi, wi).astype(np.float32)
+    seeds = rng.integers(0, 2 ** 40, n).astype(np.uint64)
+    g["phong_mat9"], g["phong_wo"], g["phong_wi"], g["phong_N"], g["phong_r12"], g["phong_seeds"] = mat9, wo, wi, Nn, r12[:n], seeds
+    g["phong_sample"] = R.phong_sample(mat9, wo, Nn, r12[:n], seeds)
+    g["phong_eval"] = R.phong_eval(mat9, wi, wo, Nn)
+    np.savez_compressed(os.path.join(OUT, "leaf_functions.npz"), **g)
+
+    # per-scene goldens: (iii) camera, (iv) BVH, (v) rays, (vii) per-sample radiance
+    for name in ("cornell", "blob32", "glossy", "glass"):
+        R = Ref()
+        mesh, cfg, oid = setup(R, name)
+        g = {}
+        g["light"] = R.light()
+        rpp, s2d, fi, fs = R.tables()
+        g["randomPerPixel"], g["samples2d"], g["filter_integral"], g["filter_size"] = rpp, s2d, fi, np.int32(fs)
+        for k in range(oid + 1):
+            t, inv, r = R.object_matrices(k)
+            g[f"obj{k}_trans"], g[f"obj{k}_inv"], g[f"obj{k}_rot"] = t, inv, r
+        d = R.mesh_dump(oid)
+        g["perm"], g["nodes_i"], g["nodes_bb"], g["groups"], g["root_bb"] = d["perm"], d["nodes_i"], d["nodes_bb"], d["groups"], d["root_bb"]
+        g["soup16"] = d["soup"][:, :16]
+        g["soup_normals"] = d["soup"][:, 22:31]
+        ij = all_pixels(cfg)
+        sel = rng.choice(ij.shape[0], 2048, replace=False)
+        jit = rng.uniform(-0.5, 0.5, (2048, 4)).astype(np.float32)
+        jit[:, 2:] *= np.float32(cfg.aperture)
+        g["cam_ij"], g["cam_jit"] = ij[sel], jit
+        rays = R.camera_rays(ij[sel], jit)
+        g["cam_rays"] = rays
+        hi, hf = R.intersect(rays)
+        P = hf[:, 1:4]
+        d2 = rng.normal(size=P.shape).astype(np.float32)
+        d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        rays2 = np.concatenate([np.where(hi[:, :1] > 0, P + np.float32(0.01) * d2, rays[:, :3]), d2], 1).astype(np.float32)
+        allrays = np.concatenate([rays, rays2], 0)
+        hi, hf = R.intersect(allrays)
+        g["rays"], g["hit_i"], g["hit_f"] = allrays, hi, hf[:, :19]
+        dist = rng.uniform(1, 80, allrays.shape[0]).astype(np.float32)
+        g["shadow_dist"], g["shadow_occluded"] = dist, R.intersect_shadow(allrays, dist)
+        rgb, dxdy = R.getcolor_samples(ij, 0, cfg.spp)
+        g["sample_rgb"], g["sample_dxdy"] = rgb, dxdy
+        img, cnt = R.render_seeded()
+        g["image"], g["count"] = img, cnt
+        np.savez_compressed(os.path.join(OUT, f"scene_{name}.npz"), **g)
+        print(name, "mean radiance / white =", float(rgb.mean() / 196964.7))
+
+    # (viii) full C0 image 256x256x64spp, stored normalised
+    R = Ref()
+    mesh, cfg, oid = setup(R, "c0full")
+    img, cnt = R.render_seeded()
+    np.savez_compressed(os.path.join(OUT, "c0_image.npz"), image=img, count=cnt)
+    print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
+
+
+if __name__ == "__main__":
+    main()

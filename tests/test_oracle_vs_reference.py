@@ -1,0 +1,68 @@
+"""CPU tests that need the COMPILED REFERENCE (oracle/_ref/libptref.so, built from
+/root/reference by oracle/Makefile): live bit-for-bit comparison of the oracle with the reference
+on scenes and random inputs beyond the committed goldens.  Skipped where the reference library is
+absent."""
+import numpy as np
+import pytest
+
+from helpers import all_pixels, assert_bits, check_scene_against, load_golden, setup_scene
+from oracle import binding
+from pathtracer_amd import scenes
+
+pytestmark = pytest.mark.skipif(not binding.ref_available(), reason="oracle/_ref/libptref.so not built")
+
+
+def test_goldens_are_current():
+    """The committed goldens are what the compiled reference produces today."""
+    R = binding.Ref()
+    R._scene = setup_scene(R, "blob32")
+    check_scene_against(R, load_golden("scene_blob32.npz"), "blob32", "reference")
+
+
+def test_default_camera_constants():
+    R = binding.Ref()   # loadScene() applies cam.rotate(0,-22deg,1)
+    cam = R.get_camera()
+    d, u = scenes.default_camera_rotated()
+    assert_bits(cam[3:6], np.asarray(d, np.float32), "camera direction")
+    assert_bits(cam[6:9], np.asarray(u, np.float32), "camera up")
+    assert_bits(cam[9:10], np.asarray([scenes.RenderConfig().fov], np.float32), "fov")
+
+
+@pytest.mark.parametrize("seed,n,W,H,spp,depth", [(1, 48, 80, 45, 6, 4), (2, 64, 64, 64, 4, 6)])
+def test_random_scene_radiance(seed, n, W, H, spp, depth):
+    rng = np.random.default_rng(seed)
+    mesh = scenes.blob_mesh(n, fine_detail=bool(seed & 1))
+    cfg = scenes.config_c1(W, H, spp)
+    cfg.nb_bounces = depth
+    cfg.aperture = float(rng.uniform(0.0, 0.5))
+    cfg.light_center = tuple(float(x) for x in rng.uniform(-20, 30, 3))
+    mat = dict(Kd=rng.uniform(0.1, 0.9, 3), Ks=rng.uniform(0, 0.5, 3), Ne=rng.uniform(1, 100, 3))
+    out = []
+    for X in (binding.Ref(), binding.Oracle()):
+        X.apply_config(cfg)
+        oid = X.add_mesh(mesh)
+        X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"])
+        X.add_group_material(2, (0.7, 0.6, 0.5), (0.2, 0.2, 0.2), (30, 30, 30))
+        X.prepare()
+        out.append(X.getcolor_samples(all_pixels(cfg), 0, spp))
+    assert_bits(out[0][0], out[1][0], "per-sample radiance")
+    assert_bits(out[0][1], out[1][1], "jitter")
+
+
+def test_mirror_and_glass():
+    mesh = scenes.blob_mesh(20)
+    cfg = scenes.config_c1(48, 27, 8)
+    cfg.nb_bounces = 10
+    res = {}
+    for mirror in (0, 1):
+        out = []
+        for X in (binding.Ref(), binding.Oracle()):
+            X.apply_config(cfg)
+            oid = X.add_mesh(mesh)
+            if mirror:
+                X.set_object_flags(oid, miroir=True)
+            else:
+                X.set_group_material(oid, 0, (0.5,) * 3, (0,) * 3, (0,) * 3, transp_col=0.0, refr=1.5)
+            X.prepare()
+            out.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
+        assert_bits(out[0], out[1], f"radiance mirror={mirror}")
