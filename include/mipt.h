@@ -1,0 +1,228 @@
+/* mipt.h — C ABI of the MI355X path-tracing core (libmipt.so).
+ *
+ * Drop-in boundary for ONE hot path of nbonneel/pathtracer: the per-pixel / per-sample radiance
+ * loop (Raytracer::getColor + Scene::intersection[_shadow] + TriMesh BVH traversal +
+ * Triangle::intersection + Phong BRDF + camera-ray generation + splat).  Everything else of the
+ * reference (GUI, file I/O, BVH *build*, scene editing) stays on the host and stays the caller's.
+ *
+ * Each entry point cites the reference interface it replaces (file:line into the reference
+ * checkout).  The reference has no FFI of its own; the seam is the public surface of
+ * `class Raytracer` (Raytracer.h:25-121) and `class Scene` (Geometry.h:1238-1400), the precedent
+ * being its USE_EMBREE compile-time switch.  INTEGRATION.md shows the C++ binding a maintainer
+ * adds on the reference side.
+ *
+ * Conventions: plain C, pointers + sizes, no C++/torch types.  Every function returns an int
+ * status (MIPT_OK = 0); mipt_last_error() gives the text.  Host arrays passed in are copied
+ * before the call returns; the library never keeps a caller pointer.  One context = one GPU =
+ * one host thread at a time; several contexts may coexist (one process per GPU under RCCL).
+ * There is NO CPU fallback: without a usable HIP device mipt_create fails with
+ * MIPT_ERR_NO_DEVICE.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPT_ABI_VERSION 1
+
+enum {
+	MIPT_OK = 0,
+	MIPT_ERR_INVALID = 1,      /* bad argument / inconsistent description */
+	MIPT_ERR_NO_DEVICE = 2,    /* no HIP device, or device id out of range */
+	MIPT_ERR_HIP = 3,          /* a HIP runtime call failed (text in mipt_last_error) */
+	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature outside the hot path (ghost, fog, SSS, ...) */
+	MIPT_ERR_NO_SCENE = 5,     /* render/trace before mipt_upload_scene */
+	MIPT_ERR_CANCELLED = 6     /* *cancel became non-zero between passes (Raytracer::stopRender) */
+};
+
+typedef struct mipt_ctx mipt_ctx;
+
+/* ---- scene description: POD mirror of what the path reads -------------------------------- */
+
+/* Texture (BRDF.h:252-426): float RGB, already decoded by the host exactly as
+ * Texture::loadColors does (rows flipped, /255.f, powf(.,2.2f)); W == 0 means "constant
+ * multiplier" (the reference's "Null" texture).  `values` = &Texture::values[0]. */
+typedef struct mipt_texture {
+	float multiplier[3];
+	int32_t W, H;
+	const float* values;      /* W*H*3 floats or NULL */
+} mipt_texture;
+
+/* BVHNodesT<float> (TriangleMesh.h:6-13), 36 bytes, byte-compatible: pass &bvh.nodes[0]. */
+typedef struct mipt_bvh_node {
+	uint8_t isleaf; uint8_t _pad[3];
+	int32_t fg, fd;           /* inner: child node indices; leaf: triangle range [fg,fd) */
+	float bbox_min[3], bbox_max[3];
+} mipt_bvh_node;
+
+/* Triangle (TriangleMesh.h:67-111), 124 bytes, byte-compatible: pass &triangleSoup[0]. */
+typedef struct mipt_triangle {
+	float A[3], u[3], v[3], N[3];
+	float m11, m12, m22, invdetm;
+	float uvs[3][2];
+	float normals[3][3];
+} mipt_triangle;
+
+/* TriangleIndices (TriangleMesh.h:53-65), 44 bytes, byte-compatible: pass &indices[0].
+ * The path reads group, uvi/uvj/uvk and ni only. */
+typedef struct mipt_triangle_indices {
+	int32_t vtxi, vtxj, vtxk;
+	int32_t uvi, uvj, uvk;
+	int32_t ni, nj, nk;
+	int32_t group;
+	uint8_t showEdges[3]; uint8_t _pad;
+} mipt_triangle_indices;
+
+/* The parts of TriMesh (TriangleMesh.h:113-258) the traversal and getMaterial read. */
+typedef struct mipt_mesh {
+	int32_t n_triangles, n_nodes, n_uvs;
+	const mipt_bvh_node* nodes;              /* bvh.nodes */
+	float bvh_bbox_min[3], bvh_bbox_max[3];  /* bvh.bbox */
+	const mipt_triangle* triangleSoup;
+	const mipt_triangle_indices* indices;
+	const float* uvs;                        /* TriMesh::uvs as Vector[n_uvs] (3 floats each) or NULL */
+	const float* tangentSoup;                /* Vector[3*n_triangles] or NULL (normal maps only) */
+} mipt_mesh;
+
+enum { MIPT_OBJ_TRIMESH = 0, MIPT_OBJ_SPHERE = 1, MIPT_OBJ_PLANE = 2 };   /* ObjectType, Geometry.h:29 */
+enum { MIPT_BRDF_PHONG = 0, MIPT_BRDF_MERL = 1 };
+
+/* Object (Geometry.h:240-735) + Sphere (:849-1103) / Plane (:1127-1217) / TriMesh fields. */
+typedef struct mipt_object {
+	int32_t type;
+	int32_t miroir, ghost, flip_normals, interp_normals;
+	float trans_matrix[12], inv_trans_matrix[12], rot_matrix[9];   /* after Object::build_matrix */
+	int32_t brdf_kind;
+	const double* merl_data;                 /* IsoMERLBRDF::data (3*90*90*180 doubles) or NULL */
+	/* the eight per-group texture lists of Object (Geometry.h:731) */
+	int32_t n_textures, n_specularmap, n_alphamap, n_roughnessmap, n_normal_map, n_subsurface, n_transparent_map, n_refr_index_map;
+	const mipt_texture *textures, *specularmap, *alphamap, *roughnessmap, *normal_map, *subsurface, *transparent_map, *refr_index_map;
+	/* Sphere */
+	float O[3], R;
+	int32_t has_envmap, envW, envH;
+	const uint8_t* envtex;                   /* Sphere::envtex, RGB8, envW*envH*3 */
+	/* Plane */
+	float A[3], vecN[3];
+	/* TriMesh */
+	const mipt_mesh* mesh;
+} mipt_object;
+
+/* Scene (Geometry.h:1238-1400).  As in Raytracer::loadScene (Raytracer.cpp:1257-1269) object 0
+ * is the light sphere (Scene::lumiere), object 1 the environment sphere, object 2.. the rest. */
+typedef struct mipt_scene_desc {
+	int32_t n_objects;
+	const mipt_object* objects;
+} mipt_scene_desc;
+
+/* Per-render inputs: the Raytracer members getColor / render_image read after
+ * Raytracer::prepare_render (Raytracer.cpp:1321-1391) has filled its tables. */
+typedef struct mipt_render_params {
+	int32_t W, H;
+	int32_t nrays;                 /* samples per pixel */
+	int32_t nb_bounces;
+	float cam_position[3], cam_direction[3], cam_up[3];    /* Camera (Vector.h:700-842) */
+	float cam_fov, cam_focus_distance, cam_aperture;
+	float double_frustum_start_t;  /* Scene::double_frustum_start_t */
+	float sigma_filter;
+	int32_t filter_size;           /* ceil(2*sigma) */
+	const float* filter_integral;  /* (2*filter_size+1)^2 summed-area table (Raytracer.cpp:1358-1369) */
+	const float* samples2d;        /* Raytracer::samples2d, Vector[nrays] (3 floats each; x,y used) */
+	const float* randomPerPixel;   /* Raytracer::randomPerPixel, Vector[W*H] (3 floats each) */
+	float centerLight[3], radiusLight, lightPower;         /* Raytracer.cpp:1377-1380 */
+	float envmap_intensity;        /* Scene::envmap_intensity */
+	/* Sampling rule (the reference's own stream assignment is an accident of link order and
+	 * thread scheduling): sample k of pixel p = i*W+j draws from
+	 * pcg32(p*seed_stride + k).  seed_stride = 65536 reproduces the oracle/golden vectors. */
+	uint64_t seed_stride;
+	int32_t sample_begin, sample_end;   /* render samples k in [begin,end); 0,nrays = all */
+	/* Work partition across GPUs (one context per GPU): pixel tiles of tile_size x tile_size,
+	 * tile t belongs to rank t % tile_nranks.  tile_nranks = 1 renders everything. */
+	int32_t tile_size, tile_rank, tile_nranks;
+	int32_t reserved[4];
+} mipt_render_params;
+
+typedef struct mipt_ray { float origin[3]; float direction[3]; } mipt_ray;
+
+/* Outputs of Scene::intersection (Geometry.h:1340): has_inter, sphere_id, triangle_id, min_t,
+ * P, and the MaterialValues (BRDF.h:7-20). */
+typedef struct mipt_hit {
+	int32_t has_inter, object_id, triangle_id;
+	float t;
+	float P[3];
+	float shadingN[3], Kd[3], Ks[3], Ne[3], Ke[3];
+	int32_t transp;
+	float refr_index;
+} mipt_hit;
+
+/* Counters and timings of the most recent mipt_render* call. */
+typedef struct mipt_stats {
+	uint64_t paths;               /* camera paths traced */
+	uint64_t rays_closest;        /* Scene::intersection calls */
+	uint64_t rays_shadow;         /* Scene::intersection_shadow calls */
+	uint64_t mesh_casts_closest;  /* TriMesh::intersection calls */
+	uint64_t mesh_casts_shadow;   /* TriMesh::intersection_shadow calls */
+	double   render_ms;           /* HIP-event time of the whole call on its stream */
+	double   traverse_ms;         /* HIP-event time summed over the traversal kernel launches */
+	uint32_t traverse_launches;
+	uint32_t passes;
+} mipt_stats;
+
+typedef void (*mipt_progress_cb)(void* user, int samples_done, int samples_total);
+
+/* ---- entry points ------------------------------------------------------------------------ */
+
+/* Opens device `device_ids[0]` (n must be 1: multi-GPU = one process and one context per GPU,
+ * partitioned by mipt_render_params::tile_*).  Replaces nothing in the reference (it has no
+ * device); called from Raytracer::Raytracer(). */
+int mipt_create(const int* device_ids, int n, mipt_ctx** out);
+void mipt_destroy(mipt_ctx* ctx);
+const char* mipt_last_error(const mipt_ctx* ctx);
+int mipt_abi_version(void);
+
+/* Copies the scene to HBM and converts it to the traversal layout.  Called where
+ * the reference calls Scene::prepare_render (Geometry.cpp:280-307), i.e. after every
+ * Object::build_matrix, from Raytracer::prepare_render (Raytracer.cpp:1375). */
+int mipt_upload_scene(mipt_ctx* ctx, const mipt_scene_desc* scene);
+
+/* The sample loop of Raytracer::render_image (Raytracer.cpp:1444-1531) /
+ * render_image_nopreviz (:1581-1685): for every owned pixel and sample: camera jitter,
+ * Camera::generateDirection, getColor, Gaussian splat.  ADDS into the caller's host buffers
+ * accum_rgb = Raytracer::imagedouble (W*H*3, row-flipped: pixel (i,j) at ((H-i-1)*W+j)*3) and
+ * accum_w = Raytracer::sample_count (W*H); the caller zero-fills them as prepare_render does.
+ * `cb` (may be NULL) is called after each pass; `cancel` (may be NULL) is polled between passes
+ * like Raytracer::stopped (Raytracer.cpp:1452). */
+int mipt_render(mipt_ctx* ctx, const mipt_render_params* p, float* accum_rgb, float* accum_w,
+                mipt_progress_cb cb, void* cb_user, volatile int* cancel);
+
+/* Same, but accumulates into a DEVICE buffer of W*H*4 floats ([W*H*3 rgb | W*H weights], same
+ * pixel order) on HIP stream `hip_stream` (a hipStream_t, NULL = default stream) and returns
+ * without synchronising the host; used for the multi-GPU framebuffer reduce (RCCL on the same
+ * buffer), which replaces the per-thread buffer sum of Raytracer.cpp:1669-1685. */
+int mipt_render_device(mipt_ctx* ctx, const mipt_render_params* p, float* d_accum_rgbw, void* hip_stream);
+
+/* Scene::intersection (Geometry.cpp:589-688) on n rays. */
+int mipt_trace(mipt_ctx* ctx, const mipt_ray* rays, int n, mipt_hit* hits);
+/* Scene::intersection_shadow (Geometry.cpp:691-744) on n rays; occluded[k] = return value. */
+int mipt_trace_shadow(mipt_ctx* ctx, const mipt_ray* rays, const float* dist_light, int n, int32_t* occluded);
+
+/* Parity hook: Raytracer::getColor (Raytracer.cpp:196-664) for pixels pixels_ij[2*q..] = (i,j) and
+ * samples k in [k0,k1), WITHOUT the splat.  out_rgb[(q*(k1-k0)+(k-k0))*3], out_dxdy[..*2] = the
+ * sensor jitter (dx,dy) the splat would use. */
+int mipt_sample_radiance(mipt_ctx* ctx, const mipt_render_params* p, const int32_t* pixels_ij, int npix,
+                         int k0, int k1, float* out_rgb, float* out_dxdy);
+
+/* Statistics of the last render call (rays counted like the oracle does, kernel time from HIP
+ * events on the render stream). */
+int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
+
+/* Tunables (name/value); unknown names return MIPT_ERR_INVALID.
+ *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default)
+ *   "paths_per_pass"  upper bound on paths in flight per pass */
+int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */

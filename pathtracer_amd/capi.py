@@ -1,0 +1,305 @@
+"""ctypes view of the product libraries.
+
+* ``libmipt.so``       — the C-ABI of include/mipt.h (HIP kernels).
+* ``libmipt_host.so``  — host-side mirror of the reference's Raytracer / Scene / TriMesh surface
+                         (pathtracer_amd/host/mipt_host.h), which owns scene construction, the BVH
+                         build and prepare_render, and hands POD descriptions to the C-ABI.
+
+``HostRaytracer`` offers the same method names as oracle/binding.py so that one test body can be
+run against the reference, the oracle and the HIP path.  Nothing here falls back to a CPU
+implementation: without a GPU ``HostRaytracer(device=...)`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBMIPT = os.path.join(_HERE, "libmipt.so")
+LIBHOST = os.path.join(_HERE, "libmipt_host.so")
+
+MIPT_OK = 0
+MIPT_ERR_NO_DEVICE = 2
+
+# every symbol include/mipt.h declares
+MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
+                "mipt_render_device", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
+
+_f = C.c_float
+_i = C.c_int
+
+
+class MiptStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("mesh_casts_closest", C.c_uint64), ("mesh_casts_shadow", C.c_uint64),
+                ("render_ms", C.c_double), ("traverse_ms", C.c_double), ("traverse_launches", C.c_uint32), ("passes", C.c_uint32)]
+
+
+class MiptHit(C.Structure):
+    _fields_ = [("has_inter", C.c_int32), ("object_id", C.c_int32), ("triangle_id", C.c_int32), ("t", _f), ("P", _f * 3),
+                ("shadingN", _f * 3), ("Kd", _f * 3), ("Ks", _f * 3), ("Ne", _f * 3), ("Ke", _f * 3), ("transp", C.c_int32), ("refr_index", _f)]
+
+
+HIT_DTYPE = np.dtype([("has_inter", np.int32), ("object_id", np.int32), ("triangle_id", np.int32), ("t", np.float32), ("P", np.float32, 3),
+                      ("shadingN", np.float32, 3), ("Kd", np.float32, 3), ("Ks", np.float32, 3), ("Ne", np.float32, 3), ("Ke", np.float32, 3),
+                      ("transp", np.int32), ("refr_index", np.float32)])
+assert HIT_DTYPE.itemsize == C.sizeof(MiptHit)
+
+_libs = None
+
+
+def load():
+    """Loads both libraries and checks every exported symbol; raises if anything is missing."""
+    global _libs
+    if _libs is not None:
+        return _libs
+    for p in (LIBMIPT, LIBHOST):
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: run `python __graft_entry__.py` (build()) first; there is no fallback path")
+    mipt = C.CDLL(LIBMIPT, mode=C.RTLD_GLOBAL)
+    host = C.CDLL(LIBHOST)
+    for s in MIPT_SYMBOLS:
+        getattr(mipt, s)
+    mipt.mipt_last_error.restype = C.c_char_p
+    mipt.mipt_last_error.argtypes = [C.c_void_p]
+    host.mh_create.restype = C.c_void_p
+    host.mh_last_error.restype = C.c_char_p
+    for name in ("mh_ctx", "mh_scene_desc", "mh_render_params", "mh_imagedouble", "mh_sample_count", "mh_image"):
+        getattr(host, name).restype = C.c_void_p
+    _libs = (mipt, host)
+    return _libs
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def light_intensity(R, scale=1.0):
+    """Scene::intensite_lumiere = 1e9*4pi/(4pi*R*R*pi) (Raytracer.cpp:1270) times the GUI slider factor
+    (mainApp.cpp:775), in double, narrowed to the float member."""
+    R = float(np.float32(R))
+    return float(np.float32(scale * 1000000000 * 4. * np.pi / (4. * np.pi * R * R * np.pi)))
+
+
+class MiptError(RuntimeError):
+    pass
+
+
+class HostRaytracer:
+    """One mipt_host::Raytracer (after loadScene()), optionally bound to a GPU."""
+
+    def __init__(self, device=None):
+        self.mipt, self.host = load()
+        self.h = C.c_void_p(self.host.mh_create())
+        self.W = self.H = self.spp = 0
+        self.device = device
+        self._uploaded = False
+        if device is not None:
+            rc = self.host.mh_open_device(self.h, int(device))
+            if rc != MIPT_OK:
+                raise MiptError(f"mipt_create(device={device}) failed with status {rc}: {self.host.mh_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.host.mh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != MIPT_OK:
+            ctx = self.host.mh_ctx(self.h)
+            msg = self.mipt.mipt_last_error(ctx).decode() if ctx else self.host.mh_last_error(self.h).decode()
+            raise MiptError(f"{what} failed with status {rc}: {msg}")
+
+    # ---- setup (names as oracle/binding.py)
+    def set_partition(self, tile_size, rank, nranks):
+        self.host.mh_set_partition(self.h, tile_size, rank, nranks)
+
+    def set_render(self, W, H, spp, nb_bounces, sigma_filter=0.5):
+        self.W, self.H, self.spp = W, H, spp
+        self.host.mh_set_render(self.h, W, H, spp, nb_bounces, _f(sigma_filter))
+
+    def set_camera(self, pos, direction, up, fov, focus, aperture):
+        a = lambda v: (_f * 3)(*v)
+        self.host.mh_set_camera(self.h, a(pos), a(direction), a(up), _f(fov), _f(focus), _f(aperture))
+
+    def set_light(self, center, R, scale=1.0):
+        self.host.mh_set_light(self.h, (_f * 3)(*center), _f(R), _f(light_intensity(R, scale)))
+
+    def set_envmap_intensity(self, v):
+        self.host.mh_set_envmap_intensity(self.h, _f(v))
+
+    def apply_config(self, cfg):
+        self.set_render(cfg.W, cfg.H, cfg.spp, cfg.nb_bounces, cfg.sigma_filter)
+        self.set_camera(cfg.cam_pos, cfg.cam_dir, cfg.cam_up, cfg.fov, cfg.focus, cfg.aperture)
+        self.set_light(cfg.light_center, cfg.light_radius, cfg.light_scale)
+        self.set_envmap_intensity(cfg.envmap_intensity)
+
+    def add_mesh(self, mesh, scale=30.0, center=True, tmpdir=None):
+        v = np.ascontiguousarray(mesh.vertices, np.float32)
+        n = np.ascontiguousarray(mesh.normals, np.float32)
+        fv = np.ascontiguousarray(mesh.faces_v, np.int32)
+        fn = np.ascontiguousarray(mesh.faces_n, np.int32)
+        if mesh.uvs is not None:
+            uv = np.ascontiguousarray(mesh.uvs, np.float32)
+            ft = np.ascontiguousarray(mesh.faces_t, np.int32)
+            uvp, ftp, nt = _p(uv, _f), _p(ft, _i), uv.shape[0]
+        else:
+            uvp, ftp, nt = None, None, 0
+        return self.host.mh_add_mesh(self.h, v.shape[0], _p(v, _f), n.shape[0], _p(n, _f), nt, uvp,
+                                     fv.shape[0], _p(fv, _i), _p(fn, _i), ftp, _f(scale), 1 if center else 0)
+
+    def set_object_flags(self, obj, miroir=False, flip_normals=False):
+        self.host.mh_set_object_flags(self.h, obj, int(miroir), int(flip_normals))
+
+    def set_group_material(self, obj, grp, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
+        a = lambda v: (_f * 3)(*v)
+        self.host.mh_set_group_material(self.h, obj, grp, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))
+
+    def add_group_material(self, obj, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
+        a = lambda v: (_f * 3)(*v)
+        self.host.mh_add_group_material(self.h, obj, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))
+
+    def set_group_texture(self, obj, grp, slot, rgb8):
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        self.host.mh_set_group_texture(self.h, obj, grp, slot, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
+
+    def set_envmap(self, rgb8):
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        self.host.mh_set_envmap(self.h, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
+
+    def prepare(self):
+        """Raytracer::prepare_render; uploads the scene when a device is open."""
+        upload = self.device is not None
+        self._check(self.host.mh_prepare(self.h, 1 if upload else 0), "prepare_render / mipt_upload_scene")
+        self._uploaded = upload
+
+    # ---- host-side dumps
+    def light(self):
+        out = np.zeros(5, np.float32)
+        self.host.mh_get_light(self.h, _p(out, _f))
+        return out
+
+    def tables(self):
+        rpp = np.zeros((self.H * self.W, 2), np.float32)
+        s2d = np.zeros((self.spp, 2), np.float32)
+        fi = np.zeros(64 * 64, np.float32)
+        fs = _i(0)
+        self.host.mh_get_tables(self.h, _p(rpp, _f), _p(s2d, _f), _p(fi, _f), C.byref(fs))
+        w = 2 * fs.value + 1
+        return rpp, s2d, fi[: w * w].copy(), fs.value
+
+    def object_matrices(self, obj):
+        t, inv, r = np.zeros(12, np.float32), np.zeros(12, np.float32), np.zeros(9, np.float32)
+        self.host.mh_get_object_matrices(self.h, obj, _p(t, _f), _p(inv, _f), _p(r, _f))
+        return t, inv, r
+
+    def mesh_dump(self, obj):
+        c = [_i(0) for _ in range(5)]
+        self.host.mh_mesh_counts(self.h, obj, *[C.byref(x) for x in c])
+        ntri, nnodes = c[0].value, c[1].value
+        perm = np.zeros(ntri, np.int32)
+        nodes_i = np.zeros((nnodes, 3), np.int32)
+        nodes_bb = np.zeros((nnodes, 6), np.float32)
+        soup = np.zeros((ntri, 31), np.float32)
+        groups = np.zeros(ntri, np.int32)
+        root = np.zeros(6, np.float32)
+        self.host.mh_mesh_dump(self.h, obj, _p(perm, _i), _p(nodes_i, _i), _p(nodes_bb, _f), _p(soup, _f), _p(groups, _i), _p(root, _f))
+        return dict(perm=perm, nodes_i=nodes_i, nodes_bb=nodes_bb, soup=soup, groups=groups, root_bb=root,
+                    nverts=c[2].value, nnormals=c[3].value, nuvs=c[4].value)
+
+    # ---- the C-ABI, called directly with the descriptions the host side built
+    @property
+    def ctx(self):
+        return C.c_void_p(self.host.mh_ctx(self.h))
+
+    @property
+    def scene_desc(self):
+        return C.c_void_p(self.host.mh_scene_desc(self.h))
+
+    @property
+    def render_params(self):
+        return C.c_void_p(self.host.mh_render_params(self.h))
+
+    def _need_device(self):
+        if not self._uploaded:
+            raise MiptError("no scene uploaded to a GPU (HostRaytracer(device=...) then prepare())")
+
+    def set_option(self, name, value):
+        self._check(self.mipt.mipt_set_option(self.ctx, name.encode(), C.c_int64(int(value))), "mipt_set_option")
+
+    def trace(self, rays6):
+        self._need_device()
+        rays6 = np.ascontiguousarray(rays6, np.float32)
+        hits = np.zeros(rays6.shape[0], HIT_DTYPE)
+        self._check(self.mipt.mipt_trace(self.ctx, rays6.ctypes.data_as(C.c_void_p), rays6.shape[0], hits.ctypes.data_as(C.c_void_p)), "mipt_trace")
+        return hits
+
+    def intersect(self, rays6):
+        """Scene::intersection in the (ids, floats) layout of oracle/binding.py."""
+        h = self.trace(rays6)
+        oi = np.stack([h["has_inter"], h["object_id"], h["triangle_id"]], 1).astype(np.int32)
+        of = np.concatenate([h["t"][:, None], h["P"], h["shadingN"], h["Kd"], h["Ks"], h["Ne"], h["Ke"],
+                             np.where(h["transp"] != 0, -h["refr_index"], h["refr_index"])[:, None]], 1).astype(np.float32)
+        return oi, of
+
+    def intersect_shadow(self, rays6, dist):
+        self._need_device()
+        rays6 = np.ascontiguousarray(rays6, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        out = np.zeros(rays6.shape[0], np.int32)
+        self._check(self.mipt.mipt_trace_shadow(self.ctx, rays6.ctypes.data_as(C.c_void_p), _p(dist, _f), rays6.shape[0], _p(out, C.c_int32)), "mipt_trace_shadow")
+        return out
+
+    def sample_radiance(self, ij, k0, k1):
+        self._need_device()
+        ij = np.ascontiguousarray(ij, np.int32)
+        n = ij.shape[0]
+        rgb = np.zeros((n, k1 - k0, 3), np.float32)
+        dxdy = np.zeros((n, k1 - k0, 2), np.float32)
+        self._check(self.mipt.mipt_sample_radiance(self.ctx, self.render_params, _p(ij, C.c_int32), n, k0, k1, _p(rgb, _f), _p(dxdy, _f)), "mipt_sample_radiance")
+        return rgb, dxdy
+
+    getcolor_samples = sample_radiance
+
+    def render(self):
+        """mipt_render into zeroed host accumulators: (imagedouble[H,W,3], sample_count[H,W])."""
+        self._need_device()
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        self._check(self.mipt.mipt_render(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), None, None, None), "mipt_render")
+        return img, cnt
+
+    render_seeded = render
+
+    def render_device(self, d_accum_ptr, stream=0):
+        self._need_device()
+        self._check(self.mipt.mipt_render_device(self.ctx, self.render_params, C.c_void_p(d_accum_ptr), C.c_void_p(stream)), "mipt_render_device")
+
+    def stats(self):
+        st = MiptStats()
+        self._check(self.mipt.mipt_get_stats(self.ctx, C.byref(st)), "mipt_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    # ---- the reference's entry points, through the host mirror
+    def render_image_nopreviz(self):
+        self._check(self.host.mh_render_image_nopreviz(self.h), "Raytracer::render_image_nopreviz")
+        return self._images()
+
+    def render_image(self):
+        self._check(self.host.mh_render_image(self.h), "Raytracer::render_image")
+        return self._images()
+
+    def _images(self):
+        n = self.W * self.H
+        img = np.ctypeslib.as_array(C.cast(self.host.mh_imagedouble(self.h), C.POINTER(_f)), shape=(n * 3,)).reshape(self.H, self.W, 3).copy()
+        cnt = np.ctypeslib.as_array(C.cast(self.host.mh_sample_count(self.h), C.POINTER(_f)), shape=(n,)).reshape(self.H, self.W).copy()
+        u8 = np.ctypeslib.as_array(C.cast(self.host.mh_image(self.h), C.POINTER(C.c_ubyte)), shape=(n * 3,)).reshape(self.H, self.W, 3).copy()
+        return img, cnt, u8

@@ -1,0 +1,613 @@
+// mipt.hip — kernels and C-ABI (include/mipt.h) of the MI355X path-tracing core.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "mipt_shade.h"
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+
+struct DCounters {
+	unsigned long long paths, rays_closest, rays_shadow;
+};
+
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v) {
+	// per-wave partial reduction, one atomic per wave (cdna_hip_programming.md Guideline 12)
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// Scene::intersection on a ray list (mipt_trace).
+__global__ void __launch_bounds__(256) k_trace(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, int n, mipt_hit* __restrict__ hits) {
+	int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n) return;
+	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
+	Hit h; f3 P = mk3(0, 0, 0); Mat m;
+	m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
+	bool hit = scene_intersect(sc, r, h, P, m);
+	mipt_hit o;
+	o.has_inter = hit ? 1 : 0; o.object_id = hit ? h.obj : -1; o.triangle_id = hit ? h.tri : -1; o.t = h.t;
+	o.P[0] = P.x; o.P[1] = P.y; o.P[2] = P.z;
+	o.shadingN[0] = m.shadingN.x; o.shadingN[1] = m.shadingN.y; o.shadingN[2] = m.shadingN.z;
+	o.Kd[0] = m.Kd.x; o.Kd[1] = m.Kd.y; o.Kd[2] = m.Kd.z; o.Ks[0] = m.Ks.x; o.Ks[1] = m.Ks.y; o.Ks[2] = m.Ks.z;
+	o.Ne[0] = m.Ne.x; o.Ne[1] = m.Ne.y; o.Ne[2] = m.Ne.z; o.Ke[0] = m.Ke.x; o.Ke[1] = m.Ke.y; o.Ke[2] = m.Ke.z;
+	o.transp = m.transp ? 1 : 0; o.refr_index = m.refr_index;
+	hits[q] = o;
+}
+
+// Scene::intersection_shadow on a ray list (mipt_trace_shadow).
+__global__ void __launch_bounds__(256) k_trace_shadow(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, const float* __restrict__ dist, int n, int* __restrict__ occluded) {
+	int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n) return;
+	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
+	occluded[q] = scene_occluded(sc, r, dist[q]) ? 1 : 0;
+}
+
+// The whole getColor loop of one (pixel, sample) in one thread.
+__device__ __forceinline__ f3 trace_path(const DScene* __restrict__ sc, const DRender& R, int i, int j, int k, float& dx, float& dy, unsigned& n_closest, unsigned& n_shadow) {
+	PathState ps;
+	path_begin(R, i, j, k, ps, dx, dy);
+	const int pix = i * R.W + j;
+	while (path_alive(ps)) {
+		Hit h; f3 P = mk3(0, 0, 0); Mat m;
+		bool hit = scene_intersect(sc, ps.ray, h, P, m);
+		n_closest++;
+		ShadowRequest sh; f3 wv;
+		bool cont = path_vertex(sc, R, ps, hit, h, P, m, pix, k, sh, wv);
+		if (sh.diffuse) {
+			f3 contrib = sh.contrib;
+			if (sh.cast) { n_shadow++; if (scene_occluded(sc, sh.ray, sh.dist)) contrib = mk3(0, 0, 0); }
+			else contrib = mk3(0, 0, 0);
+			ps.color = ps.color + wv * contrib;                           // Raytracer.cpp:566
+		}
+		if (!cont) break;
+	}
+	return ps.color;
+}
+
+// Parity hook (mipt_sample_radiance): arbitrary pixel list, samples [k0,k1), no splat.
+__global__ void __launch_bounds__(256) k_sample_radiance(const DScene* __restrict__ sc, DRender R, const int* __restrict__ ij, int npix, int k0, int k1,
+                                                         float* __restrict__ out_rgb, float* __restrict__ out_dxdy) {
+	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	int nk = k1 - k0;
+	if (tid >= (long long)npix * nk) return;
+	int q = (int)(tid / nk), k = k0 + (int)(tid % nk);
+	float dx, dy; unsigned a = 0, b = 0;
+	f3 c = trace_path(sc, R, ij[2 * q], ij[2 * q + 1], k, dx, dy, a, b);
+	out_rgb[3 * tid] = c.x; out_rgb[3 * tid + 1] = c.y; out_rgb[3 * tid + 2] = c.z;
+	if (out_dxdy) { out_dxdy[2 * tid] = dx; out_dxdy[2 * tid + 1] = dy; }
+}
+
+// Pipeline 0: one thread per path.  A wave = one 8x8 pixel block at one sample index, so the
+// primary rays of a wave are coherent.  Results go to the pass's per-sample buffers.
+struct DSamples { float *r, *g, *b, *dx, *dy; };
+
+__global__ void __launch_bounds__(256) k_render_paths(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt) {
+	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
+	unsigned n_closest = 0, n_shadow = 0, n_paths = 0;
+	if (tid < total) {
+		int kk = (int)(tid / ps.npix_slots);
+		int slot = (int)(tid % ps.npix_slots);
+		int blk = slot >> 6, in = slot & 63;
+		int i = ps.blocks[2 * blk] + (in >> 3), j = ps.blocks[2 * blk + 1] + (in & 7);
+		if (i < R.H && j < R.W) {
+			float dx, dy;
+			f3 c = trace_path(sc, R, i, j, ps.k0 + kk, dx, dy, n_closest, n_shadow);
+			out.r[tid] = c.x; out.g[tid] = c.y; out.b[tid] = c.z; out.dx[tid] = dx; out.dy[tid] = dy;
+			n_paths = 1;
+		}
+	}
+	wave_add(&cnt->paths, n_paths);
+	wave_add(&cnt->rays_closest, n_closest);
+	wave_add(&cnt->rays_shadow, n_shadow);
+}
+
+// sum_area_table (Raytracer.cpp:1276-1291)
+__device__ __forceinline__ float sum_area_table(const float* __restrict__ sat, int w, int i0, int i1, int j0, int j1) {
+	float term1 = 0; if (i0 > 0) term1 = sat[(i0 - 1) * w + j1];
+	float term2 = 0; if (j0 > 0) term2 = sat[i1 * w + j0 - 1];
+	float term3 = 0; if (i0 > 0 && j0 > 0) term3 = sat[(i0 - 1) * w + j0 - 1];
+	return sat[i1 * w + j1] - term1 - term2 + term3;
+}
+
+// Gaussian splat (Raytracer.cpp:1477-1497) as a per-destination-pixel gather: no atomics, and the
+// additions into a pixel happen in the reference's scan order (source row, source column, sample),
+// so a single-pass render reproduces the serial image bit for bit.  Only sources owned by this
+// rank contribute (multi-GPU partial images are summed by the framebuffer reduce).
+__global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples in, float denom2, float* __restrict__ accum) {
+	int pid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pid >= R.W * R.H) return;
+	const int W = R.W, H = R.H, fs = R.filter_size, ftw = 2 * R.filter_size + 1;
+	int i2 = pid / W, j2 = pid % W;
+	size_t d = (size_t)(H - i2 - 1) * W + j2;
+	float* acc_rgb = accum + 3 * d;
+	float* acc_w = accum + (size_t)3 * W * H + d;
+	float ar = acc_rgb[0], ag = acc_rgb[1], ab = acc_rgb[2], aw = *acc_w;
+	bool any = false;
+	const int nk = ps.k1 - ps.k0;
+	for (int i = max(0, i2 - fs); i <= min(H - 1, i2 + fs); i++) {
+		for (int j = max(0, j2 - fs); j <= min(W - 1, j2 + fs); j++) {
+			int slot = ps.pix2slot[i * W + j];
+			if (slot < 0) continue;
+			any = true;
+			int bmin_i = max(0, i - fs), bmax_i = min(i + fs, H - 1), bmin_j = max(0, j - fs), bmax_j = min(j + fs, W - 1);
+			float ratio = 1.f / sum_area_table(R.filter_integral, ftw, bmin_i - i + fs, bmax_i - i + fs, bmin_j - j + fs, bmax_j - j + fs);
+			float denom1 = (float)((double)ratio / ((double)(R.sigma_filter * R.sigma_filter) * 2. * MIPT_PI));
+			for (int kk = 0; kk < nk; kk++) {
+				size_t s = (size_t)kk * ps.npix_slots + slot;
+				float dx = in.dx[s], dy = in.dy[s];
+				float w = (float)(fast_exp((double)(-(sqr((float)(i2 - i) - dy) + sqr((float)(j2 - j) - dx)) * denom2)) * (double)denom1);
+				ar += in.r[s] * w; ag += in.g[s] * w; ab += in.b[s] * w; aw += w;
+			}
+		}
+	}
+	if (any) { acc_rgb[0] = ar; acc_rgb[1] = ag; acc_rgb[2] = ab; *acc_w = aw; }
+}
+
+// =====================================================================================
+// host side: context, upload, C-ABI
+// =====================================================================================
+
+struct mipt_ctx {
+	int device = -1;
+	std::string err;
+	std::vector<void*> scene_allocs;
+	DScene* d_scene = nullptr;
+	int n_mesh_objects = 0;
+	bool has_scene = false;
+	// render-time buffers (grown on demand)
+	void* pass_buf = nullptr; size_t pass_buf_bytes = 0;
+	void* tab_buf = nullptr; size_t tab_buf_bytes = 0;
+	void* blk_buf = nullptr; size_t blk_buf_bytes = 0;
+	DCounters* d_cnt = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	mipt_stats stats{};
+	int64_t opt_pipeline = 0;
+	int64_t opt_paths_per_pass = 1 << 24;
+};
+
+static int fail(mipt_ctx* c, int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	if (c) c->err = buf;
+	return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), MIPT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" int mipt_abi_version(void) { return MIPT_ABI_VERSION; }
+
+extern "C" const char* mipt_last_error(const mipt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
+	if (!out) return MIPT_ERR_INVALID;
+	*out = nullptr;
+	if (n != 1 || !device_ids) return MIPT_ERR_INVALID;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MIPT_ERR_NO_DEVICE;   // no CPU fallback
+	if (device_ids[0] < 0 || device_ids[0] >= count) return MIPT_ERR_NO_DEVICE;
+	mipt_ctx* c = new mipt_ctx;
+	c->device = device_ids[0];
+	if (hipSetDevice(c->device) != hipSuccess) { delete c; return MIPT_ERR_NO_DEVICE; }
+	if (hipMalloc((void**)&c->d_cnt, sizeof(DCounters)) != hipSuccess) { delete c; return MIPT_ERR_HIP; }
+	hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+	*out = c;
+	return MIPT_OK;
+}
+
+static void free_scene(mipt_ctx* c) {
+	for (void* p : c->scene_allocs) hipFree(p);
+	c->scene_allocs.clear();
+	c->d_scene = nullptr;
+	c->has_scene = false;
+}
+
+extern "C" void mipt_destroy(mipt_ctx* c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	free_scene(c);
+	if (c->pass_buf) hipFree(c->pass_buf);
+	if (c->tab_buf) hipFree(c->tab_buf);
+	if (c->blk_buf) hipFree(c->blk_buf);
+	if (c->d_cnt) hipFree(c->d_cnt);
+	if (c->ev0) hipEventDestroy(c->ev0);
+	if (c->ev1) hipEventDestroy(c->ev1);
+	delete c;
+}
+
+extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
+	if (!c || !name) return MIPT_ERR_INVALID;
+	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
+	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
+}
+
+template <typename T>
+static int upload(mipt_ctx* c, const T* host, size_t count, const T** dev) {
+	*dev = nullptr;
+	if (count == 0) return MIPT_OK;
+	void* p = nullptr;
+	HIPCHK(c, hipMalloc(&p, count * sizeof(T)));
+	c->scene_allocs.push_back(p);
+	HIPCHK(c, hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+	*dev = (const T*)p;
+	return MIPT_OK;
+}
+
+static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const DTex** dev) {
+	std::vector<DTex> h(n > 0 ? n : 0);
+	for (int k = 0; k < n; k++) {
+		h[k].mult[0] = list[k].multiplier[0]; h[k].mult[1] = list[k].multiplier[1]; h[k].mult[2] = list[k].multiplier[2];
+		h[k].W = list[k].W; h[k].H = list[k].H; h[k]._pad = 0; h[k].values = nullptr;
+		if (list[k].W > 0) {
+			if (!list[k].values || list[k].H <= 0) return fail(c, MIPT_ERR_INVALID, "texture %d has W>0 but no values", k);
+			int rc = upload(c, list[k].values, (size_t)list[k].W * list[k].H * 3, &h[k].values);
+			if (rc) return rc;
+		}
+	}
+	return upload(c, h.data(), (size_t)n, dev);
+}
+
+// Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
+// CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
+static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d) {
+	if (!m || m->n_triangles <= 0 || m->n_nodes <= 0 || !m->nodes || !m->triangleSoup || !m->indices) return fail(c, MIPT_ERR_INVALID, "incomplete mesh description");
+	const int nn = m->n_nodes, nt = m->n_triangles;
+	if ((unsigned)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
+	std::vector<int> fat_index(nn, -1);
+	int nfat = 0;
+	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) fat_index[i] = nfat++;
+	auto child_ref = [&](int node, uint32_t& ref) -> int {
+		if (node < 0 || node >= nn) return fail(c, MIPT_ERR_INVALID, "BVH child index out of range");
+		const mipt_bvh_node& n = m->nodes[node];
+		if (!n.isleaf) { ref = (uint32_t)fat_index[node]; return MIPT_OK; }
+		int cnt = n.fd - n.fg;
+		if (n.fg < 0 || n.fd > nt || cnt <= 0) return fail(c, MIPT_ERR_INVALID, "BVH leaf range out of bounds");
+		if (cnt > MIPT_LEAF_MAX_TRIS) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles (max %d)", cnt, MIPT_LEAF_MAX_TRIS);
+		ref = MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (uint32_t)n.fg;
+		return MIPT_OK;
+	};
+	std::vector<DFatNode> fat(nfat > 0 ? nfat : 1);
+	memset(fat.data(), 0, fat.size() * sizeof(DFatNode));
+	for (int i = 0; i < nn; i++) {
+		if (m->nodes[i].isleaf) continue;
+		DFatNode& f = fat[fat_index[i]];
+		int l = m->nodes[i].fg, r = m->nodes[i].fd;
+		int rc;
+		if ((rc = child_ref(l, f.lref))) return rc;
+		if ((rc = child_ref(r, f.rref))) return rc;
+		memcpy(f.lmin, m->nodes[l].bbox_min, 12); memcpy(f.lmax, m->nodes[l].bbox_max, 12);
+		memcpy(f.rmin, m->nodes[r].bbox_min, 12); memcpy(f.rmax, m->nodes[r].bbox_max, 12);
+	}
+	int rc;
+	if ((rc = child_ref(0, d.root_ref))) return rc;
+	memcpy(d.root_min, m->bvh_bbox_min, 12); memcpy(d.root_max, m->bvh_bbox_max, 12);
+	std::vector<DTriIsect> ti(nt);
+	std::vector<DTriShade> ts(nt);
+	std::vector<int> uvidx;
+	const bool has_uv = m->n_uvs > 0 && m->uvs;
+	if (has_uv) uvidx.resize((size_t)nt * 3);
+	for (int i = 0; i < nt; i++) {
+		const mipt_triangle& T = m->triangleSoup[i];
+		memcpy(ti[i].A, T.A, 12); memcpy(ti[i].u, T.u, 12); memcpy(ti[i].v, T.v, 12); memcpy(ti[i].N, T.N, 12);
+		ti[i].m11 = T.m11; ti[i].m12 = T.m12; ti[i].m22 = T.m22; ti[i].invdetm = T.invdetm;
+		memcpy(ts[i].normals, T.normals, 36);
+		if (has_uv) memcpy(ts[i].uvs, T.uvs, 24); else memset(ts[i].uvs, 0, 24);
+		ts[i].group = m->indices[i].group;
+		if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
+	}
+	if ((rc = upload(c, fat.data(), fat.size(), &d.nodes))) return rc;
+	if ((rc = upload(c, ti.data(), ti.size(), &d.tris))) return rc;
+	if ((rc = upload(c, ts.data(), ts.size(), &d.shade))) return rc;
+	d.ntri = nt;
+	d.nuvs = has_uv ? m->n_uvs : 0;
+	d.uvs = nullptr; d.uvidx = nullptr; d.tangent_soup = nullptr;
+	if (has_uv) {
+		if ((rc = upload(c, m->uvs, (size_t)m->n_uvs * 3, &d.uvs))) return rc;
+		if ((rc = upload(c, uvidx.data(), uvidx.size(), &d.uvidx))) return rc;
+		if (m->tangentSoup && (rc = upload(c, m->tangentSoup, (size_t)nt * 9, &d.tangent_soup))) return rc;
+	}
+	return MIPT_OK;
+}
+
+extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
+	if (!c || !s || !s->objects) return fail(c, MIPT_ERR_INVALID, "null scene");
+	if (s->n_objects < 2 || s->n_objects > MIPT_MAX_OBJECTS) return fail(c, MIPT_ERR_INVALID, "n_objects must be in [2,%d]", MIPT_MAX_OBJECTS);
+	HIPCHK(c, hipSetDevice(c->device));
+	free_scene(c);
+	std::vector<DScene> hs(1);
+	DScene& H = hs[0];
+	memset(&H, 0, sizeof H);
+	H.nobj = s->n_objects;
+	c->n_mesh_objects = 0;
+	for (int i = 0; i < s->n_objects; i++) {
+		const mipt_object& o = s->objects[i];
+		DObject& d = H.obj[i];
+		if (o.ghost) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d is a ghost object (compositing branch is outside the hot path)", i);
+		if (o.brdf_kind != MIPT_BRDF_PHONG) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: only the Phong BRDF is implemented in this round", i);
+		if (i < 2 && o.type != MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_INVALID, "objects 0 and 1 must be the light and environment spheres");
+		d.type = o.type; d.miroir = o.miroir; d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
+		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
+		d.brdf_kind = o.brdf_kind; d.merl = nullptr;
+		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
+		lists[MT_KD] = o.textures; counts[MT_KD] = o.n_textures;
+		lists[MT_KS] = o.specularmap; counts[MT_KS] = o.n_specularmap;
+		lists[MT_NORMAL] = o.normal_map; counts[MT_NORMAL] = o.n_normal_map;
+		lists[MT_ALPHA] = o.alphamap; counts[MT_ALPHA] = o.n_alphamap;
+		lists[MT_NE] = o.roughnessmap; counts[MT_NE] = o.n_roughnessmap;
+		lists[MT_TRANSP] = o.transparent_map; counts[MT_TRANSP] = o.n_transparent_map;
+		lists[MT_REFR] = o.refr_index_map; counts[MT_REFR] = o.n_refr_index_map;
+		lists[MT_KSUB] = o.subsurface; counts[MT_KSUB] = o.n_subsurface;
+		for (int k = 0; k < o.n_subsurface; k++) {
+			const mipt_texture& t = o.subsurface[k];
+			if (t.W > 0 || t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0)
+				return fail(c, MIPT_ERR_UNSUPPORTED, "object %d has a subsurface material (outside the hot path)", i);
+		}
+		for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) {
+			d.ntex[sl] = counts[sl];
+			if (counts[sl] < 0 || (counts[sl] > 0 && !lists[sl])) return fail(c, MIPT_ERR_INVALID, "object %d: bad texture list %d", i, sl);
+			int rc = upload_tex_list(c, lists[sl], counts[sl], &d.tex[sl]);
+			if (rc) return rc;
+		}
+		if (o.type == MIPT_OBJ_SPHERE) {
+			if (i >= 2) return fail(c, MIPT_ERR_UNSUPPORTED, "spheres other than the light (0) and the environment (1) are outside the hot path");
+			for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) if (counts[sl]) return fail(c, MIPT_ERR_UNSUPPORTED, "textured spheres are outside the hot path");
+			memcpy(d.O, o.O, 12); d.R = o.R; d.R2 = o.R * o.R;
+			d.has_envmap = o.has_envmap; d.envW = o.envW; d.envH = o.envH; d.envtex = nullptr;
+			if (o.has_envmap) {
+				if (!o.envtex || o.envW <= 0 || o.envH <= 0) return fail(c, MIPT_ERR_INVALID, "environment map without pixels");
+				int rc = upload(c, o.envtex, (size_t)o.envW * o.envH * 3, &d.envtex);
+				if (rc) return rc;
+			}
+		} else if (o.type == MIPT_OBJ_PLANE) {
+			memcpy(d.A, o.A, 12); memcpy(d.vecN, o.vecN, 12);
+		} else if (o.type == MIPT_OBJ_TRIMESH) {
+			int rc = convert_mesh(c, o.mesh, d);
+			if (rc) return rc;
+			d.alpha_test = 0;
+			if (d.nuvs > 0 && o.n_alphamap > 0) {
+				for (int k = 0; k < o.n_alphamap; k++) if (o.alphamap[k].W > 0 || o.alphamap[k].multiplier[0] < 0.5f) d.alpha_test = 1;
+			}
+			c->n_mesh_objects++;
+		} else return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: type %d is outside the hot path", i, o.type);
+	}
+	const DScene* dsc = nullptr;
+	int rc = upload(c, hs.data(), 1, &dsc);
+	if (rc) return rc;
+	c->d_scene = const_cast<DScene*>(dsc);
+	c->has_scene = true;
+	return MIPT_OK;
+}
+
+extern "C" int mipt_trace(mipt_ctx* c, const mipt_ray* rays, int n, mipt_hit* hits) {
+	if (!c || !rays || !hits || n < 0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
+	if (n == 0) return MIPT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	mipt_ray* d_r = nullptr; mipt_hit* d_h = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d_r, sizeof(mipt_ray) * (size_t)n));
+	HIPCHK(c, hipMalloc((void**)&d_h, sizeof(mipt_hit) * (size_t)n));
+	HIPCHK(c, hipMemcpy(d_r, rays, sizeof(mipt_ray) * (size_t)n, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_trace, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_r, n, d_h);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpy(hits, d_h, sizeof(mipt_hit) * (size_t)n, hipMemcpyDeviceToHost));
+	hipFree(d_r); hipFree(d_h);
+	return MIPT_OK;
+}
+
+extern "C" int mipt_trace_shadow(mipt_ctx* c, const mipt_ray* rays, const float* dist_light, int n, int32_t* occluded) {
+	if (!c || !rays || !dist_light || !occluded || n < 0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
+	if (n == 0) return MIPT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	mipt_ray* d_r = nullptr; float* d_d = nullptr; int* d_o = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d_r, sizeof(mipt_ray) * (size_t)n));
+	HIPCHK(c, hipMalloc((void**)&d_d, sizeof(float) * (size_t)n));
+	HIPCHK(c, hipMalloc((void**)&d_o, sizeof(int) * (size_t)n));
+	HIPCHK(c, hipMemcpy(d_r, rays, sizeof(mipt_ray) * (size_t)n, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(d_d, dist_light, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_trace_shadow, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_r, d_d, n, d_o);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpy(occluded, d_o, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+	hipFree(d_r); hipFree(d_d); hipFree(d_o);
+	return MIPT_OK;
+}
+
+static int ensure(mipt_ctx* c, void** buf, size_t* have, size_t need) {
+	if (*have >= need) return MIPT_OK;
+	if (*buf) { hipFree(*buf); *buf = nullptr; *have = 0; }
+	HIPCHK(c, hipMalloc(buf, need));
+	*have = need;
+	return MIPT_OK;
+}
+
+// Validates the parameters and uploads the per-render tables; fills the kernel constant block.
+static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender& R, float& denom2, hipStream_t st) {
+	if (!p) return fail(c, MIPT_ERR_INVALID, "null render params");
+	if (p->W <= 0 || p->H <= 0 || p->nrays <= 0 || p->nb_bounces < 0) return fail(c, MIPT_ERR_INVALID, "bad image size / sample count / depth");
+	if (!p->samples2d || !p->randomPerPixel || !p->filter_integral || p->filter_size < 0 || p->filter_size > 8) return fail(c, MIPT_ERR_INVALID, "missing prepare_render tables");
+	if ((double)p->W * p->H > 2.0e9) return fail(c, MIPT_ERR_INVALID, "image too large");
+	memset(&R, 0, sizeof R);
+	R.W = p->W; R.H = p->H; R.nrays = p->nrays; R.nb_bounces = p->nb_bounces;
+	memcpy(R.cam_pos, p->cam_position, 12); memcpy(R.cam_dir, p->cam_direction, 12); memcpy(R.cam_up, p->cam_up, 12);
+	// camera_right = cross(direction, up)  (Vector.h:794)
+	const float* a = p->cam_direction; const float* b = p->cam_up;
+	R.cam_right[0] = a[1] * b[2] - a[2] * b[1]; R.cam_right[1] = a[2] * b[0] - a[0] * b[2]; R.cam_right[2] = a[0] * b[1] - a[1] * b[0];
+	R.cam_k = (float)p->W / (2 * tanf(p->cam_fov / 2));     // Vector.h:793, host libm like the reference
+	R.focus = p->cam_focus_distance; R.aperture = p->cam_aperture; R.init_t = p->double_frustum_start_t;
+	memcpy(R.centerLight, p->centerLight, 12); R.radiusLight = p->radiusLight; R.lightPower = p->lightPower; R.envmap_intensity = p->envmap_intensity;
+	R.sigma_filter = p->sigma_filter; R.filter_size = p->filter_size;
+	R.seed_stride = p->seed_stride ? p->seed_stride : 65536ull;
+	denom2 = (float)(1.f / (2. * (double)p->sigma_filter * (double)p->sigma_filter));   // Raytracer.cpp:1430
+	// tables: compact the reference's Vector[] (stride 3) arrays to stride 2
+	const int ftw = 2 * p->filter_size + 1;
+	size_t n_fi = (size_t)ftw * ftw, n_s2 = (size_t)p->nrays * 2, n_rpp = (size_t)p->W * p->H * 2;
+	std::vector<float> h(n_fi + n_s2 + n_rpp);
+	memcpy(h.data(), p->filter_integral, n_fi * 4);
+	for (int k = 0; k < p->nrays; k++) { h[n_fi + 2 * k] = p->samples2d[3 * (size_t)k]; h[n_fi + 2 * k + 1] = p->samples2d[3 * (size_t)k + 1]; }
+	for (size_t k = 0; k < (size_t)p->W * p->H; k++) { h[n_fi + n_s2 + 2 * k] = p->randomPerPixel[3 * k]; h[n_fi + n_s2 + 2 * k + 1] = p->randomPerPixel[3 * k + 1]; }
+	int rc = ensure(c, &c->tab_buf, &c->tab_buf_bytes, h.size() * 4);
+	if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->tab_buf, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(c, hipStreamSynchronize(st));   // h goes out of scope
+	float* t = (float*)c->tab_buf;
+	R.filter_integral = t; R.samples2d = t + n_fi; R.randomPerPixel = t + n_fi + n_s2;
+	return MIPT_OK;
+}
+
+extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1, float* out_rgb, float* out_dxdy) {
+	if (!c || !pixels_ij || !out_rgb || npix < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	DRender R; float denom2;
+	int rc = make_render_consts(c, p, R, denom2, 0);
+	if (rc) return rc;
+	if (k0 < 0 || k1 > p->nrays) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays)");
+	for (int q = 0; q < npix; q++) if (pixels_ij[2 * q] < 0 || pixels_ij[2 * q] >= p->H || pixels_ij[2 * q + 1] < 0 || pixels_ij[2 * q + 1] >= p->W) return fail(c, MIPT_ERR_INVALID, "pixel outside the image");
+	size_t n = (size_t)npix * (size_t)(k1 - k0);
+	if (n == 0) return MIPT_OK;
+	int* d_ij = nullptr; float* d_rgb = nullptr; float* d_dxdy = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d_ij, sizeof(int) * 2 * (size_t)npix));
+	HIPCHK(c, hipMalloc((void**)&d_rgb, sizeof(float) * 3 * n));
+	HIPCHK(c, hipMalloc((void**)&d_dxdy, sizeof(float) * 2 * n));
+	HIPCHK(c, hipMemcpy(d_ij, pixels_ij, sizeof(int) * 2 * (size_t)npix, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_sample_radiance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c->d_scene, R, d_ij, npix, k0, k1, d_rgb, d_dxdy);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpy(out_rgb, d_rgb, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+	if (out_dxdy) HIPCHK(c, hipMemcpy(out_dxdy, d_dxdy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+	hipFree(d_ij); hipFree(d_rgb); hipFree(d_dxdy);
+	return MIPT_OK;
+}
+
+// Owned 8x8 pixel blocks of this rank: tiles of tile_size x tile_size pixels, tile t -> rank t % nranks.
+static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<int>& blocks, std::vector<int>& pix2slot) {
+	int ts = p->tile_size > 0 ? p->tile_size : 32;
+	int nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
+	int rk = p->tile_rank;
+	if (ts % 8 != 0) return fail(c, MIPT_ERR_INVALID, "tile_size must be a multiple of 8");
+	if (rk < 0 || rk >= nr) return fail(c, MIPT_ERR_INVALID, "tile_rank outside [0,tile_nranks)");
+	const int W = p->W, H = p->H;
+	int ntx = (W + ts - 1) / ts, nty = (H + ts - 1) / ts;
+	blocks.clear();
+	pix2slot.assign((size_t)W * H, -1);
+	for (int ty = 0; ty < nty; ty++) for (int tx = 0; tx < ntx; tx++) {
+		int t = ty * ntx + tx;
+		if (t % nr != rk) continue;
+		for (int bi = ty * ts; bi < std::min(H, (ty + 1) * ts); bi += 8) for (int bj = tx * ts; bj < std::min(W, (tx + 1) * ts); bj += 8) {
+			int blk = (int)(blocks.size() / 2);
+			blocks.push_back(bi); blocks.push_back(bj);
+			for (int in = 0; in < 64; in++) {
+				int i = bi + (in >> 3), j = bj + (in & 7);
+				if (i < H && j < W) pix2slot[(size_t)i * W + j] = blk * 64 + in;
+			}
+		}
+	}
+	return MIPT_OK;
+}
+
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel) {
+	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
+	DRender R; float denom2;
+	int rc = make_render_consts(c, p, R, denom2, st);
+	if (rc) return rc;
+	int kb = p->sample_begin, ke = p->sample_end;
+	if (kb == 0 && ke == 0) ke = p->nrays;
+	if (kb < 0 || ke > p->nrays || kb > ke) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays]");
+	std::vector<int> blocks, pix2slot;
+	if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
+	const int nblocks = (int)(blocks.size() / 2);
+	memset(&c->stats, 0, sizeof c->stats);
+	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DCounters), st));
+	if (nblocks == 0 || kb == ke) return MIPT_OK;
+	size_t blk_bytes = (blocks.size() + pix2slot.size()) * sizeof(int);
+	if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
+	HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size(), pix2slot.data(), pix2slot.size() * sizeof(int), hipMemcpyHostToDevice, st));
+	HIPCHK(c, hipStreamSynchronize(st));
+	const int npix_slots = nblocks * 64;
+	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
+	spp_pass = std::min(spp_pass, ke - kb);
+	size_t pass_paths = (size_t)npix_slots * spp_pass;
+	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, pass_paths * 5 * sizeof(float)))) return rc;
+	DSamples S;
+	S.r = (float*)c->pass_buf; S.g = S.r + pass_paths; S.b = S.g + pass_paths; S.dx = S.b + pass_paths; S.dy = S.dx + pass_paths;
+	DPass P;
+	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + blocks.size(); P.npix_slots = npix_slots;
+	HIPCHK(c, hipEventRecord(c->ev0, st));
+	unsigned passes = 0;
+	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
+		if (cancel && *cancel) { hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled"); }
+		P.k0 = k0; P.k1 = std::min(ke, k0 + spp_pass);
+		long long total = (long long)npix_slots * (P.k1 - P.k0);
+		hipLaunchKernelGGL(k_render_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->d_scene, R, P, S, c->d_cnt);
+		hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+		HIPCHK(c, hipGetLastError());
+		passes++;
+		if (cb) { hipStreamSynchronize(st); cb(cb_user, P.k1 - kb, ke - kb); }
+	}
+	HIPCHK(c, hipEventRecord(c->ev1, st));
+	c->stats.passes = passes;
+	return MIPT_OK;
+}
+
+static int collect_stats(mipt_ctx* c) {
+	DCounters h;
+	HIPCHK(c, hipMemcpy(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost));
+	c->stats.paths = h.paths; c->stats.rays_closest = h.rays_closest; c->stats.rays_shadow = h.rays_shadow;
+	c->stats.mesh_casts_closest = h.rays_closest * (uint64_t)c->n_mesh_objects;
+	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder
+	float ms = 0;
+	if (c->stats.passes && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.render_ms = ms;
+	c->stats.traverse_ms = c->stats.render_ms;
+	c->stats.traverse_launches = c->stats.passes;
+	return MIPT_OK;
+}
+
+extern "C" int mipt_render_device(mipt_ctx* c, const mipt_render_params* p, float* d_accum_rgbw, void* hip_stream) {
+	if (!c || !p || !d_accum_rgbw) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	return render_impl(c, p, d_accum_rgbw, (hipStream_t)hip_stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accum_rgb, float* accum_w, mipt_progress_cb cb, void* cb_user, volatile int* cancel) {
+	if (!c || !p || !accum_rgb || !accum_w) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (p->W <= 0 || p->H <= 0) return fail(c, MIPT_ERR_INVALID, "bad image size");
+	size_t npx = (size_t)p->W * p->H;
+	float* d_acc = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d_acc, npx * 4 * sizeof(float)));
+	// start from the caller's buffers so that the additions continue the caller's running sums
+	hipError_t e = hipMemcpy(d_acc, accum_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d_acc + npx * 3, accum_w, npx * sizeof(float), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { hipFree(d_acc); return fail(c, MIPT_ERR_HIP, "upload of accumulators failed: %s", hipGetErrorString(e)); }
+	int rc = render_impl(c, p, d_acc, 0, cb, cb_user, cancel);
+	hipError_t es = hipDeviceSynchronize();
+	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
+	if (rc == MIPT_OK) {
+		e = hipMemcpy(accum_rgb, d_acc, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(accum_w, d_acc + npx * 3, npx * sizeof(float), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed: %s", hipGetErrorString(e));
+	}
+	hipFree(d_acc);
+	return rc;
+}
+
+extern "C" int mipt_get_stats(mipt_ctx* c, mipt_stats* out) {
+	if (!c || !out) return MIPT_ERR_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipDeviceSynchronize());
+	int rc = collect_stats(c);
+	if (rc) return rc;
+	*out = c->stats;
+	return MIPT_OK;
+}

@@ -1,0 +1,126 @@
+// mipt_math.h — device math for the path-tracing hot path (gfx950).
+//
+// Parity rules: the reference's `Vector` is float but many expressions are
+// evaluated in double (un-suffixed literals, M_PI).  Each helper below
+// spells the evaluation order and the promotion points of the reference expression it cites.
+// The translation unit is compiled with -ffp-contract=off: IEEE + - * / sqrt are correctly
+// rounded on gfx950 exactly as on x86-64 SSE, so those expressions are bit-identical.
+// Transcendentals: sinf/cosf are re-implemented here with the algorithm of the host libm the
+// reference links against, so that direction sampling is bit-identical too; the remaining ones
+// (powf with a non-trivial exponent, acosf/atan2f, double cos/sin/pow) go through the ROCm
+// device library and may differ from glibc in the last ulp (stated tolerance: DESIGN.md §5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MIPT_DEV __device__ __forceinline__
+
+#define MIPT_PI 3.14159265358979323846       /* M_PI (double) */
+#define MIPT_TWO_PI_TRUNC 6.28318530718      /* Vector.h:16-18 M_TWO_PI */
+
+struct f3 { float x, y, z; };
+
+MIPT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MIPT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }            // Vector.h:491
+MIPT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }            // Vector.h:495
+MIPT_DEV f3 operator*(float a, f3 b) { return mk3(a * b.x, a * b.y, a * b.z); }               // Vector.h:499
+MIPT_DEV f3 operator*(f3 b, float a) { return mk3(a * b.x, a * b.y, a * b.z); }               // Vector.h:503 (a*b[k])
+MIPT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }            // Vector.h:519
+MIPT_DEV f3 operator/(f3 a, float b) { return mk3(a.x / b, a.y / b, a.z / b); }               // Vector.h:507
+MIPT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }                                 // Vector.h:515
+MIPT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                  // Vector.h:545
+MIPT_DEV float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }                      // Vector.h:366
+MIPT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // Vector.h:562
+MIPT_DEV float sqr(float x) { return x * x; }
+
+// Vector.h:294-309 invSqRoot: Quake rsqrt + 2 Newton steps with the 32-bit integer semantics of
+// the reference's native LLP64 toolchain (see oracle/Makefile fix 4).
+MIPT_DEV float inv_sq_root(float n) {
+	int i = __float_as_int(n);
+	i = 0x5f3759df - (i >> 1);
+	float y = __int_as_float(i);
+	y = y * (1.5F - ((n * 0.5F) * y * y));
+	y = y * (1.5F - ((n * 0.5F) * y * y));
+	return y;
+}
+MIPT_DEV f3 normalize(f3 a) { float n = sqrtf(norm2(a)); return mk3(a.x / n, a.y / n, a.z / n); }        // Vector.h:369
+MIPT_DEV f3 fast_normalize(f3 a) { float inv = inv_sq_root(norm2(a)); return mk3(a.x * inv, a.y * inv, a.z * inv); }  // Vector.h:376
+MIPT_DEV f3 reflect(f3 d, f3 N) { return d - (2.f * dot(d, N)) * N; }                                            // Vector.h:388
+
+// ---------------------------------------------------------------- pcg32 (pcg_random.hpp)
+// setseq_xsh_rr_64_32, default increment, seed ctor state = (seed+inc)*mult+inc, output on the
+// previous state (pcg_random.hpp:157-158, 484-486, 1663, 1866).
+#define MIPT_PCG_MULT 6364136223846793005ULL
+#define MIPT_PCG_INC 1442695040888963407ULL
+MIPT_DEV uint64_t pcg_seed(uint64_t seed) { return (seed + MIPT_PCG_INC) * MIPT_PCG_MULT + MIPT_PCG_INC; }
+MIPT_DEV uint32_t pcg_next(uint64_t& state) {
+	uint64_t old = state;
+	state = old * MIPT_PCG_MULT + MIPT_PCG_INC;
+	uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+	uint32_t rot = (uint32_t)(old >> 59u);
+	return (xs >> rot) | (xs << ((0u - rot) & 31u));
+}
+// engine()*invmax, invmax = 1.f/engine.max() = 2^-32 (Raytracer.h:28); may return exactly 1.0f
+MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.3283064365386963e-10f; }
+
+// ---------------------------------------------------------------- sinf / cosf
+// Bit-exact with the host libm the reference links (glibc 2.35 s_sinf.c / s_cosf.c, the
+// "optimized routines" double-precision polynomial scheme) for |x| < 120; verified exhaustively
+// against libm on [0, 6.5] (tests/test_device_math_host.py), the only range the path uses
+// (arguments are 2*pi*u, u in [0,1]).  Computed in fp64: quadrant reduction n = round(x*2/pi),
+// then a degree-7 sine or degree-8 cosine polynomial in the reduced argument.
+MIPT_DEV float sincos_poly(double x, double x2, int n, bool neg) {
+	// neg selects the table with negated cosine coefficients (n & 2)
+	if ((n & 1) == 0) {
+		const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+		double x3 = x * x2;
+		double t1 = s2 + x2 * s3;
+		double x7 = x3 * x2;
+		double s = x + x3 * s1;
+		return (float)(s + x7 * t1);
+	} else {
+		double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+		if (neg) { c0 = -c0; c1 = -c1; c2 = -c2; c3 = -c3; c4 = -c4; }
+		double x4 = x2 * x2;
+		double t2 = c3 + x2 * c4;
+		double t1 = c0 + x2 * c1;
+		double x6 = x4 * x2;
+		double c = t1 + x4 * c2;
+		return (float)(c + x6 * t2);
+	}
+}
+MIPT_DEV uint32_t abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ff; }
+template <bool COS>
+MIPT_DEV float sincosf_glibc(float y) {
+	double x = (double)y;
+	if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {          // |y| < pi/4
+		double x2 = x * x;
+		if (abstop12(y) < abstop12(0x1p-12f)) return COS ? 1.0f : y;
+		return sincos_poly(x, x2, COS ? 1 : 0, false);
+	}
+	// |y| < 120: fast reduction (hpi_inv is 2/pi * 2^24, quadrant in bits 24..31)
+	double r = x * 0x1.45F306DC9C883p+23;
+	int n = ((int)r + 0x800000) >> 24;
+	x = x - (double)n * 0x1.921FB54442D18p0;
+	double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign table {1,-1,-1,1}
+	return sincos_poly(x * s, x * x, COS ? (n ^ 1) : n, (n & 2) != 0);
+}
+MIPT_DEV float pt_sinf(float y) { return sincosf_glibc<false>(y); }
+MIPT_DEV float pt_cosf(float y) { return sincosf_glibc<true>(y); }
+
+// powf: exact for the cases the default materials produce (Ne = 0 -> 1, pow(1,y) = 1);
+// otherwise the device library's powf (<= 1 ulp from glibc's).
+MIPT_DEV float pt_powf(float x, float y) {
+	if (y == 0.f) return 1.f;
+	if (x == 1.f) return 1.f;
+	return powf(x, y);
+}
+
+// Raytracer.cpp:1294-1299 fast_exp (Schraudolph, on a double)
+MIPT_DEV double fast_exp(double y) {
+	int hi = (int)(1512775 * y + 1072632447);
+	return __hiloint2double(hi, 0);
+}
+
+// Texture::wrap (BRDF.h:270-275)
+MIPT_DEV float tex_wrap(float u) { u -= (float)(int)u; if (u < 0) u += 1; return u; }

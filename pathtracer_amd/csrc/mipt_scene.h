@@ -1,0 +1,96 @@
+// mipt_scene.h — HBM-resident scene layout shared by the host uploader and the kernels.
+//
+// Layout choices:
+//  * BVH: the reference's 36-byte nodes (isleaf, fg, fd, own box) are re-packed at upload into
+//    64-byte "fat" nodes that hold BOTH children's boxes and references, because the reference's
+//    traversal tests both children of every node it pops (TriangleMesh.cpp:1172-1178): one
+//    aligned 64-byte fetch per popped node instead of one 36-byte node + two more for the boxes.
+//  * Triangles: 64-byte intersection record (A,u,v,N,m11,m12,m22,invdetm = the 16 floats
+//    Triangle::intersection reads, TriangleMesh.h:82-107), separate from the 64-byte shading
+//    record (corner normals, UVs, group) that is only fetched once per path vertex.
+#pragma once
+#include <stdint.h>
+
+#define MIPT_MAX_OBJECTS 16
+#define MIPT_TEX_SLOTS 8
+// slot ids = the reference's Texture type codes (BRDF.h:256-264) + 7 for the subsurface list
+enum { MT_KD = 0, MT_KS = 1, MT_NORMAL = 2, MT_ALPHA = 3, MT_NE = 4, MT_TRANSP = 5, MT_REFR = 6, MT_KSUB = 7 };
+
+// Child reference of a fat node / traversal stack entry:
+//   ref >= 0           : inner node, index into DMesh::nodes (units of 64 B)
+//   ref <  0 (bit 31)  : leaf, bits 0..25 = first triangle, bits 26..30 = (count-1)
+#define MIPT_LEAF_BIT 0x80000000u
+#define MIPT_LEAF_MAX_TRIS 32
+#define MIPT_LEAF_FIRST_MASK 0x03ffffffu
+
+struct DTex {              // Texture (BRDF.h:252-426)
+	float mult[3];
+	int W, H;
+	int _pad;
+	const float* values;
+};
+
+struct DFatNode {          // 64 B, 64-B aligned
+	float lmin[3], lmax[3];
+	float rmin[3], rmax[3];
+	uint32_t lref, rref;
+	uint32_t _pad[2];
+};
+
+struct DTriIsect { float A[3], u[3], v[3], N[3]; float m11, m12, m22, invdetm; };   // 64 B
+struct DTriShade { float normals[9]; float uvs[6]; int group; };                    // 64 B
+
+struct DObject {
+	int type, miroir, flip_normals, interp_normals;
+	float inv[12], trans[12], rot[9];
+	int brdf_kind;
+	const double* merl;
+	int ntex[MIPT_TEX_SLOTS];
+	const DTex* tex[MIPT_TEX_SLOTS];
+	// Sphere
+	float O[3], R, R2;
+	int has_envmap, envW, envH;
+	const uint8_t* envtex;
+	// Plane
+	float A[3], vecN[3];
+	// TriMesh
+	const DFatNode* nodes;
+	const DTriIsect* tris;
+	const DTriShade* shade;
+	float root_min[3], root_max[3];
+	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
+	int ntri, nuvs;
+	int alpha_test;            // an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
+	const float* uvs;          // Vector[nuvs]
+	const int* uvidx;          // 3 ints per triangle (uvi,uvj,uvk), only when alpha_test
+	const float* tangent_soup; // Vector[3*ntri] or null
+};
+
+struct DScene {
+	int nobj;
+	int _pad[3];
+	DObject obj[MIPT_MAX_OBJECTS];
+};
+
+// Per-render constants (kernel argument, by value).
+struct DRender {
+	int W, H, nrays, nb_bounces;
+	float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
+	float cam_k;               // W / (2*tan(fov/2)) (Vector.h:793), evaluated on the host
+	float focus, aperture, init_t;
+	float centerLight[3], radiusLight, lightPower, envmap_intensity;
+	float sigma_filter; int filter_size;
+	const float* filter_integral;
+	const float* samples2d;      // nrays * 2
+	const float* randomPerPixel; // W*H * 2
+	uint64_t seed_stride;
+};
+
+// One render pass: samples [k0,k1) of every owned 8x8 pixel block.
+struct DPass {
+	int k0, k1;
+	int nblocks;               // owned 8x8 blocks
+	const int* blocks;         // (i0, j0) per block
+	const int* pix2slot;       // W*H: slot of the pixel inside this rank's block list, -1 if not owned
+	int npix_slots;            // nblocks * 64
+};

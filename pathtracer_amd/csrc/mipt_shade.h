@@ -1,0 +1,200 @@
+// mipt_shade.h — device-side camera, samplers, Phong BRDF and the vertex logic of
+// Raytracer::getColor (Raytracer.cpp:196-664, in-scope branches: light, environment sphere,
+// mirror, Fresnel dielectric, diffuse/glossy with next-event estimation).
+#pragma once
+#include "mipt_trace.h"
+
+// ---------------------------------------------------------------- Camera::generateDirection (Vector.h:792-825)
+MIPT_DEV Ray camera_ray(const DRender& R, int i, int j, float dx_sensor, float dy_sensor, float dx_aperture, float dy_aperture) {
+	f3 pos = ld3(R.cam_pos), dir = ld3(R.cam_dir), up = ld3(R.cam_up), right = ld3(R.cam_right);
+	// Vector(j - W/2 + 0.5 + dx, i - H/2 + 0.5 + dy, k): integer W/2, double sum, narrowed
+	f3 dv = mk3((float)((double)(j - R.W / 2) + 0.5 + (double)dx_sensor), (float)((double)(i - R.H / 2) + 0.5 + (double)dy_sensor), R.cam_k);
+	dv = normalize(dv);
+	dv = right * dv.x + up * dv.y + dir * dv.z;
+	f3 destination = pos + (R.focus / fabsf(dot(dv, dir))) * dv;
+	f3 new_origin = pos + dx_aperture * right + dy_aperture * up;
+	f3 new_direction = normalize(destination - new_origin);
+	Ray r;
+	r.o = new_origin + (R.init_t * new_direction) / dot(new_direction, dir);
+	r.d = new_direction;
+	return r;
+}
+
+// ---------------------------------------------------------------- samplers (Vector.h:567-600)
+MIPT_DEV f3 tangent_of(f3 N) {            // getTangent
+	float ax = fabsf(N.x), ay = fabsf(N.y), az = fabsf(N.z);
+	f3 t;
+	if (ax <= ay && ax <= az) t = mk3(0, -N.z, N.y);
+	else if (ay <= ax && ay <= az) t = mk3(-N.z, 0, N.x);
+	else t = mk3(-N.y, N.x, 0);
+	return normalize(t);
+}
+MIPT_DEV f3 random_cos(f3 N, float r1, float r2) {
+	float sr2 = sqrtf(1.f - r2);
+	const float twopi = (float)(2. * MIPT_PI);
+	f3 loc = mk3(pt_cosf(twopi * r1) * sr2, pt_sinf(twopi * r1) * sr2, sqrtf(r2));
+	f3 t1 = tangent_of(N);
+	f3 t2 = cross(t1, N);
+	return loc.z * N + loc.x * t1 + loc.y * t2;
+}
+
+// ---------------------------------------------------------------- PhongBRDF (BRDF.h:41-96)
+MIPT_DEV f3 random_phong(f3 R, float phong_exponent, float r1, float r2) {
+	float facteur = sqrtf(1 - pt_powf(r2, 2.f / (phong_exponent + 1.f)));
+	double ang = 2 * MIPT_PI * (double)r1;
+	f3 loc = mk3((float)(cos(ang) * (double)facteur), (float)(sin(ang) * (double)facteur), (float)pow((double)r2, 1. / (double)(phong_exponent + 1)));
+	f3 t1 = tangent_of(R);
+	f3 t2 = cross(t1, R);
+	return loc.z * R + loc.x * t1 + loc.y * t2;
+}
+MIPT_DEV f3 phong_sample(const Mat& mat, f3 wo, f3 N, float& pdf, float r1, float r2, uint64_t& rng) {
+	float avgNe = (mat.Ne.x + mat.Ne.y + mat.Ne.z) / 3.f;
+	float p = 1 - (mat.Ks.x + mat.Ks.y + mat.Ks.z) / 3.f;
+	f3 R = reflect(-wo, N);
+	f3 dir;
+	if ((float)pcg_next(rng) / 4294967296.f < p) dir = random_cos(N, r1, r2);   // engine()/(float)engine.max()
+	else dir = random_phong(R, avgNe, r1, r2);
+	float proba_phong = (float)((double)(avgNe + 1) / (2.f * MIPT_PI) * (double)pt_powf(dot(R, dir), avgNe));
+	float proba_globale = (float)((double)(p * dot(N, dir)) / (MIPT_PI) + (double)((1.f - p) * proba_phong));
+	pdf = proba_globale;
+	return dir;
+}
+MIPT_DEV f3 phong_eval(const Mat& mat, f3 wi, f3 wo, f3 N) {
+	f3 reflechi = reflect(-wo, N);
+	float d = dot(reflechi, wi);
+	f3 diffuse = mat.Kd / (float)MIPT_PI;
+	if (d < 0) return diffuse;
+	f3 lobe = mk3((float)((double)(pt_powf(d, mat.Ne.x) * (mat.Ne.x + 2.f)) / MIPT_TWO_PI_TRUNC),
+	              (float)((double)(pt_powf(d, mat.Ne.y) * (mat.Ne.y + 2.f)) / MIPT_TWO_PI_TRUNC),
+	              (float)((double)(pt_powf(d, mat.Ne.z) * (mat.Ne.z + 2.f)) / MIPT_TWO_PI_TRUNC));
+	return diffuse + lobe * mat.Ks;
+}
+
+// ---------------------------------------------------------------- path state
+struct PathState {
+	Ray ray;
+	f3 weight;
+	f3 color;
+	uint64_t rng;
+	int depth;          // nbrebonds
+	bool show_lights;
+};
+
+// Camera part of one (pixel, sample): seeding rule + the four draws of Raytracer.cpp:1462-1466.
+MIPT_DEV void path_begin(const DRender& R, int i, int j, int k, PathState& ps, float& dx, float& dy) {
+	uint64_t p = (uint64_t)i * (uint64_t)R.W + (uint64_t)j;
+	ps.rng = pcg_seed(p * R.seed_stride + (uint64_t)k);
+	dx = pcg_uniform(ps.rng) - 0.5f;
+	dy = pcg_uniform(ps.rng) - 0.5f;
+	float dx_ap = (pcg_uniform(ps.rng) - 0.5f) * R.aperture;
+	float dy_ap = (pcg_uniform(ps.rng) - 0.5f) * R.aperture;
+	ps.ray = camera_ray(R, i, j, dx, dy, dx_ap, dy_ap);
+	ps.weight = mk3(1.f, 1.f, 1.f);
+	ps.color = mk3(0, 0, 0);
+	ps.depth = R.nb_bounces;
+	ps.show_lights = true;
+}
+
+// What a vertex asks the scheduler to do next.
+struct ShadowRequest {
+	bool diffuse;       // the vertex took the diffuse/glossy branch: color += weight*contrib is due
+	bool cast;          // a shadow ray must be traced (otherwise the sample is "shadowed": contrib = 0)
+	Ray ray;
+	float dist;         // dist_light argument of Scene::intersection_shadow
+	f3 contrib;         // currentContrib if the light sample is visible
+};
+
+// One vertex of getColor AFTER the closest-hit query: adds emission, prepares the next-event
+// estimation (shadow request), samples the continuation ray and updates weight/depth.
+// Returns true while the path continues.  `weight_at_vertex` is the weight the direct term must
+// be multiplied with once the shadow query is resolved (color += pathWeight*currentContrib).
+MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathState& ps, bool has_inter, const Hit& h, f3 P, const Mat& mat,
+                          int pix, int sampleID, ShadowRequest& sh, f3& weight_at_vertex) {
+	sh.diffuse = false;
+	sh.cast = false;
+	sh.contrib = mk3(0, 0, 0);
+	weight_at_vertex = ps.weight;
+	if (!has_inter) return false;                                        // :654-657
+	f3 N = mat.shadingN;
+	f3 rayDirection = ps.ray.d;
+	if (h.obj == 1) {                                                    // :275-301 environment sphere
+		ps.color = ps.color + (ps.weight * R.envmap_intensity) * mat.Ke;
+		return false;
+	}
+	if (h.obj == 0) {                                                    // :303-316 light sphere
+		f3 cc = ps.show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f);
+		ps.color = ps.color + ps.weight * cc;
+		return false;
+	}
+	const DObject& obj = sc->obj[h.obj];
+	ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
+	if (obj.miroir) {                                                    // :413-436
+		ps.ray.o = P + 0.001f * N;
+		ps.ray.d = reflect(rayDirection, N);
+		ps.depth--;
+		return true;
+	}
+	if (mat.transp) {                                                    // :438-489
+		float n1 = 1.f, n2 = mat.refr_index;
+		f3 nt = N;
+		bool entering = true;
+		if (dot(rayDirection, N) > 0) { n1 = mat.refr_index; n2 = 1; nt = -N; entering = false; }
+		float radical = 1.f - sqr(n1 / n2) * (1.f - sqr(dot(nt, rayDirection)));
+		Ray nr;
+		if (radical > 0) {
+			f3 refr = (n1 / n2) * (rayDirection - dot(rayDirection, nt) * nt) - nt * sqrtf(radical);
+			float R0 = sqr((n1 - n2) / (n1 + n2));
+			float Rf;
+			if (entering) Rf = R0 + (1 - R0) * pt_powf(1.f + dot(rayDirection, N), 5.f);
+			else Rf = R0 + (1 - R0) * pt_powf(1.f - dot(refr, N), 5.f);
+			if (pcg_uniform(ps.rng) < Rf) { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
+			else { nr.o = P - 0.001f * nt; nr.d = refr; }
+		} else {
+			nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N);
+		}
+		ps.ray = nr;
+		ps.depth--;
+		return true;
+	}
+	// diffuse / glossy: next-event estimation on the sphere light (:494-566)
+	sh.diffuse = true;
+	f3 cl = ld3(R.centerLight);
+	f3 axeOP = fast_normalize(P - cl);
+	float l1 = pcg_uniform(ps.rng);
+	float l2 = pcg_uniform(ps.rng);
+	f3 dir_l = random_cos(axeOP, l1, l2);
+	f3 pt_l = dir_l * R.radiusLight + cl;
+	f3 wi = fast_normalize(pt_l - P);
+	float d_light2 = norm2(pt_l - P);
+	if (!(dot(mat.shadingN, wi) < 0)) {
+		f3 brdf = phong_eval(mat, wi, -rayDirection, N);
+		float J = dot(dir_l, -wi) / d_light2;
+		float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+		if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+		sh.cast = true;
+		sh.ray.o = P + 0.01f * wi;
+		sh.ray.d = wi;
+		sh.dist = sqrtf(d_light2) - 0.01f;
+	}
+	// indirect (:570-632): the same Cranley-Patterson-rotated lattice point at every depth
+	float ip;
+	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
+	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
+	float pdf;
+	f3 dir = phong_sample(mat, -rayDirection, N, pdf, r1, r2, ps.rng);
+	if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) return false;   // :593
+	f3 brdf_i = phong_eval(mat, dir, -rayDirection, N);
+	ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);            // :611
+	ps.ray.o = P + 0.01f * dir;
+	ps.ray.d = dir;
+	ps.show_lights = false;
+	ps.depth--;
+	return true;
+}
+
+// Termination tests at the top of the loop (Raytracer.cpp:240-241)
+MIPT_DEV bool path_alive(const PathState& ps) {
+	if (ps.depth == 0) return false;
+	if (norm2(ps.weight) < sqr(0.01f)) return false;
+	return true;
+}

@@ -1,0 +1,383 @@
+// mipt_trace.h — device-side scene intersection: AABB slab tests, triangle test, ordered BVH
+// traversal (closest hit and any hit), sphere / plane primitives, material lookup.
+//
+// The traversal reproduces the reference's visiting ORDER (near child first, ties: right child
+// first; TriangleMesh.cpp:1180-1187) and its pruning rules exactly, because the closest hit keeps
+// the FIRST triangle that reaches the minimum t (strict <, TriangleMesh.cpp:1197): a different
+// order could pick a different coplanar / shared-edge triangle (SURVEY.md §7 "hard parts").
+#pragma once
+#include "mipt_math.h"
+#include "mipt_scene.h"
+
+struct Ray { f3 o, d; };
+
+struct Mat {                       // MaterialValues (BRDF.h:7-20)
+	f3 shadingN, Kd, Ks, Ne, Ke;
+	bool transp;
+	float refr_index;
+};
+
+// Closest-hit record carried through Scene::intersection; the material is evaluated once, for
+// the winning object (see scene_intersect).
+struct Hit {
+	int obj;        // -1 = miss
+	int tri;
+	float t;
+	float beta, gamma;
+};
+
+MIPT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- object transforms (Geometry.h:362-396)
+MIPT_DEV f3 xf_point(const float* m, f3 v) {
+	return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3], m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7], m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11]);
+}
+MIPT_DEV f3 xf_dir(const float* m, f3 v) {
+	return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+MIPT_DEV f3 xf_rot(const float* r, f3 v) {
+	return mk3(r[0] * v.x + r[1] * v.y + r[2] * v.z, r[3] * v.x + r[4] * v.y + r[5] * v.z, r[6] * v.x + r[7] * v.y + r[8] * v.z);
+}
+
+// ---------------------------------------------------------------- AABB slab tests
+// One routine for the reference's three variants.  XSPLIT = true gives
+// intersection_invd_positive_x / _negative_x (Geometry.h:144-204: the x slab is rejected on the
+// sign of the un-scaled difference), used by the closest-hit traversal; XSPLIT = false gives the
+// generic intersection_invd (Geometry.h:114-142), used for the root box and by the shadow
+// traversal.  sx/sy/sz = signs[k] = (1/d[k] >= 0).  The statement order of the reference is kept
+// (NaN / inf behaviour of each comparison is part of the result).
+template <bool XSPLIT>
+MIPT_DEV bool box_test(f3 bmin, f3 bmax, f3 o, f3 invd, bool sx, bool sy, bool sz, float& t_out) {
+	bool rej;
+	float t_max, t;
+	float farx = sx ? bmax.x : bmin.x, nearx = sx ? bmin.x : bmax.x;
+	if (XSPLIT) {
+		t_max = farx - o.x;
+		rej = sx ? (t_max < 0) : (t_max > 0);
+		t_max *= invd.x;
+	} else {
+		t_max = (farx - o.x) * invd.x;
+		rej = (t_max < 0);
+	}
+	t = (nearx - o.x) * invd.x;
+	float t_max_y = ((sy ? bmax.y : bmin.y) - o.y) * invd.y;
+	rej |= (t_max_y < 0);
+	float t_min_y = ((sy ? bmin.y : bmax.y) - o.y) * invd.y;
+	rej |= (t_min_y > t_max) | (t_max_y < t);
+	if (t_min_y > t) t = t_min_y;
+	if (t_max_y < t_max) t_max = t_max_y;
+	float t_max_z = ((sz ? bmax.z : bmin.z) - o.z) * invd.z;
+	rej |= (t_max_z < 0);
+	float t_min_z = ((sz ? bmin.z : bmax.z) - o.z) * invd.z;
+	rej |= (t > t_max_z) | (t_min_z > t_max);
+	if (t_min_z > t) t = t_min_z;
+	if (t < 0) t = 0;
+	t_out = t;
+	return !rej;
+}
+
+// ---------------------------------------------------------------- Triangle::intersection (TriangleMesh.h:82-104)
+MIPT_DEV bool tri_test(const DTriIsect* __restrict__ T, f3 o, f3 d, float& t, float& beta, float& gamma) {
+	const float4* q = reinterpret_cast<const float4*>(T);
+	float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	f3 A = mk3(q0.x, q0.y, q0.z), u = mk3(q0.w, q1.x, q1.y), v = mk3(q1.z, q1.w, q2.x), N = mk3(q2.y, q2.z, q2.w);
+	float m11 = q3.x, m12 = q3.y, m22 = q3.z, invdetm = q3.w;
+	t = dot(A - o, N) / dot(d, N);
+	if (t < 0 || t != t) return false;
+	f3 P = o + t * d;
+	f3 w = P - A;
+	float b11 = dot(w, u);
+	float b21 = dot(w, v);
+	float detb = b11 * m22 - b21 * m12;
+	beta = detb * invdetm;
+	if (beta < 0) return false;
+	float detg = b21 * m11 - b11 * m12;
+	gamma = detg * invdetm;
+	if (gamma < 0) return false;
+	float alpha = 1 - beta - gamma;
+	if (alpha < 0) return false;
+	return true;
+}
+
+// ---------------------------------------------------------------- textures / queryMaterial
+MIPT_DEV int tex_index(const DTex& t, float u, float v) {     // BRDF.h:296-298
+	int x = (int)(u * (float)(uint64_t)(t.W - 1));
+	int y = (int)(v * (float)(uint64_t)(t.H - 1));
+	return (y * t.W + x) * 3;
+}
+MIPT_DEV f3 tex_getVec(const DTex& t, float u, float v) {     // BRDF.h:293-308
+	if (t.W > 0) { int idx = tex_index(t, u, v); return mk3(t.values[idx] * t.mult[0], t.values[idx + 1] * t.mult[1], t.values[idx + 2] * t.mult[2]); }
+	return mk3(t.mult[0], t.mult[1], t.mult[2]);
+}
+MIPT_DEV float tex_getValRed(const DTex& t, float u, float v) {   // BRDF.h:379-391
+	if (t.W > 0) { int idx = tex_index(t, u, v); return t.values[idx] * t.mult[0]; }
+	return t.mult[0];
+}
+MIPT_DEV f3 tex_getNormal(const DTex& t, float u, float v) {  // BRDF.h:347-357
+	if (t.W > 0) { int idx = tex_index(t, u, v); return mk3(t.values[idx], t.values[idx + 1], t.values[idx + 2]); }
+	return mk3(0.f, 0.f, 1.f);
+}
+// Object::queryMaterial (Geometry.h:399-445).  idx is compared as size_t in the reference, so a
+// negative group selects the defaults.
+MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& mat) {
+	u = tex_wrap(u);
+	v = tex_wrap(v);
+	unsigned ui = (unsigned)idx;
+	mat.Kd = (ui >= (unsigned)o.ntex[MT_KD]) ? mk3(1, 1, 1) : tex_getVec(o.tex[MT_KD][idx], u, v);
+	mat.Ks = (ui >= (unsigned)o.ntex[MT_KS]) ? mk3(0, 0, 0) : tex_getVec(o.tex[MT_KS][idx], u, v);
+	mat.Ne = (ui >= (unsigned)o.ntex[MT_NE]) ? mk3(1, 1, 1) : tex_getVec(o.tex[MT_NE][idx], u, v);
+	mat.transp = (ui >= (unsigned)o.ntex[MT_TRANSP]) ? false : (tex_getValRed(o.tex[MT_TRANSP][idx], u, v) < 0.5f);   // getBool, BRDF.h:335-346
+	mat.refr_index = (ui >= (unsigned)o.ntex[MT_REFR]) ? 1.3f : tex_getValRed(o.tex[MT_REFR][idx], u, v);
+	mat.Ke = mk3(0, 0, 0);
+	// Ksub is only read by the subsurface branch (out of scope); upload rejects non-zero Ksub.
+}
+
+// alpha-map test of the leaf loop (TriangleMesh.cpp:1198-1205 / 1300-1307)
+MIPT_DEV bool alpha_rejects(const DObject& o, int i, float alpha, float beta, float gamma) {
+	int group = o.shade[i].group;
+	const int* ix = o.uvidx + 3 * (size_t)i;
+	if ((unsigned)o.ntex[MT_ALPHA] > (unsigned)group && ix[0] >= 0 && ix[1] >= 0 && ix[2] >= 0) {
+		const float* a = o.uvs + 3 * (size_t)ix[0];
+		const float* b = o.uvs + 3 * (size_t)ix[1];
+		const float* c = o.uvs + 3 * (size_t)ix[2];
+		float u = a[0] * alpha + b[0] * beta + c[0] * gamma;
+		float v = a[1] * alpha + b[1] * beta + c[1] * gamma;
+		u = tex_wrap(u);
+		v = tex_wrap(v);
+		if ((double)tex_getValRed(o.tex[MT_ALPHA][group], u, v) < 0.5) return true;
+	}
+	return false;
+}
+
+// ---------------------------------------------------------------- BVH traversal
+// Per-lane traversal stack.  The reference pushes (node, tnear) pairs (TriangleMesh.cpp:1153-1190);
+// we continue directly into the near child instead of pushing and re-popping it (equivalent: t
+// does not change between its push and its pop), so only far children are stored.
+#define MIPT_STACK_DEPTH 48
+struct TravStack {
+	uint32_t ref[MIPT_STACK_DEPTH];
+	float tnear[MIPT_STACK_DEPTH];
+};
+
+struct TravCounters { uint32_t box, node, tri; };
+
+// TriMesh::intersection (TriangleMesh.cpp:1133-1214; SHADOW=false) and
+// TriMesh::intersection_shadow (:1239-1319; SHADOW=true) on the ray (o,d) given in the object's
+// local frame.  Closest: returns whether a triangle with t < cur_best_t exists, and t / triangle /
+// barycentrics of the first one reaching the minimum.  Shadow: returns the reference's
+// has_inter, with t of the last accepted triangle (the caller compares it with 0.999*dist).
+template <bool SHADOW>
+MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, float dist_light,
+                            float& t_out, int& tri_out, float& beta_out, float& gamma_out) {
+	float t = cur_best_t;
+	bool has_inter = false;
+	f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);      // 1./d narrowed to float == 1.f/d
+	bool sx = invd.x >= 0, sy = invd.y >= 0, sz = invd.z >= 0;
+	float t_root;
+	if (!box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, sx, sy, sz, t_root)) return false;
+	if (t_root > cur_best_t) return false;
+	if (SHADOW && t_root > dist_light) return false;
+
+	TravStack stk;
+	int sp = 0;
+	uint32_t cur = o.root_ref;
+	bool have = true;
+	const float4* __restrict__ nodes = reinterpret_cast<const float4*>(o.nodes);
+
+	for (;;) {
+		if (!have) {
+			if (sp == 0) break;
+			--sp;
+			cur = stk.ref[sp];
+			if (stk.tnear[sp] > t) continue;                 // :1160-1163
+		}
+		have = false;
+		if (!(cur & MIPT_LEAF_BIT)) {
+			const float4* q = nodes + 4 * (size_t)cur;
+			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+			f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
+			f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
+			uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+			float tl, tr;
+			bool goleft, goright;
+			if (SHADOW) {
+				goleft = box_test<false>(lmin, lmax, org, invd, sx, sy, sz, tl) && (tl < t) && (tl < dist_light);
+				goright = box_test<false>(rmin, rmax, org, invd, sx, sy, sz, tr) && (tr < t) && (tr < dist_light);
+			} else {
+				goleft = box_test<true>(lmin, lmax, org, invd, sx, sy, sz, tl) && (tl < t);
+				goright = box_test<true>(rmin, rmax, org, invd, sx, sy, sz, tr) && (tr < t);
+			}
+			if (goleft && goright) {
+				if (tl < tr) { stk.ref[sp] = rref; stk.tnear[sp] = tr; sp++; cur = lref; }
+				else { stk.ref[sp] = lref; stk.tnear[sp] = tl; sp++; cur = rref; }
+				have = true;
+			} else if (goleft) { cur = lref; have = true; }
+			else if (goright) { cur = rref; have = true; }
+		} else {
+			int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
+			int count = (int)((cur >> 26) & 31u) + 1;
+			for (int i = first; i < first + count; i++) {
+				float lt, lb, lg;
+				if (tri_test(o.tris + i, org, d, lt, lb, lg)) {
+					if (lt < t) {
+						if (o.alpha_test && alpha_rejects(o, i, 1 - lb - lg, lb, lg)) continue;
+						has_inter = true;
+						t = lt; tri_out = i; beta_out = lb; gamma_out = lg;
+						if (SHADOW && ((double)t < (double)dist_light * 0.999)) { t_out = t; return true; }   // :1309
+					}
+				}
+			}
+		}
+	}
+	t_out = t;
+	return has_inter;
+}
+
+// ---------------------------------------------------------------- Sphere / Plane (Geometry.h:918-992, 1071-1094, 1142-1157, 1185-1191)
+MIPT_DEV bool sphere_test(const DObject& s, f3 o, f3 d, float& t) {
+	f3 oc = o - ld3(s.O);
+	float b = dot(d, oc);
+	float a = norm2(d);
+	float c = norm2(oc) - s.R2;
+	float delta = b * b - a * c;
+	if (delta < 0) return false;
+	float sqDelta = sqrtf(delta);
+	float inva = 1.f / a;
+	float t2 = (-b + sqDelta) * inva;
+	if (t2 < 0) return false;
+	float t1 = (-b - sqDelta) * inva;
+	t = (t1 > 0) ? t1 : t2;
+	return true;
+}
+MIPT_DEV bool plane_test(const DObject& p, f3 o, f3 d, float& t) {
+	f3 N = ld3(p.vecN);
+	float ddot = dot(d, N);
+	if ((double)fabsf(ddot) < 1E-9) return false;
+	t = dot(ld3(p.A) - o, N) / ddot;
+	if (t <= 0.f) return false;
+	return true;
+}
+
+// ---------------------------------------------------------------- TriMesh::getMaterial (TriangleMesh.cpp:919-970)
+MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, float gamma, Mat& mat) {
+	const float4* q = reinterpret_cast<const float4*>(o.shade + tri);
+	float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
+	float uv00 = q2.y, uv01 = q2.z, uv10 = q2.w, uv11 = q3.x, uv20 = q3.y, uv21 = q3.z;
+	int group = __float_as_int(q3.w);
+	float u = 0, v = 0;
+	bool has_uv = false;
+	if (o.nuvs != 0 && group >= 0 && o.uvidx != nullptr && o.uvidx[3 * (size_t)tri] >= 0 && (unsigned)o.uvidx[3 * (size_t)tri] < (unsigned)o.nuvs) {
+		u = (uv00 * alpha + uv10 * beta + uv20 * gamma);
+		v = (uv01 * alpha + uv11 * beta + uv21 * gamma);
+		has_uv = true;
+	}
+	query_material(o, group, u, v, mat);
+	f3 N;
+	if (!o.interp_normals) {
+		const DTriIsect& T = o.tris[tri];
+		N = ld3(T.N);
+	} else {
+		N = n0 * alpha + n1 * beta + n2 * gamma;
+	}
+	N = normalize(N);
+	if (o.ntex[MT_NORMAL] != 0 && has_uv && (unsigned)group < (unsigned)o.ntex[MT_NORMAL] && o.tangent_soup != nullptr) {
+		const float* ts = o.tangent_soup + 9 * (size_t)tri;
+		f3 tangent = ld3(ts) * alpha + ld3(ts + 3) * beta + ld3(ts + 6) * gamma;
+		tangent = normalize(tangent);
+		f3 bitangent = cross(N, tangent);
+		f3 NsLocal = tex_getNormal(o.tex[MT_NORMAL][group], u, v);
+		f3 Ns = NsLocal.x * tangent + NsLocal.y * bitangent + NsLocal.z * N;
+		if (Ns.x == 0.f && Ns.y == 0.f && Ns.z == 0.f) Ns = N;
+		N = normalize(Ns);
+	}
+	if (o.flip_normals) N = -N;
+	mat.shadingN = N;
+}
+
+// Sphere material (Geometry.h:948-991)
+MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
+	f3 N = Plocal - ld3(s.O);
+	// MaterialValues() defaults for the fields a texture-less sphere never writes (BRDF.h:9-16)
+	mat.Kd = mk3(0.5f, 0.5f, 0.5f); mat.Ks = mk3(0, 0, 0); mat.Ne = mk3(100, 100, 100); mat.transp = false; mat.refr_index = 0.f;
+	if (s.has_envmap) {
+		N = fast_normalize(N);
+		float theta = 1.f - acosf(N.y) / (float)MIPT_PI;
+		float phi = (float)(((double)atan2f(-N.z, N.x) + MIPT_PI) / (double)(2.f * (float)MIPT_PI));
+		query_material(s, 0, theta, phi, mat);
+		mat.shadingN = -N;
+		int idx = 3 * ((int)(theta * ((float)s.envH - 1.f)) * s.envW + (int)(phi * ((float)s.envW - 1.f)));
+		if (idx < 0 || idx >= 3 * s.envW * s.envH) mat.Ke = mk3(0, 0, 0);
+		else mat.Ke = mk3((float)s.envtex[idx], (float)s.envtex[idx + 1], (float)s.envtex[idx + 2]) * (100000.f / 255.f);
+		return;
+	}
+	mat.shadingN = s.flip_normals ? -N : N;
+	mat.Ke = mk3(0, 0, 0);
+}
+
+// ---------------------------------------------------------------- Scene::intersection (Geometry.cpp:589-688)
+// Returns the closest hit over all objects (strict <, objects in index order) and, for a hit,
+// the world-space point and the MaterialValues.  The reference fills a scratch `localmat` while
+// it loops and copies it on every improvement; here the winner's material is evaluated once
+// after the loop from (object, t, triangle, barycentrics), which yields the same values for every
+// field its intersection() routine writes.
+MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat) {
+	h.obj = -1; h.tri = -1;
+	float min_t = __int_as_float(0x7f800000);          // min_t = 1E99 narrowed: +inf
+	h.beta = 0; h.gamma = 0;
+	const int nobj = sc->nobj;
+	for (int i = 0; i < nobj; i++) {
+		const DObject& o = sc->obj[i];
+		f3 d = xf_dir(o.inv, r.d);
+		f3 org = xf_point(o.inv, r.o);
+		float t; int tri = -1; float b = 0, g = 0;
+		bool hit;
+		if (o.type == 1) hit = sphere_test(o, org, d, t);
+		else if (o.type == 2) hit = plane_test(o, org, d, t);
+		else hit = mesh_traverse<false>(o, org, d, min_t, 0.f, t, tri, b, g);
+		if (hit && t < min_t) { min_t = t; h.obj = i; h.tri = tri; h.beta = b; h.gamma = g; }
+	}
+	h.t = min_t;
+	if (h.obj < 0) return false;
+	const DObject& o = sc->obj[h.obj];
+	f3 d = xf_dir(o.inv, r.d);
+	f3 org = xf_point(o.inv, r.o);
+	f3 Pl = org + min_t * d;                             // P = d.origin + t*d.direction in the object's frame
+	if (o.type == 1) sphere_material(o, Pl, mat);
+	else if (o.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
+	else {
+		float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
+		// NaN / Inf clean-up of the winner's barycentrics (TriangleMesh.cpp:1219-1226)
+		if (isnan(alpha) && isnan(beta) && isnan(gamma)) { alpha = 1; beta = 0; gamma = 0; }
+		if (isnan(alpha)) alpha = 0;
+		if (isnan(beta)) beta = 0;
+		if (isnan(gamma)) gamma = 0;
+		if (isinf(alpha)) alpha = 1;
+		if (isinf(beta)) beta = 1;
+		if (isinf(gamma)) gamma = 1;
+		mesh_material(o, h.tri, alpha, beta, gamma, mat);
+	}
+	P = xf_point(o.trans, Pl);
+	mat.shadingN = fast_normalize(xf_rot(o.rot, mat.shadingN));
+	return true;
+}
+
+// ---------------------------------------------------------------- Scene::intersection_shadow (Geometry.cpp:691-744)
+MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_light) {
+	const int nobj = sc->nobj;
+	const float inf = __int_as_float(0x7f800000);
+	bool occluded = false;
+	for (int i = 0; i < nobj; i++) {
+		if (occluded) break;
+		const DObject& o = sc->obj[i];
+		f3 d = xf_dir(o.inv, r.d);
+		f3 org = xf_point(o.inv, r.o);
+		float t; int tri; float b, g;
+		bool hit;
+		if (o.type == 1) hit = sphere_test(o, org, d, t);
+		else if (o.type == 2) hit = plane_test(o, org, d, t);
+		else hit = mesh_traverse<true>(o, org, d, inf, dist_light, t, tri, b, g);
+		if (hit && ((double)t < (double)dist_light * 0.999)) occluded = true;
+	}
+	return occluded;
+}

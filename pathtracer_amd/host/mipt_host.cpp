@@ -1,0 +1,582 @@
+// mipt_host.cpp — see mipt_host.h.  Host-side restatement of the parts of the reference that stay
+// on the CPU (file:line citations are into the reference checkout).  Compile with
+// -ffp-contract=off: several results (BVH splits, matrices, tables) must match the reference's
+// float arithmetic exactly because the device path consumes them.
+#include "mipt_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace mipt_host {
+
+// ---------------------------------------------------------------- small vector helpers (Vector.h)
+static inline Vector add(const Vector& a, const Vector& b) { return Vector(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+static inline Vector sub(const Vector& a, const Vector& b) { return Vector(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+static inline Vector mul(float a, const Vector& b) { return Vector(a * b[0], a * b[1], a * b[2]); }
+static inline Vector divs(const Vector& a, float b) { return Vector(a[0] / b, a[1] / b, a[2] / b); }
+static inline float dot(const Vector& a, const Vector& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline float norm2(const Vector& a) { return a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; }
+static inline Vector cross(const Vector& a, const Vector& b) { return Vector(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]); }
+static inline Vector normalized(const Vector& a) { float n = std::sqrt(norm2(a)); return Vector(a[0] / n, a[1] / n, a[2] / n); }
+
+// ---------------------------------------------------------------- Texture
+void Texture::loadColorsRGB8(const unsigned char* rgb, int w, int h) {
+	W = (size_t)w; H = (size_t)h;
+	values.resize(W * H * 3);
+	for (int i = 0; i < h; i++)
+		for (int j = 0; j < w; j++)
+			for (int k = 0; k < 3; k++) {
+				float v = rgb[((size_t)(h - 1 - i) * w + j) * 3 + k];   // load_image flips the rows (utils.cpp:112-118)
+				v /= 255.f;
+				v = std::pow(v, 2.2f);                                    // BRDF.h:399-400
+				values[((size_t)i * w + j) * 3 + k] = v;
+			}
+}
+
+// ---------------------------------------------------------------- Object
+Object::Object() {
+	for (int i = 0; i < 9; i++) mat_rotation[i] = (i % 4 == 0) ? 1.f : 0.f;   // Matrix() is the identity (Vector.h:88-94)
+	memset(trans_matrix, 0, sizeof trans_matrix); memset(inv_trans_matrix, 0, sizeof inv_trans_matrix); memset(rot_matrix, 0, sizeof rot_matrix);
+}
+
+void Object::build_matrix() {   // Geometry.h:322-360
+	const float* m = mat_rotation;
+	float mt[9];
+	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) mt[j * 3 + i] = m[i * 3 + j];
+	const float s = scale;
+	const Vector tr = max_translation;
+	for (int i = 0; i < 3; i++) {
+		Vector v2(m[0 * 3 + i], m[1 * 3 + i], m[2 * 3 + i]);
+		trans_matrix[0 * 4 + i] = v2[0] * s; trans_matrix[1 * 4 + i] = v2[1] * s; trans_matrix[2 * 4 + i] = v2[2] * s;
+		rot_matrix[0 * 3 + i] = v2[0]; rot_matrix[1 * 3 + i] = v2[1]; rot_matrix[2 * 3 + i] = v2[2];
+		v2 = Vector(mt[0 * 3 + i], mt[1 * 3 + i], mt[2 * 3 + i]);
+		inv_trans_matrix[0 * 4 + i] = v2[0] / s; inv_trans_matrix[1 * 4 + i] = v2[1] / s; inv_trans_matrix[2 * 4 + i] = v2[2] / s;
+	}
+	auto matvec = [](const float* M, const Vector& b) {   // Matrix<3,3>*Vector (Vector.h:438-450)
+		Vector r;
+		for (int i = 0; i < 3; i++) { float v = 0; for (int j = 0; j < 3; j++) v += M[i * 3 + j] * b[j]; r[i] = v; }
+		return r;
+	};
+	Vector nrc(-rotation_center[0], -rotation_center[1], -rotation_center[2]);
+	Vector v2 = matvec(m, nrc);
+	for (int k = 0; k < 3; k++) trans_matrix[k * 4 + 3] = v2[k] * s + rotation_center[k] + tr[k];
+	v2 = matvec(mt, sub(nrc, tr));
+	for (int k = 0; k < 3; k++) inv_trans_matrix[k * 4 + 3] = v2[k] / s + rotation_center[k];
+}
+
+Vector Object::apply_transformation(const Vector& v) const {   // Geometry.h:362-368
+	const float* t = trans_matrix;
+	return Vector(t[0] * v[0] + t[1] * v[1] + t[2] * v[2] + t[3], t[4] * v[0] + t[5] * v[1] + t[6] * v[2] + t[7], t[8] * v[0] + t[9] * v[1] + t[10] * v[2] + t[11]);
+}
+
+Sphere::Sphere(const Vector& origin, float rayon) {   // Sphere::init (Geometry.h:856-873)
+	type = OT_SPHERE; O = origin; R = rayon; rotation_center = origin; name = "Sphere";
+}
+void Sphere::load_envmap_rgb8(const unsigned char* rgb, int w, int h) {
+	envtex.resize((size_t)w * h * 3);
+	for (int i = 0; i < h; i++) memcpy(&envtex[(size_t)i * w * 3], rgb + (size_t)(h - 1 - i) * w * 3, (size_t)w * 3);
+	envW = w; envH = h; has_envmap = true; flip_normals = true;
+}
+Plane::Plane(const Vector& A_, const Vector& N) { type = OT_PLANE; A = A_; vecN = N; name = "Plane"; }
+
+// ---------------------------------------------------------------- TriMesh
+TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt, const float* uv,
+                 int nf, const int* fv, const int* fn, const int* ft, bool center) {
+	type = OT_TRIMESH; interp_normals = true; name = "mesh";
+	vertices.resize(nv); normals.resize(nn); uvs.resize(nt);
+	for (int i = 0; i < nv; i++) vertices[i] = Vector(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+	for (int i = 0; i < nn; i++) normals[i] = Vector(norms[3 * i], norms[3 * i + 1], norms[3 * i + 2]);
+	for (int i = 0; i < nt; i++) uvs[i] = Vector(uv[2 * i], uv[2 * i + 1], 0);
+	indices.resize(nf);
+	for (int i = 0; i < nf; i++) {
+		mipt_triangle_indices& t = indices[i];
+		memset(&t, 0, sizeof t);
+		t.vtxi = fv[3 * i]; t.vtxj = fv[3 * i + 1]; t.vtxk = fv[3 * i + 2];
+		t.ni = fn ? fn[3 * i] : -1; t.nj = fn ? fn[3 * i + 1] : -1; t.nk = fn ? fn[3 * i + 2] : -1;
+		t.uvi = ft ? ft[3 * i] : -1; t.uvj = ft ? ft[3 * i + 1] : -1; t.uvk = ft ? ft[3 * i + 2] : -1;
+		t.group = 0;   // no usemtl: every face in group 0, "Default" (TriangleMesh.cpp:462-467)
+		t.showEdges[0] = t.showEdges[1] = t.showEdges[2] = 1;
+	}
+	// readOBJ's per-group default material lists (TriangleMesh.cpp:470-480)
+	add_col_texture(Vector(0.5f, 0.5f, 0.5f)); add_col_specular(Vector(0, 0, 0)); add_col_roughness(Vector(0, 0, 0));
+	add_null_normalmap(); add_col_alpha(1.f); add_col_refr(1.3f); add_col_transp(1.f); add_col_subsurface(Vector(0, 0, 0));
+	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
+	for (auto& v : vertices) { std::swap(v[0], v[2]); v[0] = -v[0]; }
+	for (auto& v : normals) { std::swap(v[0], v[2]); v[0] = -v[0]; }
+	float bmin[3] = {1E9f, 1E9f, 1E9f}, bmax[3] = {-1E9f, -1E9f, -1E9f};
+	for (const auto& v : vertices) for (int k = 0; k < 3; k++) { bmin[k] = std::min(bmin[k], v[k]); bmax[k] = std::max(bmax[k], v[k]); }
+	if (center) {   // :760-770 with scaling = 1, offset = 0
+		float s = std::max(bmax[0] - bmin[0], std::max(bmax[1] - bmin[1], bmax[2] - bmin[2]));
+		float c[3] = {(bmin[0] + bmax[0]) * 0.5f, (bmin[1] + bmax[1]) * 0.5f, (bmin[2] + bmax[2]) * 0.5f};
+		for (auto& v : vertices) for (int k = 0; k < 3; k++) v[k] = (v[k] - c[k]) / s * 1.f + 0.f;
+	}
+	permuted_triangle_index.resize(nf);
+	for (int i = 0; i < nf; i++) permuted_triangle_index[i] = i;
+	// build_bvh (:878-885)
+	build_bbox(0, nf, bvh.bbox);
+	bvh.nodes.reserve((size_t)nf * 2);
+	build_bvh_recur(0, 0, nf, 0);
+	build_bbox(0, nf, bbox);
+	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
+	triangleSoup.resize(nf);
+	for (int i = 0; i < nf; i++) {
+		mipt_triangle& T = triangleSoup[i];
+		memset(&T, 0, sizeof T);
+		const Vector &A = vertices[indices[i].vtxi], &B = vertices[indices[i].vtxj], &C = vertices[indices[i].vtxk];
+		Vector u = sub(B, A), v = sub(C, A), N = cross(u, v);
+		for (int k = 0; k < 3; k++) { T.A[k] = A[k]; T.u[k] = u[k]; T.v[k] = v[k]; T.N[k] = N[k]; }
+		T.m11 = norm2(u); T.m22 = norm2(v); T.m12 = dot(u, v);
+		T.invdetm = 1.f / (T.m11 * T.m22 - T.m12 * T.m12);   // 1./x narrowed == 1.f/x
+		if (nn != 0) {
+			const int nidx[3] = {indices[i].ni, indices[i].nj, indices[i].nk};
+			for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) T.normals[k][l] = normals[nidx[k]][l];
+		}
+		if (nt != 0) {
+			const int tidx[3] = {indices[i].uvi, indices[i].uvj, indices[i].uvk};
+			for (int k = 0; k < 3; k++) { T.uvs[k][0] = uvs[tidx[k]][0]; T.uvs[k][1] = uvs[tidx[k]][1]; }
+		}
+	}
+	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
+	if (nt != 0) setup_tangents();
+}
+
+void TriMesh::build_bbox(int i0, int i1, float* o) const {   // :843-858
+	const Vector& f = vertices[indices[i0].vtxi];
+	for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[k]; }
+	for (int i = i0; i < i1; i++) {
+		const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
+		for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) { o[k] = std::min(o[k], vertices[vi[c]][k]); o[3 + k] = std::max(o[3 + k], vertices[vi[c]][k]); }
+	}
+}
+void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
+	auto center = [&](int i) { return divs(add(add(vertices[indices[i].vtxi], vertices[indices[i].vtxj]), vertices[indices[i].vtxk]), 3.f); };
+	Vector c0 = center(i0);
+	for (int k = 0; k < 3; k++) { o[k] = c0[k]; o[3 + k] = c0[k]; }
+	for (int i = i0; i < i1; i++) {
+		Vector c = center(i);
+		for (int k = 0; k < 3; k++) { o[k] = std::min(o[k], c[k]); o[3 + k] = std::max(o[3 + k], c[k]); }
+	}
+}
+
+// build_bvh_recur (TriangleMesh.cpp:1029-1130): longest centroid axis, 16 candidate planes,
+// cost area_L*n_L + area_R*n_R, in-place partition, <= 4 triangles per leaf, nodes in preorder.
+void TriMesh::build_bvh_recur(int node, int i0, int i1, int depth) {
+	BVHNodes n;
+	build_bbox(i0, i1, n.bbox);
+	n.fg = i0; n.fd = i1; n.isleaf = true;
+	bvh.nodes.push_back(n);
+	float cb[6];
+	build_centers_bbox(i0, i1, cb);
+	const float diag[3] = {cb[3] - cb[0], cb[4] - cb[1], cb[5] - cb[2]};
+	int split_dim;
+	if (diag[0] >= diag[1] && diag[0] >= diag[2]) split_dim = 0;
+	else if (diag[1] >= diag[0] && diag[1] >= diag[2]) split_dim = 1;
+	else split_dim = 2;
+	auto centroid = [&](int i) {   // (a+b+c)/3. narrowed == /3.f
+		return (vertices[indices[i].vtxi][split_dim] + vertices[indices[i].vtxj][split_dim] + vertices[indices[i].vtxk][split_dim]) / 3.f;
+	};
+	auto area = [](const float* mn, const float* mx) { float s0 = mx[0] - mn[0], s1 = mx[1] - mn[1], s2 = mx[2] - mn[2]; return 2 * (s0 * s1 + s0 * s2 + s1 * s2); };
+	float best_split_factor = 0.5f;
+	float best_area_bb = std::numeric_limits<float>::infinity();   // 1E50 narrowed
+	const int max_tests = 16;
+	for (int test_split = 0; test_split < max_tests; test_split++) {
+		float cur_split_factor = (test_split + 1) / (float)(max_tests + 1);
+		float split_val = cb[split_dim] + diag[split_dim] * cur_split_factor;
+		float lmin[3] = {1E10f, 1E10f, 1E10f}, lmax[3] = {-1E10f, -1E10f, -1E10f}, rmin[3] = {1E10f, 1E10f, 1E10f}, rmax[3] = {-1E10f, -1E10f, -1E10f};
+		int nl = 0, nr = 0;
+		for (int i = i0; i < i1; i++) {
+			const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
+			if (centroid(i) <= split_val) {
+				for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { lmin[k] = std::min(lmin[k], vertices[vi[c]][k]); lmax[k] = std::max(lmax[k], vertices[vi[c]][k]); }
+				nl++;
+			} else {
+				for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { rmin[k] = std::min(rmin[k], vertices[vi[c]][k]); rmax[k] = std::max(rmax[k], vertices[vi[c]][k]); }
+				nr++;
+			}
+		}
+		float sum_area_bb = area(lmin, lmax) * nl + area(rmin, rmax) * nr;
+		if (sum_area_bb < best_area_bb) { best_split_factor = cur_split_factor; best_area_bb = sum_area_bb; }
+	}
+	float split_val = cb[split_dim] + diag[split_dim] * best_split_factor;
+	int pivot = i0 - 1;
+	for (int i = i0; i < i1; i++) {
+		if (centroid(i) <= split_val) {
+			pivot++;
+			std::swap(indices[i], indices[pivot]);
+			std::swap(permuted_triangle_index[i], permuted_triangle_index[pivot]);
+		}
+	}
+	if (pivot < i0 || pivot >= i1 - 1 || i1 <= i0 + 4) return;
+	bvh.nodes[node].isleaf = false;
+	bvh.nodes[node].fg = (int)bvh.nodes.size();
+	build_bvh_recur(bvh.nodes[node].fg, i0, pivot + 1, depth + 1);
+	bvh.nodes[node].fd = (int)bvh.nodes.size();
+	build_bvh_recur(bvh.nodes[node].fd, pivot + 1, i1, depth + 1);
+}
+
+// setup_tangents (TriangleMesh.cpp:601-711): only tangentSoup is read by the path (normal maps).
+void TriMesh::setup_tangents() {
+	const int nv = (int)vertices.size(), nf = (int)indices.size();
+	std::vector<Vector> tan1(nv), tan2(nv);
+	for (int i = 0; i < nf; i++) {
+		const auto& t = indices[i];
+		if (t.uvi == -1 || t.uvj == -1 || t.uvk == -1) continue;
+		Vector vA = sub(vertices[t.vtxj], vertices[t.vtxi]), vB = sub(vertices[t.vtxk], vertices[t.vtxi]);
+		Vector sA = sub(uvs[t.uvj], uvs[t.uvi]), sB = sub(uvs[t.uvk], uvs[t.uvi]);
+		float det = (sA[0] * sB[1] - sB[0] * sA[1]);
+		Vector sdir, tdir;
+		if (det != 0) { sdir = divs(sub(mul(sB[1], vA), mul(sA[1], vB)), det); tdir = divs(sub(mul(sA[0], vB), mul(sB[0], vA)), det); }
+		else { sdir = mul(0.00001f, vA); tdir = mul(0.00001f, vB); }
+		for (int a : {t.vtxi, t.vtxj, t.vtxk}) { tan1[a] = add(tan1[a], sdir); tan2[a] = add(tan2[a], tdir); }
+	}
+	std::vector<int> v2n(nv, 0);
+	for (int i = 0; i < nf; i++) { v2n[indices[i].vtxi] = indices[i].ni; v2n[indices[i].vtxj] = indices[i].nj; v2n[indices[i].vtxk] = indices[i].nk; }
+	std::vector<Vector> tangents(nv);
+	for (int i = 0; i < nv; i++) {
+		Vector N = normalized(normals[v2n[i]]);
+		tangents[i] = normalized(sub(tan1[i], mul(dot(tan1[i], N), N)));
+	}
+	tangentSoup.resize((size_t)nf * 3);
+	for (int i = 0; i < nf; i++) { tangentSoup[3 * i] = tangents[indices[i].vtxi]; tangentSoup[3 * i + 1] = tangents[indices[i].vtxj]; tangentSoup[3 * i + 2] = tangents[indices[i].vtxk]; }
+}
+
+// ---------------------------------------------------------------- Scene
+Scene::~Scene() { for (Object* o : objects) delete o; }
+void Scene::prepare_render() { for (Object* o : objects) o->build_matrix(); }
+
+bool Scene::intersection(const mipt_ray& d, Vector& P, int& sphere_id, float& min_t, mipt_hit& mat, int& triangle_id) const {
+	mipt_hit h;
+	if (!owner || !owner->ctx || mipt_trace(owner->ctx, &d, 1, &h) != MIPT_OK) { memset(&mat, 0, sizeof mat); min_t = std::numeric_limits<float>::infinity(); return false; }
+	mat = h; min_t = h.t;
+	if (h.has_inter) { P = Vector(h.P[0], h.P[1], h.P[2]); sphere_id = h.object_id; triangle_id = h.triangle_id; }
+	return h.has_inter != 0;
+}
+bool Scene::intersection_shadow(const mipt_ray& d, float& min_t, float dist_light) const {
+	int32_t occ = 0;
+	min_t = std::numeric_limits<float>::infinity();
+	if (!owner || !owner->ctx || mipt_trace_shadow(owner->ctx, &d, &dist_light, 1, &occ) != MIPT_OK) return false;
+	return occ != 0;
+}
+
+// ---------------------------------------------------------------- Raytracer
+static double fast_exp(double y) {   // Raytracer.cpp:1294-1299
+	double d; int32_t w[2]; w[0] = 0; w[1] = (int32_t)(1512775 * y + 1072632447); memcpy(&d, w, 8); return d;
+}
+static uint32_t ReverseBits(uint32_t n) {   // Raytracer.cpp:1302-1309
+	n = (n << 16) | (n >> 16);
+	n = ((n & 0x00ff00ff) << 8) | ((n & 0xff00ff00) >> 8);
+	n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
+	n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2);
+	n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1);
+	return n;
+}
+static Vector extensibleLattice2d(uint32_t id) {   // Raytracer.cpp:1311-1319
+	uint32_t rid = ReverseBits(id);
+	float phi_id = (float)(rid * std::pow(2.0, -32));
+	float tmp;
+	float x = std::modf((float)(phi_id * 1 + 0.456789123), &tmp);
+	float y = std::modf((float)(phi_id * 182667 + 0.123456789), &tmp);
+	return Vector(x, y, 0);
+}
+// pcg32 (pcg_random.hpp: setseq_xsh_rr_64_32, default increment)
+struct pcg32 {
+	uint64_t state;
+	explicit pcg32(uint64_t seed) { const uint64_t inc = 1442695040888963407ULL, mult = 6364136223846793005ULL; state = (seed + inc) * mult + inc; }
+	uint32_t operator()() {
+		uint64_t old = state;
+		state = old * 6364136223846793005ULL + 1442695040888963407ULL;
+		uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+		return (xs >> rot) | (xs << ((0u - rot) & 31u));
+	}
+};
+
+Raytracer::Raytracer() { s.owner = this; }
+Raytracer::~Raytracer() { if (ctx) mipt_destroy(ctx); }
+
+void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
+	W = 1000; H = 800; nrays = 100;
+	cam = Camera();
+	cam.fov = (float)(35 * M_PI / 180);
+	cam.focus_distance = 50; cam.aperture = 0.1f;
+	sigma_filter = 0.5f; nb_bounces = 3;
+	Sphere* slum = new Sphere(Vector(10, 23, 15), 10);
+	Sphere* s2 = new Sphere(Vector(0, 0, 0), 1000000); s2->flip_normals = true;
+	Plane* plane = new Plane(Vector(0, 0, 0), Vector(0.f, 1.f, 0.f));
+	plane->max_translation = Vector(0.f, -27.3f, 0.f);
+	s.addObject(slum); s.addObject(s2); s.addObject(plane);
+	s.lumiere = slum;
+	s.intensite_lumiere = (float)(1000000000 * 4. * M_PI / (4. * M_PI * s.lumiere->R * s.lumiere->R * M_PI));
+	s.envmap_intensity = 1;
+	// cam.rotate(0, -22 deg, 1) (Vector.h:725-750): cosf/sinf of float(-22*pi/180)
+	float ay = (float)(-22 * M_PI / 180);
+	float c = std::cos(ay), sn = std::sin(ay);
+	Vector d = cam.direction, u = cam.up;
+	cam.direction = Vector(d[0], c * d[1] - sn * d[2], sn * d[1] + c * d[2]);
+	cam.up = Vector(u[0], c * u[1] - sn * u[2], sn * u[1] + c * u[2]);
+}
+
+void Raytracer::clear_image() {
+	image.assign((size_t)W * H * 3, 0);
+	imagedouble.assign((size_t)W * H * 3, 0.f);
+	sample_count.assign((size_t)W * H, 0.f);
+}
+
+int Raytracer::open_device(int device_id) {
+	if (ctx) { mipt_destroy(ctx); ctx = nullptr; }
+	last_status = mipt_create(&device_id, 1, &ctx);
+	if (last_status != MIPT_OK) err_ = "mipt_create failed (no usable HIP device: this library has no CPU path)";
+	return last_status;
+}
+const char* Raytracer::last_error() const { return (ctx && last_status != MIPT_OK && err_.empty()) ? mipt_last_error(ctx) : err_.c_str(); }
+
+void Raytracer::prepare_render(float) {   // Raytracer.cpp:1321-1391
+	pcg32 engine0(0);                       // engine[0] = pcg32(0) (:1325-1327)
+	const float invmax = 1.f / 4294967296.f;   // Raytracer.h:28
+	if (randomPerPixel.size() != (size_t)W * H) {
+		randomPerPixel.resize((size_t)W * H);
+		for (size_t i = 0; i < (size_t)W * H; i++) { randomPerPixel[i][0] = engine0() * invmax; randomPerPixel[i][1] = engine0() * invmax; }
+	}
+	if (image.size() != (size_t)W * H * 3) clear_image();
+	if (nrays != last_nrays) {
+		samples2d.resize(nrays);
+		for (int i = 0; i < nrays; i++) samples2d[i] = extensibleLattice2d((uint32_t)i);
+		last_nrays = nrays;
+	}
+	if (sigma_filter != lastfilter) {       // :1354-1374
+		filter_size = (int)std::ceil(sigma_filter * 2);
+		filter_total_width = 2 * filter_size + 1;
+		filter_integral.assign((size_t)filter_total_width * filter_total_width, 0.f);
+		filter_value.assign((size_t)filter_total_width * filter_total_width, 0.f);
+		for (int i = -filter_size; i <= filter_size; i++) for (int j = -filter_size; j <= filter_size; j++) {
+			float integ = 0;
+			for (int i2 = -filter_size; i2 <= i; i2++) for (int j2 = -filter_size; j2 <= j; j2++) {
+				float w = (float)(fast_exp(-(i2 * i2 + j2 * j2) / (2. * sigma_filter * sigma_filter)) / (sigma_filter * sigma_filter * 2. * M_PI));
+				integ += w;
+			}
+			filter_integral[(i + filter_size) * filter_total_width + (j + filter_size)] = integ;
+			filter_value[(i + filter_size) * filter_total_width + (j + filter_size)] = (float)(std::exp(-(i * i + j * j) / (2. * sigma_filter * sigma_filter)) / (sigma_filter * sigma_filter * 2. * M_PI));
+		}
+		lastfilter = sigma_filter;
+	}
+	s.prepare_render();
+	centerLight = s.lumiere->apply_transformation(s.lumiere->O);   // :1377-1380
+	lum_scale = s.lumiere->scale;
+	radiusLight = lum_scale * s.lumiere->R;
+	lightPower = s.intensite_lumiere / (lum_scale * lum_scale);
+	std::fill(sample_count.begin(), sample_count.end(), 0.f);
+	std::fill(imagedouble.begin(), imagedouble.end(), 0.f);
+	build_descs();
+}
+
+static void tex_list(const std::vector<Texture>& in, std::vector<mipt_texture>& out) {
+	out.resize(in.size());
+	for (size_t k = 0; k < in.size(); k++) {
+		for (int c = 0; c < 3; c++) out[k].multiplier[c] = in[k].multiplier[c];
+		out[k].W = (int32_t)in[k].W; out[k].H = (int32_t)in[k].H;
+		out[k].values = in[k].W > 0 ? in[k].values.data() : nullptr;
+	}
+}
+
+// The reference-side binding of INTEGRATION.md: fill the POD descriptions from the live objects.
+void Raytracer::build_descs() {
+	const size_t n = s.objects.size();
+	desc_objects_.assign(n, mipt_object{});
+	desc_meshes_.assign(n, mipt_mesh{});
+	desc_tex_.assign(n * 8, {});
+	for (size_t i = 0; i < n; i++) {
+		Object* o = s.objects[i];
+		mipt_object& d = desc_objects_[i];
+		d.type = o->type; d.miroir = o->miroir; d.ghost = o->ghost; d.flip_normals = o->flip_normals; d.interp_normals = o->interp_normals;
+		memcpy(d.trans_matrix, o->trans_matrix, 48); memcpy(d.inv_trans_matrix, o->inv_trans_matrix, 48); memcpy(d.rot_matrix, o->rot_matrix, 36);
+		d.brdf_kind = MIPT_BRDF_PHONG; d.merl_data = nullptr;
+		const std::vector<Texture>* lists[8] = {&o->textures, &o->specularmap, &o->alphamap, &o->roughnessmap, &o->normal_map, &o->subsurface, &o->transparent_map, &o->refr_index_map};
+		for (int l = 0; l < 8; l++) tex_list(*lists[l], desc_tex_[i * 8 + l]);
+		auto ptr = [&](int l) { return desc_tex_[i * 8 + l].empty() ? nullptr : desc_tex_[i * 8 + l].data(); };
+		d.n_textures = (int)o->textures.size(); d.textures = ptr(0);
+		d.n_specularmap = (int)o->specularmap.size(); d.specularmap = ptr(1);
+		d.n_alphamap = (int)o->alphamap.size(); d.alphamap = ptr(2);
+		d.n_roughnessmap = (int)o->roughnessmap.size(); d.roughnessmap = ptr(3);
+		d.n_normal_map = (int)o->normal_map.size(); d.normal_map = ptr(4);
+		d.n_subsurface = (int)o->subsurface.size(); d.subsurface = ptr(5);
+		d.n_transparent_map = (int)o->transparent_map.size(); d.transparent_map = ptr(6);
+		d.n_refr_index_map = (int)o->refr_index_map.size(); d.refr_index_map = ptr(7);
+		if (o->type == OT_SPHERE) {
+			Sphere* sp = static_cast<Sphere*>(o);
+			for (int k = 0; k < 3; k++) d.O[k] = sp->O[k];
+			d.R = sp->R; d.has_envmap = sp->has_envmap; d.envW = sp->envW; d.envH = sp->envH; d.envtex = sp->has_envmap ? sp->envtex.data() : nullptr;
+		} else if (o->type == OT_PLANE) {
+			Plane* pl = static_cast<Plane*>(o);
+			for (int k = 0; k < 3; k++) { d.A[k] = pl->A[k]; d.vecN[k] = pl->vecN[k]; }
+		} else {
+			TriMesh* g = static_cast<TriMesh*>(o);
+			mipt_mesh& m = desc_meshes_[i];
+			m.n_triangles = (int)g->indices.size(); m.n_nodes = (int)g->bvh.nodes.size(); m.n_uvs = (int)g->uvs.size();
+			m.nodes = reinterpret_cast<const mipt_bvh_node*>(g->bvh.nodes.data());
+			memcpy(m.bvh_bbox_min, g->bvh.bbox, 12); memcpy(m.bvh_bbox_max, g->bvh.bbox + 3, 12);
+			m.triangleSoup = g->triangleSoup.data(); m.indices = g->indices.data();
+			m.uvs = g->uvs.empty() ? nullptr : &g->uvs[0][0];
+			m.tangentSoup = g->tangentSoup.empty() ? nullptr : &g->tangentSoup[0][0];
+			d.mesh = &m;
+		}
+	}
+	scene_desc.n_objects = (int)n; scene_desc.objects = desc_objects_.data();
+	mipt_render_params& p = render_params;
+	memset(&p, 0, sizeof p);
+	p.W = W; p.H = H; p.nrays = nrays; p.nb_bounces = nb_bounces;
+	for (int k = 0; k < 3; k++) { p.cam_position[k] = cam.position[k]; p.cam_direction[k] = cam.direction[k]; p.cam_up[k] = cam.up[k]; p.centerLight[k] = centerLight[k]; }
+	p.cam_fov = cam.fov; p.cam_focus_distance = cam.focus_distance; p.cam_aperture = cam.aperture;
+	p.double_frustum_start_t = s.double_frustum_start_t;
+	p.sigma_filter = sigma_filter; p.filter_size = filter_size; p.filter_integral = filter_integral.data();
+	p.samples2d = &samples2d[0][0]; p.randomPerPixel = &randomPerPixel[0][0];
+	p.radiusLight = radiusLight; p.lightPower = lightPower; p.envmap_intensity = s.envmap_intensity;
+	p.seed_stride = seed_stride; p.sample_begin = 0; p.sample_end = nrays;
+	p.tile_size = tile_size_; p.tile_rank = tile_rank_; p.tile_nranks = tile_nranks_;
+}
+
+void Raytracer::tone_map(bool divided) {   // Raytracer.cpp:1540-1547 / 1701-1708
+	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) for (int c = 0; c < 3; c++) {
+		size_t idx = ((size_t)(H - i - 1) * W + j) * 3 + c;
+		double v = divided ? imagedouble[idx] / 196964.7 : imagedouble[idx] / 196964.7 / std::max(sample_count[(size_t)(H - i - 1) * W + j], 1.f);
+		image[idx] = (unsigned char)std::min(255., std::max(0., 255. * std::pow(v, (double)(1 / gamma))));
+	}
+}
+
+// Progressive render: one pass per sample index, buffers valid after every pass, `stopped`
+// polled between passes (Raytracer.cpp:1444-1453).
+void Raytracer::render_image() {
+	prepare_render((float)s.current_frame);
+	if (!ctx) { last_status = MIPT_ERR_NO_DEVICE; err_ = "no device opened"; return; }
+	err_.clear();
+	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
+	stopped = 0;
+	for (int k = 0; k < nrays; k++) {
+		current_nb_rays = k;
+		if (stopped) return;
+		mipt_render_params p = render_params;
+		p.sample_begin = k; p.sample_end = k + 1;
+		if ((last_status = mipt_render(ctx, &p, imagedouble.data(), sample_count.data(), nullptr, nullptr, &stopped)) != MIPT_OK) return;
+	}
+	tone_map(false);
+	stopped = 1;
+}
+
+// Offline render: all samples in as few passes as memory allows, then imagedouble /= sample_count
+// (Raytracer.cpp:1687-1694) and the tone map.
+void Raytracer::render_image_nopreviz() {
+	prepare_render((float)s.current_frame);
+	if (!ctx) { last_status = MIPT_ERR_NO_DEVICE; err_ = "no device opened"; return; }
+	err_.clear();
+	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
+	stopped = 0;
+	if ((last_status = mipt_render(ctx, &render_params, imagedouble.data(), sample_count.data(), nullptr, nullptr, &stopped)) != MIPT_OK) return;
+	for (size_t i = 0; i < (size_t)W * H; i++) for (int j = 0; j < 3; j++) imagedouble[i * 3 + j] /= sample_count[i];
+	tone_map(true);
+}
+
+}  // namespace mipt_host
+
+// ---------------------------------------------------------------- flat C view
+using namespace mipt_host;
+struct mh_raytracer { Raytracer rt; };
+
+extern "C" {
+mh_raytracer* mh_create(void) { mh_raytracer* h = new mh_raytracer; h->rt.loadScene(); return h; }
+void mh_destroy(mh_raytracer* h) { delete h; }
+int mh_open_device(mh_raytracer* h, int device_id) { return h->rt.open_device(device_id); }
+void mh_set_partition(mh_raytracer* h, int ts, int rank, int nranks) { h->rt.set_partition(ts, rank, nranks); }
+void mh_set_render(mh_raytracer* h, int W, int H, int nrays, int nb_bounces, float sigma) {
+	Raytracer& r = h->rt; r.W = W; r.H = H; r.nrays = nrays; r.nb_bounces = nb_bounces; r.sigma_filter = sigma;
+	r.last_nrays = -1; r.lastfilter = -1; r.randomPerPixel.clear(); r.clear_image();
+}
+void mh_set_camera(mh_raytracer* h, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture) {
+	Camera& c = h->rt.cam;
+	c.position = Vector(pos[0], pos[1], pos[2]); c.direction = Vector(dir[0], dir[1], dir[2]); c.up = Vector(up[0], up[1], up[2]);
+	c.fov = fov; c.focus_distance = focus; c.aperture = aperture;
+}
+void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite) {
+	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
+}
+void mh_set_envmap_intensity(mh_raytracer* h, float v) { h->rt.s.envmap_intensity = v; }
+int mh_add_mesh(mh_raytracer* h, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs, int nf, const int* fv, const int* fn, const int* ft, float scale, int center) {
+	Raytracer& r = h->rt;
+	TriMesh* g = new TriMesh(nv, verts, nn, normals, nt, uvs, nf, fv, fn, ft, center != 0);
+	g->scale = scale;   // GUI placement, mainApp.cpp:2402-2410
+	g->max_translation = Vector(0, r.s.objects[2]->max_translation[1] - g->bbox[1] * g->scale, 0);
+	r.s.addObject(g);
+	return (int)r.s.objects.size() - 1;
+}
+void mh_set_object_flags(mh_raytracer* h, int obj, int miroir, int flip) { h->rt.s.objects[obj]->miroir = miroir != 0; h->rt.s.objects[obj]->flip_normals = flip != 0; }
+void mh_set_group_material(mh_raytracer* h, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
+	Object* o = h->rt.s.objects[obj];
+	if (grp < (int)o->textures.size()) o->textures[grp].multiplier = Vector(Kd[0], Kd[1], Kd[2]);
+	if (grp < (int)o->specularmap.size()) o->specularmap[grp].multiplier = Vector(Ks[0], Ks[1], Ks[2]);
+	if (grp < (int)o->roughnessmap.size()) o->roughnessmap[grp].multiplier = Vector(Ne[0], Ne[1], Ne[2]);
+	if (grp < (int)o->transparent_map.size()) o->transparent_map[grp].multiplier = Vector(transp_col, transp_col, transp_col);
+	if (grp < (int)o->refr_index_map.size()) o->refr_index_map[grp].multiplier = Vector(refr, refr, refr);
+}
+void mh_add_group_material(mh_raytracer* h, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
+	Object* o = h->rt.s.objects[obj];
+	o->add_col_texture(Vector(Kd[0], Kd[1], Kd[2])); o->add_col_specular(Vector(Ks[0], Ks[1], Ks[2])); o->add_col_roughness(Vector(Ne[0], Ne[1], Ne[2]));
+	o->add_col_transp(transp_col); o->add_col_refr(refr);
+}
+void mh_set_group_texture(mh_raytracer* h, int obj, int grp, int slot, int W, int H, const unsigned char* rgb) {
+	Object* o = h->rt.s.objects[obj];
+	std::vector<Texture>* lists[8] = {&o->textures, &o->specularmap, &o->normal_map, &o->alphamap, &o->roughnessmap, &o->transparent_map, &o->refr_index_map, &o->subsurface};
+	if (slot < 0 || slot > 7 || grp < 0 || grp >= (int)lists[slot]->size()) return;
+	(*lists[slot])[grp].loadColorsRGB8(rgb, W, H);
+}
+void mh_set_envmap(mh_raytracer* h, int W, int H, const unsigned char* rgb) { static_cast<Sphere*>(h->rt.s.objects[1])->load_envmap_rgb8(rgb, W, H); }
+int mh_prepare(mh_raytracer* h, int upload) {
+	Raytracer& r = h->rt;
+	r.prepare_render((float)r.s.current_frame);
+	if (!upload) return MIPT_OK;
+	if (!r.ctx) return MIPT_ERR_NO_DEVICE;
+	r.last_status = mipt_upload_scene(r.ctx, &r.scene_desc);
+	return r.last_status;
+}
+int mh_render_image(mh_raytracer* h) { h->rt.render_image(); return h->rt.last_status; }
+int mh_render_image_nopreviz(mh_raytracer* h) { h->rt.render_image_nopreviz(); return h->rt.last_status; }
+const char* mh_last_error(mh_raytracer* h) { return h->rt.last_error(); }
+void* mh_ctx(mh_raytracer* h) { return h->rt.ctx; }
+const void* mh_scene_desc(mh_raytracer* h) { return &h->rt.scene_desc; }
+const void* mh_render_params(mh_raytracer* h) { return &h->rt.render_params; }
+float* mh_imagedouble(mh_raytracer* h) { return h->rt.imagedouble.data(); }
+float* mh_sample_count(mh_raytracer* h) { return h->rt.sample_count.data(); }
+unsigned char* mh_image(mh_raytracer* h) { return h->rt.image.data(); }
+
+void mh_get_light(mh_raytracer* h, float* o) { Raytracer& r = h->rt; o[0] = r.centerLight[0]; o[1] = r.centerLight[1]; o[2] = r.centerLight[2]; o[3] = r.radiusLight; o[4] = r.lightPower; }
+void mh_get_tables(mh_raytracer* h, float* rpp, float* s2d, float* fi, int* fs) {
+	Raytracer& r = h->rt;
+	if (rpp) for (size_t i = 0; i < r.randomPerPixel.size(); i++) { rpp[2 * i] = r.randomPerPixel[i][0]; rpp[2 * i + 1] = r.randomPerPixel[i][1]; }
+	if (s2d) for (size_t i = 0; i < r.samples2d.size(); i++) { s2d[2 * i] = r.samples2d[i][0]; s2d[2 * i + 1] = r.samples2d[i][1]; }
+	if (fi) memcpy(fi, r.filter_integral.data(), r.filter_integral.size() * 4);
+	if (fs) *fs = r.filter_size;
+}
+void mh_get_object_matrices(mh_raytracer* h, int obj, float* t, float* inv, float* rot) {
+	Object* o = h->rt.s.objects[obj]; memcpy(t, o->trans_matrix, 48); memcpy(inv, o->inv_trans_matrix, 48); memcpy(rot, o->rot_matrix, 36);
+}
+void mh_mesh_counts(mh_raytracer* h, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs) {
+	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
+	*ntri = (int)g->indices.size(); *nnodes = (int)g->bvh.nodes.size(); *nverts = (int)g->vertices.size(); *nnormals = (int)g->normals.size(); *nuvs = (int)g->uvs.size();
+}
+void mh_mesh_dump(mh_raytracer* h, int obj, int* perm, int* nodes_i, float* nodes_bb, float* soup, int* groups, float* root_bb) {
+	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
+	const int nt = (int)g->indices.size();
+	for (int i = 0; i < nt; i++) {
+		if (perm) perm[i] = g->permuted_triangle_index[i];
+		if (groups) groups[i] = g->indices[i].group;
+		if (soup) memcpy(soup + (size_t)i * 31, &g->triangleSoup[i], 124);
+	}
+	for (size_t i = 0; i < g->bvh.nodes.size(); i++) {
+		if (nodes_i) { nodes_i[3 * i] = g->bvh.nodes[i].isleaf ? 1 : 0; nodes_i[3 * i + 1] = g->bvh.nodes[i].fg; nodes_i[3 * i + 2] = g->bvh.nodes[i].fd; }
+		if (nodes_bb) memcpy(nodes_bb + 6 * i, g->bvh.nodes[i].bbox, 24);
+	}
+	if (root_bb) memcpy(root_bb, g->bvh.bbox, 24);
+}
+}

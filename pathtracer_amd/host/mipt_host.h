@@ -1,0 +1,211 @@
+// mipt_host.h — host side of the drop-in boundary: C++ mirror of the reference's operator
+// interface for the hot path (class names, member names and argument meaning follow
+// Raytracer.h:25-121, Geometry.h:240-445 / 849-1217 / 1238-1400, TriangleMesh.h:113-258), with
+// the radiance loop delegated to libmipt.so through include/mipt.h.
+//
+// What stays on the host, as in the reference: scene construction, TriMesh::init (axis swap,
+// normalisation, BVH build, triangle soup, tangents), Object::build_matrix,
+// Raytracer::prepare_render (lattice, per-pixel rotations, filter tables, light constants) and
+// the tone map.  What moves to the GPU: everything inside the sample loops of
+// render_image / render_image_nopreviz, and Scene::intersection / intersection_shadow.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+
+namespace mipt_host {
+
+struct Vector {
+	float c[3];
+	Vector(float x = 0, float y = 0, float z = 0) { c[0] = x; c[1] = y; c[2] = z; }
+	float& operator[](int i) { return c[i]; }
+	const float& operator[](int i) const { return c[i]; }
+};
+
+struct Texture {                      // BRDF.h:252-426
+	Vector multiplier{1, 1, 1};
+	size_t W = 0, H = 0;
+	std::vector<float> values;
+	// Texture::loadColors on an 8-bit RGB image given top row first (what stb_image returns):
+	// load_image's row flip (utils.cpp:112-118), /255.f and powf(.,2.2f) (BRDF.h:393-404).
+	void loadColorsRGB8(const unsigned char* rgb, int w, int h);
+};
+
+struct BVHNodes { bool isleaf; int fg, fd; float bbox[6]; };   // TriangleMesh.h:6-13 (36 bytes)
+static_assert(sizeof(BVHNodes) == sizeof(mipt_bvh_node), "BVH node layout");
+
+enum ObjectType { OT_TRIMESH = MIPT_OBJ_TRIMESH, OT_SPHERE = MIPT_OBJ_SPHERE, OT_PLANE = MIPT_OBJ_PLANE };
+
+class Object {                        // Geometry.h:240-735
+public:
+	virtual ~Object() {}
+	Object();
+	void build_matrix();              // Geometry.h:322-360 (no keyframes, is_recording = false)
+	Vector apply_transformation(const Vector& v) const;
+	void add_col_texture(const Vector& c) { textures.push_back(constant(c)); }
+	void add_col_specular(const Vector& c) { specularmap.push_back(constant(c)); }
+	void add_col_roughness(const Vector& c) { roughnessmap.push_back(constant(c)); }
+	void add_col_alpha(float c) { alphamap.push_back(constant(Vector(c, c, c))); }
+	void add_col_refr(float c) { refr_index_map.push_back(constant(Vector(c, c, c))); }
+	void add_col_transp(float c) { transparent_map.push_back(constant(Vector(c, c, c))); }
+	void add_col_subsurface(const Vector& c) { subsurface.push_back(constant(c)); }
+	void add_null_normalmap() { normal_map.push_back(constant(Vector(0, 0, 1))); }
+
+	std::string name;
+	ObjectType type = OT_TRIMESH;
+	bool miroir = false, ghost = false, flip_normals = false, interp_normals = true;
+	float scale = 1;
+	Vector max_translation, rotation_center;
+	float mat_rotation[9];
+	float trans_matrix[12], inv_trans_matrix[12], rot_matrix[9];
+	std::vector<Texture> textures, specularmap, alphamap, roughnessmap, normal_map, subsurface, transparent_map, refr_index_map;
+private:
+	static Texture constant(const Vector& c) { Texture t; t.multiplier = c; return t; }
+};
+
+class Sphere : public Object {        // Geometry.h:849-1103
+public:
+	Sphere(const Vector& origin, float rayon);
+	void load_envmap_rgb8(const unsigned char* rgb, int w, int h);   // Sphere::load_envmap (:912-916), rows as in the file
+	Vector O; float R = 0; bool has_envmap = false;
+	std::vector<unsigned char> envtex; int envW = 0, envH = 0;
+};
+
+class Plane : public Object {         // Geometry.h:1127-1217
+public:
+	Plane(const Vector& A, const Vector& N);
+	Vector A, vecN;
+};
+
+class TriMesh : public Object {       // TriangleMesh.h:113-258
+public:
+	// TriMesh::init (TriangleMesh.cpp:718-841) on in-memory OBJ arrays (what readOBJ would have
+	// parsed): scaling = 1, offset = 0, preserve_input = false.
+	TriMesh(int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
+	        int nf, const int* fv, const int* fn, const int* ft, bool center);
+	std::vector<Vector> vertices, normals, uvs;
+	std::vector<mipt_triangle_indices> indices;
+	std::vector<mipt_triangle> triangleSoup;
+	std::vector<Vector> tangentSoup;
+	std::vector<int> permuted_triangle_index;
+	struct { float bbox[6]; std::vector<BVHNodes> nodes; } bvh;
+	float bbox[6];
+private:
+	void build_bbox(int i0, int i1, float* out6) const;
+	void build_centers_bbox(int i0, int i1, float* out6) const;
+	void build_bvh_recur(int node, int i0, int i1, int depth);
+	void setup_tangents();
+};
+
+struct Camera {                       // Vector.h:700-842 (fields the path reads)
+	Vector position{0, 0, 50}, direction{0, 0, -1}, up{0, 1, 0};
+	float fov = 0, focus_distance = 50, aperture = 0.1f;
+};
+
+class Raytracer;
+
+class Scene {                         // Geometry.h:1238-1400
+public:
+	~Scene();
+	void addObject(Object* o) { objects.push_back(o); }
+	void prepare_render();            // build_matrix on every object (Geometry.cpp:280-284)
+	// Scene::intersection / intersection_shadow (Geometry.h:1340-1344) through mipt_trace*.
+	bool intersection(const mipt_ray& d, Vector& P, int& sphere_id, float& min_t, mipt_hit& mat, int& triangle_id) const;
+	bool intersection_shadow(const mipt_ray& d, float& min_t, float dist_light) const;
+	std::vector<Object*> objects;
+	Sphere* lumiere = nullptr;
+	float intensite_lumiere = 0, envmap_intensity = 1;
+	float double_frustum_start_t = 0;
+	int current_frame = 0;
+	Raytracer* owner = nullptr;
+};
+
+class Raytracer {                     // Raytracer.h:25-121
+public:
+	Raytracer();
+	~Raytracer();
+	void loadScene();                 // Raytracer.cpp:1238-1274
+	void prepare_render(float time);  // Raytracer.cpp:1321-1391 + scene upload
+	void render_image();              // Raytracer.cpp:1424-1563: progressive, one pass per sample
+	void render_image_nopreviz();     // Raytracer.cpp:1565-1718: offline, image divided by sample_count
+	void clear_image();
+	void stopRender() { stopped = 1; }
+	// the GPU this Raytracer renders on, and its share of the image (multi-GPU: one process per GPU)
+	int open_device(int device_id);
+	void set_partition(int tile_size, int rank, int nranks) { tile_size_ = tile_size; tile_rank_ = rank; tile_nranks_ = nranks; }
+	const char* last_error() const;
+
+	int W = 1000, H = 800;
+	int nrays = 100, last_nrays = -1;
+	Camera cam;
+	float sigma_filter = 0.5f, lastfilter = -1;
+	int filter_size = 0, filter_total_width = 0;
+	int nb_bounces = 3;
+	float gamma = 2.2f;
+	Scene s;
+	volatile int stopped = 0;
+	int current_nb_rays = 0;
+	std::vector<unsigned char> image;
+	std::vector<float> imagedouble;
+	std::vector<float> sample_count;
+	std::vector<float> filter_value, filter_integral;
+	std::vector<Vector> samples2d, randomPerPixel;
+	Vector centerLight;
+	float lum_scale = 1, radiusLight = 0, lightPower = 0;
+	uint64_t seed_stride = 65536;
+
+	// the C-ABI view of the current state (valid after prepare_render)
+	mipt_ctx* ctx = nullptr;
+	mipt_scene_desc scene_desc{};
+	mipt_render_params render_params{};
+	int last_status = 0;
+private:
+	void build_descs();
+	void tone_map(bool divide_by_count);
+	std::vector<mipt_object> desc_objects_;
+	std::vector<mipt_mesh> desc_meshes_;
+	std::vector<std::vector<mipt_texture>> desc_tex_;
+	int tile_size_ = 32, tile_rank_ = 0, tile_nranks_ = 1;
+	std::string err_;
+};
+
+}  // namespace mipt_host
+
+// ---- flat C view for ctypes (tests, bench.py) --------------------------------------------
+extern "C" {
+typedef struct mh_raytracer mh_raytracer;
+mh_raytracer* mh_create(void);                           // new Raytracer + loadScene()
+void mh_destroy(mh_raytracer*);
+int  mh_open_device(mh_raytracer*, int device_id);        // mipt_create; returns mipt status
+void mh_set_partition(mh_raytracer*, int tile_size, int rank, int nranks);
+void mh_set_render(mh_raytracer*, int W, int H, int nrays, int nb_bounces, float sigma_filter);
+void mh_set_camera(mh_raytracer*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);
+void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_lumiere);
+void mh_set_envmap_intensity(mh_raytracer*, float v);
+int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
+                 int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
+void mh_set_object_flags(mh_raytracer*, int obj, int miroir, int flip_normals);
+void mh_set_group_material(mh_raytracer*, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
+void mh_add_group_material(mh_raytracer*, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
+void mh_set_group_texture(mh_raytracer*, int obj, int grp, int slot, int W, int H, const unsigned char* rgb);
+void mh_set_envmap(mh_raytracer*, int W, int H, const unsigned char* rgb);
+int  mh_prepare(mh_raytracer*, int upload);               // prepare_render; upload=0 skips the device (CPU tests)
+int  mh_render_image(mh_raytracer*);
+int  mh_render_image_nopreviz(mh_raytracer*);
+const char* mh_last_error(mh_raytracer*);
+// views
+void* mh_ctx(mh_raytracer*);                              // mipt_ctx*
+const void* mh_scene_desc(mh_raytracer*);                 // const mipt_scene_desc*
+const void* mh_render_params(mh_raytracer*);              // const mipt_render_params*
+float* mh_imagedouble(mh_raytracer*);
+float* mh_sample_count(mh_raytracer*);
+unsigned char* mh_image(mh_raytracer*);
+// dumps with the layouts of oracle/ref_harness.cpp (so one test body serves all three)
+void mh_get_light(mh_raytracer*, float* out5);
+void mh_get_tables(mh_raytracer*, float* randomPerPixel, float* samples2d, float* filter_integral, int* filter_size);
+void mh_get_object_matrices(mh_raytracer*, int obj, float* trans12, float* inv12, float* rot9);
+void mh_mesh_counts(mh_raytracer*, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs);
+void mh_mesh_dump(mh_raytracer*, int obj, int* perm, int* nodes_i, float* nodes_bb, float* soup, int* groups, float* root_bb);
+}

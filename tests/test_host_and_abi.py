@@ -1,0 +1,83 @@
+"""CPU tests of the PRODUCT's host side (no GPU needed, no oracle involved):
+
+* libmipt.so loads and exports every symbol include/mipt.h declares; without a GPU mipt_create
+  reports MIPT_ERR_NO_DEVICE (there is no CPU fallback to fall into);
+* the host mirror (TriMesh::init + BVH build, build_matrix, prepare_render tables, light constants,
+  loadScene camera) reproduces the golden vectors generated from the compiled reference, bit for bit.
+"""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, assert_bits, load_golden, setup_scene
+from pathtracer_amd import capi, scenes
+
+
+def test_header_symbols_exported():
+    mipt, host = capi.load()
+    header = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    declared = set(re.findall(r"\b(mipt_[a-z_]+)\s*\(", header)) - {"mipt_progress_cb"}
+    assert declared == set(capi.MIPT_SYMBOLS), declared ^ set(capi.MIPT_SYMBOLS)
+    for s in declared:
+        assert hasattr(mipt, s), s
+    assert mipt.mipt_abi_version() == 1
+
+
+def test_no_device_means_error_not_fallback():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    mipt, _ = capi.load()
+    ctx = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert mipt.mipt_create(dev, 1, C.byref(ctx)) == capi.MIPT_ERR_NO_DEVICE
+    assert not ctx.value
+    with pytest.raises(capi.MiptError):
+        capi.HostRaytracer(device=0)
+    rt = capi.HostRaytracer()          # host-only use is fine ...
+    rt.apply_config(scenes.config_c0())
+    rt.add_mesh(scenes.cornell_mesh())
+    rt.prepare()
+    with pytest.raises(capi.MiptError):  # ... but nothing renders without the device
+        rt.render()
+    with pytest.raises(capi.MiptError):
+        rt.render_image_nopreviz()
+
+
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy"])
+def test_host_side_matches_reference_goldens(name):
+    g = load_golden(f"scene_{name}.npz")
+    H = capi.HostRaytracer()
+    mesh, cfg, oid = setup_scene(H, name)
+    assert_bits(H.light(), g["light"], "light constants")
+    rpp, s2d, fi, fs = H.tables()
+    assert_bits(rpp, g["randomPerPixel"], "randomPerPixel")
+    assert_bits(s2d, g["samples2d"], "samples2d")
+    assert_bits(fi, g["filter_integral"], "filter_integral")
+    assert fs == int(g["filter_size"])
+    for k in range(oid + 1):
+        for arr, key in zip(H.object_matrices(k), ("trans", "inv", "rot")):
+            assert_bits(arr, g[f"obj{k}_{key}"], f"obj{k}.{key}")
+    d = H.mesh_dump(oid)
+    for key in ("perm", "nodes_i", "nodes_bb", "groups", "root_bb"):
+        assert_bits(d[key], g[key], "mesh." + key)
+    assert_bits(d["soup"][:, :16], g["soup16"], "triangleSoup intersection record")
+    assert_bits(d["soup"][:, 22:31], g["soup_normals"], "triangleSoup normals")
+
+
+def test_loadscene_camera():
+    import ctypes
+    mipt, host = capi.load()
+    H = capi.HostRaytracer()
+    H.set_render(8, 8, 1, 1)
+    H.prepare()
+    p = ctypes.cast(H.render_params, ctypes.POINTER(ctypes.c_float))
+    # mipt_render_params: 4 ints, then cam_position[3], cam_direction[3], cam_up[3], fov, focus, aperture
+    cam = np.array([p[4 + k] for k in range(12)], np.float32)
+    d, u = scenes.default_camera_rotated()
+    assert_bits(cam[3:6], np.asarray(d, np.float32), "camera direction after cam.rotate")
+    assert_bits(cam[6:9], np.asarray(u, np.float32), "camera up after cam.rotate")
+    assert_bits(cam[9:10], np.asarray([scenes.RenderConfig().fov], np.float32), "fov")
