@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[1] — 133 128-triangle diffuse blob, Phong BRDF,
+1920x1080, depth 4, default loadScene() light and camera.  One STEP = one pass of the hot path
+(camera rays -> getColor -> splat) over the whole frame at SPP_PER_STEP samples per pixel; the
+default K = 32 steps x 8 spp is exactly the 256 spp of the config.  With N GPUs the frame's
+32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
+the per-rank accumulators are summed by ONE all-reduce at the end (RCCL), so the total work is
+fixed: "scaling": "strong".
+
+value = rays (closest-hit + shadow, counted like the oracle counts them) of all ranks / wall time
+of the K timed steps (+ the final reduce), inputs resident in HBM, barrier + synchronize on both
+sides, max over ranks.
+
+roofline: the dominant kernel's ALGORITHMIC bytes per launch / its mean launch duration (HIP events
+on the render stream, measured here).  Algorithmic bytes per ray come from the CPU oracle's counters
+of the reference's ordered traversal on a bounded sample of the same scene and camera
+(B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.
+
+cpu_baseline (rank 0, N=1 only): the compiled reference's own render_image_nopreviz() on all host
+cores when oracle/_ref/libptref.so is present (kind "reference"), otherwise the oracle's threaded
+restatement (kind "port"), on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SPP_PER_STEP = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--grid", type=int, default=258, help="blob tessellation (258 -> 133 128 triangles)")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", action="store_true", help="profiling run: skip the CPU legs")
+    return ap.parse_args()
+
+
+def oracle_bytes_per_ray(mesh, cfg_full):
+    """Mean algorithmic bytes per closest-hit / shadow ray on a bounded sample (same scene, same
+    camera, 1/8 resolution, 2 spp), from the oracle's counters of the reference traversal."""
+    import copy
+    from oracle.binding import Oracle
+    cfg = copy.copy(cfg_full)
+    cfg.W, cfg.H, cfg.spp = max(8, cfg_full.W // 8), max(8, cfg_full.H // 8), 2
+    O = Oracle()
+    O.apply_config(cfg)
+    O.add_mesh(mesh)
+    O.prepare()
+    O.counters_reset()
+    t, img, cnt, rays = O.render_omp(O.cdll.o_max_threads())
+    c = O.counters().astype(float)
+    b_closest = (24 * c[0] + 8 * c[1] + 64 * c[2]) / max(1.0, float(rays[0]))
+    b_shadow = (24 * c[3] + 8 * c[4] + 64 * c[5]) / max(1.0, float(rays[1]))
+    return dict(bytes_closest=b_closest, bytes_shadow=b_shadow, rays_per_path=float(rays[0] + rays[1]) / (cfg.W * cfg.H * cfg.spp),
+                sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp")
+
+
+def cpu_baseline(mesh, cfg_full, rays_per_path):
+    import copy
+    from oracle import binding
+    cfg = copy.copy(cfg_full)
+    cfg.W, cfg.H = cfg_full.W // 4, cfg_full.H // 4
+    cores = os.cpu_count() or 1
+    # size the sample for roughly 10-30 s of CPU work: ~0.25 Mpaths/s/core observed on this scene
+    est_rate = 0.2e6 * cores
+    cfg.spp = int(max(2, min(64, 15.0 * est_rate / (cfg.W * cfg.H))))
+    if binding.ref_available():
+        R = binding.Ref()
+        R.apply_config(cfg)
+        R.add_mesh(mesh)
+        threads = R.max_threads()
+        secs, _ = R.time_render_nopreviz(threads)
+        kind = "reference"
+    else:
+        O = binding.Oracle()
+        O.apply_config(cfg)
+        O.add_mesh(mesh)
+        O.prepare()
+        threads = O.cdll.o_max_threads()
+        secs, _, _, _ = O.render_omp(threads)
+        kind = "port"
+    mpaths = cfg.W * cfg.H * cfg.spp / secs / 1e6
+    return dict(value=mpaths * rays_per_path, unit="Mrays/s", cores=int(threads), kind=kind,
+                sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp of the same scene/camera/depth, {secs:.1f}s wall; "
+                       f"{mpaths:.3f} Mpaths/s x {rays_per_path:.2f} rays/path (oracle count)",
+                mpaths_per_s=mpaths)
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from pathtracer_amd import capi, scenes
+
+    total_spp = SPP_PER_STEP * (args.steps + args.warmup)
+    cfg = scenes.config_c1(args.width, args.height, total_spp)
+    mesh = scenes.blob_mesh(args.grid)
+
+    rt = capi.HostRaytracer(device=local_rank)
+    rt.apply_config(cfg)
+    rt.set_partition(32, rank, world)
+    rt.add_mesh(mesh)
+    t0 = time.time()
+    rt.prepare()
+    t_prepare = time.time() - t0
+    if args.pipeline >= 0:
+        rt.set_option("pipeline", args.pipeline)
+    rt.set_option("paths_per_pass", args.width * args.height * SPP_PER_STEP)
+
+    import ctypes as C
+    accum = torch.zeros(args.width * args.height * 4, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    P = rt.params       # live view of the host mirror's mipt_render_params; patched per step
+    assert P.W == args.width and P.nrays == total_spp and P.seed_stride == 65536 and P.tile_nranks == world
+
+    def step(s):
+        P.sample_begin, P.sample_end = s * SPP_PER_STEP, (s + 1) * SPP_PER_STEP
+        rt.render_device(accum.data_ptr(), stream)
+        st = rt.stats()    # synchronises; cheap next to a step
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    sync()
+    t0 = time.perf_counter()
+    rays = paths = 0
+    kern_ms = 0.0
+    launches = 0
+    rays_c = rays_s = 0
+    for s in range(args.warmup, args.warmup + args.steps):
+        st = step(s)
+        rays_c += st["rays_closest"]; rays_s += st["rays_shadow"]; paths += st["paths"]
+        kern_ms += st["traverse_ms"]; launches += st["traverse_launches"]
+    if world > 1:
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM)     # the framebuffer reduce (RCCL over xGMI)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(rays_c), float(rays_s), float(paths), kern_ms, float(launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); rays_c, rays_s, paths = float(tsum[1]), float(tsum[2]), float(tsum[3])
+    rays = rays_c + rays_s
+
+    if rank == 0:
+        img = accum[: args.width * args.height * 3]
+        finite = bool(torch.isfinite(img).all().item())
+        out = {
+            "metric": "Msamples/s (primary+secondary rays) at 1080p; 1/2/4/8-GPU scaling",
+            "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {mesh.ntri}-triangle diffuse blob, {args.width}x{args.height}, "
+                                   f"{SPP_PER_STEP * args.steps} spp timed ({SPP_PER_STEP} spp/step), depth {cfg.nb_bounces}, Phong BRDF",
+                       "parallelism": f"tiles32x{world}", "pipeline": int(args.pipeline)},
+            "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
+            "prepare_s": t_prepare, "finite": finite,
+        }
+        if world == 1 and not args.pmc:
+            ob = oracle_bytes_per_ray(mesh, cfg)
+            my_launches = max(1, launches)
+            bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
+            ms_per_launch = kern_ms / my_launches
+            achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": None, "kernel": "k_render_paths" if args.pipeline <= 0 else "k_extend",
+                               "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
+                               "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"]}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(mesh, cfg, ob["rays_per_path"])
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,18 @@ class MiptHit(C.Structure):
                 ("shadingN", _f * 3), ("Kd", _f * 3), ("Ks", _f * 3), ("Ne", _f * 3), ("Ke", _f * 3), ("transp", C.c_int32), ("refr_index", _f)]
 
 
+class MiptRenderParams(C.Structure):
+    """mipt_render_params (include/mipt.h)."""
+    _fields_ = [("W", C.c_int32), ("H", C.c_int32), ("nrays", C.c_int32), ("nb_bounces", C.c_int32),
+                ("cam_position", _f * 3), ("cam_direction", _f * 3), ("cam_up", _f * 3),
+                ("cam_fov", _f), ("cam_focus_distance", _f), ("cam_aperture", _f),
+                ("double_frustum_start_t", _f), ("sigma_filter", _f), ("filter_size", C.c_int32),
+                ("filter_integral", C.c_void_p), ("samples2d", C.c_void_p), ("randomPerPixel", C.c_void_p),
+                ("centerLight", _f * 3), ("radiusLight", _f), ("lightPower", _f), ("envmap_intensity", _f),
+                ("seed_stride", C.c_uint64), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
+                ("tile_size", C.c_int32), ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 HIT_DTYPE = np.dtype([("has_inter", np.int32), ("object_id", np.int32), ("triangle_id", np.int32), ("t", np.float32), ("P", np.float32, 3),
                       ("shadingN", np.float32, 3), ("Kd", np.float32, 3), ("Ks", np.float32, 3), ("Ne", np.float32, 3), ("Ke", np.float32, 3),
                       ("transp", np.int32), ("refr_index", np.float32)])
@@ -227,6 +239,11 @@ class HostRaytracer:
     @property
     def render_params(self):
         return C.c_void_p(self.host.mh_render_params(self.h))
+
+    @property
+    def params(self):
+        """Live ctypes view of the host mirror's mipt_render_params (valid after prepare())."""
+        return C.cast(self.host.mh_render_params(self.h), C.POINTER(MiptRenderParams)).contents
 
     def _need_device(self):
         if not self._uploaded:

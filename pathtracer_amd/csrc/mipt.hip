@@ -173,6 +173,11 @@ struct mipt_ctx {
 	DCounters* d_cnt = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	mipt_stats stats{};
+	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
+	// size changes, or after mipt_set_option("invalidate_tables", 1))
+	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; } tab_key;
+	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0; } blk_key;
+	int blk_nblocks = 0;
 	int64_t opt_pipeline = 0;
 	int64_t opt_paths_per_pass = 1 << 24;
 };
@@ -229,6 +234,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!c || !name) return MIPT_ERR_INVALID;
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
 }
 
@@ -452,14 +458,20 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	// tables: compact the reference's Vector[] (stride 3) arrays to stride 2
 	const int ftw = 2 * p->filter_size + 1;
 	size_t n_fi = (size_t)ftw * ftw, n_s2 = (size_t)p->nrays * 2, n_rpp = (size_t)p->W * p->H * 2;
-	std::vector<float> h(n_fi + n_s2 + n_rpp);
-	memcpy(h.data(), p->filter_integral, n_fi * 4);
-	for (int k = 0; k < p->nrays; k++) { h[n_fi + 2 * k] = p->samples2d[3 * (size_t)k]; h[n_fi + 2 * k + 1] = p->samples2d[3 * (size_t)k + 1]; }
-	for (size_t k = 0; k < (size_t)p->W * p->H; k++) { h[n_fi + n_s2 + 2 * k] = p->randomPerPixel[3 * k]; h[n_fi + n_s2 + 2 * k + 1] = p->randomPerPixel[3 * k + 1]; }
-	int rc = ensure(c, &c->tab_buf, &c->tab_buf_bytes, h.size() * 4);
-	if (rc) return rc;
-	HIPCHK(c, hipMemcpyAsync(c->tab_buf, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
-	HIPCHK(c, hipStreamSynchronize(st));   // h goes out of scope
+	const bool cached = c->tab_buf && c->tab_key.fi == p->filter_integral && c->tab_key.s2 == p->samples2d && c->tab_key.rpp == p->randomPerPixel &&
+	                    c->tab_key.W == p->W && c->tab_key.H == p->H && c->tab_key.nrays == p->nrays && c->tab_key.fs == p->filter_size;
+	if (!cached) {
+		std::vector<float> h(n_fi + n_s2 + n_rpp);
+		memcpy(h.data(), p->filter_integral, n_fi * 4);
+		for (int k = 0; k < p->nrays; k++) { h[n_fi + 2 * k] = p->samples2d[3 * (size_t)k]; h[n_fi + 2 * k + 1] = p->samples2d[3 * (size_t)k + 1]; }
+		for (size_t k = 0; k < (size_t)p->W * p->H; k++) { h[n_fi + n_s2 + 2 * k] = p->randomPerPixel[3 * k]; h[n_fi + n_s2 + 2 * k + 1] = p->randomPerPixel[3 * k + 1]; }
+		int rc = ensure(c, &c->tab_buf, &c->tab_buf_bytes, h.size() * 4);
+		if (rc) return rc;
+		HIPCHK(c, hipMemcpyAsync(c->tab_buf, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+		HIPCHK(c, hipStreamSynchronize(st));   // h goes out of scope
+		c->tab_key.fi = p->filter_integral; c->tab_key.s2 = p->samples2d; c->tab_key.rpp = p->randomPerPixel;
+		c->tab_key.W = p->W; c->tab_key.H = p->H; c->tab_key.nrays = p->nrays; c->tab_key.fs = p->filter_size;
+	}
 	float* t = (float*)c->tab_buf;
 	R.filter_integral = t; R.samples2d = t + n_fi; R.randomPerPixel = t + n_fi + n_s2;
 	return MIPT_OK;
@@ -523,17 +535,25 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	int kb = p->sample_begin, ke = p->sample_end;
 	if (kb == 0 && ke == 0) ke = p->nrays;
 	if (kb < 0 || ke > p->nrays || kb > ke) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays]");
-	std::vector<int> blocks, pix2slot;
-	if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
-	const int nblocks = (int)(blocks.size() / 2);
+	{
+		int ts = p->tile_size > 0 ? p->tile_size : 32, nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
+		const bool cached = c->blk_buf && c->blk_key.W == p->W && c->blk_key.H == p->H && c->blk_key.ts == ts && c->blk_key.rk == p->tile_rank && c->blk_key.nr == nr;
+		if (!cached) {
+			std::vector<int> blocks, pix2slot;
+			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
+			c->blk_nblocks = (int)(blocks.size() / 2);
+			size_t blk_bytes = (blocks.size() + pix2slot.size()) * sizeof(int);
+			if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
+			if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
+			HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size(), pix2slot.data(), pix2slot.size() * sizeof(int), hipMemcpyHostToDevice, st));
+			HIPCHK(c, hipStreamSynchronize(st));
+			c->blk_key.W = p->W; c->blk_key.H = p->H; c->blk_key.ts = ts; c->blk_key.rk = p->tile_rank; c->blk_key.nr = nr;
+		}
+	}
+	const int nblocks = c->blk_nblocks;
 	memset(&c->stats, 0, sizeof c->stats);
 	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DCounters), st));
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
-	size_t blk_bytes = (blocks.size() + pix2slot.size()) * sizeof(int);
-	if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
-	HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
-	HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size(), pix2slot.data(), pix2slot.size() * sizeof(int), hipMemcpyHostToDevice, st));
-	HIPCHK(c, hipStreamSynchronize(st));
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
 	spp_pass = std::min(spp_pass, ke - kb);
@@ -542,7 +562,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	DSamples S;
 	S.r = (float*)c->pass_buf; S.g = S.r + pass_paths; S.b = S.g + pass_paths; S.dx = S.b + pass_paths; S.dy = S.dx + pass_paths;
 	DPass P;
-	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + blocks.size(); P.npix_slots = npix_slots;
+	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {

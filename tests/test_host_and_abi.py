@@ -81,3 +81,21 @@ def test_loadscene_camera():
     assert_bits(cam[3:6], np.asarray(d, np.float32), "camera direction after cam.rotate")
     assert_bits(cam[6:9], np.asarray(u, np.float32), "camera up after cam.rotate")
     assert_bits(cam[9:10], np.asarray([scenes.RenderConfig().fov], np.float32), "fov")
+
+
+def test_render_params_layout():
+    """The ctypes mirror of mipt_render_params matches the C struct (checked through the values the
+    host side wrote into it)."""
+    H = capi.HostRaytracer()
+    cfg = scenes.config_c0()
+    H.apply_config(cfg)
+    H.set_partition(16, 1, 3)
+    H.add_mesh(scenes.cornell_mesh())
+    H.prepare()
+    P = H.params
+    assert (P.W, P.H, P.nrays, P.nb_bounces) == (cfg.W, cfg.H, cfg.spp, cfg.nb_bounces)
+    assert tuple(P.cam_position) == tuple(np.float32(cfg.cam_pos))
+    assert P.cam_aperture == np.float32(cfg.aperture) and P.filter_size == 1 and P.sigma_filter == 0.5
+    assert P.seed_stride == 65536 and (P.sample_begin, P.sample_end) == (0, cfg.spp)
+    assert (P.tile_size, P.tile_rank, P.tile_nranks) == (16, 1, 3)
+    assert_bits(np.array(list(P.centerLight) + [P.radiusLight, P.lightPower], np.float32), H.light(), "light block")
