@@ -76,7 +76,7 @@ def cpu_baseline(mesh, cfg_full, rays_per_path):
     from oracle import binding
     cfg = copy.copy(cfg_full)
     cfg.W, cfg.H = cfg_full.W // 4, cfg_full.H // 4
-    cores = os.cpu_count() or 1
+    cores = min(64, os.cpu_count() or 1)   # the reference supports at most 64 OpenMP threads
     # size the sample for roughly 10-30 s of CPU work: ~0.25 Mpaths/s/core observed on this scene
     est_rate = 0.2e6 * cores
     cfg.spp = int(max(2, min(64, 15.0 * est_rate / (cfg.W * cfg.H))))
@@ -96,7 +96,15 @@ def cpu_baseline(mesh, cfg_full, rays_per_path):
         secs, _, _, _ = O.render_omp(threads)
         kind = "port"
     mpaths = cfg.W * cfg.H * cfg.spp / secs / 1e6
-    return dict(value=mpaths * rays_per_path, unit="Mrays/s", cores=int(threads), kind=kind,
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=mpaths * rays_per_path, unit="Mrays/s", cores=int(threads), kind=kind, cpu_model=model, host_logical_cpus=os.cpu_count(),
                 sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp of the same scene/camera/depth, {secs:.1f}s wall; "
                        f"{mpaths:.3f} Mpaths/s x {rays_per_path:.2f} rays/path (oracle count)",
                 mpaths_per_s=mpaths)

@@ -1431,4 +1431,4 @@ double o_render_omp(o_ctx* c, int threads, float* imagedouble, float* sample_cou
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
-int o_max_threads(void) { return omp_get_max_threads(); }
+int o_max_threads(void) { return omp_get_num_procs(); }

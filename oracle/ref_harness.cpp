@@ -33,7 +33,13 @@ struct RefCtx {
 	Raytracer* rt;
 };
 
+// The reference sizes its per-thread state for at most 64 OpenMP threads (engine[64] Vector.h:29,
+// contribsArray[64][..] Raytracer.h:115) and indexes it with omp_get_max_threads() in its
+// constructors: on a host with more hardware threads it overruns those arrays.  Cap at 64.
+static int ref_thread_cap() { return omp_get_num_procs() < 64 ? omp_get_num_procs() : 64; }
+
 RefCtx* ref_create() {
+	if (omp_get_max_threads() > 64) omp_set_num_threads(64);
 	RefCtx* c = new RefCtx;
 	c->rt = new Raytracer();  // heap: contribsArray is ~600 KB
 	Raytracer* rt = c->rt;
@@ -352,7 +358,7 @@ void ref_render_seeded(RefCtx* c, float* imagedouble, float* sample_count) {
 // threads; returns wall seconds of the call (includes its prepare_render + tone-map).
 double ref_time_render_nopreviz(RefCtx* c, int threads, float* imagedouble_out) {
 	Raytracer* rt = c->rt;
-	omp_set_num_threads(threads);
+	omp_set_num_threads(threads > 64 ? 64 : threads);
 	rt->clear_image();
 	auto t0 = std::chrono::steady_clock::now();
 	rt->render_image_nopreviz();
@@ -362,7 +368,7 @@ double ref_time_render_nopreviz(RefCtx* c, int threads, float* imagedouble_out) 
 }
 double ref_time_render_image(RefCtx* c, int threads, float* imagedouble_out, float* sample_count_out) {
 	Raytracer* rt = c->rt;
-	omp_set_num_threads(threads);
+	omp_set_num_threads(threads > 64 ? 64 : threads);
 	rt->clear_image();
 	rt->stopped = false;
 	auto t0 = std::chrono::steady_clock::now();
@@ -373,6 +379,6 @@ double ref_time_render_image(RefCtx* c, int threads, float* imagedouble_out, flo
 	return std::chrono::duration<double>(t1 - t0).count();
 }
 
-int ref_max_threads() { return omp_get_max_threads(); }
+int ref_max_threads() { return ref_thread_cap(); }
 
 }  // extern "C"

@@ -172,6 +172,8 @@ struct mipt_ctx {
 	void* blk_buf = nullptr; size_t blk_buf_bytes = 0;
 	DCounters* d_cnt = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::vector<hipEvent_t> kev;      // begin/end event pairs around the dominant kernel of each pass
+	unsigned kev_used = 0;
 	mipt_stats stats{};
 	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
 	// size changes, or after mipt_set_option("invalidate_tables", 1))
@@ -227,6 +229,7 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	if (c->d_cnt) hipFree(c->d_cnt);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
+	for (hipEvent_t e : c->kev) hipEventDestroy(e);
 	delete c;
 }
 
@@ -552,6 +555,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	const int nblocks = c->blk_nblocks;
 	memset(&c->stats, 0, sizeof c->stats);
+	c->kev_used = 0;
 	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DCounters), st));
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
 	const int npix_slots = nblocks * 64;
@@ -569,7 +573,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		if (cancel && *cancel) { hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled"); }
 		P.k0 = k0; P.k1 = std::min(ke, k0 + spp_pass);
 		long long total = (long long)npix_slots * (P.k1 - P.k0);
+		while (c->kev.size() < 2 * (size_t)(passes + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
+		HIPCHK(c, hipEventRecord(c->kev[2 * passes], st));
 		hipLaunchKernelGGL(k_render_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->d_scene, R, P, S, c->d_cnt);
+		HIPCHK(c, hipEventRecord(c->kev[2 * passes + 1], st));
 		hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());
 		passes++;
@@ -577,6 +584,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	HIPCHK(c, hipEventRecord(c->ev1, st));
 	c->stats.passes = passes;
+	c->kev_used = passes;
 	return MIPT_OK;
 }
 
@@ -588,8 +596,10 @@ static int collect_stats(mipt_ctx* c) {
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder
 	float ms = 0;
 	if (c->stats.passes && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.render_ms = ms;
-	c->stats.traverse_ms = c->stats.render_ms;
-	c->stats.traverse_launches = c->stats.passes;
+	double kms = 0;
+	for (unsigned k = 0; k < c->kev_used; k++) { float t = 0; if (hipEventElapsedTime(&t, c->kev[2 * k], c->kev[2 * k + 1]) == hipSuccess) kms += t; }
+	c->stats.traverse_ms = kms;
+	c->stats.traverse_launches = c->kev_used;
 	return MIPT_OK;
 }
 
