@@ -172,13 +172,16 @@ def main():
     sync()
     t0 = time.perf_counter()
     rays = paths = 0
-    kern_ms = 0.0
-    launches = 0
+    kern_ms = sh_ms = shade_ms = 0.0
+    launches = sh_launches = 0
     rays_c = rays_s = 0
+    pipeline = -1
     for s in range(args.warmup, args.warmup + args.steps):
         st = step(s)
         rays_c += st["rays_closest"]; rays_s += st["rays_shadow"]; paths += st["paths"]
         kern_ms += st["traverse_ms"]; launches += st["traverse_launches"]
+        sh_ms += st["shadow_ms"]; sh_launches += st["shadow_launches"]; shade_ms += st["shade_ms"]
+        pipeline = st["pipeline"]
     if world > 1:
         dist.all_reduce(accum, op=dist.ReduceOp.SUM)     # the framebuffer reduce (RCCL over xGMI)
     sync()
@@ -202,20 +205,31 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {mesh.ntri}-triangle diffuse blob, {args.width}x{args.height}, "
                                    f"{SPP_PER_STEP * args.steps} spp timed ({SPP_PER_STEP} spp/step), depth {cfg.nb_bounces}, Phong BRDF",
-                       "parallelism": f"tiles32x{world}", "pipeline": int(args.pipeline)},
+                       "parallelism": f"tiles32x{world}", "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
             "prepare_s": t_prepare, "finite": finite,
         }
         if world == 1 and not args.pmc:
             ob = oracle_bytes_per_ray(mesh, cfg)
             my_launches = max(1, launches)
-            bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
             ms_per_launch = kern_ms / my_launches
+            if pipeline == 0:     # one kernel casts both kinds of rays
+                kernel = "k_render_paths"
+                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
+            else:                 # dominant kernel = closest-hit traversal
+                kernel = "k_wf_extend"
+                bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "traffic": None, "kernel": "k_render_paths" if args.pipeline <= 0 else "k_extend",
+                               "traffic": None, "kernel": kernel,
                                "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
-                               "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"]}
+                               "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],
+                               "rays_per_launch": (rays_c if pipeline else rays_c + rays_s) / my_launches}
+            if pipeline == 1 and sh_launches:
+                sh_ach = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
+                out["roofline_shadow_kernel"] = {"kernel": "k_wf_shadow", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,
+                                                 "launches": int(sh_launches)}
+                out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(mesh, cfg, ob["rays_per_path"])
         print(json.dumps(out))

@@ -164,9 +164,14 @@ typedef struct mipt_stats {
 	uint64_t mesh_casts_closest;  /* TriMesh::intersection calls */
 	uint64_t mesh_casts_shadow;   /* TriMesh::intersection_shadow calls */
 	double   render_ms;           /* HIP-event time of the whole call on its stream */
-	double   traverse_ms;         /* HIP-event time summed over the traversal kernel launches */
+	double   traverse_ms;         /* HIP-event time summed over the launches of the dominant kernel:
+	                                 pipeline 0: the per-path kernel; pipeline 1: the closest-hit (extend) kernel */
+	double   shadow_ms;           /* pipeline 1: summed over the any-hit (shadow) kernel launches */
+	double   shade_ms;            /* pipeline 1: summed over generate + shade launches */
 	uint32_t traverse_launches;
+	uint32_t shadow_launches;
 	uint32_t passes;
+	uint32_t pipeline;            /* pipeline that produced these numbers */
 } mipt_stats;
 
 typedef void (*mipt_progress_cb)(void* user, int samples_done, int samples_total);
@@ -219,6 +224,7 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
 
 /* Tunables (name/value); unknown names return MIPT_ERR_INVALID.
  *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default)
+ *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
  *   "paths_per_pass"  upper bound on paths in flight per pass */
 int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);
 

@@ -27,14 +27,21 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v
 	if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
 }
 
+#define MIPT_BLOCK 256
+// traversal stack of the calling lane, in the block's LDS slab
+#define MIPT_DECLARE_LDS_STACK(stk) \
+	__shared__ uint2 lds_stack_[MIPT_LDS_STACK * MIPT_BLOCK]; \
+	LdsStack stk; stk.base = lds_stack_ + threadIdx.x; stk.stride = MIPT_BLOCK;
+
 // Scene::intersection on a ray list (mipt_trace).
-__global__ void __launch_bounds__(256) k_trace(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, int n, mipt_hit* __restrict__ hits) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_trace(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, int n, mipt_hit* __restrict__ hits) {
+	MIPT_DECLARE_LDS_STACK(stk);
 	int q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n) return;
 	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
 	Hit h; f3 P = mk3(0, 0, 0); Mat m;
 	m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
-	bool hit = scene_intersect(sc, r, h, P, m);
+	bool hit = scene_intersect(sc, r, h, P, m, stk);
 	mipt_hit o;
 	o.has_inter = hit ? 1 : 0; o.object_id = hit ? h.obj : -1; o.triangle_id = hit ? h.tri : -1; o.t = h.t;
 	o.P[0] = P.x; o.P[1] = P.y; o.P[2] = P.z;
@@ -46,27 +53,29 @@ __global__ void __launch_bounds__(256) k_trace(const DScene* __restrict__ sc, co
 }
 
 // Scene::intersection_shadow on a ray list (mipt_trace_shadow).
-__global__ void __launch_bounds__(256) k_trace_shadow(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, const float* __restrict__ dist, int n, int* __restrict__ occluded) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_trace_shadow(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, const float* __restrict__ dist, int n, int* __restrict__ occluded) {
+	MIPT_DECLARE_LDS_STACK(stk);
 	int q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n) return;
 	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
-	occluded[q] = scene_occluded(sc, r, dist[q]) ? 1 : 0;
+	occluded[q] = scene_occluded(sc, r, dist[q], stk) ? 1 : 0;
 }
 
-// The whole getColor loop of one (pixel, sample) in one thread.
-__device__ __forceinline__ f3 trace_path(const DScene* __restrict__ sc, const DRender& R, int i, int j, int k, float& dx, float& dy, unsigned& n_closest, unsigned& n_shadow) {
+// The whole getColor loop of one (pixel, sample) in one thread (pipeline 0).
+template <class STK>
+__device__ __forceinline__ f3 trace_path(const DScene* __restrict__ sc, const DRender& R, int i, int j, int k, float& dx, float& dy, unsigned& n_closest, unsigned& n_shadow, STK& stk) {
 	PathState ps;
 	path_begin(R, i, j, k, ps, dx, dy);
 	const int pix = i * R.W + j;
 	while (path_alive(ps)) {
 		Hit h; f3 P = mk3(0, 0, 0); Mat m;
-		bool hit = scene_intersect(sc, ps.ray, h, P, m);
+		bool hit = scene_intersect(sc, ps.ray, h, P, m, stk);
 		n_closest++;
 		ShadowRequest sh; f3 wv;
 		bool cont = path_vertex(sc, R, ps, hit, h, P, m, pix, k, sh, wv);
 		if (sh.diffuse) {
 			f3 contrib = sh.contrib;
-			if (sh.cast) { n_shadow++; if (scene_occluded(sc, sh.ray, sh.dist)) contrib = mk3(0, 0, 0); }
+			if (sh.cast) { n_shadow++; if (scene_occluded(sc, sh.ray, sh.dist, stk)) contrib = mk3(0, 0, 0); }
 			else contrib = mk3(0, 0, 0);
 			ps.color = ps.color + wv * contrib;                           // Raytracer.cpp:566
 		}
@@ -76,23 +85,27 @@ __device__ __forceinline__ f3 trace_path(const DScene* __restrict__ sc, const DR
 }
 
 // Parity hook (mipt_sample_radiance): arbitrary pixel list, samples [k0,k1), no splat.
-__global__ void __launch_bounds__(256) k_sample_radiance(const DScene* __restrict__ sc, DRender R, const int* __restrict__ ij, int npix, int k0, int k1,
-                                                         float* __restrict__ out_rgb, float* __restrict__ out_dxdy) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_sample_radiance(const DScene* __restrict__ sc, DRender R, const int* __restrict__ ij, int npix, int k0, int k1,
+                                                                float* __restrict__ out_rgb, float* __restrict__ out_dxdy) {
+	MIPT_DECLARE_LDS_STACK(stk);
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	int nk = k1 - k0;
 	if (tid >= (long long)npix * nk) return;
 	int q = (int)(tid / nk), k = k0 + (int)(tid % nk);
 	float dx, dy; unsigned a = 0, b = 0;
-	f3 c = trace_path(sc, R, ij[2 * q], ij[2 * q + 1], k, dx, dy, a, b);
+	f3 c = trace_path(sc, R, ij[2 * q], ij[2 * q + 1], k, dx, dy, a, b, stk);
 	out_rgb[3 * tid] = c.x; out_rgb[3 * tid + 1] = c.y; out_rgb[3 * tid + 2] = c.z;
 	if (out_dxdy) { out_dxdy[2 * tid] = dx; out_dxdy[2 * tid + 1] = dy; }
 }
 
-// Pipeline 0: one thread per path.  A wave = one 8x8 pixel block at one sample index, so the
-// primary rays of a wave are coherent.  Results go to the pass's per-sample buffers.
-struct DSamples { float *r, *g, *b, *dx, *dy; };
+// Per-sample results of one pass: radiance (xyz) and sensor jitter, indexed by path id
+// = (k - k0) * npix_slots + slot.
+struct DSamples { float4* col; float2* dxdy; };
 
-__global__ void __launch_bounds__(256) k_render_paths(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt) {
+// Pipeline 0: one thread per path.  A wave = one 8x8 pixel block at one sample index, so the
+// primary rays of a wave are coherent.
+__global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt) {
+	MIPT_DECLARE_LDS_STACK(stk);
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	unsigned n_closest = 0, n_shadow = 0, n_paths = 0;
@@ -103,8 +116,8 @@ __global__ void __launch_bounds__(256) k_render_paths(const DScene* __restrict__
 		int i = ps.blocks[2 * blk] + (in >> 3), j = ps.blocks[2 * blk + 1] + (in & 7);
 		if (i < R.H && j < R.W) {
 			float dx, dy;
-			f3 c = trace_path(sc, R, i, j, ps.k0 + kk, dx, dy, n_closest, n_shadow);
-			out.r[tid] = c.x; out.g[tid] = c.y; out.b[tid] = c.z; out.dx[tid] = dx; out.dy[tid] = dy;
+			f3 c = trace_path(sc, R, i, j, ps.k0 + kk, dx, dy, n_closest, n_shadow, stk);
+			out.col[tid] = make_float4(c.x, c.y, c.z, 0.f); out.dxdy[tid] = make_float2(dx, dy);
 			n_paths = 1;
 		}
 	}
@@ -146,14 +159,17 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 			float denom1 = (float)((double)ratio / ((double)(R.sigma_filter * R.sigma_filter) * 2. * MIPT_PI));
 			for (int kk = 0; kk < nk; kk++) {
 				size_t s = (size_t)kk * ps.npix_slots + slot;
-				float dx = in.dx[s], dy = in.dy[s];
-				float w = (float)(fast_exp((double)(-(sqr((float)(i2 - i) - dy) + sqr((float)(j2 - j) - dx)) * denom2)) * (double)denom1);
-				ar += in.r[s] * w; ag += in.g[s] * w; ab += in.b[s] * w; aw += w;
+				float2 jit = in.dxdy[s];
+				float4 c = in.col[s];
+				float w = (float)(fast_exp((double)(-(sqr((float)(i2 - i) - jit.y) + sqr((float)(j2 - j) - jit.x)) * denom2)) * (double)denom1);
+				ar += c.x * w; ag += c.y * w; ab += c.z * w; aw += w;
 			}
 		}
 	}
 	if (any) { acc_rgb[0] = ar; acc_rgb[1] = ag; acc_rgb[2] = ab; *acc_w = aw; }
 }
+
+#include "mipt_wavefront.h"
 
 // =====================================================================================
 // host side: context, upload, C-ABI
@@ -172,15 +188,17 @@ struct mipt_ctx {
 	void* blk_buf = nullptr; size_t blk_buf_bytes = 0;
 	DCounters* d_cnt = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	std::vector<hipEvent_t> kev;      // begin/end event pairs around the dominant kernel of each pass
+	std::vector<hipEvent_t> kev;      // begin/end event pairs around the timed kernel launches
+	std::vector<int> kev_kind;        // 0 = dominant (per-path / extend), 1 = shadow, 2 = generate / shade
 	unsigned kev_used = 0;
+	int n_cus = 256;
 	mipt_stats stats{};
 	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
 	// size changes, or after mipt_set_option("invalidate_tables", 1))
 	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; } tab_key;
 	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0; } blk_key;
 	int blk_nblocks = 0;
-	int64_t opt_pipeline = 0;
+	int64_t opt_pipeline = 1;
 	int64_t opt_paths_per_pass = 1 << 24;
 };
 
@@ -208,6 +226,8 @@ extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
 	if (hipSetDevice(c->device) != hipSuccess) { delete c; return MIPT_ERR_NO_DEVICE; }
 	if (hipMalloc((void**)&c->d_cnt, sizeof(DCounters)) != hipSuccess) { delete c; return MIPT_ERR_HIP; }
 	hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
 	*out = c;
 	return MIPT_OK;
 }
@@ -561,22 +581,67 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
 	spp_pass = std::min(spp_pass, ke - kb);
-	size_t pass_paths = (size_t)npix_slots * spp_pass;
-	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, pass_paths * 5 * sizeof(float)))) return rc;
+	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
+	const int pipeline = (int)c->opt_pipeline;
+	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
+	// carve the pass buffer
+	size_t bytes = N * (sizeof(float4) + sizeof(float2));
+	if (pipeline == 1) bytes += N * (7 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(unsigned)) + MIPT_WF_COUNTERS * sizeof(unsigned) + 256;
+	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, bytes))) return rc;
+	char* base = (char*)c->pass_buf;
+	auto carve = [&](size_t b) { char* r = base; base += (b + 15) & ~(size_t)15; return r; };
 	DSamples S;
-	S.r = (float*)c->pass_buf; S.g = S.r + pass_paths; S.b = S.g + pass_paths; S.dx = S.b + pass_paths; S.dy = S.dx + pass_paths;
+	S.col = (float4*)carve(N * sizeof(float4)); S.dxdy = (float2*)carve(N * sizeof(float2));
+	DWave wf{};
+	if (pipeline == 1) {
+		wf.ray_o = (float4*)carve(N * sizeof(float4)); wf.ray_d = (float4*)carve(N * sizeof(float4));
+		wf.wgt = (float4*)carve(N * sizeof(float4)); wf.hit = (float4*)carve(N * sizeof(float4));
+		wf.sh_o = (float4*)carve(N * sizeof(float4)); wf.sh_d = (float4*)carve(N * sizeof(float4)); wf.sh_c = (float4*)carve(N * sizeof(float4));
+		wf.rng = (uint2*)carve(N * sizeof(uint2));
+		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned));
+		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
+		wf.out = S;
+	}
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
+	c->kev_kind.clear();
+	unsigned nev = 0;
+	auto timed_begin = [&](int kind) -> int {
+		while (c->kev.size() < 2 * (size_t)(nev + 1)) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MIPT_ERR_HIP; c->kev.push_back(e); }
+		c->kev_kind.push_back(kind);
+		return hipEventRecord(c->kev[2 * nev], st) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP;
+	};
+	auto timed_end = [&]() -> int { int r = hipEventRecord(c->kev[2 * nev + 1], st) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP; nev++; return r; };
+	const unsigned persistent_blocks = (unsigned)c->n_cus * 8u;   // >= resident capacity of every stage kernel
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
 		if (cancel && *cancel) { hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled"); }
 		P.k0 = k0; P.k1 = std::min(ke, k0 + spp_pass);
 		long long total = (long long)npix_slots * (P.k1 - P.k0);
-		while (c->kev.size() < 2 * (size_t)(passes + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
-		HIPCHK(c, hipEventRecord(c->kev[2 * passes], st));
-		hipLaunchKernelGGL(k_render_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c->d_scene, R, P, S, c->d_cnt);
-		HIPCHK(c, hipEventRecord(c->kev[2 * passes + 1], st));
+		const unsigned grid_all = (unsigned)((total + MIPT_BLOCK - 1) / MIPT_BLOCK);
+		if (pipeline == 0) {
+			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+			hipLaunchKernelGGL(k_render_paths, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt);
+			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+		} else {
+			HIPCHK(c, hipMemsetAsync(wf.counters, 0, MIPT_WF_COUNTERS * sizeof(unsigned), st));
+			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
+			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, R, P, wf, c->d_cnt);
+			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+			const unsigned grid_p = std::min(persistent_blocks, grid_all);
+			for (int b = 0; b < p->nb_bounces; b++) {
+				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+				hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
+				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
+				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, c->d_cnt);
+				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
+				hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
+				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+			}
+		}
 		hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());
 		passes++;
@@ -584,7 +649,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	HIPCHK(c, hipEventRecord(c->ev1, st));
 	c->stats.passes = passes;
-	c->kev_used = passes;
+	c->stats.pipeline = (uint32_t)pipeline;
+	c->kev_used = nev;
 	return MIPT_OK;
 }
 
@@ -596,10 +662,14 @@ static int collect_stats(mipt_ctx* c) {
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder
 	float ms = 0;
 	if (c->stats.passes && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.render_ms = ms;
-	double kms = 0;
-	for (unsigned k = 0; k < c->kev_used; k++) { float t = 0; if (hipEventElapsedTime(&t, c->kev[2 * k], c->kev[2 * k + 1]) == hipSuccess) kms += t; }
-	c->stats.traverse_ms = kms;
-	c->stats.traverse_launches = c->kev_used;
+	double ms_kind[3] = {0, 0, 0}; unsigned n_kind[3] = {0, 0, 0};
+	for (unsigned k = 0; k < c->kev_used; k++) {
+		float t = 0;
+		if (hipEventElapsedTime(&t, c->kev[2 * k], c->kev[2 * k + 1]) == hipSuccess) { ms_kind[c->kev_kind[k]] += t; n_kind[c->kev_kind[k]]++; }
+	}
+	c->stats.traverse_ms = ms_kind[0]; c->stats.traverse_launches = n_kind[0];
+	c->stats.shadow_ms = ms_kind[1]; c->stats.shadow_launches = n_kind[1];
+	c->stats.shade_ms = ms_kind[2];
 	return MIPT_OK;
 }
 

@@ -154,9 +154,30 @@ MIPT_DEV bool alpha_rejects(const DObject& o, int i, float alpha, float beta, fl
 // we continue directly into the near child instead of pushing and re-popping it (equivalent: t
 // does not change between its push and its pop), so only far children are stored.
 #define MIPT_STACK_DEPTH 48
-struct TravStack {
+struct ScratchStack {            // private (scratch) memory: any occupancy, slower pops
 	uint32_t ref[MIPT_STACK_DEPTH];
 	float tnear[MIPT_STACK_DEPTH];
+	MIPT_DEV void push(int sp, uint32_t r, float t) { ref[sp] = r; tnear[sp] = t; }
+	MIPT_DEV void pop(int sp, uint32_t& r, float& t) const { r = ref[sp]; t = tnear[sp]; }
+};
+// LDS-resident stack: entry sp of a lane lives at lds[sp * blockDim.x + threadIdx.x] (one 8-byte
+// word, conflict-free for ds_read/write_b64 when the lanes of a group use the same sp).  Entries
+// beyond MIPT_LDS_STACK spill to a small private array that is normally never touched.
+#define MIPT_LDS_STACK 16
+#define MIPT_SPILL_STACK (MIPT_STACK_DEPTH - MIPT_LDS_STACK)
+struct LdsStack {
+	uint2* base;                  // &lds[threadIdx.x]
+	int stride;                   // blockDim.x
+	uint32_t sref[MIPT_SPILL_STACK];
+	float stn[MIPT_SPILL_STACK];
+	MIPT_DEV void push(int sp, uint32_t r, float t) {
+		if (sp < MIPT_LDS_STACK) base[sp * stride] = make_uint2(r, __float_as_uint(t));
+		else { sref[sp - MIPT_LDS_STACK] = r; stn[sp - MIPT_LDS_STACK] = t; }
+	}
+	MIPT_DEV void pop(int sp, uint32_t& r, float& t) const {
+		if (sp < MIPT_LDS_STACK) { uint2 e = base[sp * stride]; r = e.x; t = __uint_as_float(e.y); }
+		else { r = sref[sp - MIPT_LDS_STACK]; t = stn[sp - MIPT_LDS_STACK]; }
+	}
 };
 
 struct TravCounters { uint32_t box, node, tri; };
@@ -166,9 +187,9 @@ struct TravCounters { uint32_t box, node, tri; };
 // local frame.  Closest: returns whether a triangle with t < cur_best_t exists, and t / triangle /
 // barycentrics of the first one reaching the minimum.  Shadow: returns the reference's
 // has_inter, with t of the last accepted triangle (the caller compares it with 0.999*dist).
-template <bool SHADOW>
+template <bool SHADOW, class STK>
 MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, float dist_light,
-                            float& t_out, int& tri_out, float& beta_out, float& gamma_out) {
+                            float& t_out, int& tri_out, float& beta_out, float& gamma_out, STK& stk) {
 	float t = cur_best_t;
 	bool has_inter = false;
 	f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);      // 1./d narrowed to float == 1.f/d
@@ -178,7 +199,6 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 	if (t_root > cur_best_t) return false;
 	if (SHADOW && t_root > dist_light) return false;
 
-	TravStack stk;
 	int sp = 0;
 	uint32_t cur = o.root_ref;
 	bool have = true;
@@ -188,8 +208,9 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 		if (!have) {
 			if (sp == 0) break;
 			--sp;
-			cur = stk.ref[sp];
-			if (stk.tnear[sp] > t) continue;                 // :1160-1163
+			float tn;
+			stk.pop(sp, cur, tn);
+			if (tn > t) continue;                            // :1160-1163
 		}
 		have = false;
 		if (!(cur & MIPT_LEAF_BIT)) {
@@ -208,8 +229,8 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 				goright = box_test<true>(rmin, rmax, org, invd, sx, sy, sz, tr) && (tr < t);
 			}
 			if (goleft && goright) {
-				if (tl < tr) { stk.ref[sp] = rref; stk.tnear[sp] = tr; sp++; cur = lref; }
-				else { stk.ref[sp] = lref; stk.tnear[sp] = tl; sp++; cur = rref; }
+				if (tl < tr) { stk.push(sp, rref, tr); sp++; cur = lref; }
+				else { stk.push(sp, lref, tl); sp++; cur = rref; }
 				have = true;
 			} else if (goleft) { cur = lref; have = true; }
 			else if (goright) { cur = rref; have = true; }
@@ -321,7 +342,8 @@ MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
 // it loops and copies it on every improvement; here the winner's material is evaluated once
 // after the loop from (object, t, triangle, barycentrics), which yields the same values for every
 // field its intersection() routine writes.
-MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat) {
+template <class STK>
+MIPT_DEV bool scene_closest(const DScene* __restrict__ sc, Ray r, Hit& h, STK& stk) {
 	h.obj = -1; h.tri = -1;
 	float min_t = __int_as_float(0x7f800000);          // min_t = 1E99 narrowed: +inf
 	h.beta = 0; h.gamma = 0;
@@ -334,15 +356,20 @@ MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& 
 		bool hit;
 		if (o.type == 1) hit = sphere_test(o, org, d, t);
 		else if (o.type == 2) hit = plane_test(o, org, d, t);
-		else hit = mesh_traverse<false>(o, org, d, min_t, 0.f, t, tri, b, g);
+		else hit = mesh_traverse<false>(o, org, d, min_t, 0.f, t, tri, b, g, stk);
 		if (hit && t < min_t) { min_t = t; h.obj = i; h.tri = tri; h.beta = b; h.gamma = g; }
 	}
 	h.t = min_t;
-	if (h.obj < 0) return false;
+	return h.obj >= 0;
+}
+
+// World-space hit point and MaterialValues of the winning object (tail of Scene::intersection,
+// Geometry.cpp:668-684, plus the winner's own material code).
+MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f3& P, Mat& mat) {
 	const DObject& o = sc->obj[h.obj];
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
-	f3 Pl = org + min_t * d;                             // P = d.origin + t*d.direction in the object's frame
+	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
 	if (o.type == 1) sphere_material(o, Pl, mat);
 	else if (o.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
 	else {
@@ -359,11 +386,18 @@ MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& 
 	}
 	P = xf_point(o.trans, Pl);
 	mat.shadingN = fast_normalize(xf_rot(o.rot, mat.shadingN));
+}
+
+template <class STK>
+MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat, STK& stk) {
+	if (!scene_closest(sc, r, h, stk)) return false;
+	hit_material(sc, r, h, P, mat);
 	return true;
 }
 
 // ---------------------------------------------------------------- Scene::intersection_shadow (Geometry.cpp:691-744)
-MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_light) {
+template <class STK>
+MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_light, STK& stk) {
 	const int nobj = sc->nobj;
 	const float inf = __int_as_float(0x7f800000);
 	bool occluded = false;
@@ -376,7 +410,7 @@ MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_li
 		bool hit;
 		if (o.type == 1) hit = sphere_test(o, org, d, t);
 		else if (o.type == 2) hit = plane_test(o, org, d, t);
-		else hit = mesh_traverse<true>(o, org, d, inf, dist_light, t, tri, b, g);
+		else hit = mesh_traverse<true>(o, org, d, inf, dist_light, t, tri, b, g, stk);
 		if (hit && ((double)t < (double)dist_light * 0.999)) occluded = true;
 	}
 	return occluded;

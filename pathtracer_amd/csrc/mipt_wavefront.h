@@ -1,0 +1,187 @@
+// mipt_wavefront.h — pipeline 1: the getColor loop as a wavefront of per-stage kernels over
+// queues of path ids (included by mipt.hip after the common kernels).
+//
+//   generate -> [ extend (closest hit) -> shade (+NEE request, continuation) -> shadow (any hit) ] x depth
+//
+// Why: the per-path kernel needs ~185 VGPRs (2 waves/SIMD); the traversal alone needs ~75, so the
+// split triples the number of rays in flight per CU while the BVH fetches are outstanding, and
+// paths that ended stop occupying lanes (the queues are compacted with wave-aggregated appends).
+//
+// Path state lives in HBM as float4-packed arrays indexed by path id (a path keeps its id for the
+// whole pass, only the id lists are compacted); every stage is a persistent kernel whose waves pull
+// 64-entry chunks from a device-side counter, so the launch geometry does not depend on queue sizes
+// that only the device knows.
+//
+// Float semantics: every stage calls the same device functions as the per-path kernel; the
+// additions into a path's colour happen in the reference's order (emission of vertex b, direct
+// term of vertex b, then vertex b+1) because shadow(b) precedes shade(b+1) on the stream.
+#pragma once
+
+struct DWave {
+	float4 *ray_o, *ray_d;      // current ray
+	float4* wgt;                // xyz = path weight, w = bits: depth | show_lights << 16
+	uint2* rng;                 // pcg32 state
+	float4* hit;                // x = t, y = beta, z = gamma, w = bits: packed object / triangle
+	float4 *sh_o, *sh_d, *sh_c; // shadow request: origin (w = dist_light), direction, weight*contrib
+	unsigned* list[2];          // path ids to extend at even / odd depth
+	unsigned* list_sh;          // path ids with a pending shadow ray
+	unsigned* counters;         // per depth b: [4b] n_extend, [4b+1] extend head, [4b+2] n_shadow, [4b+3] shadow head; then shade heads
+	DSamples out;
+};
+#define MIPT_WF_MAX_DEPTH 255
+#define MIPT_WF_COUNTERS (4 * (MIPT_WF_MAX_DEPTH + 2) + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_HIT_MISS 0xffffffffu
+#define MIPT_HIT_NOTRI 0x07ffffffu
+
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave-aggregated append of `id` for the lanes with pred set (order inside a wave is kept)
+__device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned* __restrict__ count, bool pred, unsigned id) {
+	unsigned long long m = __ballot(pred);
+	if (m == 0) return;
+	unsigned lane = lane_id();
+	unsigned n = (unsigned)__popcll(m);
+	unsigned prefix = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+	int leader = __ffsll((long long)m) - 1;
+	unsigned base = 0;
+	if ((int)lane == leader) base = atomicAdd(count, n);
+	base = __shfl(base, leader, 64);
+	if (pred) list[base + prefix] = id;
+}
+
+// next 64-entry chunk of a queue of n entries; returns false when the queue is drained
+__device__ __forceinline__ bool queue_pull(unsigned* __restrict__ head, unsigned n, unsigned& idx, bool& active) {
+	unsigned base = 0;
+	unsigned lane = lane_id();
+	if (lane == 0) base = atomicAdd(head, 64u);
+	base = __builtin_amdgcn_readfirstlane(base);
+	if (base >= n) return false;
+	idx = base + lane;
+	active = idx < n;
+	return true;
+}
+
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt) {
+	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
+	bool valid = false, alive = false;
+	if (tid < total) {
+		int kk = (int)(tid / ps.npix_slots);
+		int slot = (int)(tid % ps.npix_slots);
+		int blk = slot >> 6, in = slot & 63;
+		int i = ps.blocks[2 * blk] + (in >> 3), j = ps.blocks[2 * blk + 1] + (in & 7);
+		if (i < R.H && j < R.W) {
+			valid = true;
+			PathState p; float dx, dy;
+			path_begin(R, i, j, ps.k0 + kk, p, dx, dy);
+			wf.out.col[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+			wf.out.dxdy[tid] = make_float2(dx, dy);
+			alive = path_alive(p);
+			if (alive) {
+				wf.ray_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
+				wf.ray_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
+				wf.wgt[tid] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float((unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
+				wf.rng[tid] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
+			}
+		}
+	}
+	queue_push(wf.list[0], &wf.counters[0], alive, (unsigned)tid);
+	wave_add(&cnt->paths, valid ? 1u : 0u);
+}
+
+// extend: Scene::intersection without the material (closest object / triangle / t / barycentrics)
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restrict__ sc, DWave wf, int b) {
+	MIPT_DECLARE_LDS_STACK(stk);
+	const unsigned n = wf.counters[4 * b];
+	unsigned* head = &wf.counters[4 * b + 1];
+	const unsigned* __restrict__ list = wf.list[b & 1];
+	unsigned idx; bool active;
+	while (queue_pull(head, n, idx, active)) {
+		if (!active) continue;
+		unsigned id = list[idx];
+		float4 o = wf.ray_o[id], d = wf.ray_d[id];
+		Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
+		Hit h;
+		bool hit = scene_closest(sc, r, h, stk);
+		unsigned packed = hit ? (((unsigned)h.obj << 27) | (h.tri < 0 ? MIPT_HIT_NOTRI : (unsigned)h.tri)) : MIPT_HIT_MISS;
+		wf.hit[id] = make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed));
+	}
+}
+
+// shade: material of the hit, emission, next-event-estimation request, continuation sampling
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, DCounters* __restrict__ cnt) {
+	const unsigned n = wf.counters[4 * b];
+	unsigned* head = &wf.counters[4 * (MIPT_WF_MAX_DEPTH + 2) + b];
+	const unsigned* __restrict__ list = wf.list[b & 1];
+	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
+	unsigned n_closest = 0, n_shadow = 0;
+	unsigned idx; bool active;
+	while (queue_pull(head, n, idx, active)) {
+		bool cont = false, cast = false;
+		unsigned id = 0;
+		if (active) {
+			id = list[idx];
+			n_closest++;
+			float4 o = wf.ray_o[id], d = wf.ray_d[id], w = wf.wgt[id], hr = wf.hit[id], col = wf.out.col[id];
+			uint2 rs = wf.rng[id];
+			PathState p;
+			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
+			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
+			p.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+			unsigned fl = __float_as_uint(w.w);
+			p.depth = (int)(fl & 0xffffu); p.show_lights = (fl & 0x10000u) != 0;
+			unsigned packed = __float_as_uint(hr.w);
+			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
+			bool has_inter = packed != MIPT_HIT_MISS;
+			h.obj = has_inter ? (int)(packed >> 27) : -1;
+			h.tri = has_inter ? (((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI)) : -1;
+			f3 P = mk3(0, 0, 0); Mat m;
+			m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
+			if (has_inter) hit_material(sc, p.ray, h, P, m);
+			// pixel of this path (for the per-pixel Cranley-Patterson rotation) and its sample index
+			int kk = (int)(id / (unsigned)ps.npix_slots), slot = (int)(id % (unsigned)ps.npix_slots);
+			int blk = slot >> 6, in = slot & 63;
+			int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
+			ShadowRequest sh; f3 wv;
+			cont = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			wf.out.col[id] = make_float4(p.color.x, p.color.y, p.color.z, 0.f);
+			if (sh.diffuse && sh.cast) {
+				cast = true; n_shadow++;
+				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
+				wf.sh_o[id] = make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist);
+				wf.sh_d[id] = make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f);
+				wf.sh_c[id] = make_float4(pc.x, pc.y, pc.z, 0.f);
+			}
+			cont = cont && path_alive(p);                             // Raytracer.cpp:240-241 at the top of the next iteration
+			if (cont) {
+				wf.ray_o[id] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
+				wf.ray_d[id] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
+				wf.wgt[id] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float((unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
+				wf.rng[id] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
+			}
+		}
+		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast, id);
+		queue_push(next, &wf.counters[4 * (b + 1)], cont, id);
+	}
+	wave_add(&cnt->rays_closest, n_closest);
+	wave_add(&cnt->rays_shadow, n_shadow);
+}
+
+// shadow: Scene::intersection_shadow; a visible light sample adds weight*contrib to the path colour
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restrict__ sc, DWave wf, int b) {
+	MIPT_DECLARE_LDS_STACK(stk);
+	const unsigned n = wf.counters[4 * b + 2];
+	unsigned* head = &wf.counters[4 * b + 3];
+	const unsigned* __restrict__ list = wf.list_sh;
+	unsigned idx; bool active;
+	while (queue_pull(head, n, idx, active)) {
+		if (!active) continue;
+		unsigned id = list[idx];
+		float4 o = wf.sh_o[id], d = wf.sh_d[id];
+		Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
+		if (!scene_occluded(sc, r, o.w, stk)) {
+			float4 c = wf.out.col[id], pc = wf.sh_c[id];
+			wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+		}
+	}
+}

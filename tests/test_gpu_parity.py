@@ -48,8 +48,7 @@ def test_rays_bit_exact(name):
 
 
 @pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False)])
-@pytest.mark.parametrize("pipeline", [0])
-def test_per_sample_radiance(name, exact, pipeline):
+def test_per_sample_radiance(name, exact):
     g = load_golden(f"scene_{name}.npz")
     rt, (mesh, cfg, oid) = gpu(name)
     rgb, dxdy = rt.sample_radiance(all_pixels(cfg), 0, cfg.spp)
@@ -68,13 +67,13 @@ def test_per_sample_radiance(name, exact, pipeline):
 
 
 @pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False)])
-@pytest.mark.parametrize("pipeline", [0])
+@pytest.mark.parametrize("pipeline", [0, 1])
 def test_rendered_image(name, exact, pipeline):
     g = load_golden(f"scene_{name}.npz")
     rt, (mesh, cfg, oid) = gpu(name, pipeline=pipeline)
     img, cnt = rt.render()
     st = rt.stats()
-    assert st["paths"] == cfg.W * cfg.H * cfg.spp
+    assert st["paths"] == cfg.W * cfg.H * cfg.spp and st["pipeline"] == pipeline
     assert_bits(cnt, g["count"], "splat weights")
     err = np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max()
     print(f"{name}: per-pixel L_inf {err:.3e}; rays closest {st['rays_closest']} shadow {st['rays_shadow']}")
@@ -83,10 +82,11 @@ def test_rendered_image(name, exact, pipeline):
     assert err < TOL
 
 
-def test_c0_full_image():
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_c0_full_image(pipeline):
     """BASELINE.json configs[0]: 12-triangle Cornell scene, 256x256, 64 spp, depth 4."""
     g = load_golden("c0_image.npz")
-    rt, (mesh, cfg, oid) = gpu("c0full")
+    rt, (mesh, cfg, oid) = gpu("c0full", pipeline=pipeline)
     img, cnt = rt.render()
     err = np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max()
     print(f"C0 per-pixel L_inf {err:.3e}")
@@ -94,10 +94,22 @@ def test_c0_full_image():
     assert_bits(img, g["image"], "C0 image")
 
 
-def test_multi_pass_and_partition_sum():
+def test_pipelines_agree_on_ray_counts():
+    """Both schedulers cast exactly the rays the reference's loop casts."""
+    counts = []
+    for pipeline in (0, 1):
+        rt, (mesh, cfg, oid) = gpu("glass", pipeline=pipeline)
+        img, cnt = rt.render()
+        st = rt.stats()
+        counts.append((st["paths"], st["rays_closest"], st["rays_shadow"], img.tobytes()))
+    assert counts[0] == counts[1]
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_multi_pass_and_partition_sum(pipeline):
     """Several passes and a 3-way tile partition change only the float summation order."""
     g = load_golden("scene_blob32.npz")
-    rt, (mesh, cfg, oid) = gpu("blob32", paths_per_pass=64 * 64)
+    rt, (mesh, cfg, oid) = gpu("blob32", paths_per_pass=64 * 64, pipeline=pipeline)
     img, cnt = rt.render()
     assert rt.stats()["passes"] > 1
     ref = normalised(g["image"], g["count"])
@@ -108,6 +120,7 @@ def test_multi_pass_and_partition_sum():
         r2 = capi.HostRaytracer(device=0)
         r2.set_partition(16, rank, 3)
         setup_scene(r2, "blob32")
+        r2.set_option("pipeline", pipeline)
         i2, c2 = r2.render()
         paths += r2.stats()["paths"]
         acc_i += i2
