@@ -632,10 +632,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const unsigned grid_p = std::min(persistent_blocks, grid_all);
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
+				hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, c->d_cnt);
+				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);

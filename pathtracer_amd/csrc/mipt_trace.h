@@ -200,20 +200,24 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 	if (SHADOW && t_root > dist_light) return false;
 
 	int sp = 0;
+	const uint32_t NONE = 0x7fffffffu;                   // not a valid inner index, no leaf bit
 	uint32_t cur = o.root_ref;
-	bool have = true;
 	const float4* __restrict__ nodes = reinterpret_cast<const float4*>(o.nodes);
-
-	for (;;) {
-		if (!have) {
-			if (sp == 0) break;
+	// next stack entry that is still worth visiting (TriangleMesh.cpp:1160-1163), or NONE
+	auto pop_next = [&]() -> uint32_t {
+		while (sp > 0) {
 			--sp;
-			float tn;
-			stk.pop(sp, cur, tn);
-			if (tn > t) continue;                            // :1160-1163
+			uint32_t r; float tn;
+			stk.pop(sp, r, tn);
+			if (!(tn > t)) return r;
 		}
-		have = false;
-		if (!(cur & MIPT_LEAF_BIT)) {
+		return NONE;
+	};
+	// "while-while" schedule: all lanes of the wave first descend through inner nodes until each
+	// holds a leaf (or is done), then all process their leaves: the two kinds of work, which need
+	// different code, are not interleaved lane by lane.  Per lane the visiting order is unchanged.
+	for (;;) {
+		while (cur != NONE && !(cur & MIPT_LEAF_BIT)) {
 			const float4* q = nodes + 4 * (size_t)cur;
 			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 			f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
@@ -231,24 +235,25 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 			if (goleft && goright) {
 				if (tl < tr) { stk.push(sp, rref, tr); sp++; cur = lref; }
 				else { stk.push(sp, lref, tl); sp++; cur = rref; }
-				have = true;
-			} else if (goleft) { cur = lref; have = true; }
-			else if (goright) { cur = rref; have = true; }
-		} else {
-			int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
-			int count = (int)((cur >> 26) & 31u) + 1;
-			for (int i = first; i < first + count; i++) {
-				float lt, lb, lg;
-				if (tri_test(o.tris + i, org, d, lt, lb, lg)) {
-					if (lt < t) {
-						if (o.alpha_test && alpha_rejects(o, i, 1 - lb - lg, lb, lg)) continue;
-						has_inter = true;
-						t = lt; tri_out = i; beta_out = lb; gamma_out = lg;
-						if (SHADOW && ((double)t < (double)dist_light * 0.999)) { t_out = t; return true; }   // :1309
-					}
+			} else if (goleft) cur = lref;
+			else if (goright) cur = rref;
+			else cur = pop_next();
+		}
+		if (cur == NONE) break;
+		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
+		int count = (int)((cur >> 26) & 31u) + 1;
+		for (int i = first; i < first + count; i++) {
+			float lt, lb, lg;
+			if (tri_test(o.tris + i, org, d, lt, lb, lg)) {
+				if (lt < t) {
+					if (o.alpha_test && alpha_rejects(o, i, 1 - lb - lg, lb, lg)) continue;
+					has_inter = true;
+					t = lt; tri_out = i; beta_out = lb; gamma_out = lg;
+					if (SHADOW && ((double)t < (double)dist_light * 0.999)) { t_out = t; return true; }   // :1309
 				}
 			}
 		}
+		cur = pop_next();
 	}
 	t_out = t;
 	return has_inter;

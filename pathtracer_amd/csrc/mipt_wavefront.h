@@ -35,36 +35,53 @@ struct DWave {
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// wave-aggregated append of `id` for the lanes with pred set (order inside a wave is kept)
-__device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned* __restrict__ count, bool pred, unsigned id) {
-	unsigned long long m = __ballot(pred);
-	if (m == 0) return;
-	unsigned lane = lane_id();
-	unsigned n = (unsigned)__popcll(m);
-	unsigned prefix = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-	int leader = __ffsll((long long)m) - 1;
-	unsigned base = 0;
-	if ((int)lane == leader) base = atomicAdd(count, n);
-	base = __shfl(base, leader, 64);
-	if (pred) list[base + prefix] = id;
+// One same-address atomic costs ~11 ns chip-wide (MI355X_MICROARCH.md "dequeue": one word saturates at
+// ~88 ops/us), so queue traffic is batched: a wave pulls MIPT_WF_UNROLL*64 entries per atomic and
+// appends the survivors of all its sub-chunks with one atomic per destination queue.
+#define MIPT_WF_UNROLL 4
+#define MIPT_WF_CHUNK (64u * MIPT_WF_UNROLL)
+
+// next chunk of a queue of n entries; returns false when the queue is drained
+__device__ __forceinline__ bool queue_pull(unsigned* __restrict__ head, unsigned n, unsigned& base) {
+	unsigned b = 0;
+	if (lane_id() == 0) b = atomicAdd(head, MIPT_WF_CHUNK);
+	base = __builtin_amdgcn_readfirstlane(b);
+	return base < n;
 }
 
-// next 64-entry chunk of a queue of n entries; returns false when the queue is drained
-__device__ __forceinline__ bool queue_pull(unsigned* __restrict__ head, unsigned n, unsigned& idx, bool& active) {
-	unsigned base = 0;
+// wave-aggregated append for the lanes whose bit u of `bits` is set (sub-chunk u of the chunk at
+// `base` of the source list; src == nullptr means the identity list): one atomic for all sub-chunks
+__device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned* __restrict__ count, unsigned bits,
+                                           const unsigned* __restrict__ src, unsigned src_base) {
+	unsigned long long m[MIPT_WF_UNROLL];
+	unsigned total = 0;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) { m[u] = __ballot((bits >> u) & 1u); total += (unsigned)__popcll(m[u]); }
+	if (total == 0) return;
 	unsigned lane = lane_id();
-	if (lane == 0) base = atomicAdd(head, 64u);
+	unsigned base = 0;
+	if (lane == 0) base = atomicAdd(count, total);
 	base = __builtin_amdgcn_readfirstlane(base);
-	if (base >= n) return false;
-	idx = base + lane;
-	active = idx < n;
-	return true;
+	unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+		if ((bits >> u) & 1u) {
+			unsigned idx = src_base + 64u * u + lane;
+			list[base + (unsigned)__popcll(m[u] & below)] = src ? src[idx] : idx;
+		}
+		base += (unsigned)__popcll(m[u]);
+	}
 }
+
+// bit 31 of wgt.w marks a path slot that holds a live path (slots of 8x8 blocks that stick out of
+// the image never do); depth 0 of a pass uses the identity list, so generation needs no queue.
+#define MIPT_WF_VALID 0x80000000u
 
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt) {
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	bool valid = false, alive = false;
+	if (tid < total) wf.wgt[tid] = make_float4(0.f, 0.f, 0.f, 0.f);      // not a live path until proven otherwise
 	if (tid < total) {
 		int kk = (int)(tid / ps.npix_slots);
 		int slot = (int)(tid % ps.npix_slots);
@@ -80,55 +97,64 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 			if (alive) {
 				wf.ray_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
 				wf.ray_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
-				wf.wgt[tid] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float((unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
+				wf.wgt[tid] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
 				wf.rng[tid] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
 			}
 		}
 	}
-	queue_push(wf.list[0], &wf.counters[0], alive, (unsigned)tid);
 	wave_add(&cnt->paths, valid ? 1u : 0u);
 }
 
-// extend: Scene::intersection without the material (closest object / triangle / t / barycentrics)
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restrict__ sc, DWave wf, int b) {
+// extend: Scene::intersection without the material (closest object / triangle / t / barycentrics).
+// Depth 0 walks the identity list of all n0 path slots and skips the dead ones.
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0) {
 	MIPT_DECLARE_LDS_STACK(stk);
-	const unsigned n = wf.counters[4 * b];
+	const unsigned n = b == 0 ? n0 : wf.counters[4 * b];
 	unsigned* head = &wf.counters[4 * b + 1];
 	const unsigned* __restrict__ list = wf.list[b & 1];
-	unsigned idx; bool active;
-	while (queue_pull(head, n, idx, active)) {
-		if (!active) continue;
-		unsigned id = list[idx];
-		float4 o = wf.ray_o[id], d = wf.ray_d[id];
-		Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
-		Hit h;
-		bool hit = scene_closest(sc, r, h, stk);
-		unsigned packed = hit ? (((unsigned)h.obj << 27) | (h.tri < 0 ? MIPT_HIT_NOTRI : (unsigned)h.tri)) : MIPT_HIT_MISS;
-		wf.hit[id] = make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed));
+	unsigned base;
+	while (queue_pull(head, n, base)) {
+#pragma unroll 1
+		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+			unsigned idx = base + 64u * u + lane_id();
+			if (idx >= n) continue;
+			unsigned id = b == 0 ? idx : list[idx];
+			if (b == 0 && !(__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID)) continue;
+			float4 o = wf.ray_o[id], d = wf.ray_d[id];
+			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
+			Hit h;
+			bool hit = scene_closest(sc, r, h, stk);
+			unsigned packed = hit ? (((unsigned)h.obj << 27) | (h.tri < 0 ? MIPT_HIT_NOTRI : (unsigned)h.tri)) : MIPT_HIT_MISS;
+			wf.hit[id] = make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed));
+		}
 	}
 }
 
 // shade: material of the hit, emission, next-event-estimation request, continuation sampling
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, DCounters* __restrict__ cnt) {
-	const unsigned n = wf.counters[4 * b];
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+	const unsigned n = b == 0 ? n0 : wf.counters[4 * b];
 	unsigned* head = &wf.counters[4 * (MIPT_WF_MAX_DEPTH + 2) + b];
 	const unsigned* __restrict__ list = wf.list[b & 1];
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
-	unsigned idx; bool active;
-	while (queue_pull(head, n, idx, active)) {
-		bool cont = false, cast = false;
-		unsigned id = 0;
-		if (active) {
-			id = list[idx];
+	unsigned base;
+	while (queue_pull(head, n, base)) {
+		unsigned cont_bits = 0, cast_bits = 0;
+#pragma unroll 1
+		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+			unsigned idx = base + 64u * u + lane_id();
+			if (idx >= n) continue;
+			unsigned id = b == 0 ? idx : list[idx];
+			float4 w = wf.wgt[id];
+			unsigned fl = __float_as_uint(w.w);
+			if (b == 0 && !(fl & MIPT_WF_VALID)) continue;
 			n_closest++;
-			float4 o = wf.ray_o[id], d = wf.ray_d[id], w = wf.wgt[id], hr = wf.hit[id], col = wf.out.col[id];
+			float4 o = wf.ray_o[id], d = wf.ray_d[id], hr = wf.hit[id], col = wf.out.col[id];
 			uint2 rs = wf.rng[id];
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
 			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
 			p.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
-			unsigned fl = __float_as_uint(w.w);
 			p.depth = (int)(fl & 0xffffu); p.show_lights = (fl & 0x10000u) != 0;
 			unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
@@ -143,25 +169,27 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 			int blk = slot >> 6, in = slot & 63;
 			int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
 			ShadowRequest sh; f3 wv;
-			cont = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			bool c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			wf.out.col[id] = make_float4(p.color.x, p.color.y, p.color.z, 0.f);
 			if (sh.diffuse && sh.cast) {
-				cast = true; n_shadow++;
+				cast_bits |= 1u << u; n_shadow++;
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
 				wf.sh_o[id] = make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist);
 				wf.sh_d[id] = make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f);
 				wf.sh_c[id] = make_float4(pc.x, pc.y, pc.z, 0.f);
 			}
-			cont = cont && path_alive(p);                             // Raytracer.cpp:240-241 at the top of the next iteration
-			if (cont) {
+			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
+			if (c) {
 				wf.ray_o[id] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
 				wf.ray_d[id] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
-				wf.wgt[id] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float((unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
+				wf.wgt[id] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
 				wf.rng[id] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
 			}
+			if (c) cont_bits |= 1u << u;
 		}
-		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast, id);
-		queue_push(next, &wf.counters[4 * (b + 1)], cont, id);
+		const unsigned* src = b == 0 ? nullptr : list;
+		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast_bits, src, base);
+		queue_push(next, &wf.counters[4 * (b + 1)], cont_bits, src, base);
 	}
 	wave_add(&cnt->rays_closest, n_closest);
 	wave_add(&cnt->rays_shadow, n_shadow);
@@ -173,15 +201,19 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restri
 	const unsigned n = wf.counters[4 * b + 2];
 	unsigned* head = &wf.counters[4 * b + 3];
 	const unsigned* __restrict__ list = wf.list_sh;
-	unsigned idx; bool active;
-	while (queue_pull(head, n, idx, active)) {
-		if (!active) continue;
-		unsigned id = list[idx];
-		float4 o = wf.sh_o[id], d = wf.sh_d[id];
-		Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
-		if (!scene_occluded(sc, r, o.w, stk)) {
-			float4 c = wf.out.col[id], pc = wf.sh_c[id];
-			wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+	unsigned base;
+	while (queue_pull(head, n, base)) {
+#pragma unroll 1
+		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+			unsigned idx = base + 64u * u + lane_id();
+			if (idx >= n) continue;
+			unsigned id = list[idx];
+			float4 o = wf.sh_o[id], d = wf.sh_d[id];
+			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
+			if (!scene_occluded(sc, r, o.w, stk)) {
+				float4 c = wf.out.col[id], pc = wf.sh_c[id];
+				wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+			}
 		}
 	}
 }
