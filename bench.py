@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=258, help="blob tessellation (258 -> 133 128 triangles)")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="profiling run: skip the CPU legs")
     return ap.parse_args()
@@ -148,6 +149,9 @@ def main():
     if args.pipeline >= 0:
         rt.set_option("pipeline", args.pipeline)
     rt.set_option("paths_per_pass", args.width * args.height * SPP_PER_STEP)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        rt.set_option(k, int(v))
 
     import ctypes as C
     accum = torch.zeros(args.width * args.height * 4, dtype=torch.float32, device=dev)
@@ -209,6 +213,8 @@ def main():
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
             "prepare_s": t_prepare, "finite": finite,
         }
+        if world == 1 and args.pmc and pipeline == 1:
+            out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
         if world == 1 and not args.pmc:
             ob = oracle_bytes_per_ray(mesh, cfg)
             my_launches = max(1, launches)

@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 }
 
 #include "mipt_wavefront.h"
+#include "mipt_persistent.h"
 
 // =====================================================================================
 // host side: context, upload, C-ABI
@@ -199,6 +200,8 @@ struct mipt_ctx {
 	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0; } blk_key;
 	int blk_nblocks = 0;
 	int64_t opt_pipeline = 1;
+	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
+	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_paths_per_pass = 1 << 24;
 };
 
@@ -257,6 +260,8 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!c || !name) return MIPT_ERR_INVALID;
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
+	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
 }
@@ -287,9 +292,12 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 	return upload(c, h.data(), (size_t)n, dev);
 }
 
+// staging of all meshes' traversal records (one device buffer each)
+struct MeshStaging { std::vector<DFatNode> fat; std::vector<DTriIsect> ti; std::vector<DTriShade> ts; };
+
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
-static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d) {
+static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging& stg) {
 	if (!m || m->n_triangles <= 0 || m->n_nodes <= 0 || !m->nodes || !m->triangleSoup || !m->indices) return fail(c, MIPT_ERR_INVALID, "incomplete mesh description");
 	const int nn = m->n_nodes, nt = m->n_triangles;
 	if ((unsigned)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
@@ -335,9 +343,11 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d) {
 		ts[i].group = m->indices[i].group;
 		if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
 	}
-	if ((rc = upload(c, fat.data(), fat.size(), &d.nodes))) return rc;
-	if ((rc = upload(c, ti.data(), ti.size(), &d.tris))) return rc;
-	if ((rc = upload(c, ts.data(), ts.size(), &d.shade))) return rc;
+	if (stg.ti.size() + ti.size() > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
+	d.node_base = (uint32_t)stg.fat.size(); d.tri_base = (uint32_t)stg.ti.size();
+	stg.fat.insert(stg.fat.end(), fat.begin(), fat.end());
+	stg.ti.insert(stg.ti.end(), ti.begin(), ti.end());
+	stg.ts.insert(stg.ts.end(), ts.begin(), ts.end());
 	d.ntri = nt;
 	d.nuvs = has_uv ? m->n_uvs : 0;
 	d.uvs = nullptr; d.uvidx = nullptr; d.tangent_soup = nullptr;
@@ -359,6 +369,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	memset(&H, 0, sizeof H);
 	H.nobj = s->n_objects;
 	c->n_mesh_objects = 0;
+	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
 		DObject& d = H.obj[i];
@@ -401,7 +412,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 		} else if (o.type == MIPT_OBJ_PLANE) {
 			memcpy(d.A, o.A, 12); memcpy(d.vecN, o.vecN, 12);
 		} else if (o.type == MIPT_OBJ_TRIMESH) {
-			int rc = convert_mesh(c, o.mesh, d);
+			int rc = convert_mesh(c, o.mesh, d, stg);
 			if (rc) return rc;
 			d.alpha_test = 0;
 			if (d.nuvs > 0 && o.n_alphamap > 0) {
@@ -410,8 +421,18 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 			c->n_mesh_objects++;
 		} else return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: type %d is outside the hot path", i, o.type);
 	}
+	const DTriShade* all_shade = nullptr;
+	int rc;
+	if ((rc = upload(c, stg.fat.data(), stg.fat.size(), &H.all_nodes))) return rc;
+	if ((rc = upload(c, stg.ti.data(), stg.ti.size(), &H.all_tris))) return rc;
+	if ((rc = upload(c, stg.ts.data(), stg.ts.size(), &all_shade))) return rc;
+	for (int i = 0; i < s->n_objects; i++) {
+		DObject& d = H.obj[i];
+		if (d.type != MIPT_OBJ_TRIMESH) continue;
+		d.nodes = H.all_nodes + d.node_base; d.tris = H.all_tris + d.tri_base; d.shade = all_shade + d.tri_base;
+	}
 	const DScene* dsc = nullptr;
-	int rc = upload(c, hs.data(), 1, &dsc);
+	rc = upload(c, hs.data(), 1, &dsc);
 	if (rc) return rc;
 	c->d_scene = const_cast<DScene*>(dsc);
 	c->has_scene = true;
@@ -632,13 +653,15 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const unsigned grid_p = std::min(persistent_blocks, grid_all);
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total, (int)c->opt_refill_threshold);
+				else hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, 0u, (int)c->opt_refill_threshold);
+				else hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
 		}
@@ -701,6 +724,14 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	hipFree(d_acc);
 	return rc;
 }
+
+#ifdef MIPT_PROFILE_SIMD
+extern "C" int mipt_debug_simd_profile(unsigned long long* out4, int reset) {
+	if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_simd_prof), 32) != hipSuccess) return MIPT_ERR_HIP;
+	if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 32) != hipSuccess) return MIPT_ERR_HIP; }
+	return MIPT_OK;
+}
+#endif
 
 extern "C" int mipt_get_stats(mipt_ctx* c, mipt_stats* out) {
 	if (!c || !out) return MIPT_ERR_INVALID;

@@ -54,9 +54,10 @@ struct DObject {
 	// Plane
 	float A[3], vecN[3];
 	// TriMesh
-	const DFatNode* nodes;
-	const DTriIsect* tris;
+	const DFatNode* nodes;     // = DScene::all_nodes + node_base (child references are mesh-local)
+	const DTriIsect* tris;     // = DScene::all_tris + tri_base
 	const DTriShade* shade;
+	uint32_t node_base, tri_base;
 	float root_min[3], root_max[3];
 	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
 	int ntri, nuvs;
@@ -69,6 +70,8 @@ struct DObject {
 struct DScene {
 	int nobj;
 	int _pad[3];
+	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
+	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];
 };
 

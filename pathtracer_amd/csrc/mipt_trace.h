@@ -153,6 +153,11 @@ MIPT_DEV bool alpha_rejects(const DObject& o, int i, float alpha, float beta, fl
 // Per-lane traversal stack.  The reference pushes (node, tnear) pairs (TriangleMesh.cpp:1153-1190);
 // we continue directly into the near child instead of pushing and re-popping it (equivalent: t
 // does not change between its push and its pop), so only far children are stored.
+#ifdef MIPT_PROFILE_SIMD
+// diagnostic build only: [0] inner-step wave iterations, [1] active lanes summed, [2] leaf-step wave iterations, [3] active lanes
+__device__ unsigned long long g_simd_prof[4];
+MIPT_DEV unsigned lane_id_() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#endif
 #define MIPT_STACK_DEPTH 48
 struct ScratchStack {            // private (scratch) memory: any occupancy, slower pops
 	uint32_t ref[MIPT_STACK_DEPTH];
@@ -218,6 +223,9 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 	// different code, are not interleaved lane by lane.  Per lane the visiting order is unchanged.
 	for (;;) {
 		while (cur != NONE && !(cur & MIPT_LEAF_BIT)) {
+#ifdef MIPT_PROFILE_SIMD
+			{ unsigned long long m = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[0], 1ull); atomicAdd(&g_simd_prof[1], (unsigned long long)__popcll(m)); } }
+#endif
 			const float4* q = nodes + 4 * (size_t)cur;
 			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 			f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
@@ -240,6 +248,9 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 			else cur = pop_next();
 		}
 		if (cur == NONE) break;
+#ifdef MIPT_PROFILE_SIMD
+		{ unsigned long long m = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[2], 1ull); atomicAdd(&g_simd_prof[3], (unsigned long long)__popcll(m)); } }
+#endif
 		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
 		int count = (int)((cur >> 26) & 31u) + 1;
 		for (int i = first; i < first + count; i++) {
