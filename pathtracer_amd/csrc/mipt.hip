@@ -201,6 +201,7 @@ struct mipt_ctx {
 	int blk_nblocks = 0;
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
+	int64_t opt_inner_min = 16;
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_paths_per_pass = 1 << 24;
 };
@@ -261,6 +262,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
+	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
@@ -653,14 +655,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const unsigned grid_p = std::min(persistent_blocks, grid_all);
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total, (int)c->opt_refill_threshold);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
 				else hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, 0u, (int)c->opt_refill_threshold);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, 0u, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
 				else hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}

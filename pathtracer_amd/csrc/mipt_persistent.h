@@ -66,7 +66,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 }
 
 template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0, int refill_threshold) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
 	MIPT_DECLARE_LDS_STACK(stk);
 	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
@@ -159,9 +159,19 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 		if (__ballot(alive) == 0) { if (drained) break; else continue; }
 
 		// ---- inner-node phase: every live lane descends until it holds a leaf or runs out of nodes
-		if (alive) {
+		//      (the phase also ends when fewer than inner_min lanes are still descending while others
+		//      already wait with a leaf: the stragglers simply resume in the next round)
+		{
 			const bool sx = st.signs & 1u, sy = st.signs & 2u, sz = st.signs & 4u;
-			while (st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT)) {
+			for (;;) {
+				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
+				const unsigned long long mi = __ballot(inner);
+				if (mi == 0) break;
+				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
+				if (!inner) continue;
+#ifdef MIPT_PROFILE_SIMD
+				{ unsigned long long m = __ballot(1); if (lane == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[0], 1ull); atomicAdd(&g_simd_prof[1], (unsigned long long)__popcll(m)); } }
+#endif
 				const float4* q = nodes + 4 * (size_t)(st.node_base + st.cur);
 				float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 				f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
@@ -185,7 +195,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 			}
 		}
 		// ---- leaf phase
-		if (alive && st.cur != MIPT_NONE) {
+		if (alive && st.cur != MIPT_NONE && (st.cur & MIPT_LEAF_BIT)) {
+#ifdef MIPT_PROFILE_SIMD
+			{ unsigned long long m = __ballot(1); if (lane == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[2], 1ull); atomicAdd(&g_simd_prof[3], (unsigned long long)__popcll(m)); } }
+#endif
 			int first = (int)(st.cur & MIPT_LEAF_FIRST_MASK);
 			int count = (int)((st.cur >> 26) & 31u) + 1;
 			bool decided = false;
