@@ -28,14 +28,17 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v
 }
 
 #define MIPT_BLOCK 256
-// traversal stack of the calling lane, in the block's LDS slab
-#define MIPT_DECLARE_LDS_STACK(stk) \
+// traversal stack of the calling lane: private memory for the simple kernels ...
+#define MIPT_DECLARE_STACK(stk) ScratchStack stk;
+// ... and the block's LDS slab (+ global spill columns) for the persistent traversal kernels
+#define MIPT_DECLARE_LDS_STACK(stk, spill_buf) \
 	__shared__ uint2 lds_stack_[MIPT_LDS_STACK * MIPT_BLOCK]; \
-	LdsStack stk; stk.base = lds_stack_ + threadIdx.x; stk.stride = MIPT_BLOCK;
+	LdsStack stk; stk.base = (lds_uint2*)lds_stack_ + threadIdx.x; stk.stride = MIPT_BLOCK; \
+	stk.spill = (glb_uint2*)(spill_buf) + (size_t)blockIdx.x * MIPT_BLOCK + threadIdx.x; stk.spill_stride = (int)(gridDim.x * MIPT_BLOCK);
 
 // Scene::intersection on a ray list (mipt_trace).
 __global__ void __launch_bounds__(MIPT_BLOCK) k_trace(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, int n, mipt_hit* __restrict__ hits) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	int q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n) return;
 	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
@@ -54,7 +57,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_trace(const DScene* __restrict__
 
 // Scene::intersection_shadow on a ray list (mipt_trace_shadow).
 __global__ void __launch_bounds__(MIPT_BLOCK) k_trace_shadow(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, const float* __restrict__ dist, int n, int* __restrict__ occluded) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	int q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n) return;
 	Ray r; r.o = ld3(rays[q].origin); r.d = ld3(rays[q].direction);
@@ -87,7 +90,7 @@ __device__ __forceinline__ f3 trace_path(const DScene* __restrict__ sc, const DR
 // Parity hook (mipt_sample_radiance): arbitrary pixel list, samples [k0,k1), no splat.
 __global__ void __launch_bounds__(MIPT_BLOCK) k_sample_radiance(const DScene* __restrict__ sc, DRender R, const int* __restrict__ ij, int npix, int k0, int k1,
                                                                 float* __restrict__ out_rgb, float* __restrict__ out_dxdy) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	int nk = k1 - k0;
 	if (tid >= (long long)npix * nk) return;
@@ -105,7 +108,7 @@ struct DSamples { float4* col; float2* dxdy; };
 // Pipeline 0: one thread per path.  A wave = one 8x8 pixel block at one sample index, so the
 // primary rays of a wave are coherent.
 __global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	unsigned n_closest = 0, n_shadow = 0, n_paths = 0;
@@ -181,6 +184,9 @@ struct mipt_ctx {
 	std::string err;
 	std::vector<void*> scene_allocs;
 	DScene* d_scene = nullptr;
+	const DFatNode* d_all_nodes = nullptr;
+	const DTriIsect* d_all_tris = nullptr;
+	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
 	int n_mesh_objects = 0;
 	bool has_scene = false;
 	// render-time buffers (grown on demand)
@@ -249,6 +255,7 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
 	if (c->tab_buf) hipFree(c->tab_buf);
+	if (c->spill_buf) hipFree(c->spill_buf);
 	if (c->blk_buf) hipFree(c->blk_buf);
 	if (c->d_cnt) hipFree(c->d_cnt);
 	if (c->ev0) hipEventDestroy(c->ev0);
@@ -437,6 +444,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	rc = upload(c, hs.data(), 1, &dsc);
 	if (rc) return rc;
 	c->d_scene = const_cast<DScene*>(dsc);
+	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
 	return MIPT_OK;
 }
@@ -624,6 +632,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned));
 		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
 		wf.out = S;
+		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
+		wf.spill = (uint2*)c->spill_buf;
 	}
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
@@ -655,14 +665,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const unsigned grid_p = std::min(persistent_blocks, grid_all);
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, (const float4*)c->d_all_nodes, c->d_all_tris, wf, b, (unsigned)total, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
 				else hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, 0u, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
+				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, (const float4*)c->d_all_nodes, c->d_all_tris, wf, b, 0u, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
 				else hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}

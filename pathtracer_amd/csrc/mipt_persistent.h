@@ -66,14 +66,13 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 }
 
 template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
-	MIPT_DECLARE_LDS_STACK(stk);
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
+	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
 	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
 	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
 	const bool identity = !SHADOW && b == 0;
-	const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc->all_nodes);
-	const DTriIsect* __restrict__ tris = sc->all_tris;
+	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
 	// ids reserved per global atomic: large enough to keep the same-address atomic rate low, small
 	// enough that every wave of the grid gets several chunks (tail balance)
 	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_BLOCK / 64) * 8u)) & ~63u));

@@ -165,23 +165,30 @@ struct ScratchStack {            // private (scratch) memory: any occupancy, slo
 	MIPT_DEV void push(int sp, uint32_t r, float t) { ref[sp] = r; tnear[sp] = t; }
 	MIPT_DEV void pop(int sp, uint32_t& r, float& t) const { r = ref[sp]; t = tnear[sp]; }
 };
-// LDS-resident stack: entry sp of a lane lives at lds[sp * blockDim.x + threadIdx.x] (one 8-byte
-// word, conflict-free for ds_read/write_b64 when the lanes of a group use the same sp).  Entries
-// beyond MIPT_LDS_STACK spill to a small private array that is normally never touched.
+// LDS-resident stack of the persistent traversal kernels: entry sp of a lane lives at
+// lds[sp * blockDim.x + threadIdx.x] (one 8-byte word; conflict-free for ds_read/write_b64 when the
+// lanes of a group use the same sp).  Entries beyond MIPT_LDS_STACK spill to a per-thread column of a
+// global scratch buffer that is normally never touched.  Both pointers carry their address space in
+// the type so that pushes and pops compile to ds_* / global_* instructions, not flat ones.
 #define MIPT_LDS_STACK 16
 #define MIPT_SPILL_STACK (MIPT_STACK_DEPTH - MIPT_LDS_STACK)
+typedef __attribute__((address_space(3))) uint2 lds_uint2;
+typedef __attribute__((address_space(1))) uint2 glb_uint2;
 struct LdsStack {
-	uint2* base;                  // &lds[threadIdx.x]
+	lds_uint2* base;              // &lds[threadIdx.x]
+	glb_uint2* spill;             // &spill[global thread id]
 	int stride;                   // blockDim.x
-	uint32_t sref[MIPT_SPILL_STACK];
-	float stn[MIPT_SPILL_STACK];
+	int spill_stride;             // total threads of the grid
 	MIPT_DEV void push(int sp, uint32_t r, float t) {
-		if (sp < MIPT_LDS_STACK) base[sp * stride] = make_uint2(r, __float_as_uint(t));
-		else { sref[sp - MIPT_LDS_STACK] = r; stn[sp - MIPT_LDS_STACK] = t; }
+		uint2 e = make_uint2(r, __float_as_uint(t));
+		if (sp < MIPT_LDS_STACK) { lds_uint2* p = base + sp * stride; p->x = e.x; p->y = e.y; }
+		else { glb_uint2* p = spill + (size_t)(sp - MIPT_LDS_STACK) * spill_stride; p->x = e.x; p->y = e.y; }
 	}
 	MIPT_DEV void pop(int sp, uint32_t& r, float& t) const {
-		if (sp < MIPT_LDS_STACK) { uint2 e = base[sp * stride]; r = e.x; t = __uint_as_float(e.y); }
-		else { r = sref[sp - MIPT_LDS_STACK]; t = stn[sp - MIPT_LDS_STACK]; }
+		uint32_t x, y;
+		if (sp < MIPT_LDS_STACK) { const lds_uint2* p = base + sp * stride; x = p->x; y = p->y; }
+		else { const glb_uint2* p = spill + (size_t)(sp - MIPT_LDS_STACK) * spill_stride; x = p->x; y = p->y; }
+		r = x; t = __uint_as_float(y);
 	}
 };
 

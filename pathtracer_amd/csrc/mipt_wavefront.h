@@ -25,6 +25,7 @@ struct DWave {
 	float4 *sh_o, *sh_d, *sh_c; // shadow request: origin (w = dist_light), direction, weight*contrib
 	unsigned* list[2];          // path ids to extend at even / odd depth
 	unsigned* list_sh;          // path ids with a pending shadow ray
+	uint2* spill;               // traversal-stack overflow columns (persistent kernels)
 	unsigned* counters;         // per depth b: [4b] n_extend, [4b+1] extend head, [4b+2] n_shadow, [4b+3] shadow head; then shade heads
 	DSamples out;
 };
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 // extend: Scene::intersection without the material (closest object / triangle / t / barycentrics).
 // Depth 0 walks the identity list of all n0 path slots and skips the dead ones.
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	const unsigned n = b == 0 ? n0 : wf.counters[4 * b];
 	unsigned* head = &wf.counters[4 * b + 1];
 	const unsigned* __restrict__ list = wf.list[b & 1];
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 
 // shadow: Scene::intersection_shadow; a visible light sample adds weight*contrib to the path colour
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restrict__ sc, DWave wf, int b) {
-	MIPT_DECLARE_LDS_STACK(stk);
+	MIPT_DECLARE_STACK(stk);
 	const unsigned n = wf.counters[4 * b + 2];
 	unsigned* head = &wf.counters[4 * b + 3];
 	const unsigned* __restrict__ list = wf.list_sh;
