@@ -17,8 +17,13 @@
 // kernels
 // =====================================================================================
 
+// Statistics counters, sharded over MIPT_COUNTER_SHARDS cache lines: same-address atomics run at only
+// ~88 per microsecond chip-wide (MI355X_MICROARCH.md "dequeue"), which at one atomic per wave was
+// 3 ms per 16.6 M-path pass.  A wave adds to the shard of its block; the host sums the shards.
+#define MIPT_COUNTER_SHARDS 256
 struct DCounters {
 	unsigned long long paths, rays_closest, rays_shadow;
+	unsigned long long _pad[5];      // one 64-byte line per shard
 };
 
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v) {
@@ -26,6 +31,7 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
 	if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
 }
+#define MIPT_MY_COUNTERS(cnt) ((cnt) + (blockIdx.x & (MIPT_COUNTER_SHARDS - 1)))
 
 #define MIPT_BLOCK 256
 // traversal stack of the calling lane: private memory for the simple kernels ...
@@ -124,9 +130,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths(const DScene* __res
 			n_paths = 1;
 		}
 	}
-	wave_add(&cnt->paths, n_paths);
-	wave_add(&cnt->rays_closest, n_closest);
-	wave_add(&cnt->rays_shadow, n_shadow);
+	DCounters* my = MIPT_MY_COUNTERS(cnt);
+	wave_add(&my->paths, n_paths);
+	wave_add(&my->rays_closest, n_closest);
+	wave_add(&my->rays_shadow, n_shadow);
 }
 
 // sum_area_table (Raytracer.cpp:1276-1291)
@@ -188,6 +195,7 @@ struct mipt_ctx {
 	const DTriIsect* d_all_tris = nullptr;
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
 	int n_mesh_objects = 0;
+	uint64_t host_paths = 0;
 	bool has_scene = false;
 	// render-time buffers (grown on demand)
 	void* pass_buf = nullptr; size_t pass_buf_bytes = 0;
@@ -205,6 +213,7 @@ struct mipt_ctx {
 	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; } tab_key;
 	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0; } blk_key;
 	int blk_nblocks = 0;
+	uint64_t blk_valid_pixels = 0;
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
@@ -234,7 +243,7 @@ extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
 	mipt_ctx* c = new mipt_ctx;
 	c->device = device_ids[0];
 	if (hipSetDevice(c->device) != hipSuccess) { delete c; return MIPT_ERR_NO_DEVICE; }
-	if (hipMalloc((void**)&c->d_cnt, sizeof(DCounters)) != hipSuccess) { delete c; return MIPT_ERR_HIP; }
+	if (hipMalloc((void**)&c->d_cnt, sizeof(DCounters) * MIPT_COUNTER_SHARDS) != hipSuccess) { delete c; return MIPT_ERR_HIP; }
 	hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
@@ -596,6 +605,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			std::vector<int> blocks, pix2slot;
 			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
 			c->blk_nblocks = (int)(blocks.size() / 2);
+			c->blk_valid_pixels = 0;
+			for (int v : pix2slot) if (v >= 0) c->blk_valid_pixels++;
 			size_t blk_bytes = (blocks.size() + pix2slot.size()) * sizeof(int);
 			if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
 			if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -607,7 +618,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	const int nblocks = c->blk_nblocks;
 	memset(&c->stats, 0, sizeof c->stats);
 	c->kev_used = 0;
-	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DCounters), st));
+	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DCounters) * MIPT_COUNTER_SHARDS, st));
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
@@ -684,14 +695,18 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	HIPCHK(c, hipEventRecord(c->ev1, st));
 	c->stats.passes = passes;
+	c->host_paths = c->blk_valid_pixels * (uint64_t)(ke - kb);
 	c->stats.pipeline = (uint32_t)pipeline;
 	c->kev_used = nev;
 	return MIPT_OK;
 }
 
 static int collect_stats(mipt_ctx* c) {
-	DCounters h;
-	HIPCHK(c, hipMemcpy(&h, c->d_cnt, sizeof h, hipMemcpyDeviceToHost));
+	std::vector<DCounters> hs(MIPT_COUNTER_SHARDS);
+	HIPCHK(c, hipMemcpy(hs.data(), c->d_cnt, sizeof(DCounters) * MIPT_COUNTER_SHARDS, hipMemcpyDeviceToHost));
+	DCounters h{};
+	for (const DCounters& x : hs) { h.paths += x.paths; h.rays_closest += x.rays_closest; h.rays_shadow += x.rays_shadow; }
+	if (c->stats.pipeline == 1) h.paths = c->host_paths;     // the wavefront generate stage does not count on the device
 	c->stats.paths = h.paths; c->stats.rays_closest = h.rays_closest; c->stats.rays_shadow = h.rays_shadow;
 	c->stats.mesh_casts_closest = h.rays_closest * (uint64_t)c->n_mesh_objects;
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder

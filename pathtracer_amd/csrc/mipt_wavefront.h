@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 			}
 		}
 	}
-	wave_add(&cnt->paths, valid ? 1u : 0u);
+	(void)valid; (void)cnt;     // paths are counted on the host (valid pixels x samples)
 }
 
 // extend: Scene::intersection without the material (closest object / triangle / t / barycentrics).
@@ -192,8 +192,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast_bits, src, base);
 		queue_push(next, &wf.counters[4 * (b + 1)], cont_bits, src, base);
 	}
-	wave_add(&cnt->rays_closest, n_closest);
-	wave_add(&cnt->rays_shadow, n_shadow);
+	DCounters* my = MIPT_MY_COUNTERS(cnt);
+	wave_add(&my->rays_closest, n_closest);
+	wave_add(&my->rays_shadow, n_shadow);
 }
 
 // shadow: Scene::intersection_shadow; a visible light sample adds weight*contrib to the path colour
