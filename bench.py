@@ -78,9 +78,9 @@ def cpu_baseline(mesh, cfg_full, rays_per_path):
     cfg = copy.copy(cfg_full)
     cfg.W, cfg.H = cfg_full.W // 4, cfg_full.H // 4
     cores = min(64, os.cpu_count() or 1)   # the reference supports at most 64 OpenMP threads
-    # size the sample for roughly 10-30 s of CPU work: ~0.25 Mpaths/s/core observed on this scene
-    est_rate = 0.2e6 * cores
-    cfg.spp = int(max(2, min(64, 15.0 * est_rate / (cfg.W * cfg.H))))
+    # size the sample for roughly 15 s of CPU work: ~0.15 Mpaths/s per thread measured on this scene
+    est_rate = 0.15e6 * cores
+    cfg.spp = int(max(2, min(4096, 15.0 * est_rate / (cfg.W * cfg.H))))
     if binding.ref_available():
         R = binding.Ref()
         R.apply_config(cfg)
@@ -223,7 +223,7 @@ def main():
                 kernel = "k_render_paths"
                 bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
             else:                 # dominant kernel = closest-hit traversal
-                kernel = "k_wf_extend"
+                kernel = "k_wf_traverse<false> (closest-hit / extend stage)"
                 bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -233,7 +233,7 @@ def main():
                                "rays_per_launch": (rays_c if pipeline else rays_c + rays_s) / my_launches}
             if pipeline == 1 and sh_launches:
                 sh_ach = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
-                out["roofline_shadow_kernel"] = {"kernel": "k_wf_shadow", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,
+                out["roofline_shadow_kernel"] = {"kernel": "k_wf_traverse<true> (any-hit / shadow stage)", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,
                                                  "launches": int(sh_launches)}
                 out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
             if not args.no_cpu_baseline:
