@@ -218,6 +218,10 @@ int mipt_trace_shadow(mipt_ctx* ctx, const mipt_ray* rays, const float* dist_lig
 int mipt_sample_radiance(mipt_ctx* ctx, const mipt_render_params* p, const int32_t* pixels_ij, int npix,
                          int k0, int k1, float* out_rgb, float* out_dxdy);
 
+/* Work partition used by mipt_render*: the rank in [0, tile_nranks) that renders pixel (i, j) of a
+ * W-pixel-wide image, or -1 for bad parameters.  Pure host function (no device needed). */
+int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j);
+
 /* Statistics of the last render call (rays counted like the oracle does, kernel time from HIP
  * events on the render stream). */
 int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);

@@ -25,7 +25,7 @@ MIPT_ERR_NO_DEVICE = 2
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
+                "mipt_render_device", "mipt_tile_owner", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
 
 _f = C.c_float
 _i = C.c_int

@@ -564,6 +564,13 @@ extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, co
 	return MIPT_OK;
 }
 
+extern "C" int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j) {
+	int ts = tile_size > 0 ? tile_size : 32, nr = tile_nranks > 0 ? tile_nranks : 1;
+	if (W <= 0 || i < 0 || j < 0 || j >= W || ts % 8 != 0) return -1;
+	int ntx = (W + ts - 1) / ts;
+	return ((i / ts) * ntx + (j / ts)) % nr;
+}
+
 // Owned 8x8 pixel blocks of this rank: tiles of tile_size x tile_size pixels, tile t -> rank t % nranks.
 static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<int>& blocks, std::vector<int>& pix2slot) {
 	int ts = p->tile_size > 0 ? p->tile_size : 32;
@@ -576,8 +583,7 @@ static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<in
 	blocks.clear();
 	pix2slot.assign((size_t)W * H, -1);
 	for (int ty = 0; ty < nty; ty++) for (int tx = 0; tx < ntx; tx++) {
-		int t = ty * ntx + tx;
-		if (t % nr != rk) continue;
+		if (mipt_tile_owner(W, ts, nr, ty * ts, tx * ts) != rk) continue;
 		for (int bi = ty * ts; bi < std::min(H, (ty + 1) * ts); bi += 8) for (int bj = tx * ts; bj < std::min(W, (tx + 1) * ts); bj += 8) {
 			int blk = (int)(blocks.size() / 2);
 			blocks.push_back(bi); blocks.push_back(bj);

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mipt_sincos.h"
 
 #define MIPT_DEV __device__ __forceinline__
 
@@ -64,49 +65,9 @@ MIPT_DEV uint32_t pcg_next(uint64_t& state) {
 MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.3283064365386963e-10f; }
 
 // ---------------------------------------------------------------- sinf / cosf
-// Bit-exact with the host libm the reference links (glibc 2.35 s_sinf.c / s_cosf.c, the
-// "optimized routines" double-precision polynomial scheme) for |x| < 120; verified exhaustively
-// against libm on [0, 6.5] (tests/test_device_math_host.py), the only range the path uses
-// (arguments are 2*pi*u, u in [0,1]).  Computed in fp64: quadrant reduction n = round(x*2/pi),
-// then a degree-7 sine or degree-8 cosine polynomial in the reduced argument.
-MIPT_DEV float sincos_poly(double x, double x2, int n, bool neg) {
-	// neg selects the table with negated cosine coefficients (n & 2)
-	if ((n & 1) == 0) {
-		const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
-		double x3 = x * x2;
-		double t1 = s2 + x2 * s3;
-		double x7 = x3 * x2;
-		double s = x + x3 * s1;
-		return (float)(s + x7 * t1);
-	} else {
-		double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
-		if (neg) { c0 = -c0; c1 = -c1; c2 = -c2; c3 = -c3; c4 = -c4; }
-		double x4 = x2 * x2;
-		double t2 = c3 + x2 * c4;
-		double t1 = c0 + x2 * c1;
-		double x6 = x4 * x2;
-		double c = t1 + x4 * c2;
-		return (float)(c + x6 * t2);
-	}
-}
-MIPT_DEV uint32_t abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ff; }
-template <bool COS>
-MIPT_DEV float sincosf_glibc(float y) {
-	double x = (double)y;
-	if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {          // |y| < pi/4
-		double x2 = x * x;
-		if (abstop12(y) < abstop12(0x1p-12f)) return COS ? 1.0f : y;
-		return sincos_poly(x, x2, COS ? 1 : 0, false);
-	}
-	// |y| < 120: fast reduction (hpi_inv is 2/pi * 2^24, quadrant in bits 24..31)
-	double r = x * 0x1.45F306DC9C883p+23;
-	int n = ((int)r + 0x800000) >> 24;
-	x = x - (double)n * 0x1.921FB54442D18p0;
-	double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign table {1,-1,-1,1}
-	return sincos_poly(x * s, x * x, COS ? (n ^ 1) : n, (n & 2) != 0);
-}
-MIPT_DEV float pt_sinf(float y) { return sincosf_glibc<false>(y); }
-MIPT_DEV float pt_cosf(float y) { return sincosf_glibc<true>(y); }
+// Bit-exact with the host libm (see mipt_sincos.h; checked on every float of the range the path uses).
+MIPT_DEV float pt_sinf(float y) { return mipt_sincosf<false>(y); }
+MIPT_DEV float pt_cosf(float y) { return mipt_sincosf<true>(y); }
 
 // powf: exact for the cases the default materials produce (Ne = 0 -> 1, pow(1,y) = 1);
 // otherwise the device library's powf (<= 1 ulp from glibc's).

@@ -1,0 +1,17 @@
+"""CPU test of the PRODUCT's sinf/cosf: the header the HIP kernels compile (csrc/mipt_sincos.h) is
+built with g++ and compared with the host libm — the libm the reference's direction sampling calls —
+on every float in [0, 6.5] (arguments on the path are float(2*pi)*u with u in [0,1])."""
+import os
+import subprocess
+
+from helpers import ROOT
+
+
+def test_sincos_bit_exact_with_libm(tmp_path):
+    exe = str(tmp_path / "sincos_check")
+    subprocess.run(["g++", "-O2", "-fopenmp", "-ffp-contract=off", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "sincos_check.cpp"), "-lm"], check=True)
+    out = subprocess.run([exe, "6.5"], check=True, capture_output=True, text=True).stdout.split()
+    n, bad_sin, bad_cos = int(out[0]), int(out[1]), int(out[2])
+    assert n > 1_000_000_000
+    assert bad_sin == 0 and bad_cos == 0, (bad_sin, bad_cos)

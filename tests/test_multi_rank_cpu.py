@@ -1,0 +1,76 @@
+"""CPU test of the N>1 path (world size 2, gloo): the tile partition of include/mipt.h
+(`mipt_tile_owner`, the function `mipt_render*` uses to pick a rank's pixels) gives every pixel to
+exactly one rank, and summing the ranks' partial accumulators with ONE all-reduce — what bench.py does
+over RCCL — reproduces the single-rank frame even though splats cross tile borders."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pathtracer_amd import capi
+
+W, H, TS = 80, 48, 16
+
+
+def splat(owner_of, rank, samples):
+    """3x3 splat of the samples whose SOURCE pixel belongs to `rank` (None = all) into a full frame."""
+    acc = np.zeros((H, W, 4), np.float64)
+    for (i, j, c) in samples:
+        if rank is not None and owner_of[i, j] != rank:
+            continue
+        for i2 in range(max(0, i - 1), min(H, i + 2)):
+            for j2 in range(max(0, j - 1), min(W, j + 2)):
+                w = np.exp(-((i2 - i) ** 2 + (j2 - j) ** 2) / 0.5)
+                acc[H - 1 - i2, j2, :3] += c * w
+                acc[H - 1 - i2, j2, 3] += w
+    return acc
+
+
+def owners(nranks):
+    mipt, _ = capi.load()
+    o = np.array([[mipt.mipt_tile_owner(W, TS, nranks, i, j) for j in range(W)] for i in range(H)])
+    return o
+
+
+def make_samples():
+    rng = np.random.default_rng(5)
+    return [(int(i), int(j), rng.uniform(0, 1, 3)) for i, j in zip(rng.integers(0, H, 4000), rng.integers(0, W, 4000))]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    part = torch.from_numpy(splat(owners(world), rank, make_samples()))
+    dist.all_reduce(part, op=dist.ReduceOp.SUM)          # the framebuffer reduce
+    if rank == 0:
+        np.save(out, part.numpy())
+    dist.destroy_process_group()
+
+
+def test_partition_is_a_partition():
+    for nranks in (1, 2, 3, 8):
+        o = owners(nranks)
+        assert o.min() == 0 and o.max() == min(nranks, (W // TS + (W % TS > 0)) * (H // TS + (H % TS > 0))) - 1 or o.max() < nranks
+        assert ((o >= 0) & (o < nranks)).all()
+        # tiles are TS x TS and constant inside
+        assert (o[:TS, :TS] == o[0, 0]).all()
+        if nranks > 1:
+            counts = np.bincount(o.ravel(), minlength=nranks)
+            assert counts.min() > 0
+    mipt, _ = capi.load()
+    assert mipt.mipt_tile_owner(W, 12, 2, 0, 0) == -1        # tile_size must be a multiple of 8
+
+
+def test_two_rank_reduce_matches_single_rank(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    full = splat(owners(1), None, make_samples())
+    np.testing.assert_allclose(np.load(out), full, rtol=1e-12, atol=1e-12)
