@@ -107,6 +107,19 @@ class _Base:
         a = lambda v: (_f * 3)(*v)
         self.lib.ref_add_group_material(self.ctx, obj, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))
 
+    def set_group_texture(self, obj, grp, slot, rgb8):
+        """Image texture (H,W,3 uint8, top row first) for one material group; slot 0 Kd, 1 Ks, 2 normal map,
+        3 alpha, 4 Ne."""
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        self._set_group_texture(obj, grp, slot, rgb8)
+
+    def _set_group_texture(self, obj, grp, slot, rgb8):
+        self.lib.ref_set_group_texture(self.ctx, obj, grp, slot, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
+
+    def set_envmap(self, rgb8):
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        self.lib.ref_set_envmap(self.ctx, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
+
     def apply_config(self, cfg):
         self.set_render(cfg.W, cfg.H, cfg.spp, cfg.nb_bounces, cfg.sigma_filter)
         self.set_camera(cfg.cam_pos, cfg.cam_dir, cfg.cam_up, cfg.fov, cfg.focus, cfg.aperture)
@@ -262,6 +275,22 @@ class Ref(_Base):
         path = os.path.join(d, mesh.name + ".obj")
         scenes.write_obj(mesh, path)
         return self.lib.ref_add_mesh(self.ctx, path.encode(), _f(scale), 1 if center else 0)
+
+    @staticmethod
+    def _write_ppm(rgb8):
+        import tempfile
+        f = tempfile.NamedTemporaryFile(prefix="ptref_tex_", suffix=".ppm", delete=False)
+        f.write(b"P6\n%d %d\n255\n" % (rgb8.shape[1], rgb8.shape[0]))
+        f.write(rgb8.tobytes())
+        f.close()
+        return f.name
+
+    def _set_group_texture(self, obj, grp, slot, rgb8):
+        self.cdll.ref_set_group_texture_file(self.ctx, obj, grp, slot, self._write_ppm(rgb8).encode())
+
+    def set_envmap(self, rgb8):
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        self.cdll.ref_set_envmap_file(self.ctx, self._write_ppm(rgb8).encode())
 
     def time_render_nopreviz(self, threads):
         img = np.zeros((self.H, self.W, 3), np.float32)

@@ -1138,12 +1138,19 @@ void o_set_group_texture(o_ctx* c, int obj, int grp, int slot, int W, int H, con
 	free(t->values);
 	t->W = W; t->H = H;
 	t->values = (float*)malloc(sizeof(float) * (size_t)W * H * 3);
-	/* load_image: copy then flip rows (utils.cpp:104-118); loadColors: /255.f, powf(.,2.2f) (BRDF.h:393-404) */
-	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) for (int k = 0; k < 3; k++) {
-		float v = rgb[((size_t)(H - 1 - i) * W + j) * 3 + k];
-		v /= 255.f;
-		v = powf(v, 2.2f);
-		t->values[((size_t)i * W + j) * 3 + k] = v;
+	/* Object::set_alphamap / set_roughnessmap build a fresh Texture with multiplier (1,1,1)
+	 * (Geometry.cpp:138-146); set_texture / set_specularmap / set_normalmap keep the multiplier (:60-86) */
+	if (slot == T_ALPHA || slot == T_NE) t->multiplier = V(1., 1., 1.);
+	/* load_image: copy then flip rows (utils.cpp:104-118) */
+	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) for (int k = 0; k < 3; k++)
+		t->values[((size_t)i * W + j) * 3 + k] = rgb[((size_t)(H - 1 - i) * W + j) * 3 + k];
+	if (slot == T_NORMAL) {     /* Texture::loadNormals (BRDF.h:406-418) */
+		for (size_t i = 0; i < (size_t)W * H; i++) {
+			v3 v = vnormalize(V(t->values[i * 3] - 128, t->values[i * 3 + 1] - 128, t->values[i * 3 + 2] - 128));
+			t->values[i * 3] = v.x; t->values[i * 3 + 1] = v.y; t->values[i * 3 + 2] = v.z;
+		}
+	} else {                    /* Texture::loadColors: /255.f, powf(.,2.2f) (BRDF.h:393-404) */
+		for (size_t i = 0; i < (size_t)W * H * 3; i++) { float v = t->values[i]; v /= 255.f; t->values[i] = powf(v, 2.2f); }
 	}
 }
 void o_set_envmap(o_ctx* c, int W, int H, const unsigned char* rgb) {

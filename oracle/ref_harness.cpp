@@ -132,6 +132,22 @@ void ref_add_group_material(RefCtx* c, int obj, const float* Kd, const float* Ks
 	o->add_col_refr(refr);
 }
 
+// Image textures through the reference's own loaders (stb_image reads the binary PPM the test wrote).
+// slot: 0 Kd (Object::set_texture), 1 Ks (set_specularmap), 2 normal map (set_normalmap),
+// 3 alpha (set_alphamap), 4 roughness / Ne (set_roughnessmap)   (Geometry.cpp:60-146)
+void ref_set_group_texture_file(RefCtx* c, int obj, int grp, int slot, const char* file) {
+	Object* o = c->rt->s.objects[obj];
+	switch (slot) {
+	case 0: o->set_texture(file, grp); break;
+	case 1: o->set_specularmap(file, grp); break;
+	case 2: o->set_normalmap(file, grp); break;
+	case 3: o->set_alphamap(file, grp); break;
+	case 4: o->set_roughnessmap(file, grp); break;
+	}
+}
+// mainApp.cpp:2593: ((Sphere*)objects[1])->load_envmap(file)
+void ref_set_envmap_file(RefCtx* c, const char* file) { ((Sphere*)c->rt->s.objects[1])->load_envmap(file); }
+
 void ref_prepare(RefCtx* c) {
 	omp_set_num_threads(1);
 	c->rt->prepare_render(c->rt->s.current_frame);

@@ -39,6 +39,18 @@ void Texture::loadColorsRGB8(const unsigned char* rgb, int w, int h) {
 			}
 }
 
+void Texture::loadNormalsRGB8(const unsigned char* rgb, int w, int h) {
+	W = (size_t)w; H = (size_t)h;
+	values.resize(W * H * 3);
+	for (int i = 0; i < h; i++)
+		for (int j = 0; j < w; j++) {
+			const unsigned char* px = rgb + ((size_t)(h - 1 - i) * w + j) * 3;
+			Vector v((float)px[0] - 128, (float)px[1] - 128, (float)px[2] - 128);
+			v = normalized(v);
+			for (int k = 0; k < 3; k++) values[((size_t)i * w + j) * 3 + k] = v[k];
+		}
+}
+
 // ---------------------------------------------------------------- Object
 Object::Object() {
 	for (int i = 0; i < 9; i++) mat_rotation[i] = (i % 4 == 0) ? 1.f : 0.f;   // Matrix() is the identity (Vector.h:88-94)
@@ -529,7 +541,10 @@ void mh_set_group_texture(mh_raytracer* h, int obj, int grp, int slot, int W, in
 	Object* o = h->rt.s.objects[obj];
 	std::vector<Texture>* lists[8] = {&o->textures, &o->specularmap, &o->normal_map, &o->alphamap, &o->roughnessmap, &o->transparent_map, &o->refr_index_map, &o->subsurface};
 	if (slot < 0 || slot > 7 || grp < 0 || grp >= (int)lists[slot]->size()) return;
-	(*lists[slot])[grp].loadColorsRGB8(rgb, W, H);
+	Texture& t = (*lists[slot])[grp];
+	// set_alphamap / set_roughnessmap build a fresh Texture with multiplier 1 (Geometry.cpp:138-146)
+	if (slot == 3 || slot == 4) t.multiplier = Vector(1, 1, 1);
+	if (slot == 2) t.loadNormalsRGB8(rgb, W, H); else t.loadColorsRGB8(rgb, W, H);
 }
 void mh_set_envmap(mh_raytracer* h, int W, int H, const unsigned char* rgb) { static_cast<Sphere*>(h->rt.s.objects[1])->load_envmap_rgb8(rgb, W, H); }
 int mh_prepare(mh_raytracer* h, int upload) {

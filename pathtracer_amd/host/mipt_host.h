@@ -31,6 +31,8 @@ struct Texture {                      // BRDF.h:252-426
 	// Texture::loadColors on an 8-bit RGB image given top row first (what stb_image returns):
 	// load_image's row flip (utils.cpp:112-118), /255.f and powf(.,2.2f) (BRDF.h:393-404).
 	void loadColorsRGB8(const unsigned char* rgb, int w, int h);
+	// Texture::loadNormals (BRDF.h:406-418): (v - 128) normalised, no gamma.
+	void loadNormalsRGB8(const unsigned char* rgb, int w, int h);
 };
 
 struct BVHNodes { bool isleaf; int fg, fd; float bbox[6]; };   // TriangleMesh.h:6-13 (36 bytes)

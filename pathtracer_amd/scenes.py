@@ -169,3 +169,39 @@ def config_c1(W=1920, H=1080, spp=256) -> RenderConfig:
     loadScene() light and camera."""
     d, u = default_camera_rotated()
     return RenderConfig(W=W, H=H, spp=spp, nb_bounces=4, cam_dir=d, cam_up=u)
+
+
+def checker_texture(W=64, H=32, seed=7, cells=8):
+    """Procedural RGB8 albedo: coloured checker modulated by value noise (config C2's Kd texture)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    chk = ((xx * cells // W + yy * cells // H) & 1).astype(np.float64)
+    coarse = rng.uniform(0.55, 1.0, (cells + 1, cells + 1, 3))
+    noise = coarse[(yy * cells // H)[..., None], (xx * cells // W)[..., None], np.arange(3)]
+    base = np.where(chk[..., None] > 0, np.array([0.85, 0.35, 0.25]), np.array([0.25, 0.55, 0.85]))
+    return np.clip(base * noise * 255.0, 0, 255).astype(np.uint8)
+
+
+def sky_envmap(W=128, H=64):
+    """Procedural RGB8 environment map: vertical gradient plus a bright patch (config C2's env map)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    t = yy / (H - 1.0)
+    img = np.stack([40 + 60 * t, 70 + 90 * t, 140 + 100 * t], -1)
+    sun = np.exp(-(((xx - 0.3 * W) / (0.05 * W)) ** 2 + ((yy - 0.75 * H) / (0.08 * H)) ** 2))
+    img += 120 * sun[..., None]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def alpha_texture(W=32, H=32):
+    """RGB8 cut-out mask: opaque (255) except a grid of round holes (0)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    hole = (((xx % 8) - 3.5) ** 2 + ((yy % 8) - 3.5) ** 2) < 5.0
+    a = np.where(hole, 0, 255).astype(np.uint8)
+    return np.stack([a, a, a], -1)
+
+
+def bump_texture(W=32, H=32, seed=3):
+    """RGB8 tangent-space normal map (128 = 0), gentle random tilt."""
+    rng = np.random.default_rng(seed)
+    n = np.stack([rng.normal(0, 25, (H, W)), rng.normal(0, 25, (H, W)), np.full((H, W), 110.0)], -1) + 128
+    return np.clip(n, 0, 255).astype(np.uint8)

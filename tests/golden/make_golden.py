@@ -35,6 +35,14 @@ def golden_scene(name):
         cfg = scenes.config_c1(64, 36, 8)
         cfg.nb_bounces = 8
         return scenes.blob_mesh(24), cfg, dict(Kd=(0.5, 0.5, 0.5), Ks=(0, 0, 0), Ne=(0, 0, 0), transp=0.0, refr=1.3)
+    if name == "textured":   # config C2 in small: UV mesh, Kd / Ks / Ne image textures, env map
+        cfg = scenes.config_c1(64, 36, 8)
+        return scenes.blob_mesh(24, with_uv=True), cfg, dict(Kd=(1.0, 1.0, 1.0), Ks=(0.3, 0.3, 0.3), Ne=(20.0, 20.0, 20.0),
+                                                                   tex={0: scenes.checker_texture()}, envmap=scenes.sky_envmap())
+    if name == "cutout":     # alpha-map rejection inside the leaf loop + tangent-space normal map
+        cfg = scenes.config_c1(64, 36, 8)
+        return scenes.blob_mesh(24, with_uv=True), cfg, dict(Kd=(0.8, 0.8, 0.8), Ks=(0, 0, 0), Ne=(0, 0, 0),
+                                                                   tex={3: scenes.alpha_texture(), 2: scenes.bump_texture(), 0: scenes.checker_texture(16, 16, 2, 4)})
     if name == "c0full":
         return scenes.cornell_mesh(), scenes.config_c0(), None
     raise KeyError(name)
@@ -46,6 +54,10 @@ def setup(X, name):
     oid = X.add_mesh(mesh)
     if mat is not None:
         X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"], mat.get("transp", 1.0), mat.get("refr", 1.3))
+        for slot, img in mat.get("tex", {}).items():
+            X.set_group_texture(oid, 0, slot, img)
+        if "envmap" in mat:
+            X.set_envmap(mat["envmap"])
     X.prepare()
     return mesh, cfg, oid
 
@@ -85,7 +97,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "leaf_functions.npz"), **g)
 
     # per-scene goldens: (iii) camera, (iv) BVH, (v) rays, (vii) per-sample radiance
-    for name in ("cornell", "blob32", "glossy", "glass"):
+    for name in ("cornell", "blob32", "glossy", "glass", "textured", "cutout"):
         R = Ref()
         mesh, cfg, oid = setup(R, name)
         g = {}

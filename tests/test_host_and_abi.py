@@ -47,7 +47,7 @@ def test_no_device_means_error_not_fallback():
         rt.render_image_nopreviz()
 
 
-@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy"])
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "textured", "cutout"])
 def test_host_side_matches_reference_goldens(name):
     g = load_golden(f"scene_{name}.npz")
     H = capi.HostRaytracer()

@@ -4,7 +4,7 @@ root = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[(k, row["Counter_Name"])][0] += float(row["Counter_Value"])
         acc[(k, row["Counter_Name"])][1] += 1
 kernels = sorted({k for k, _ in acc})
