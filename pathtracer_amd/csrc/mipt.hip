@@ -540,6 +540,11 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	return MIPT_OK;
 }
 
+// Parity hook plumbing: instead of splatting, hand the per-sample results of ONE pass back to the host.
+struct SampleDump { const int32_t* ij; int npix; float* out_rgb; float* out_dxdy; };
+static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<int>& blocks, std::vector<int>& pix2slot);
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump);
+
 extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1, float* out_rgb, float* out_dxdy) {
 	if (!c || !pixels_ij || !out_rgb || npix < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
 	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
@@ -551,6 +556,14 @@ extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, co
 	for (int q = 0; q < npix; q++) if (pixels_ij[2 * q] < 0 || pixels_ij[2 * q] >= p->H || pixels_ij[2 * q + 1] < 0 || pixels_ij[2 * q + 1] >= p->W) return fail(c, MIPT_ERR_INVALID, "pixel outside the image");
 	size_t n = (size_t)npix * (size_t)(k1 - k0);
 	if (n == 0) return MIPT_OK;
+	if (c->opt_pipeline == 1) {      // same stage kernels as mipt_render, results handed back instead of splatted
+		mipt_render_params q = *p;
+		q.sample_begin = k0; q.sample_end = k1; q.tile_nranks = 1; q.tile_rank = 0;
+		SampleDump dump{pixels_ij, npix, out_rgb, out_dxdy};
+		rc = render_impl(c, &q, nullptr, 0, nullptr, nullptr, nullptr, &dump);
+		hipDeviceSynchronize();
+		return rc;
+	}
 	int* d_ij = nullptr; float* d_rgb = nullptr; float* d_dxdy = nullptr;
 	HIPCHK(c, hipMalloc((void**)&d_ij, sizeof(int) * 2 * (size_t)npix));
 	HIPCHK(c, hipMalloc((void**)&d_rgb, sizeof(float) * 3 * n));
@@ -596,7 +609,7 @@ static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<in
 	return MIPT_OK;
 }
 
-static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel) {
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump) {
 	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
 	DRender R; float denom2;
 	int rc = make_render_consts(c, p, R, denom2, st);
@@ -629,6 +642,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
 	spp_pass = std::min(spp_pass, ke - kb);
+	if (dump && spp_pass < ke - kb) return fail(c, MIPT_ERR_INVALID, "mipt_sample_radiance with the wavefront pipeline needs paths_per_pass >= pixels x samples");
 	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
 	const int pipeline = (int)c->opt_pipeline;
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
@@ -694,8 +708,26 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
 		}
-		hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+		if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());
+		if (dump) {
+			HIPCHK(c, hipStreamSynchronize(st));
+			std::vector<float4> hc(N); std::vector<float2> hj(N);
+			HIPCHK(c, hipMemcpy(hc.data(), S.col, N * sizeof(float4), hipMemcpyDeviceToHost));
+			HIPCHK(c, hipMemcpy(hj.data(), S.dxdy, N * sizeof(float2), hipMemcpyDeviceToHost));
+			std::vector<int> blocks, pix2slot;
+			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
+			const int nk = ke - kb;
+			for (int q = 0; q < dump->npix; q++) {
+				int slot = pix2slot[(size_t)dump->ij[2 * q] * p->W + dump->ij[2 * q + 1]];
+				if (slot < 0) return fail(c, MIPT_ERR_INVALID, "pixel not owned by this rank");
+				for (int k = 0; k < nk; k++) {
+					size_t s = (size_t)k * npix_slots + slot, o = (size_t)q * nk + k;
+					dump->out_rgb[3 * o] = hc[s].x; dump->out_rgb[3 * o + 1] = hc[s].y; dump->out_rgb[3 * o + 2] = hc[s].z;
+					if (dump->out_dxdy) { dump->out_dxdy[2 * o] = hj[s].x; dump->out_dxdy[2 * o + 1] = hj[s].y; }
+				}
+			}
+		}
 		passes++;
 		if (cb) { hipStreamSynchronize(st); cb(cb_user, P.k1 - kb, ke - kb); }
 	}
@@ -732,7 +764,7 @@ static int collect_stats(mipt_ctx* c) {
 extern "C" int mipt_render_device(mipt_ctx* c, const mipt_render_params* p, float* d_accum_rgbw, void* hip_stream) {
 	if (!c || !p || !d_accum_rgbw) return fail(c, MIPT_ERR_INVALID, "bad arguments");
 	HIPCHK(c, hipSetDevice(c->device));
-	return render_impl(c, p, d_accum_rgbw, (hipStream_t)hip_stream, nullptr, nullptr, nullptr);
+	return render_impl(c, p, d_accum_rgbw, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accum_rgb, float* accum_w, mipt_progress_cb cb, void* cb_user, volatile int* cancel) {
@@ -746,7 +778,7 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	hipError_t e = hipMemcpy(d_acc, accum_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(d_acc + npx * 3, accum_w, npx * sizeof(float), hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(d_acc); return fail(c, MIPT_ERR_HIP, "upload of accumulators failed: %s", hipGetErrorString(e)); }
-	int rc = render_impl(c, p, d_acc, 0, cb, cb_user, cancel);
+	int rc = render_impl(c, p, d_acc, 0, cb, cb_user, cancel, nullptr);
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
 	if (rc == MIPT_OK) {

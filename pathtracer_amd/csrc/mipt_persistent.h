@@ -204,9 +204,12 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 			for (int i = first; i < first + count; i++) {
 				float lt, lb, lg;
 				if (tri_test(tris + st.tri_base + i, st.org, st.d, lt, lb, lg)) {
-					if (lt < st.t) {
+					bool accept = lt < st.t;
+					if (accept) {
 						const DObject& o = sc->obj[st.obj];
-						if (o.alpha_test && alpha_rejects(o, i, 1 - lb - lg, lb, lg)) continue;
+						if (o.alpha_test) accept = !alpha_rejects(o, i, 1 - lb - lg, lb, lg);
+					}
+					if (accept) {
 						st.t = lt;
 						if (SHADOW) {
 							if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309

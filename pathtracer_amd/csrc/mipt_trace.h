@@ -133,7 +133,9 @@ MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& m
 }
 
 // alpha-map test of the leaf loop (TriangleMesh.cpp:1198-1205 / 1300-1307)
-MIPT_DEV bool alpha_rejects(const DObject& o, int i, float alpha, float beta, float gamma) {
+// (not inlined: a rare path, and keeping its control flow out of the traversal loops avoids the hipcc
+// 7.2 mis-scheduling described at the call sites)
+__device__ __attribute__((noinline)) bool alpha_rejects(const DObject& o, int i, float alpha, float beta, float gamma) {
 	int group = o.shade[i].group;
 	const int* ix = o.uvidx + 3 * (size_t)i;
 	if ((unsigned)o.ntex[MT_ALPHA] > (unsigned)group && ix[0] >= 0 && ix[1] >= 0 && ix[2] >= 0) {
@@ -263,8 +265,12 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 		for (int i = first; i < first + count; i++) {
 			float lt, lb, lg;
 			if (tri_test(o.tris + i, org, d, lt, lb, lg)) {
-				if (lt < t) {
-					if (o.alpha_test && alpha_rejects(o, i, 1 - lb - lg, lb, lg)) continue;
+				// Accept test written as one flag: with the alpha test nested inside `if (lt < t)` hipcc 7.2
+				// (gfx950, -O3) moved the `t` / `beta` updates into the alpha_test == 0 arm only
+				// (seen in the ISA of k_wf_extend; the cut-out golden scene caught it).
+				bool accept = lt < t;
+				if (accept && o.alpha_test) accept = !alpha_rejects(o, i, 1 - lb - lg, lb, lg);
+				if (accept) {
 					has_inter = true;
 					t = lt; tri_out = i; beta_out = lb; gamma_out = lg;
 					if (SHADOW && ((double)t < (double)dist_light * 0.999)) { t_out = t; return true; }   // :1309

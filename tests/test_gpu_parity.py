@@ -48,9 +48,10 @@ def test_rays_bit_exact(name):
 
 
 @pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False), ("textured", False), ("cutout", False)])
-def test_per_sample_radiance(name, exact):
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_per_sample_radiance(name, exact, pipeline):
     g = load_golden(f"scene_{name}.npz")
-    rt, (mesh, cfg, oid) = gpu(name)
+    rt, (mesh, cfg, oid) = gpu(name, pipeline=pipeline)
     rgb, dxdy = rt.sample_radiance(all_pixels(cfg), 0, cfg.spp)
     assert_bits(dxdy, g["sample_dxdy"], "sensor jitter")
     same = bits_equal(rgb, g["sample_rgb"]).all(-1)
