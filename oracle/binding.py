@@ -120,6 +120,15 @@ class _Base:
         rgb8 = np.ascontiguousarray(rgb8, np.uint8)
         self.lib.ref_set_envmap(self.ctx, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
 
+    def set_brdf_merl(self, obj, table):
+        """IsoMERLBRDF on one object; table = float64 array of 3*90*90*180 values (MERL .binary payload)."""
+        table = np.ascontiguousarray(table, np.float64).ravel()
+        assert table.size == 3 * 90 * 90 * 180
+        self._set_brdf_merl(obj, table)
+
+    def _set_brdf_merl(self, obj, table):
+        self.lib.ref_set_brdf_merl(self.ctx, obj, _p(table, C.c_double))
+
     def apply_config(self, cfg):
         self.set_render(cfg.W, cfg.H, cfg.spp, cfg.nb_bounces, cfg.sigma_filter)
         self.set_camera(cfg.cam_pos, cfg.cam_dir, cfg.cam_up, cfg.fov, cfg.focus, cfg.aperture)
@@ -285,6 +294,24 @@ class Ref(_Base):
         f.close()
         return f.name
 
+    @staticmethod
+    def _write_merl(table):
+        import tempfile
+        f = tempfile.NamedTemporaryFile(prefix="ptref_merl_", suffix=".binary", delete=False)
+        f.write(np.array([90, 90, 180], np.int32).tobytes())
+        f.write(np.ascontiguousarray(table, np.float64).tobytes())
+        f.close()
+        return f.name
+
+    def _set_brdf_merl(self, obj, table):
+        self.cdll.ref_set_brdf_merl_file(self.ctx, obj, self._write_merl(table).encode())
+
+    def merl_eval(self, table, wi, wo, N):
+        wi = np.ascontiguousarray(wi, np.float32); wo = np.ascontiguousarray(wo, np.float32); N = np.ascontiguousarray(N, np.float32)
+        out = np.zeros_like(wi)
+        self.cdll.ref_merl_eval(self._write_merl(table).encode(), wi.shape[0], _p(wi, _f), _p(wo, _f), _p(N, _f), _p(out, _f))
+        return out
+
     def _set_group_texture(self, obj, grp, slot, rgb8):
         self.cdll.ref_set_group_texture_file(self.ctx, obj, grp, slot, self._write_ppm(rgb8).encode())
 
@@ -327,6 +354,13 @@ class Oracle(_Base):
             uvp, ftp, nt = None, None, 0
         return self.lib.ref_add_mesh(self.ctx, v.shape[0], _p(v, _f), n.shape[0], _p(n, _f), nt, uvp,
                                      fv.shape[0], _p(fv, _i), _p(fn, _i), ftp, _f(scale), 1 if center else 0)
+
+    def merl_eval(self, table, wi, wo, N):
+        table = np.ascontiguousarray(table, np.float64).ravel()
+        wi = np.ascontiguousarray(wi, np.float32); wo = np.ascontiguousarray(wo, np.float32); N = np.ascontiguousarray(N, np.float32)
+        out = np.zeros_like(wi)
+        self.cdll.o_merl_eval(_p(table, C.c_double), wi.shape[0], _p(wi, _f), _p(wo, _f), _p(N, _f), _p(out, _f))
+        return out
 
     def render_omp(self, threads):
         img = np.zeros((self.H, self.W, 3), np.float32)

@@ -122,6 +122,7 @@ typedef struct {
 	float scale; v3 max_translation; float mat_rotation[9]; v3 rotation_center;
 	float trans[12], inv[12], rot[9];                /* Geometry.h:322-360 */
 	int ntex[T_NSLOTS]; o_tex* tex[T_NSLOTS];
+	const double* merl;          /* IsoMERLBRDF::data or NULL (PhongBRDF) */
 	/* sphere */ v3 O; float R, R2; int has_envmap; unsigned char* envtex; int envW, envH;
 	/* plane  */ v3 A, vecN;
 	/* mesh   */ o_mesh* mesh;
@@ -750,6 +751,86 @@ static v3 phong_eval(const o_mat* mat, v3 wi, v3 wo, v3 N) {
 	return vadd(vdivs(mat->Kd, (float)M_PI), vmul(lobe, mat->Ks));
 }
 
+
+/* ------------------------------------------------------------------ IsoMERLBRDF (BRDF.h:192-247, MERLBRDFRead.cpp:29-206) */
+#define MERL_TH 90
+#define MERL_TD 90
+#define MERL_PD 360
+static void merl_rotate_vector(const double* vector, const double* axis, double angle, double* out) {   /* MERLBRDFRead.cpp:49-72 */
+	double temp;
+	double cross[3];
+	double cos_ang = cos(angle);
+	double sin_ang = sin(angle);
+	out[0] = vector[0] * cos_ang; out[1] = vector[1] * cos_ang; out[2] = vector[2] * cos_ang;
+	temp = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
+	temp = temp * (1.0 - cos_ang);
+	out[0] += axis[0] * temp; out[1] += axis[1] * temp; out[2] += axis[2] * temp;
+	cross[0] = axis[1] * vector[2] - axis[2] * vector[1];
+	cross[1] = axis[2] * vector[0] - axis[0] * vector[2];
+	cross[2] = axis[0] * vector[1] - axis[1] * vector[0];
+	out[0] += cross[0] * sin_ang; out[1] += cross[1] * sin_ang; out[2] += cross[2] * sin_ang;
+}
+static void merl_normalize(double* v) { double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len; }
+static void merl_lookup(const double* brdf, double theta_in, double fi_in, double theta_out, double fi_out, double* r, double* g, double* b) {
+	/* std_coords_to_half_diff_coords (MERLBRDFRead.cpp:76-127) */
+	double in_vec_z = cos(theta_in), proj_in_vec = sin(theta_in);
+	double in_vec_x = proj_in_vec * cos(fi_in), in_vec_y = proj_in_vec * sin(fi_in);
+	double in[3] = { in_vec_x, in_vec_y, in_vec_z };
+	merl_normalize(in);
+	double out_vec_z = cos(theta_out), proj_out_vec = sin(theta_out);
+	double out_vec_x = proj_out_vec * cos(fi_out), out_vec_y = proj_out_vec * sin(fi_out);
+	double half[3] = { (in_vec_x + out_vec_x) / 2.0f, (in_vec_y + out_vec_y) / 2.0f, (in_vec_z + out_vec_z) / 2.0f };
+	merl_normalize(half);
+	double theta_half = acos(half[2]);
+	double fi_half = atan2(half[1], half[0]);
+	double bi_normal[3] = { 0.0, 1.0, 0.0 }, normal[3] = { 0.0, 0.0, 1.0 }, temp[3], diff[3];
+	merl_rotate_vector(in, normal, -fi_half, temp);
+	merl_rotate_vector(temp, bi_normal, -theta_half, diff);
+	double theta_diff = acos(diff[2]);
+	double fi_diff = atan2(diff[1], diff[0]);
+	/* index functions (MERLBRDFRead.cpp:134-180) */
+	int th_idx;
+	if (theta_half <= 0.0) th_idx = 0;
+	else {
+		double theta_half_deg = ((theta_half / (M_PI / 2.0)) * MERL_TH);
+		double t = sqrt(theta_half_deg * MERL_TH);
+		th_idx = (int)t;
+		if (th_idx < 0) th_idx = 0;
+		if (th_idx >= MERL_TH) th_idx = MERL_TH - 1;
+	}
+	int td = (int)(theta_diff / (M_PI * 0.5) * MERL_TD);
+	int td_idx = td < 0 ? 0 : (td < MERL_TD - 1 ? td : MERL_TD - 1);
+	if (fi_diff < 0.0) fi_diff += M_PI;
+	int pd = (int)(fi_diff / M_PI * MERL_PD / 2);
+	int pd_idx = pd < 0 ? 0 : (pd < MERL_PD / 2 - 1 ? pd : MERL_PD / 2 - 1);
+	int ind = pd_idx + td_idx * MERL_PD / 2 + th_idx * MERL_PD / 2 * MERL_TD;
+	*r = brdf[ind] * (1.0 / 1500.0);
+	*g = brdf[ind + MERL_TH * MERL_TD * MERL_PD / 2] * (1.15 / 1500.0);
+	*b = brdf[ind + MERL_TH * MERL_TD * MERL_PD] * (1.66 / 1500.0);
+}
+static v3 merl_eval(const double* data, v3 wi, v3 wo, v3 N) {   /* BRDF.h:204-246 */
+	v3 tangent1;
+	v3 absN = V(fabsf(N.x), fabsf(N.y), fabsf(N.z));
+	if (absN.x <= absN.y && absN.x <= absN.z) tangent1 = V(0, -N.z, N.y);
+	else if (absN.y <= absN.x && absN.y <= absN.z) tangent1 = V(-N.z, 0, N.x);
+	else tangent1 = V(-N.y, N.x, 0);
+	tangent1 = vnormalize(tangent1);
+	v3 tangent2 = vcross(tangent1, N);
+	v3 wil = V(vdot(wi, tangent1), vdot(wi, tangent2), vdot(wi, N));
+	v3 wol = V(vdot(wo, tangent1), vdot(wo, tangent2), vdot(wo, N));
+	float thetai = acosf(wil.z);
+	if (thetai >= M_PI / 2) return V(0., 0., 0.);
+	float thetao = acosf(wol.z);
+	if (thetao >= M_PI / 2) return V(0., 0., 0.);
+	float phio = atan2f(wol.y, wol.x);
+	if (phio < 0) phio += 2 * M_PI;
+	float phii = atan2f(wil.y, wil.x);
+	if (phii < 0) phii += 2 * M_PI;
+	double r, g, b;
+	merl_lookup(data, thetai, phii, thetao, phio, &r, &g, &b);
+	return V((float)r, (float)g, (float)b);
+}
+
 /* ------------------------------------------------------------------ camera (Vector.h:792-825, non-lenticular) */
 static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, float dx_sensor, float dy_sensor, float dx_aperture, float dy_aperture, int W, int H) {
 	float k = W / (2 * tanf(c->fov / 2));
@@ -846,7 +927,7 @@ static v3 get_color(const o_ctx* c, o_ray r, int sampleID, int screenI, int scre
 		else { isShadowed = scene_intersection_shadow(c, &ray_light, sqrtf(d_light2) - 0.01f); if (nrays2) nrays2[1]++; }
 		v3 currentContrib = V(0, 0, 0);
 		if (!isShadowed) {
-			v3 BRDF = phong_eval(&mat, wi, vneg(rayDirection), N);
+			v3 BRDF = obj->merl ? merl_eval(obj->merl, wi, vneg(rayDirection), N) : phong_eval(&mat, wi, vneg(rayDirection), N);
 			float J = vdot(Np, vneg(wi)) / d_light2;
 			float proba = vdot(axeOP, dir_aleatoire) / (M_PI * c->radiusLight * c->radiusLight);   /* double, narrowed */
 			if (proba > 0.f) {
@@ -860,9 +941,14 @@ static v3 get_color(const o_ctx* c, o_ray r, int sampleID, int screenI, int scre
 		float tmp;
 		float r1 = modff(c->randomPerPixel[(screenI * c->W + screenJ) * 2 + 0] + c->samples2d[sampleID * 2 + 0], &tmp);
 		float r2 = modff(c->randomPerPixel[(screenI * c->W + screenJ) * 2 + 1] + c->samples2d[sampleID * 2 + 1], &tmp);
-		v3 direction_aleatoire = phong_sample(&mat, vneg(rayDirection), N, &proba_globale, r1, r2, &has_sampled_diffuse, rng);
+		v3 direction_aleatoire;
+		if (obj->merl) {   /* IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw */
+			direction_aleatoire = random_cos12(N, r1, r2);
+			proba_globale = vdot(N, direction_aleatoire) / (M_PI);
+			has_sampled_diffuse = 0;
+		} else direction_aleatoire = phong_sample(&mat, vneg(rayDirection), N, &proba_globale, r1, r2, &has_sampled_diffuse, rng);
 		if (vdot(direction_aleatoire, N) < 0 || vdot(direction_aleatoire, vreflect(rayDirection, N)) < 0 || proba_globale <= 0) break;   /* :593 */
-		v3 BRDFindirect = phong_eval(&mat, direction_aleatoire, vneg(rayDirection), N);
+		v3 BRDFindirect = obj->merl ? merl_eval(obj->merl, direction_aleatoire, vneg(rayDirection), N) : phong_eval(&mat, direction_aleatoire, vneg(rayDirection), N);
 		v3 newpathWeight = vscale((vdot(N, direction_aleatoire) / proba_globale), vmul(vmul(pathWeight, subsW), BRDFindirect));   /* :611 */
 		currentRay.origin = vadd(P, vscale(0.01f, direction_aleatoire));
 		currentRay.direction = direction_aleatoire;
@@ -1033,6 +1119,7 @@ void o_destroy(o_ctx* c) {
 		o_obj* o = &c->objs[i];
 		for (int s = 0; s < T_NSLOTS; s++) { for (int k = 0; k < o->ntex[s]; k++) free(o->tex[s][k].values); free(o->tex[s]); }
 		free(o->envtex);
+		free((void*)o->merl);
 		free_mesh(o->mesh);
 	}
 	free(c->objs); free(c->randomPerPixel); free(c->samples2d); free(c->filter_integral); free(c);
@@ -1151,6 +1238,19 @@ void o_set_group_texture(o_ctx* c, int obj, int grp, int slot, int W, int H, con
 		}
 	} else {                    /* Texture::loadColors: /255.f, powf(.,2.2f) (BRDF.h:393-404) */
 		for (size_t i = 0; i < (size_t)W * H * 3; i++) { float v = t->values[i]; v /= 255.f; t->values[i] = powf(v, 2.2f); }
+	}
+}
+void o_set_brdf_merl(o_ctx* c, int obj, const double* table) {
+	size_t n = (size_t)3 * MERL_TH * MERL_TD * MERL_PD / 2;
+	double* t = (double*)malloc(n * sizeof(double));
+	memcpy(t, table, n * sizeof(double));
+	free((void*)c->objs[obj].merl);
+	c->objs[obj].merl = t;
+}
+void o_merl_eval(const double* table, int n, const float* wi3, const float* wo3, const float* N3, float* out3) {
+	for (int i = 0; i < n; i++) {
+		v3 v = merl_eval(table, V(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), V(N3[3 * i], N3[3 * i + 1], N3[3 * i + 2]));
+		out3[3 * i] = v.x; out3[3 * i + 1] = v.y; out3[3 * i + 2] = v.z;
 	}
 }
 void o_set_envmap(o_ctx* c, int W, int H, const unsigned char* rgb) {

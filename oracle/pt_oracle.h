@@ -40,6 +40,9 @@ void   o_add_group_material(o_ctx*, int obj, const float* Kd, const float* Ks, c
 void   o_set_group_texture(o_ctx*, int obj, int grp, int slot, int W, int H, const unsigned char* rgb);
 /* Sphere::load_envmap on object 1 (Geometry.h:912-916): 8-bit RGB, rows as in file */
 void   o_set_envmap(o_ctx*, int W, int H, const unsigned char* rgb);
+/* IsoMERLBRDF on one object (BRDF.h:192-247): table = 3 x 90*90*180 doubles (MERL .binary payload) */
+void   o_set_brdf_merl(o_ctx*, int obj, const double* table);
+void   o_merl_eval(const double* table, int n, const float* wi3, const float* wo3, const float* N3, float* out3);
 void   o_prepare(o_ctx*);              /* Raytracer::prepare_render (Raytracer.cpp:1321-1391) */
 
 /* dumps (same layouts as oracle/ref_harness.cpp) */

@@ -148,6 +148,18 @@ void ref_set_group_texture_file(RefCtx* c, int obj, int grp, int slot, const cha
 // mainApp.cpp:2593: ((Sphere*)objects[1])->load_envmap(file)
 void ref_set_envmap_file(RefCtx* c, const char* file) { ((Sphere*)c->rt->s.objects[1])->load_envmap(file); }
 
+// mainApp.cpp:2436: objects[selected]->brdf = new IsoMERLBRDF(file)  (MERL ".binary" layout)
+void ref_set_brdf_merl_file(RefCtx* c, int obj, const char* file) { c->rt->s.objects[obj]->brdf = new IsoMERLBRDF(std::string(file)); }
+// IsoMERLBRDF::eval on explicit tuples (BRDF.h:204-246)
+void ref_merl_eval(const char* file, int n, const float* wi3, const float* wo3, const float* N3, float* out3) {
+	IsoMERLBRDF brdf{std::string(file)};
+	MaterialValues m;
+	for (int i = 0; i < n; i++) {
+		Vector v = brdf.eval(m, Vector(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), Vector(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), Vector(N3[3 * i], N3[3 * i + 1], N3[3 * i + 2]));
+		out3[3 * i] = v[0]; out3[3 * i + 1] = v[1]; out3[3 * i + 2] = v[2];
+	}
+}
+
 void ref_prepare(RefCtx* c) {
 	omp_set_num_threads(1);
 	c->rt->prepare_render(c->rt->s.current_frame);

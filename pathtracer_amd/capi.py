@@ -188,6 +188,11 @@ class HostRaytracer:
         rgb8 = np.ascontiguousarray(rgb8, np.uint8)
         self.host.mh_set_envmap(self.h, rgb8.shape[1], rgb8.shape[0], _p(rgb8, C.c_ubyte))
 
+    def set_brdf_merl(self, obj, table):
+        table = np.ascontiguousarray(table, np.float64).ravel()
+        assert table.size == 3 * 90 * 90 * 180
+        self.host.mh_set_brdf_merl(self.h, obj, _p(table, C.c_double))
+
     def prepare(self):
         """Raytracer::prepare_render; uploads the scene when a device is open."""
         upload = self.device is not None

@@ -392,11 +392,13 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 		const mipt_object& o = s->objects[i];
 		DObject& d = H.obj[i];
 		if (o.ghost) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d is a ghost object (compositing branch is outside the hot path)", i);
-		if (o.brdf_kind != MIPT_BRDF_PHONG) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: only the Phong BRDF is implemented in this round", i);
+		if (o.brdf_kind != MIPT_BRDF_PHONG && o.brdf_kind != MIPT_BRDF_MERL) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: unknown BRDF kind %d", i, o.brdf_kind);
+		if (o.brdf_kind == MIPT_BRDF_MERL && !o.merl_data) return fail(c, MIPT_ERR_INVALID, "object %d: MERL BRDF without a table", i);
 		if (i < 2 && o.type != MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_INVALID, "objects 0 and 1 must be the light and environment spheres");
 		d.type = o.type; d.miroir = o.miroir; d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
 		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
 		d.brdf_kind = o.brdf_kind; d.merl = nullptr;
+		if (o.brdf_kind == MIPT_BRDF_MERL) { int rc = upload(c, o.merl_data, (size_t)3 * 90 * 90 * 180, &d.merl); if (rc) return rc; }
 		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
 		lists[MT_KD] = o.textures; counts[MT_KD] = o.n_textures;
 		lists[MT_KS] = o.specularmap; counts[MT_KS] = o.n_specularmap;

@@ -70,6 +70,72 @@ MIPT_DEV f3 phong_eval(const Mat& mat, f3 wi, f3 wo, f3 N) {
 	return diffuse + lobe * mat.Ks;
 }
 
+// ---------------------------------------------------------------- IsoMERLBRDF (BRDF.h:192-247, MERLBRDFRead.cpp:29-206)
+// fp64 half/difference-angle transform and table lookup, as the reference.  The trigonometric calls go
+// through the ROCm device library: a last-ulp difference from glibc can move a sample into the
+// neighbouring table cell, so MERL scenes are held to the stated tolerance, not to bit equality.
+MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, double* out) {   // rotate_vector :49-72
+	double ca = cos(angle), sa = sin(angle);
+	out[0] = v[0] * ca; out[1] = v[1] * ca; out[2] = v[2] * ca;
+	double temp = axis[0] * v[0] + axis[1] * v[1] + axis[2] * v[2];
+	temp = temp * (1.0 - ca);
+	out[0] += axis[0] * temp; out[1] += axis[1] * temp; out[2] += axis[2] * temp;
+	double cx = axis[1] * v[2] - axis[2] * v[1], cy = axis[2] * v[0] - axis[0] * v[2], cz = axis[0] * v[1] - axis[1] * v[0];
+	out[0] += cx * sa; out[1] += cy * sa; out[2] += cz * sa;
+}
+MIPT_DEV f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
+	f3 t1 = tangent_of(N);
+	f3 t2 = cross(t1, N);
+	f3 wil = mk3(dot(wi, t1), dot(wi, t2), dot(wi, N));
+	f3 wol = mk3(dot(wo, t1), dot(wo, t2), dot(wo, N));
+	float thetai = acosf(wil.z);
+	if ((double)thetai >= MIPT_PI / 2) return mk3(0, 0, 0);
+	float thetao = acosf(wol.z);
+	if ((double)thetao >= MIPT_PI / 2) return mk3(0, 0, 0);
+	float phio = atan2f(wol.y, wol.x);
+	if (phio < 0) phio = (float)((double)phio + 2 * MIPT_PI);
+	float phii = atan2f(wil.y, wil.x);
+	if (phii < 0) phii = (float)((double)phii + 2 * MIPT_PI);
+	// std_coords_to_half_diff_coords (:76-127)
+	double theta_in = thetai, fi_in = phii, theta_out = thetao, fi_out = phio;
+	double in_z = cos(theta_in), pin = sin(theta_in);
+	double in_x = pin * cos(fi_in), in_y = pin * sin(fi_in);
+	double in[3] = {in_x, in_y, in_z};
+	{ double len = sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]); in[0] = in[0] / len; in[1] = in[1] / len; in[2] = in[2] / len; }
+	double out_z = cos(theta_out), pout = sin(theta_out);
+	double out_x = pout * cos(fi_out), out_y = pout * sin(fi_out);
+	double half[3] = {(in_x + out_x) / 2.0, (in_y + out_y) / 2.0, (in_z + out_z) / 2.0};
+	{ double len = sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]); half[0] = half[0] / len; half[1] = half[1] / len; half[2] = half[2] / len; }
+	double theta_half = acos(half[2]);
+	double fi_half = atan2(half[1], half[0]);
+	const double bi_normal[3] = {0.0, 1.0, 0.0}, normal[3] = {0.0, 0.0, 1.0};
+	double temp[3], diff[3];
+	merl_rotate(in, normal, -fi_half, temp);
+	merl_rotate(temp, bi_normal, -theta_half, diff);
+	double theta_diff = acos(diff[2]);
+	double fi_diff = atan2(diff[1], diff[0]);
+	// index functions (:134-180)
+	int th_idx;
+	if (theta_half <= 0.0) th_idx = 0;
+	else {
+		double deg = ((theta_half / (MIPT_PI / 2.0)) * 90);
+		double t = sqrt(deg * 90);
+		th_idx = (int)t;
+		if (th_idx < 0) th_idx = 0;
+		if (th_idx >= 90) th_idx = 89;
+	}
+	int td = (int)(theta_diff / (MIPT_PI * 0.5) * 90);
+	int td_idx = td < 0 ? 0 : (td < 89 ? td : 89);
+	if (fi_diff < 0.0) fi_diff += MIPT_PI;
+	int pd = (int)(fi_diff / MIPT_PI * 360 / 2);
+	int pd_idx = pd < 0 ? 0 : (pd < 179 ? pd : 179);
+	int ind = pd_idx + td_idx * 180 + th_idx * 180 * 90;
+	double r = data[ind] * (1.0 / 1500.0);
+	double g = data[ind + 90 * 90 * 180] * (1.15 / 1500.0);
+	double b = data[ind + 90 * 90 * 360] * (1.66 / 1500.0);
+	return mk3((float)r, (float)g, (float)b);
+}
+
 // ---------------------------------------------------------------- path state
 struct PathState {
 	Ray ray;
@@ -167,7 +233,7 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	f3 wi = fast_normalize(pt_l - P);
 	float d_light2 = norm2(pt_l - P);
 	if (!(dot(mat.shadingN, wi) < 0)) {
-		f3 brdf = phong_eval(mat, wi, -rayDirection, N);
+		f3 brdf = obj.merl ? merl_eval(obj.merl, wi, -rayDirection, N) : phong_eval(mat, wi, -rayDirection, N);
 		float J = dot(dir_l, -wi) / d_light2;
 		float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
 		if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
@@ -181,9 +247,13 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
 	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
 	float pdf;
-	f3 dir = phong_sample(mat, -rayDirection, N, pdf, r1, r2, ps.rng);
+	f3 dir;
+	if (obj.merl) {                                   // IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw
+		dir = random_cos(N, r1, r2);
+		pdf = (float)((double)dot(N, dir) / (MIPT_PI));
+	} else dir = phong_sample(mat, -rayDirection, N, pdf, r1, r2, ps.rng);
 	if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) return false;   // :593
-	f3 brdf_i = phong_eval(mat, dir, -rayDirection, N);
+	f3 brdf_i = obj.merl ? merl_eval(obj.merl, dir, -rayDirection, N) : phong_eval(mat, dir, -rayDirection, N);
 	ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);            // :611
 	ps.ray.o = P + 0.01f * dir;
 	ps.ray.d = dir;

@@ -406,7 +406,8 @@ void Raytracer::build_descs() {
 		mipt_object& d = desc_objects_[i];
 		d.type = o->type; d.miroir = o->miroir; d.ghost = o->ghost; d.flip_normals = o->flip_normals; d.interp_normals = o->interp_normals;
 		memcpy(d.trans_matrix, o->trans_matrix, 48); memcpy(d.inv_trans_matrix, o->inv_trans_matrix, 48); memcpy(d.rot_matrix, o->rot_matrix, 36);
-		d.brdf_kind = MIPT_BRDF_PHONG; d.merl_data = nullptr;
+		d.brdf_kind = o->merl_data.empty() ? MIPT_BRDF_PHONG : MIPT_BRDF_MERL;
+		d.merl_data = o->merl_data.empty() ? nullptr : o->merl_data.data();
 		const std::vector<Texture>* lists[8] = {&o->textures, &o->specularmap, &o->alphamap, &o->roughnessmap, &o->normal_map, &o->subsurface, &o->transparent_map, &o->refr_index_map};
 		for (int l = 0; l < 8; l++) tex_list(*lists[l], desc_tex_[i * 8 + l]);
 		auto ptr = [&](int l) { return desc_tex_[i * 8 + l].empty() ? nullptr : desc_tex_[i * 8 + l].data(); };
@@ -547,6 +548,7 @@ void mh_set_group_texture(mh_raytracer* h, int obj, int grp, int slot, int W, in
 	if (slot == 2) t.loadNormalsRGB8(rgb, W, H); else t.loadColorsRGB8(rgb, W, H);
 }
 void mh_set_envmap(mh_raytracer* h, int W, int H, const unsigned char* rgb) { static_cast<Sphere*>(h->rt.s.objects[1])->load_envmap_rgb8(rgb, W, H); }
+void mh_set_brdf_merl(mh_raytracer* h, int obj, const double* table) { h->rt.s.objects[obj]->merl_data.assign(table, table + (size_t)3 * 90 * 90 * 180); }
 int mh_prepare(mh_raytracer* h, int upload) {
 	Raytracer& r = h->rt;
 	r.prepare_render((float)r.s.current_frame);

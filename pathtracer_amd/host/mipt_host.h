@@ -62,6 +62,7 @@ public:
 	Vector max_translation, rotation_center;
 	float mat_rotation[9];
 	float trans_matrix[12], inv_trans_matrix[12], rot_matrix[9];
+	std::vector<double> merl_data;    // IsoMERLBRDF::data (3 x 90*90*180) when the object's brdf is a MERL table, else empty (PhongBRDF)
 	std::vector<Texture> textures, specularmap, alphamap, roughnessmap, normal_map, subsurface, transparent_map, refr_index_map;
 private:
 	static Texture constant(const Vector& c) { Texture t; t.multiplier = c; return t; }
@@ -193,6 +194,7 @@ void mh_set_group_material(mh_raytracer*, int obj, int grp, const float* Kd, con
 void mh_add_group_material(mh_raytracer*, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
 void mh_set_group_texture(mh_raytracer*, int obj, int grp, int slot, int W, int H, const unsigned char* rgb);
 void mh_set_envmap(mh_raytracer*, int W, int H, const unsigned char* rgb);
+void mh_set_brdf_merl(mh_raytracer*, int obj, const double* table);   // objects[obj]->brdf = new IsoMERLBRDF(...) (mainApp.cpp:2436)
 int  mh_prepare(mh_raytracer*, int upload);               // prepare_render; upload=0 skips the device (CPU tests)
 int  mh_render_image(mh_raytracer*);
 int  mh_render_image_nopreviz(mh_raytracer*);

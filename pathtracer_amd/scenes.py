@@ -205,3 +205,19 @@ def bump_texture(W=32, H=32, seed=3):
     rng = np.random.default_rng(seed)
     n = np.stack([rng.normal(0, 25, (H, W)), rng.normal(0, 25, (H, W)), np.full((H, W), 110.0)], -1) + 128
     return np.clip(n, 0, 255).astype(np.uint8)
+
+
+def synthetic_merl_table(kd=(0.25, 0.2, 0.15), ks=0.4, shininess=60.0):
+    """Analytic Blinn-like lobe sampled into the MERL isotropic layout (config C4's measured BRDF):
+    3 colour planes x 90 theta_half x 90 theta_diff x 180 phi_diff doubles, stored pre-divided by
+    the per-channel scales the reader multiplies back (1, 1.15, 1.66)/1500."""
+    th_i = np.arange(90)
+    theta_half = (th_i + 0.5) ** 2 / 90.0 * (np.pi / 2) / 90.0     # inverse of theta_half_index (sqrt mapping)
+    theta_diff = (np.arange(90) + 0.5) / 90.0 * (np.pi / 2)
+    spec = ks * (shininess + 2) / (2 * np.pi) * np.cos(theta_half) ** shininess
+    fres = 0.04 + 0.96 * (1 - np.cos(theta_diff)) ** 5
+    val = spec[:, None, None] * (0.5 + fres)[None, :, None] * np.ones(180)[None, None, :]
+    planes = []
+    for c, scale in zip(range(3), (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)):
+        planes.append((kd[c] / np.pi + val) / scale)
+    return np.ascontiguousarray(np.stack(planes, 0), np.float64)

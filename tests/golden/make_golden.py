@@ -43,6 +43,10 @@ def golden_scene(name):
         cfg = scenes.config_c1(64, 36, 8)
         return scenes.blob_mesh(24, with_uv=True), cfg, dict(Kd=(0.8, 0.8, 0.8), Ks=(0, 0, 0), Ne=(0, 0, 0),
                                                                    tex={3: scenes.alpha_texture(), 2: scenes.bump_texture(), 0: scenes.checker_texture(16, 16, 2, 4)})
+    if name == "merl":       # config C4 in small: measured (MERL-layout) BRDF + thin-lens depth of field
+        cfg = scenes.config_c1(64, 36, 8)
+        cfg.aperture = 0.5
+        return scenes.blob_mesh(24), cfg, dict(Kd=(0.5, 0.5, 0.5), Ks=(0, 0, 0), Ne=(0, 0, 0), merl=scenes.synthetic_merl_table())
     if name == "c0full":
         return scenes.cornell_mesh(), scenes.config_c0(), None
     raise KeyError(name)
@@ -56,6 +60,8 @@ def setup(X, name):
         X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"], mat.get("transp", 1.0), mat.get("refr", 1.3))
         for slot, img in mat.get("tex", {}).items():
             X.set_group_texture(oid, 0, slot, img)
+        if "merl" in mat:
+            X.set_brdf_merl(oid, mat["merl"])
         if "envmap" in mat:
             X.set_envmap(mat["envmap"])
     X.prepare()
@@ -97,7 +103,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "leaf_functions.npz"), **g)
 
     # per-scene goldens: (iii) camera, (iv) BVH, (v) rays, (vii) per-sample radiance
-    for name in ("cornell", "blob32", "glossy", "glass", "textured", "cutout"):
+    for name in ("cornell", "blob32", "glossy", "glass", "textured", "cutout", "merl"):
         R = Ref()
         mesh, cfg, oid = setup(R, name)
         g = {}

@@ -31,7 +31,7 @@ def normalised(img, cnt):
     return img / np.maximum(cnt, 1e-30)[..., None] / WHITE
 
 
-@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout"])
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout", "merl"])
 def test_rays_bit_exact(name):
     g = load_golden(f"scene_{name}.npz")
     rt, _ = gpu(name)
@@ -47,7 +47,7 @@ def test_rays_bit_exact(name):
     assert_bits(rt.intersect_shadow(g["rays"], g["shadow_dist"]), g["shadow_occluded"], "occlusion")
 
 
-@pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False), ("textured", False), ("cutout", False)])
+@pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False), ("textured", False), ("cutout", False), ("merl", False)])
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_per_sample_radiance(name, exact, pipeline):
     g = load_golden(f"scene_{name}.npz")
@@ -67,7 +67,7 @@ def test_per_sample_radiance(name, exact, pipeline):
         assert pix_err < TOL, pix_err
 
 
-@pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False), ("textured", False), ("cutout", False)])
+@pytest.mark.parametrize("name,exact", [("cornell", True), ("blob32", True), ("glossy", False), ("glass", False), ("textured", False), ("cutout", False), ("merl", False)])
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_rendered_image(name, exact, pipeline):
     g = load_golden(f"scene_{name}.npz")

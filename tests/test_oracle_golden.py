@@ -22,7 +22,7 @@ def test_leaf_functions():
     assert_bits(O.phong_eval(g["phong_mat9"], g["phong_wi"], g["phong_wo"], g["phong_N"]), g["phong_eval"], "PhongBRDF::eval")
 
 
-@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout"])
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout", "merl"])
 def test_scene(name):
     g = load_golden(f"scene_{name}.npz")
     O = Oracle()
