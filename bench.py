@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=258, help="blob tessellation (258 -> 133 128 triangles)")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (repeatable)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for functional tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="functional test: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="profiling run: skip the CPU legs")
     return ap.parse_args()
@@ -120,11 +122,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    on_device = world == 1 or args.backend == "nccl"      # gloo reduces host copies
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -186,11 +194,14 @@ def main():
         kern_ms += st["traverse_ms"]; launches += st["traverse_launches"]
         sh_ms += st["shadow_ms"]; sh_launches += st["shadow_launches"]; shade_ms += st["shade_ms"]
         pipeline = st["pipeline"]
-    if world > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)     # the framebuffer reduce (RCCL over xGMI)
+    if world > 1:                                        # the framebuffer reduce (RCCL over xGMI)
+        if on_device:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+        else:
+            host = accum.cpu(); dist.all_reduce(host, op=dist.ReduceOp.SUM); accum.copy_(host)
     sync()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed, float(rays_c), float(rays_s), float(paths), kern_ms, float(launches)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(rays_c), float(rays_s), float(paths), kern_ms, float(launches)], dtype=torch.float64, device=dev if on_device else "cpu")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)

@@ -229,6 +229,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
 /* Tunables (name/value); unknown names return MIPT_ERR_INVALID.
  *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default)
  *   "refill"          pipeline 1: 1 = traversal stages refill idle lanes from the queue (default), 0 = one ray per lane
+ *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
+ *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
  *   "paths_per_pass"  upper bound on paths in flight per pass */
 int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);

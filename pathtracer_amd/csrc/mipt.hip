@@ -217,6 +217,7 @@ struct mipt_ctx {
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
+	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_paths_per_pass = 1 << 24;
 };
@@ -279,6 +280,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
+	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
@@ -650,7 +652,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
 	// carve the pass buffer
 	size_t bytes = N * (sizeof(float4) + sizeof(float2));
-	if (pipeline == 1) bytes += N * (7 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(unsigned)) + MIPT_WF_COUNTERS * sizeof(unsigned) + 256;
+	if (pipeline == 1) bytes += N * (7 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned)) + MIPT_WF_COUNTERS * sizeof(unsigned) + 256;
 	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, bytes))) return rc;
 	char* base = (char*)c->pass_buf;
 	auto carve = [&](size_t b) { char* r = base; base += (b + 15) & ~(size_t)15; return r; };
@@ -662,7 +664,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.wgt = (float4*)carve(N * sizeof(float4)); wf.hit = (float4*)carve(N * sizeof(float4));
 		wf.sh_o = (float4*)carve(N * sizeof(float4)); wf.sh_d = (float4*)carve(N * sizeof(float4)); wf.sh_c = (float4*)carve(N * sizeof(float4));
 		wf.rng = (uint2*)carve(N * sizeof(uint2));
-		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned));
+		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned)); wf.list_slow = (unsigned*)carve(N * sizeof(unsigned));
 		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
 		wf.out = S;
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
@@ -702,7 +704,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				else hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipLaunchKernelGGL(k_wf_shade, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+				if (c->opt_fast_shade) {
+					hipLaunchKernelGGL(k_wf_shade<1>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					hipLaunchKernelGGL(k_wf_shade<2>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+				} else hipLaunchKernelGGL(k_wf_shade<0>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, (const float4*)c->d_all_nodes, c->d_all_tris, wf, b, 0u, (int)c->opt_refill_threshold, (int)c->opt_inner_min);

@@ -71,10 +71,11 @@ MIPT_DEV float pt_cosf(float y) { return mipt_sincosf<true>(y); }
 
 // powf: exact for the cases the default materials produce (Ne = 0 -> 1, pow(1,y) = 1);
 // otherwise the device library's powf (<= 1 ulp from glibc's).
+__device__ __attribute__((noinline)) float powf_general(float x, float y) { return powf(x, y); }
 MIPT_DEV float pt_powf(float x, float y) {
 	if (y == 0.f) return 1.f;
 	if (x == 1.f) return 1.f;
-	return powf(x, y);
+	return powf_general(x, y);
 }
 
 // Raytracer.cpp:1294-1299 fast_exp (Schraudolph, on a double)

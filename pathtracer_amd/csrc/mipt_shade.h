@@ -39,7 +39,7 @@ MIPT_DEV f3 random_cos(f3 N, float r1, float r2) {
 }
 
 // ---------------------------------------------------------------- PhongBRDF (BRDF.h:41-96)
-MIPT_DEV f3 random_phong(f3 R, float phong_exponent, float r1, float r2) {
+__device__ __attribute__((noinline)) f3 random_phong(f3 R, float phong_exponent, float r1, float r2) {
 	float facteur = sqrtf(1 - pt_powf(r2, 2.f / (phong_exponent + 1.f)));
 	double ang = 2 * MIPT_PI * (double)r1;
 	f3 loc = mk3((float)(cos(ang) * (double)facteur), (float)(sin(ang) * (double)facteur), (float)pow((double)r2, 1. / (double)(phong_exponent + 1)));
@@ -83,7 +83,9 @@ MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, dou
 	double cx = axis[1] * v[2] - axis[2] * v[1], cy = axis[2] * v[0] - axis[0] * v[2], cz = axis[0] * v[1] - axis[1] * v[0];
 	out[0] += cx * sa; out[1] += cy * sa; out[2] += cz * sa;
 }
-MIPT_DEV f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
+// (cold paths of the shade stage are kept out of line so that they do not inflate the register
+// allocation and the instruction footprint of the common diffuse path)
+__device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
 	f3 wil = mk3(dot(wi, t1), dot(wi, t2), dot(wi, N));
@@ -260,6 +262,75 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	ps.show_lights = false;
 	ps.depth--;
 	return true;
+}
+
+
+// Fast tier of the shade stage: the same vertex logic restricted to what a plain diffuse vertex needs
+// (miss, light / environment sphere, Lambert-only Phong material with the diffuse lobe picked).
+// Anything else — mirror, dielectric, measured BRDF, a specular coefficient, a negative exponent, or the
+// 2^-25 event of the lobe pick choosing the Phong lobe at p = 1 — returns VERTEX_DEFER *before any
+// state is modified*, and the general kernel redoes that vertex.  For the vertices it does handle the
+// arithmetic is the reference's with the terms that are exactly zero left out:
+//   eval  = Kd/pi + lobe*Ks            with Ks = 0 and 0 <= lobe < inf   ->  Kd/pi      (x + (+0) = x)
+//   pdf   = p*dot/pi + (1-p)*proba_phong with p = 1 and proba_phong finite -> dot/pi    (needs dot(R,dir) >= 0;
+//           otherwise the sample is rejected by the reflect test whatever pdf is)
+enum { VERTEX_END = 0, VERTEX_CONTINUE = 1, VERTEX_DEFER = 2 };
+MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, PathState& ps, bool has_inter, const Hit& h, f3 P, const Mat& mat,
+                              int pix, int sampleID, ShadowRequest& sh, f3& weight_at_vertex) {
+	sh.diffuse = false;
+	sh.cast = false;
+	sh.contrib = mk3(0, 0, 0);
+	weight_at_vertex = ps.weight;
+	if (!has_inter) return VERTEX_END;
+	f3 N = mat.shadingN;
+	f3 rayDirection = ps.ray.d;
+	if (h.obj == 1) { ps.color = ps.color + (ps.weight * R.envmap_intensity) * mat.Ke; return VERTEX_END; }
+	if (h.obj == 0) {
+		f3 cc = ps.show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f);
+		ps.color = ps.color + ps.weight * cc;
+		return VERTEX_END;
+	}
+	const DObject& obj = sc->obj[h.obj];
+	const bool plain = !obj.miroir && !mat.transp && obj.merl == nullptr &&
+	                   mat.Ks.x == 0.f && mat.Ks.y == 0.f && mat.Ks.z == 0.f && mat.Ne.x >= 0.f && mat.Ne.y >= 0.f && mat.Ne.z >= 0.f;
+	if (!plain) return VERTEX_DEFER;
+	uint64_t rng = ps.rng;
+	f3 cl = ld3(R.centerLight);
+	f3 axeOP = fast_normalize(P - cl);
+	float l1 = pcg_uniform(rng);
+	float l2 = pcg_uniform(rng);
+	// lobe pick of PhongBRDF::sample (BRDF.h:73) with p = 1 - 0/3.f = 1: the diffuse lobe unless u == 1.0f
+	if (!((float)pcg_next(rng) / 4294967296.f < 1.f)) return VERTEX_DEFER;
+	f3 color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
+	sh.diffuse = true;
+	f3 dir_l = random_cos(axeOP, l1, l2);
+	f3 pt_l = dir_l * R.radiusLight + cl;
+	f3 wi = fast_normalize(pt_l - P);
+	float d_light2 = norm2(pt_l - P);
+	const f3 brdf = mat.Kd / (float)MIPT_PI;
+	if (!(dot(mat.shadingN, wi) < 0)) {
+		float J = dot(dir_l, -wi) / d_light2;
+		float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+		if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+		sh.cast = true;
+		sh.ray.o = P + 0.01f * wi;
+		sh.ray.d = wi;
+		sh.dist = sqrtf(d_light2) - 0.01f;
+	}
+	ps.color = color;
+	ps.rng = rng;
+	float ip;
+	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
+	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
+	f3 dir = random_cos(N, r1, r2);
+	float pdf = (float)((double)(1.f * dot(N, dir)) / (MIPT_PI) + (double)(0.f));
+	if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) return VERTEX_END;   // :593
+	ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf) * (dot(N, dir) / pdf);                   // :611
+	ps.ray.o = P + 0.01f * dir;
+	ps.ray.d = dir;
+	ps.show_lights = false;
+	ps.depth--;
+	return VERTEX_CONTINUE;
 }
 
 // Termination tests at the top of the loop (Raytracer.cpp:240-241)

@@ -25,12 +25,17 @@ struct DWave {
 	float4 *sh_o, *sh_d, *sh_c; // shadow request: origin (w = dist_light), direction, weight*contrib
 	unsigned* list[2];          // path ids to extend at even / odd depth
 	unsigned* list_sh;          // path ids with a pending shadow ray
+	unsigned* list_slow;        // path ids whose vertex the fast shade tier deferred to the general one
 	uint2* spill;               // traversal-stack overflow columns (persistent kernels)
 	unsigned* counters;         // per depth b: [4b] n_extend, [4b+1] extend head, [4b+2] n_shadow, [4b+3] shadow head; then shade heads
 	DSamples out;
 };
 #define MIPT_WF_MAX_DEPTH 255
-#define MIPT_WF_COUNTERS (4 * (MIPT_WF_MAX_DEPTH + 2) + (MIPT_WF_MAX_DEPTH + 2))
+// counters layout: [4b..4b+3] per depth (see DWave), then per depth: fast-shade head, then n_slow, then slow head
+#define MIPT_WF_CNT_SHADE_HEAD (4 * (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_CNT_NSLOW (MIPT_WF_CNT_SHADE_HEAD + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_CNT_SLOW_HEAD (MIPT_WF_CNT_NSLOW + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_COUNTERS (MIPT_WF_CNT_SLOW_HEAD + (MIPT_WF_MAX_DEPTH + 2))
 #define MIPT_HIT_MISS 0xffffffffu
 #define MIPT_HIT_NOTRI 0x07ffffffu
 
@@ -131,25 +136,28 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 	}
 }
 
-// shade: material of the hit, emission, next-event-estimation request, continuation sampling
+// shade: material of the hit, emission, next-event-estimation request, continuation sampling.
+// TIER 0: every vertex with the general code.  TIER 1: fast tier over the same queue; vertices it cannot
+// handle go to list_slow.  TIER 2: the general code over list_slow.
+template <int TIER>
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
-	const unsigned n = b == 0 ? n0 : wf.counters[4 * b];
-	unsigned* head = &wf.counters[4 * (MIPT_WF_MAX_DEPTH + 2) + b];
-	const unsigned* __restrict__ list = wf.list[b & 1];
+	const unsigned n = TIER == 2 ? wf.counters[MIPT_WF_CNT_NSLOW + b] : (b == 0 ? n0 : wf.counters[4 * b]);
+	unsigned* head = &wf.counters[(TIER == 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b];
+	const unsigned* __restrict__ list = TIER == 2 ? wf.list_slow : wf.list[b & 1];
+	const bool identity = TIER != 2 && b == 0;
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
 	while (queue_pull(head, n, base)) {
-		unsigned cont_bits = 0, cast_bits = 0;
+		unsigned cont_bits = 0, cast_bits = 0, slow_bits = 0;
 #pragma unroll 1
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
 			unsigned idx = base + 64u * u + lane_id();
 			if (idx >= n) continue;
-			unsigned id = b == 0 ? idx : list[idx];
+			unsigned id = identity ? idx : list[idx];
 			float4 w = wf.wgt[id];
 			unsigned fl = __float_as_uint(w.w);
-			if (b == 0 && !(fl & MIPT_WF_VALID)) continue;
-			n_closest++;
+			if (identity && !(fl & MIPT_WF_VALID)) continue;
 			float4 o = wf.ray_o[id], d = wf.ray_d[id], hr = wf.hit[id], col = wf.out.col[id];
 			uint2 rs = wf.rng[id];
 			PathState p;
@@ -170,7 +178,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 			int blk = slot >> 6, in = slot & 63;
 			int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
 			ShadowRequest sh; f3 wv;
-			bool c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			bool c;
+			if (TIER == 1) {
+				int r = path_vertex_fast(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+				if (r == VERTEX_DEFER) { slow_bits |= 1u << u; continue; }
+				c = r == VERTEX_CONTINUE;
+			} else c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			n_closest++;
 			wf.out.col[id] = make_float4(p.color.x, p.color.y, p.color.z, 0.f);
 			if (sh.diffuse && sh.cast) {
 				cast_bits |= 1u << u; n_shadow++;
@@ -188,9 +202,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 			}
 			if (c) cont_bits |= 1u << u;
 		}
-		const unsigned* src = b == 0 ? nullptr : list;
+		const unsigned* src = identity ? nullptr : list;
 		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast_bits, src, base);
 		queue_push(next, &wf.counters[4 * (b + 1)], cont_bits, src, base);
+		if (TIER == 1) queue_push(wf.list_slow, &wf.counters[MIPT_WF_CNT_NSLOW + b], slow_bits, src, base);
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);
