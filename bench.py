@@ -242,6 +242,12 @@ def main():
                                "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
                                "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],
                                "rays_per_launch": (rays_c if pipeline else rays_c + rays_s) / my_launches}
+            try:   # HBM bytes per launch of the dominant kernel from the committed PMC run (same workload)
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic.json")))["kernels"]["k_wf_traverse<false>" if pipeline == 1 else "k_render_paths"]
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_high"]
+                out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, profiles/r1_c_pmc_summary.txt; the BVH is served from L2 / Infinity Cache, HBM traffic is path state"
+            except Exception:
+                pass
             if pipeline == 1 and sh_launches:
                 sh_ach = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
                 out["roofline_shadow_kernel"] = {"kernel": "k_wf_traverse<true> (any-hit / shadow stage)", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,

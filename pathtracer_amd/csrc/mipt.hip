@@ -150,7 +150,8 @@ __device__ __forceinline__ float sum_area_table(const float* __restrict__ sat, i
 // rank contribute (multi-GPU partial images are summed by the framebuffer reduce).
 __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples in, float denom2, float* __restrict__ accum) {
 	int pid = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pid >= R.W * R.H) return;
+	if (ps.dest) { if (pid >= ps.ndest) return; pid = ps.dest[pid]; }
+	else if (pid >= R.W * R.H) return;
 	const int W = R.W, H = R.H, fs = R.filter_size, ftw = 2 * R.filter_size + 1;
 	int i2 = pid / W, j2 = pid % W;
 	size_t d = (size_t)(H - i2 - 1) * W + j2;
@@ -211,7 +212,8 @@ struct mipt_ctx {
 	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
 	// size changes, or after mipt_set_option("invalidate_tables", 1))
 	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; } tab_key;
-	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0; } blk_key;
+	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0, fs = -1; } blk_key;
+	int blk_ndest = 0;
 	int blk_nblocks = 0;
 	uint64_t blk_valid_pixels = 0;
 	int64_t opt_pipeline = 1;
@@ -623,19 +625,33 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (kb < 0 || ke > p->nrays || kb > ke) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays]");
 	{
 		int ts = p->tile_size > 0 ? p->tile_size : 32, nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
-		const bool cached = c->blk_buf && c->blk_key.W == p->W && c->blk_key.H == p->H && c->blk_key.ts == ts && c->blk_key.rk == p->tile_rank && c->blk_key.nr == nr;
+		const bool cached = c->blk_buf && c->blk_key.W == p->W && c->blk_key.H == p->H && c->blk_key.ts == ts && c->blk_key.rk == p->tile_rank && c->blk_key.nr == nr && c->blk_key.fs == p->filter_size;
 		if (!cached) {
 			std::vector<int> blocks, pix2slot;
 			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
 			c->blk_nblocks = (int)(blocks.size() / 2);
 			c->blk_valid_pixels = 0;
 			for (int v : pix2slot) if (v >= 0) c->blk_valid_pixels++;
-			size_t blk_bytes = (blocks.size() + pix2slot.size()) * sizeof(int);
+			// destinations of this rank's splats: owned pixels dilated by the filter radius (only needed
+			// when the image is shared between ranks; a single rank resolves every pixel)
+			std::vector<int> dest;
+			if (nr > 1) {
+				const int W = p->W, H = p->H, fs = p->filter_size;
+				for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+					bool any = false;
+					for (int a = std::max(0, i - fs); a <= std::min(H - 1, i + fs) && !any; a++)
+						for (int b = std::max(0, j - fs); b <= std::min(W - 1, j + fs); b++) if (pix2slot[(size_t)a * W + b] >= 0) { any = true; break; }
+					if (any) dest.push_back(i * W + j);
+				}
+			}
+			c->blk_ndest = (int)dest.size();
+			size_t blk_bytes = (blocks.size() + pix2slot.size() + dest.size()) * sizeof(int);
 			if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
+			if (!dest.empty()) HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size() + pix2slot.size(), dest.data(), dest.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size(), pix2slot.data(), pix2slot.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			HIPCHK(c, hipStreamSynchronize(st));
-			c->blk_key.W = p->W; c->blk_key.H = p->H; c->blk_key.ts = ts; c->blk_key.rk = p->tile_rank; c->blk_key.nr = nr;
+			c->blk_key.W = p->W; c->blk_key.H = p->H; c->blk_key.ts = ts; c->blk_key.rk = p->tile_rank; c->blk_key.nr = nr; c->blk_key.fs = p->filter_size;
 		}
 	}
 	const int nblocks = c->blk_nblocks;
@@ -672,6 +688,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
+	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;
+	const long long resolve_threads = P.dest ? (long long)P.ndest : (long long)R.W * R.H;
 	c->kev_kind.clear();
 	unsigned nev = 0;
 	auto timed_begin = [&](int kind) -> int {
@@ -715,7 +733,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
 		}
-		if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+		if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());
 		if (dump) {
 			HIPCHK(c, hipStreamSynchronize(st));

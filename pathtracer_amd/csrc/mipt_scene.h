@@ -96,4 +96,6 @@ struct DPass {
 	const int* blocks;         // (i0, j0) per block
 	const int* pix2slot;       // W*H: slot of the pixel inside this rank's block list, -1 if not owned
 	int npix_slots;            // nblocks * 64
+	const int* dest;           // pixels that receive a splat from an owned pixel (owned pixels dilated by the
+	int ndest;                 // filter radius), or null = every pixel of the image (single rank)
 };
