@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload): BASELINE.json configs[1] — 133 128-triangle diffuse blob, Phong BRDF,
-1920x1080, depth 4, default loadScene() light and camera.  One STEP = one pass of the hot path
-(camera rays -> getColor -> splat) over the whole frame at SPP_PER_STEP samples per pixel; the
-default K = 32 steps x 8 spp is exactly the 256 spp of the config.  With N GPUs the frame's
+Workload (config.workload): the configuration BASELINE.json's metric is quoted on ("1080p x 1024 spp",
+"the 2.5M-triangle scene") = configs[2]: 2 508 800-triangle blob with a 2048x2048 Kd texture and a
+4096x2048 environment map, Phong BRDF, 1920x1080, depth 4, default loadScene() light and camera; it
+fits one GPU.  --workload c1 / c3 / c4 select the other configs (c1 = 133 128-triangle diffuse blob).
+One STEP = one pass of the hot path (camera rays -> getColor -> splat) over the whole frame at
+--spp-per-step samples per pixel; the default K = 128 steps x 8 spp is exactly the 1024 spp of the
+config.  With N GPUs the frame's
 32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
 the per-rank accumulators are summed by ONE all-reduce at the end (RCCL), so the total work is
 fixed: "scaling": "strong".
@@ -40,11 +43,13 @@ SPP_PER_STEP = 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--grid", type=int, default=258, help="blob tessellation (258 -> 133 128 triangles)")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
+    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--grid", type=int, default=None, help="override the blob tessellation n (2 n^2 triangles)")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (repeatable)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for functional tests)")
@@ -54,16 +59,17 @@ def parse():
     return ap.parse_args()
 
 
-def oracle_bytes_per_ray(mesh, cfg_full):
+def oracle_bytes_per_ray(mesh, mat, cfg_full):
     """Mean algorithmic bytes per closest-hit / shadow ray on a bounded sample (same scene, same
     camera, 1/8 resolution, 2 spp), from the oracle's counters of the reference traversal."""
     import copy
     from oracle.binding import Oracle
     cfg = copy.copy(cfg_full)
     cfg.W, cfg.H, cfg.spp = max(8, cfg_full.W // 8), max(8, cfg_full.H // 8), 2
+    from pathtracer_amd import scenes
     O = Oracle()
     O.apply_config(cfg)
-    O.add_mesh(mesh)
+    scenes.install(O, mesh, mat)
     O.prepare()
     O.counters_reset()
     t, img, cnt, rays = O.render_omp(O.cdll.o_max_threads())
@@ -74,9 +80,10 @@ def oracle_bytes_per_ray(mesh, cfg_full):
                 sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp")
 
 
-def cpu_baseline(mesh, cfg_full, rays_per_path):
+def cpu_baseline(mesh, mat, cfg_full, rays_per_path):
     import copy
     from oracle import binding
+    from pathtracer_amd import scenes
     cfg = copy.copy(cfg_full)
     cfg.W, cfg.H = cfg_full.W // 4, cfg_full.H // 4
     cores = min(64, os.cpu_count() or 1)   # the reference supports at most 64 OpenMP threads
@@ -86,14 +93,14 @@ def cpu_baseline(mesh, cfg_full, rays_per_path):
     if binding.ref_available():
         R = binding.Ref()
         R.apply_config(cfg)
-        R.add_mesh(mesh)
+        scenes.install(R, mesh, mat)
         threads = R.max_threads()
         secs, _ = R.time_render_nopreviz(threads)
         kind = "reference"
     else:
         O = binding.Oracle()
         O.apply_config(cfg)
-        O.add_mesh(mesh)
+        scenes.install(O, mesh, mat)
         O.prepare()
         threads = O.cdll.o_max_threads()
         secs, _, _, _ = O.render_omp(threads)
@@ -143,20 +150,23 @@ def main():
         dist.barrier()
     from pathtracer_amd import capi, scenes
 
-    total_spp = SPP_PER_STEP * (args.steps + args.warmup)
-    cfg = scenes.config_c1(args.width, args.height, total_spp)
-    mesh = scenes.blob_mesh(args.grid)
+    SPS = args.spp_per_step
+    total_spp = SPS * (args.steps + args.warmup)
+    mesh, cfg, mat, wl_text = scenes.workload(args.workload, args.width, args.height, total_spp, args.grid)
+    args.width, args.height = cfg.W, cfg.H
 
     rt = capi.HostRaytracer(device=local_rank)
     rt.apply_config(cfg)
     rt.set_partition(32, rank, world)
-    rt.add_mesh(mesh)
+    t0 = time.time()
+    scenes.install(rt, mesh, mat)
+    t_build = time.time() - t0
     t0 = time.time()
     rt.prepare()
     t_prepare = time.time() - t0
     if args.pipeline >= 0:
         rt.set_option("pipeline", args.pipeline)
-    rt.set_option("paths_per_pass", args.width * args.height * SPP_PER_STEP)
+    rt.set_option("paths_per_pass", args.width * args.height * SPS)
     for kv in args.opt:
         k, v = kv.split("=")
         rt.set_option(k, int(v))
@@ -168,7 +178,7 @@ def main():
     assert P.W == args.width and P.nrays == total_spp and P.seed_stride == 65536 and P.tile_nranks == world
 
     def step(s):
-        P.sample_begin, P.sample_end = s * SPP_PER_STEP, (s + 1) * SPP_PER_STEP
+        P.sample_begin, P.sample_end = s * SPS, (s + 1) * SPS
         rt.render_device(accum.data_ptr(), stream)
         st = rt.stats()    # synchronises; cheap next to a step
         return st
@@ -212,22 +222,21 @@ def main():
         img = accum[: args.width * args.height * 3]
         finite = bool(torch.isfinite(img).all().item())
         out = {
-            "metric": "Msamples/s (primary+secondary rays) at 1080p; 1/2/4/8-GPU scaling",
+            "metric": "Msamples/s (primary+secondary rays) at 1080p\u00d71024spp; 1/2/4/8-GPU scaling",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {mesh.ntri}-triangle diffuse blob, {args.width}x{args.height}, "
-                                   f"{SPP_PER_STEP * args.steps} spp timed ({SPP_PER_STEP} spp/step), depth {cfg.nb_bounces}, Phong BRDF",
+            "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
                        "parallelism": f"tiles32x{world}", "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
-            "prepare_s": t_prepare, "finite": finite,
+            "host_bvh_build_s": t_build, "prepare_s": t_prepare, "finite": finite,
         }
         if world == 1 and args.pmc and pipeline == 1:
             out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
         if world == 1 and not args.pmc:
-            ob = oracle_bytes_per_ray(mesh, cfg)
+            ob = oracle_bytes_per_ray(mesh, mat, cfg)
             my_launches = max(1, launches)
             ms_per_launch = kern_ms / my_launches
             if pipeline == 0:     # one kernel casts both kinds of rays
@@ -243,9 +252,10 @@ def main():
                                "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],
                                "rays_per_launch": (rays_c if pipeline else rays_c + rays_s) / my_launches}
             try:   # HBM bytes per launch of the dominant kernel from the committed PMC run (same workload)
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic.json")))["kernels"]["k_wf_traverse<false>" if pipeline == 1 else "k_render_paths"]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))[args.workload]
+                tr = tj["kernels"]["k_wf_traverse<false>" if pipeline == 1 else "k_render_paths"]
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_high"]
-                out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, profiles/r1_c_pmc_summary.txt; the BVH is served from L2 / Infinity Cache, HBM traffic is path state"
+                out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of this kernel on this workload, " + tj["source"]
             except Exception:
                 pass
             if pipeline == 1 and sh_launches:
@@ -254,7 +264,7 @@ def main():
                                                  "launches": int(sh_launches)}
                 out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(mesh, cfg, ob["rays_per_path"])
+                out["cpu_baseline"] = cpu_baseline(mesh, mat, cfg, ob["rays_per_path"])
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -282,8 +282,26 @@ class Ref(_Base):
         from pathtracer_amd import scenes
         d = tmpdir or tempfile.mkdtemp(prefix="ptref_obj_")
         path = os.path.join(d, mesh.name + ".obj")
-        scenes.write_obj(mesh, path)
-        return self.lib.ref_add_mesh(self.ctx, path.encode(), _f(scale), 1 if center else 0)
+        if hasattr(self.lib, "ref_write_obj") and mesh.faces_v.shape[0] > 100000:    # same text, written from C
+            v = np.ascontiguousarray(mesh.vertices, np.float32); n = np.ascontiguousarray(mesh.normals, np.float32)
+            fv = np.ascontiguousarray(mesh.faces_v, np.int32); fn = np.ascontiguousarray(mesh.faces_n, np.int32)
+            uv = ft = None
+            if mesh.uvs is not None:
+                uv = np.ascontiguousarray(mesh.uvs, np.float32); ft = np.ascontiguousarray(mesh.faces_t, np.int32)
+            self.lib.ref_write_obj.restype = C.c_int
+            rc = self.lib.ref_write_obj(path.encode(), v.shape[0], _p(v, _f), n.shape[0], _p(n, _f), 0 if uv is None else uv.shape[0],
+                                        None if uv is None else _p(uv, _f), fv.shape[0], _p(fv, _i), _p(fn, _i), None if ft is None else _p(ft, _i))
+            if rc != 0:
+                raise OSError("ref_write_obj failed: " + path)
+        else:
+            scenes.write_obj(mesh, path)
+        rid = self.lib.ref_add_mesh(self.ctx, path.encode(), _f(scale), 1 if center else 0)
+        if tmpdir is None:
+            try:
+                os.remove(path); os.rmdir(d)
+            except OSError:
+                pass
+        return rid
 
     @staticmethod
     def _write_ppm(rgb8):

@@ -990,12 +990,45 @@ static float bb_area(v3 bmin, v3 bmax) {                                        
 static v3 vmin3(v3 a, v3 b) { return V(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
 static v3 vmax3(v3 a, v3 b) { return V(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 
-static void build_bvh_recur(o_mesh* g, int node, int i0, int i1, int depth) {
-	if (g->nnodes == g->cap_nodes) { g->cap_nodes = g->cap_nodes ? g->cap_nodes * 2 : 1024; g->nodes = (o_node*)realloc(g->nodes, sizeof(o_node) * g->cap_nodes); }
+/* One candidate plane of the loop at TriangleMesh.cpp:1062-1100: cost area_L*n_L + area_R*n_R */
+static float split_cost(const o_mesh* g, int i0, int i1, int split_dim, float split_val) {
+	v3 lmin = V(1E10, 1E10, 1E10), lmax = V(-1E10, -1E10, -1E10), rmin = V(1E10, 1E10, 1E10), rmax = V(-1E10, -1E10, -1E10);
+	int nl = 0, nr = 0;
+	for (int i = i0; i < i1; i++) {
+		const o_idx* ix = &g->indices[i];
+		float center_split_dim = (vget(g->vertices[ix->vtx[0]], split_dim) + vget(g->vertices[ix->vtx[1]], split_dim) + vget(g->vertices[ix->vtx[2]], split_dim)) / 3.f;  /* /3. narrowed == /3.f */
+		if (center_split_dim <= split_val) {
+			for (int c = 0; c < 3; c++) lmin = vmin3(lmin, g->vertices[ix->vtx[c]]);
+			for (int c = 0; c < 3; c++) lmax = vmax3(lmax, g->vertices[ix->vtx[c]]);
+			nl++;
+		} else {
+			for (int c = 0; c < 3; c++) rmin = vmin3(rmin, g->vertices[ix->vtx[c]]);
+			for (int c = 0; c < 3; c++) rmax = vmax3(rmax, g->vertices[ix->vtx[c]]);
+			nr++;
+		}
+	}
+	return bb_area(lmin, lmax) * nl + bb_area(rmin, rmax) * nr;
+}
+
+/* build_bvh_recur (TriangleMesh.cpp:1029-1130).  The tree and the node order are the reference's; to keep
+ * multi-million-triangle test scenes practical, a large right subtree is built as an OpenMP task into its
+ * own node array (child references relative to it) and spliced behind the left subtree, which gives the
+ * same preorder positions as the reference's push_back order; the 16 candidate planes of a large node are
+ * costed concurrently and the first minimum in plane order is taken, as the serial loop does. */
+typedef struct { o_node* a; int n, cap; } nodevec;
+static void nv_push(nodevec* v, o_node n) {
+	if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->a = (o_node*)realloc(v->a, sizeof(o_node) * (size_t)v->cap); }
+	v->a[v->n++] = n;
+}
+static int g_build_fork = 1 << 15, g_build_planes = 1 << 18;
+void o_set_build_thresholds(int fork_tris, int planes_tris) { g_build_fork = fork_tris; g_build_planes = planes_tris; }
+
+static void build_bvh_recur(o_mesh* g, nodevec* out, int i0, int i1, int depth) {
+	const int node = out->n;
 	o_node n;
 	bbox_of(g, i0, i1, &n.bmin, &n.bmax);
 	n.fg = i0; n.fd = i1; n.isleaf = 1;
-	g->nodes[g->nnodes++] = n;
+	nv_push(out, n);
 
 	v3 cmin, cmax;
 	centers_bbox_of(g, i0, i1, &cmin, &cmax);
@@ -1005,30 +1038,14 @@ static void build_bvh_recur(o_mesh* g, int node, int i0, int i1, int depth) {
 	else if ((diag.y >= diag.x) && (diag.y >= diag.z)) split_dim = 1;
 	else split_dim = 2;
 
+	enum { max_tests = 16 };
+	float cost[max_tests], factor[max_tests];
+	for (int t = 0; t < max_tests; t++) factor[t] = (t + 1) / (float)(max_tests + 1);
+	#pragma omp taskloop shared(cost, factor) if(i1 - i0 >= g_build_planes)
+	for (int t = 0; t < max_tests; t++) cost[t] = split_cost(g, i0, i1, split_dim, vget(cmin, split_dim) + vget(diag, split_dim) * factor[t]);
 	float best_split_factor = 0.5;
 	float best_area_bb = INFINITY;   /* 1E50 narrowed */
-	const int max_tests = 16;
-	for (int test_split = 0; test_split < max_tests; test_split++) {
-		float cur_split_factor = (test_split + 1) / (float)(max_tests + 1);
-		float split_val = vget(cmin, split_dim) + vget(diag, split_dim) * cur_split_factor;
-		v3 lmin = V(1E10, 1E10, 1E10), lmax = V(-1E10, -1E10, -1E10), rmin = V(1E10, 1E10, 1E10), rmax = V(-1E10, -1E10, -1E10);
-		int nl = 0, nr = 0;
-		for (int i = i0; i < i1; i++) {
-			const o_idx* ix = &g->indices[i];
-			float center_split_dim = (vget(g->vertices[ix->vtx[0]], split_dim) + vget(g->vertices[ix->vtx[1]], split_dim) + vget(g->vertices[ix->vtx[2]], split_dim)) / 3.f;  /* /3. narrowed == /3.f */
-			if (center_split_dim <= split_val) {
-				for (int c = 0; c < 3; c++) lmin = vmin3(lmin, g->vertices[ix->vtx[c]]);
-				for (int c = 0; c < 3; c++) lmax = vmax3(lmax, g->vertices[ix->vtx[c]]);
-				nl++;
-			} else {
-				for (int c = 0; c < 3; c++) rmin = vmin3(rmin, g->vertices[ix->vtx[c]]);
-				for (int c = 0; c < 3; c++) rmax = vmax3(rmax, g->vertices[ix->vtx[c]]);
-				nr++;
-			}
-		}
-		float sum_area_bb = bb_area(lmin, lmax) * nl + bb_area(rmin, rmax) * nr;
-		if (sum_area_bb < best_area_bb) { best_split_factor = cur_split_factor; best_area_bb = sum_area_bb; }
-	}
+	for (int t = 0; t < max_tests; t++) if (cost[t] < best_area_bb) { best_split_factor = factor[t]; best_area_bb = cost[t]; }
 	float split_val = vget(cmin, split_dim) + vget(diag, split_dim) * best_split_factor;
 	int pivot = i0 - 1;
 	for (int i = i0; i < i1; i++) {
@@ -1041,11 +1058,24 @@ static void build_bvh_recur(o_mesh* g, int node, int i0, int i1, int depth) {
 		}
 	}
 	if (pivot < i0 || pivot >= i1 - 1 || i1 <= i0 + 4) return;
-	g->nodes[node].isleaf = 0;
-	g->nodes[node].fg = g->nnodes;
-	build_bvh_recur(g, g->nodes[node].fg, i0, pivot + 1, depth + 1);
-	g->nodes[node].fd = g->nnodes;
-	build_bvh_recur(g, g->nodes[node].fd, pivot + 1, i1, depth + 1);
+	out->a[node].isleaf = 0;
+	if (i1 - (pivot + 1) >= g_build_fork && pivot + 1 - i0 >= g_build_fork) {
+		nodevec right = {0, 0, 0};
+		#pragma omp task shared(right)
+		build_bvh_recur(g, &right, pivot + 1, i1, depth + 1);
+		out->a[node].fg = out->n;
+		build_bvh_recur(g, out, i0, pivot + 1, depth + 1);
+		#pragma omp taskwait
+		const int off = out->n;
+		out->a[node].fd = off;
+		for (int k = 0; k < right.n; k++) { o_node r = right.a[k]; if (!r.isleaf) { r.fg += off; r.fd += off; } nv_push(out, r); }
+		free(right.a);
+	} else {
+		out->a[node].fg = out->n;
+		build_bvh_recur(g, out, i0, pivot + 1, depth + 1);
+		out->a[node].fd = out->n;
+		build_bvh_recur(g, out, pivot + 1, i1, depth + 1);
+	}
 }
 
 /* setup_tangents (TriangleMesh.cpp:601-711), only what getMaterial's normal-map branch reads */
@@ -1175,7 +1205,13 @@ int o_add_mesh(o_ctx* c, int nv, const float* verts, int nn, const float* normal
 	for (int i = 0; i < nf; i++) g->perm[i] = i;
 	/* build_bvh (:878-885) */
 	bbox_of(g, 0, nf, &g->root_min, &g->root_max);
-	build_bvh_recur(g, 0, 0, nf, 0);
+	{
+		nodevec nv = {0, 0, 0};
+		#pragma omp parallel
+		#pragma omp single
+		build_bvh_recur(g, &nv, 0, nf, 0);
+		g->nodes = nv.a; g->nnodes = nv.n; g->cap_nodes = nv.cap;
+	}
 	bbox_of(g, 0, nf, &g->bb_min, &g->bb_max);
 	/* triangle soup (:812-829), after the reorder */
 	g->soup = (o_tri*)calloc((size_t)nf, sizeof(o_tri));

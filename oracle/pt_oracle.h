@@ -31,6 +31,8 @@ void   o_set_envmap_intensity(o_ctx*, float v);
  * followed by the GUI placement (mainApp.cpp:2402-2410).  ft/uvs may be NULL. Returns object id. */
 int    o_add_mesh(o_ctx*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
                   int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
+/* test hook: triangle counts above which the (tree-identical) parallel build forks subtrees / costs planes concurrently */
+void   o_set_build_thresholds(int fork_tris, int planes_tris);
 void   o_set_object_flags(o_ctx*, int obj, int miroir, int flip_normals);
 void   o_set_group_material(o_ctx*, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
 void   o_add_group_material(o_ctx*, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);

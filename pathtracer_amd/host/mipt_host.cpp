@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -133,7 +134,7 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 	// build_bvh (:878-885)
 	build_bbox(0, nf, bvh.bbox);
 	bvh.nodes.reserve((size_t)nf * 2);
-	build_bvh_recur(0, 0, nf, 0);
+	build_bvh_recur(bvh.nodes, 0, nf, 0);
 	build_bbox(0, nf, bbox);
 	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
 	triangleSoup.resize(nf);
@@ -178,11 +179,42 @@ void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
 
 // build_bvh_recur (TriangleMesh.cpp:1029-1130): longest centroid axis, 16 candidate planes,
 // cost area_L*n_L + area_R*n_R, in-place partition, <= 4 triangles per leaf, nodes in preorder.
-void TriMesh::build_bvh_recur(int node, int i0, int i1, int depth) {
+//
+// Same tree as the reference, built in parallel: the two children of a node work on disjoint index
+// ranges, so a large right subtree is built on another thread into its own node vector (child
+// references relative to that vector) and spliced behind the left subtree afterwards — preorder
+// positions are then exactly what the serial push_back order gives.  The 16 candidate planes of a
+// large node are evaluated concurrently as well (the first minimum in plane order wins, as in the loop).
+namespace {
+int kParallelSubtree = 1 << 15;      // ranges above this many triangles fork
+int kParallelPlanes = 1 << 18;       // ranges above this evaluate the candidate planes on threads
+}
+extern "C" void mh_set_build_thresholds(int fork_tris, int planes_tris) { kParallelSubtree = fork_tris; kParallelPlanes = planes_tris; }
+
+float TriMesh::split_cost(int i0, int i1, int split_dim, float split_val) const {
+	float lmin[3] = {1E10f, 1E10f, 1E10f}, lmax[3] = {-1E10f, -1E10f, -1E10f}, rmin[3] = {1E10f, 1E10f, 1E10f}, rmax[3] = {-1E10f, -1E10f, -1E10f};
+	int nl = 0, nr = 0;
+	for (int i = i0; i < i1; i++) {
+		const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
+		const float c = (vertices[vi[0]][split_dim] + vertices[vi[1]][split_dim] + vertices[vi[2]][split_dim]) / 3.f;   // (a+b+c)/3. narrowed == /3.f
+		if (c <= split_val) {
+			for (int c2 = 0; c2 < 3; c2++) for (int k = 0; k < 3; k++) { lmin[k] = std::min(lmin[k], vertices[vi[c2]][k]); lmax[k] = std::max(lmax[k], vertices[vi[c2]][k]); }
+			nl++;
+		} else {
+			for (int c2 = 0; c2 < 3; c2++) for (int k = 0; k < 3; k++) { rmin[k] = std::min(rmin[k], vertices[vi[c2]][k]); rmax[k] = std::max(rmax[k], vertices[vi[c2]][k]); }
+			nr++;
+		}
+	}
+	auto area = [](const float* mn, const float* mx) { float s0 = mx[0] - mn[0], s1 = mx[1] - mn[1], s2 = mx[2] - mn[2]; return 2 * (s0 * s1 + s0 * s2 + s1 * s2); };
+	return area(lmin, lmax) * nl + area(rmin, rmax) * nr;
+}
+
+void TriMesh::build_bvh_recur(std::vector<BVHNodes>& out, int i0, int i1, int depth) {
+	const int node = (int)out.size();
 	BVHNodes n;
 	build_bbox(i0, i1, n.bbox);
 	n.fg = i0; n.fd = i1; n.isleaf = true;
-	bvh.nodes.push_back(n);
+	out.push_back(n);
 	float cb[6];
 	build_centers_bbox(i0, i1, cb);
 	const float diag[3] = {cb[3] - cb[0], cb[4] - cb[1], cb[5] - cb[2]};
@@ -190,46 +222,46 @@ void TriMesh::build_bvh_recur(int node, int i0, int i1, int depth) {
 	if (diag[0] >= diag[1] && diag[0] >= diag[2]) split_dim = 0;
 	else if (diag[1] >= diag[0] && diag[1] >= diag[2]) split_dim = 1;
 	else split_dim = 2;
-	auto centroid = [&](int i) {   // (a+b+c)/3. narrowed == /3.f
-		return (vertices[indices[i].vtxi][split_dim] + vertices[indices[i].vtxj][split_dim] + vertices[indices[i].vtxk][split_dim]) / 3.f;
-	};
-	auto area = [](const float* mn, const float* mx) { float s0 = mx[0] - mn[0], s1 = mx[1] - mn[1], s2 = mx[2] - mn[2]; return 2 * (s0 * s1 + s0 * s2 + s1 * s2); };
+	const int max_tests = 16;
+	float cost[max_tests], factor[max_tests];
+	for (int t = 0; t < max_tests; t++) factor[t] = (t + 1) / (float)(max_tests + 1);
+	if (i1 - i0 >= kParallelPlanes) {
+		std::vector<std::thread> th;
+		for (int t = 0; t < max_tests; t++) th.emplace_back([&, t] { cost[t] = split_cost(i0, i1, split_dim, cb[split_dim] + diag[split_dim] * factor[t]); });
+		for (auto& x : th) x.join();
+	} else {
+		for (int t = 0; t < max_tests; t++) cost[t] = split_cost(i0, i1, split_dim, cb[split_dim] + diag[split_dim] * factor[t]);
+	}
 	float best_split_factor = 0.5f;
 	float best_area_bb = std::numeric_limits<float>::infinity();   // 1E50 narrowed
-	const int max_tests = 16;
-	for (int test_split = 0; test_split < max_tests; test_split++) {
-		float cur_split_factor = (test_split + 1) / (float)(max_tests + 1);
-		float split_val = cb[split_dim] + diag[split_dim] * cur_split_factor;
-		float lmin[3] = {1E10f, 1E10f, 1E10f}, lmax[3] = {-1E10f, -1E10f, -1E10f}, rmin[3] = {1E10f, 1E10f, 1E10f}, rmax[3] = {-1E10f, -1E10f, -1E10f};
-		int nl = 0, nr = 0;
-		for (int i = i0; i < i1; i++) {
-			const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
-			if (centroid(i) <= split_val) {
-				for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { lmin[k] = std::min(lmin[k], vertices[vi[c]][k]); lmax[k] = std::max(lmax[k], vertices[vi[c]][k]); }
-				nl++;
-			} else {
-				for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { rmin[k] = std::min(rmin[k], vertices[vi[c]][k]); rmax[k] = std::max(rmax[k], vertices[vi[c]][k]); }
-				nr++;
-			}
-		}
-		float sum_area_bb = area(lmin, lmax) * nl + area(rmin, rmax) * nr;
-		if (sum_area_bb < best_area_bb) { best_split_factor = cur_split_factor; best_area_bb = sum_area_bb; }
-	}
+	for (int t = 0; t < max_tests; t++) if (cost[t] < best_area_bb) { best_split_factor = factor[t]; best_area_bb = cost[t]; }
 	float split_val = cb[split_dim] + diag[split_dim] * best_split_factor;
 	int pivot = i0 - 1;
 	for (int i = i0; i < i1; i++) {
-		if (centroid(i) <= split_val) {
+		const float c = (vertices[indices[i].vtxi][split_dim] + vertices[indices[i].vtxj][split_dim] + vertices[indices[i].vtxk][split_dim]) / 3.f;
+		if (c <= split_val) {
 			pivot++;
 			std::swap(indices[i], indices[pivot]);
 			std::swap(permuted_triangle_index[i], permuted_triangle_index[pivot]);
 		}
 	}
 	if (pivot < i0 || pivot >= i1 - 1 || i1 <= i0 + 4) return;
-	bvh.nodes[node].isleaf = false;
-	bvh.nodes[node].fg = (int)bvh.nodes.size();
-	build_bvh_recur(bvh.nodes[node].fg, i0, pivot + 1, depth + 1);
-	bvh.nodes[node].fd = (int)bvh.nodes.size();
-	build_bvh_recur(bvh.nodes[node].fd, pivot + 1, i1, depth + 1);
+	out[node].isleaf = false;
+	if (i1 - (pivot + 1) >= kParallelSubtree && pivot + 1 - i0 >= kParallelSubtree) {
+		std::vector<BVHNodes> right;
+		std::thread worker([&] { build_bvh_recur(right, pivot + 1, i1, depth + 1); });
+		out[node].fg = (int)out.size();
+		build_bvh_recur(out, i0, pivot + 1, depth + 1);
+		worker.join();
+		const int off = (int)out.size();
+		out[node].fd = off;
+		for (BVHNodes& r : right) { if (!r.isleaf) { r.fg += off; r.fd += off; } out.push_back(r); }
+	} else {
+		out[node].fg = (int)out.size();
+		build_bvh_recur(out, i0, pivot + 1, depth + 1);
+		out[node].fd = (int)out.size();
+		build_bvh_recur(out, pivot + 1, i1, depth + 1);
+	}
 }
 
 // setup_tangents (TriangleMesh.cpp:601-711): only tangentSoup is read by the path (normal maps).

@@ -98,7 +98,8 @@ public:
 private:
 	void build_bbox(int i0, int i1, float* out6) const;
 	void build_centers_bbox(int i0, int i1, float* out6) const;
-	void build_bvh_recur(int node, int i0, int i1, int depth);
+	float split_cost(int i0, int i1, int split_dim, float split_val) const;
+	void build_bvh_recur(std::vector<BVHNodes>& out, int i0, int i1, int depth);
 	void setup_tangents();
 };
 
@@ -189,6 +190,7 @@ void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_l
 void mh_set_envmap_intensity(mh_raytracer*, float v);
 int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
                  int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
+void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks
 void mh_set_object_flags(mh_raytracer*, int obj, int miroir, int flip_normals);
 void mh_set_group_material(mh_raytracer*, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
 void mh_add_group_material(mh_raytracer*, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);

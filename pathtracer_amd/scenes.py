@@ -221,3 +221,49 @@ def synthetic_merl_table(kd=(0.25, 0.2, 0.15), ks=0.4, shininess=60.0):
     for c, scale in zip(range(3), (1.0 / 1500.0, 1.15 / 1500.0, 1.66 / 1500.0)):
         planes.append((kd[c] / np.pi + val) / scale)
     return np.ascontiguousarray(np.stack(planes, 0), np.float64)
+
+
+# ---------------------------------------------------------------- BASELINE.json configs as workloads
+def workload(name: str, width: int = None, height: int = None, spp: int = None, grid: int = None):
+    """(mesh, cfg, material, description) of BASELINE.json configs[1..4] (SURVEY.md §8d synthetic inputs).
+    `material` is None (OBJ/MTL defaults) or a dict understood by install()."""
+    name = name.lower()
+    if name == "c1":      # 133k-triangle diffuse blob, 1080p, 256 spp, depth 4
+        g = grid or 258
+        cfg = config_c1(width or 1920, height or 1080, spp or 256)
+        return blob_mesh(g), cfg, None, f"configs[1]: {2 * g * g}-triangle diffuse blob, Phong BRDF"
+    if name == "c2":      # 2.5M triangles, Kd texture, env map, 1024 spp
+        g = grid or 1120
+        cfg = config_c1(width or 1920, height or 1080, spp or 1024)
+        mat = dict(Kd=(1.0, 1.0, 1.0), Ks=(0.0, 0.0, 0.0), Ne=(0.0, 0.0, 0.0),
+                   tex={0: checker_texture(2048, 2048, 7, 64)}, envmap=sky_envmap(4096, 2048))
+        return blob_mesh(g, with_uv=True), cfg, mat, f"configs[2]: {2 * g * g}-triangle blob, 2048x2048 Kd texture, 4096x2048 env map, Phong BRDF"
+    if name == "c3":      # same mesh, fully transparent (Fresnel dielectric n = 1.3), depth 12
+        g = grid or 1120
+        cfg = config_c1(width or 1920, height or 1080, spp or 1024)
+        cfg.nb_bounces = 12
+        mat = dict(Kd=(0.5, 0.5, 0.5), Ks=(0.0, 0.0, 0.0), Ne=(0.0, 0.0, 0.0), transp=0.0, refr=1.3)
+        return blob_mesh(g), cfg, mat, f"configs[3]: {2 * g * g}-triangle dielectric blob (n=1.3), depth 12"
+    if name == "c4":      # 23.7M triangles, MERL-layout measured BRDF, depth of field, 4K, 4096 spp
+        g = grid or 3444
+        cfg = config_c1(width or 3840, height or 2160, spp or 4096)
+        cfg.aperture = 0.5
+        cfg.focus = 50.0
+        mat = dict(Kd=(0.5, 0.5, 0.5), Ks=(0.0, 0.0, 0.0), Ne=(0.0, 0.0, 0.0), merl=synthetic_merl_table())
+        return blob_mesh(g, fine_detail=True), cfg, mat, f"configs[4]: {2 * g * g}-triangle blob, MERL-layout BRDF table, aperture 0.5"
+    raise KeyError(name)
+
+
+def install(X, mesh, mat):
+    """Adds the workload's mesh and material to X: a capi.HostRaytracer, an oracle.binding.Oracle or a
+    binding.Ref (they share these method names).  Returns the object id."""
+    oid = X.add_mesh(mesh)
+    if mat is not None:
+        X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"], mat.get("transp", 1.0), mat.get("refr", 1.3))
+        for slot, img in mat.get("tex", {}).items():
+            X.set_group_texture(oid, 0, slot, img)
+        if "merl" in mat:
+            X.set_brdf_merl(oid, mat["merl"])
+        if "envmap" in mat:
+            X.set_envmap(mat["envmap"])
+    return oid

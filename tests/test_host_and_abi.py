@@ -99,3 +99,27 @@ def test_render_params_layout():
     assert P.seed_stride == 65536 and (P.sample_begin, P.sample_end) == (0, cfg.spp)
     assert (P.tile_size, P.tile_rank, P.tile_nranks) == (16, 1, 3)
     assert_bits(np.array(list(P.centerLight) + [P.radiusLight, P.lightPower], np.float32), H.light(), "light block")
+
+
+def test_parallel_bvh_build_gives_the_serial_tree():
+    """The host mirror (std::thread) and the oracle (OpenMP tasks) fork large subtrees and cost the 16
+    candidate planes of large nodes concurrently; the tree, node order and triangle permutation must be
+    those of the serial build (which the goldens pin to the reference)."""
+    from oracle.binding import Oracle
+    mipt, host = capi.load()
+    mesh = scenes.blob_mesh(48, with_uv=True)          # 4608 triangles
+    cfg = scenes.config_c1(16, 16, 1)
+    dumps = []
+    for fork, planes in ((1 << 30, 1 << 30), (64, 512)):
+        host.mh_set_build_thresholds(fork, planes)
+        H = capi.HostRaytracer(); H.apply_config(cfg)
+        dumps.append(("host", fork, H.mesh_dump(H.add_mesh(mesh))))
+        O = Oracle(); O.cdll.o_set_build_thresholds(fork, planes); O.apply_config(cfg)
+        dumps.append(("oracle", fork, O.mesh_dump(O.add_mesh(mesh))))
+    host.mh_set_build_thresholds(1 << 15, 1 << 18)
+    O.cdll.o_set_build_thresholds(1 << 15, 1 << 18)
+    ref = dumps[0][2]
+    assert ref["nodes_i"].shape[0] > 2000
+    for who, fork, d in dumps[1:]:
+        for key in ("perm", "nodes_i", "nodes_bb", "soup", "root_bb"):
+            assert_bits(d[key], ref[key], f"{who} fork={fork} mesh.{key}")
