@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBMIPT = os.path.join(_HERE, "libmipt.so")
+LIBMIPT = os.environ.get("MIPT_LIB_OVERRIDE") or os.path.join(_HERE, "libmipt.so")   # override: tuning builds (tools/)
 LIBHOST = os.path.join(_HERE, "libmipt_host.so")
 
 MIPT_OK = 0

@@ -323,17 +323,21 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	if (!m || m->n_triangles <= 0 || m->n_nodes <= 0 || !m->nodes || !m->triangleSoup || !m->indices) return fail(c, MIPT_ERR_INVALID, "incomplete mesh description");
 	const int nn = m->n_nodes, nt = m->n_triangles;
 	if ((unsigned)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
+	if (stg.ti.size() + (size_t)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
+	// child references are scene-wide: inner = index into the scene's node buffer, leaf = first triangle in the
+	// scene's triangle buffer (the traversal then needs no per-mesh base registers)
+	const uint32_t node_base = (uint32_t)stg.fat.size(), tri_base = (uint32_t)stg.ti.size();
 	std::vector<int> fat_index(nn, -1);
 	int nfat = 0;
 	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) fat_index[i] = nfat++;
 	auto child_ref = [&](int node, uint32_t& ref) -> int {
 		if (node < 0 || node >= nn) return fail(c, MIPT_ERR_INVALID, "BVH child index out of range");
 		const mipt_bvh_node& n = m->nodes[node];
-		if (!n.isleaf) { ref = (uint32_t)fat_index[node]; return MIPT_OK; }
+		if (!n.isleaf) { ref = node_base + (uint32_t)fat_index[node]; return MIPT_OK; }
 		int cnt = n.fd - n.fg;
 		if (n.fg < 0 || n.fd > nt || cnt <= 0) return fail(c, MIPT_ERR_INVALID, "BVH leaf range out of bounds");
 		if (cnt > MIPT_LEAF_MAX_TRIS) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles (max %d)", cnt, MIPT_LEAF_MAX_TRIS);
-		ref = MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (uint32_t)n.fg;
+		ref = MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (tri_base + (uint32_t)n.fg);
 		return MIPT_OK;
 	};
 	std::vector<DFatNode> fat(nfat > 0 ? nfat : 1);
@@ -365,8 +369,7 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		ts[i].group = m->indices[i].group;
 		if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
 	}
-	if (stg.ti.size() + ti.size() > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
-	d.node_base = (uint32_t)stg.fat.size(); d.tri_base = (uint32_t)stg.ti.size();
+	d.node_base = node_base; d.tri_base = tri_base;
 	stg.fat.insert(stg.fat.end(), fat.begin(), fat.end());
 	stg.ti.insert(stg.ti.end(), ti.begin(), ti.end());
 	stg.ts.insert(stg.ts.end(), ts.begin(), ts.end());
@@ -453,7 +456,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
 		if (d.type != MIPT_OBJ_TRIMESH) continue;
-		d.nodes = H.all_nodes + d.node_base; d.tris = H.all_tris + d.tri_base; d.shade = all_shade + d.tri_base;
+		d.nodes = H.all_nodes; d.tris = H.all_tris; d.shade = all_shade + d.tri_base;
 	}
 	const DScene* dsc = nullptr;
 	rc = upload(c, hs.data(), 1, &dsc);
@@ -816,9 +819,9 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 }
 
 #ifdef MIPT_PROFILE_SIMD
-extern "C" int mipt_debug_simd_profile(unsigned long long* out4, int reset) {
-	if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_simd_prof), 32) != hipSuccess) return MIPT_ERR_HIP;
-	if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 32) != hipSuccess) return MIPT_ERR_HIP; }
+extern "C" int mipt_debug_simd_profile(unsigned long long* out16, int reset) {
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_simd_prof), 128) != hipSuccess) return MIPT_ERR_HIP;
+	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 128) != hipSuccess) return MIPT_ERR_HIP; }
 	return MIPT_OK;
 }
 #endif

@@ -20,13 +20,11 @@ struct LaneState {
 	float t;                // closest: best t over the objects visited so far; shadow: t of the current mesh
 	float beta, gamma;      // closest: barycentrics of the best triangle
 	float dist;             // shadow: dist_light
-	uint32_t cur;           // current node reference (mesh-local) or NONE
-	uint32_t node_base, tri_base;
+	uint32_t cur;           // current node reference (scene-wide) or NONE
 	int sp;
 	int obj;                // object being traversed / next object to visit
 	int best;               // closest: packed best hit (MIPT_HIT_MISS = none); shadow: 1 = occluded
 	unsigned id;            // path id
-	unsigned signs;         // bit0 sx, bit1 sy, bit2 sz
 };
 
 #define MIPT_NONE 0x7fffffffu
@@ -58,15 +56,16 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 	if (SHADOW && enter && t_root > st.dist) enter = false;
 	if (!enter) return false;
 	st.org = org; st.d = d; st.invd = invd;
-	st.signs = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
 	if (SHADOW) st.t = cur_best_t;
 	st.cur = o.root_ref; st.sp = 0;
-	st.node_base = o.node_base; st.tri_base = o.tri_base;
 	return true;
 }
 
+#ifndef MIPT_TRAVERSE_WAVES
+#define MIPT_TRAVERSE_WAVES 4
+#endif
 template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
 	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
@@ -80,8 +79,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 	const unsigned long long below = (1ull << lane) - 1ull;
 
 	LaneState st;
-	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0; st.signs = 0;
-	st.node_base = 0; st.tri_base = 0; st.org = mk3(0, 0, 0); st.d = mk3(0, 0, 0); st.invd = mk3(0, 0, 0);
+	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0;
+	st.org = mk3(0, 0, 0); st.d = mk3(0, 0, 0); st.invd = mk3(0, 0, 0);
 	bool alive = false;                  // the lane holds a ray that is inside a mesh traversal
 	bool need = false;                   // the lane holds a ray that must visit its next object(s)
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
@@ -99,6 +98,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 	};
 
 	for (;;) {
+		MIPT_PROF_CLOCK(c0);
+		if (alive) MIPT_PROF_COUNT(8)
 		// ---- refill idle lanes from the queue
 		unsigned long long idle = __ballot(!alive && !need);
 		int nidle = __popcll(idle);
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 					bool valid = true;
 					if (identity) valid = (__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID) != 0;
 					if (valid) {
+						MIPT_PROF_COUNT(10)
 						st.id = id; st.obj = 0; need = true;
 						if (SHADOW) { st.dist = wf.sh_o[id].w; st.best = 0; }
 						else { st.t = __int_as_float(0x7f800000); st.best = (int)MIPT_HIT_MISS; st.beta = 0; st.gamma = 0; }
@@ -136,6 +138,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
 			}
+			if (need) MIPT_PROF_COUNT(6)
 			for (int i = 0; i < nobj; i++) {
 				if (need && st.obj == i) {
 					if (visit_object<SHADOW>(sc->obj[i], i, ro, rd, st)) { need = false; alive = true; }
@@ -155,23 +158,27 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 				need = false;
 			}
 		}
-		if (__ballot(alive) == 0) { if (drained) break; else continue; }
+		{
+			const int nalive = __popcll(__ballot(alive));
+			if (nalive == 0) { if (drained) break; else continue; }
+			if (!drained && 64 - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
+		}
+		MIPT_PROF_CLOCK(c1);
+		MIPT_PROF_CYCLES(12, c0, c1)
 
 		// ---- inner-node phase: every live lane descends until it holds a leaf or runs out of nodes
 		//      (the phase also ends when fewer than inner_min lanes are still descending while others
 		//      already wait with a leaf: the stragglers simply resume in the next round)
 		{
-			const bool sx = st.signs & 1u, sy = st.signs & 2u, sz = st.signs & 4u;
+			const bool sx = st.invd.x >= 0, sy = st.invd.y >= 0, sz = st.invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
 			for (;;) {
 				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
 				const unsigned long long mi = __ballot(inner);
 				if (mi == 0) break;
 				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
 				if (!inner) continue;
-#ifdef MIPT_PROFILE_SIMD
-				{ unsigned long long m = __ballot(1); if (lane == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[0], 1ull); atomicAdd(&g_simd_prof[1], (unsigned long long)__popcll(m)); } }
-#endif
-				const float4* q = nodes + 4 * (size_t)(st.node_base + st.cur);
+				MIPT_PROF_COUNT(0)
+				const float4* q = nodes + 4 * (size_t)st.cur;
 				float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 				f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
 				f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
@@ -193,28 +200,31 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 				else st.cur = pop_next();
 			}
 		}
+		MIPT_PROF_CLOCK(c2);
+		MIPT_PROF_CYCLES(13, c1, c2)
 		// ---- leaf phase
 		if (alive && st.cur != MIPT_NONE && (st.cur & MIPT_LEAF_BIT)) {
-#ifdef MIPT_PROFILE_SIMD
-			{ unsigned long long m = __ballot(1); if (lane == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[2], 1ull); atomicAdd(&g_simd_prof[3], (unsigned long long)__popcll(m)); } }
-#endif
+			MIPT_PROF_COUNT(2)
 			int first = (int)(st.cur & MIPT_LEAF_FIRST_MASK);
 			int count = (int)((st.cur >> 26) & 31u) + 1;
 			bool decided = false;
 			for (int i = first; i < first + count; i++) {
+				MIPT_PROF_COUNT(4)
 				float lt, lb, lg;
-				if (tri_test(tris + st.tri_base + i, st.org, st.d, lt, lb, lg)) {
+				if (tri_test(tris + i, st.org, st.d, lt, lb, lg)) {
 					bool accept = lt < st.t;
+					int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 					if (accept) {
 						const DObject& o = sc->obj[st.obj];
-						if (o.alpha_test) accept = !alpha_rejects(o, i, 1 - lb - lg, lb, lg);
+						local = i - (int)o.tri_base;
+						if (o.alpha_test) accept = !alpha_rejects(o, local, 1 - lb - lg, lb, lg);
 					}
 					if (accept) {
 						st.t = lt;
 						if (SHADOW) {
 							if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
 						} else {
-							st.best = (int)(((unsigned)st.obj << 27) | (unsigned)i); st.beta = lb; st.gamma = lg;
+							st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg;
 						}
 					}
 				}
@@ -222,6 +232,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_traverse(const DScene* __rest
 			if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
 			else st.cur = pop_next();
 		}
+		MIPT_PROF_CLOCK(c3);
+		MIPT_PROF_CYCLES(14, c2, c3)
 		// ---- mesh finished: the ray goes on with the objects behind it (next iteration's object loop)
 		if (alive && st.cur == MIPT_NONE) {
 			alive = false; need = true;

@@ -54,8 +54,8 @@ struct DObject {
 	// Plane
 	float A[3], vecN[3];
 	// TriMesh
-	const DFatNode* nodes;     // = DScene::all_nodes + node_base (child references are mesh-local)
-	const DTriIsect* tris;     // = DScene::all_tris + tri_base
+	const DFatNode* nodes;     // = DScene::all_nodes (child references are scene-wide)
+	const DTriIsect* tris;     // = DScene::all_tris (leaf references are scene-wide; mesh-local index = i - tri_base)
 	const DTriShade* shade;
 	uint32_t node_base, tri_base;
 	float root_min[3], root_max[3];

@@ -156,9 +156,17 @@ __device__ __attribute__((noinline)) bool alpha_rejects(const DObject& o, int i,
 // we continue directly into the near child instead of pushing and re-popping it (equivalent: t
 // does not change between its push and its pop), so only far children are stored.
 #ifdef MIPT_PROFILE_SIMD
-// diagnostic build only: [0] inner-step wave iterations, [1] active lanes summed, [2] leaf-step wave iterations, [3] active lanes
-__device__ unsigned long long g_simd_prof[4];
+// diagnostic build only (tools/simd_prof.py).  (events, active lanes) pairs: 0 inner step, 2 leaf phase, 4 leaf triangle
+// iteration, 6 object-loop pass, 8 outer iteration, 10 refill; wave cycles: 12 refill + object loop, 13 inner phase, 14 leaf phase
+__device__ unsigned long long g_simd_prof[16];
 MIPT_DEV unsigned lane_id_() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#define MIPT_PROF_COUNT(slot) { unsigned long long m_ = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_simd_prof[slot], 1ull); atomicAdd(&g_simd_prof[(slot) + 1], (unsigned long long)__popcll(m_)); } }
+#define MIPT_PROF_CLOCK(var) long long var = clock64()
+#define MIPT_PROF_CYCLES(slot, from, to) { if (lane_id_() == 0) atomicAdd(&g_simd_prof[slot], (unsigned long long)((to) - (from))); }
+#else
+#define MIPT_PROF_COUNT(slot) {}
+#define MIPT_PROF_CLOCK(var) {}
+#define MIPT_PROF_CYCLES(slot, from, to) {}
 #endif
 #define MIPT_STACK_DEPTH 48
 struct ScratchStack {            // private (scratch) memory: any occupancy, slower pops
@@ -172,7 +180,9 @@ struct ScratchStack {            // private (scratch) memory: any occupancy, slo
 // lanes of a group use the same sp).  Entries beyond MIPT_LDS_STACK spill to a per-thread column of a
 // global scratch buffer that is normally never touched.  Both pointers carry their address space in
 // the type so that pushes and pops compile to ds_* / global_* instructions, not flat ones.
-#define MIPT_LDS_STACK 16
+#ifndef MIPT_LDS_STACK
+#define MIPT_LDS_STACK 10
+#endif
 #define MIPT_SPILL_STACK (MIPT_STACK_DEPTH - MIPT_LDS_STACK)
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
 typedef __attribute__((address_space(1))) uint2 glb_uint2;
@@ -232,9 +242,7 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 	// different code, are not interleaved lane by lane.  Per lane the visiting order is unchanged.
 	for (;;) {
 		while (cur != NONE && !(cur & MIPT_LEAF_BIT)) {
-#ifdef MIPT_PROFILE_SIMD
-			{ unsigned long long m = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[0], 1ull); atomicAdd(&g_simd_prof[1], (unsigned long long)__popcll(m)); } }
-#endif
+			MIPT_PROF_COUNT(0)
 			const float4* q = nodes + 4 * (size_t)cur;
 			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 			f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
@@ -257,9 +265,7 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 			else cur = pop_next();
 		}
 		if (cur == NONE) break;
-#ifdef MIPT_PROFILE_SIMD
-		{ unsigned long long m = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m) - 1)) { atomicAdd(&g_simd_prof[2], 1ull); atomicAdd(&g_simd_prof[3], (unsigned long long)__popcll(m)); } }
-#endif
+		MIPT_PROF_COUNT(2)
 		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
 		int count = (int)((cur >> 26) & 31u) + 1;
 		for (int i = first; i < first + count; i++) {
@@ -269,10 +275,10 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 				// (gfx950, -O3) moved the `t` / `beta` updates into the alpha_test == 0 arm only
 				// (seen in the ISA of k_wf_extend; the cut-out golden scene caught it).
 				bool accept = lt < t;
-				if (accept && o.alpha_test) accept = !alpha_rejects(o, i, 1 - lb - lg, lb, lg);
+				if (accept && o.alpha_test) accept = !alpha_rejects(o, i - (int)o.tri_base, 1 - lb - lg, lb, lg);
 				if (accept) {
 					has_inter = true;
-					t = lt; tri_out = i; beta_out = lb; gamma_out = lg;
+					t = lt; tri_out = i - (int)o.tri_base; beta_out = lb; gamma_out = lg;
 					if (SHADOW && ((double)t < (double)dist_light * 0.999)) { t_out = t; return true; }   // :1309
 				}
 			}
@@ -325,7 +331,7 @@ MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, 
 	query_material(o, group, u, v, mat);
 	f3 N;
 	if (!o.interp_normals) {
-		const DTriIsect& T = o.tris[tri];
+		const DTriIsect& T = o.tris[o.tri_base + tri];
 		N = ld3(T.N);
 	} else {
 		N = n0 * alpha + n1 * beta + n2 * gamma;

@@ -1,23 +1,26 @@
-import sys, os, ctypes as C, shutil
+"""Diagnostic: lane utilisation and phase shares of the persistent traversal kernels (profiling build of the library:
+tools/build_variant.sh prof -DMIPT_PROFILE_SIMD).  usage: python tools/simd_prof.py [c1|c2] [name=value ...]"""
+import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd())
-# diagnostic: swap in the profiling build of the library
-from pathtracer_amd import capi
-capi.LIBMIPT = capi.LIBMIPT.replace("libmipt.so", "libmipt_prof.so")
-import numpy as np
+os.environ["MIPT_LIB_OVERRIDE"] = os.path.join(os.getcwd(), "pathtracer_amd", "libmipt_prof.so")
 from pathtracer_amd import capi, scenes
-cfg = scenes.config_c1(1920, 1080, 4)
-mesh = scenes.blob_mesh(258)
+wl = sys.argv[1] if len(sys.argv) > 1 else "c1"
+mesh, cfg, mat, text = scenes.workload(wl, spp=4)
 rt = capi.HostRaytracer(device=0)
-rt.apply_config(cfg); rt.add_mesh(mesh); rt.prepare()
+rt.apply_config(cfg); scenes.install(rt, mesh, mat); rt.prepare()
 rt.set_option("pipeline", 1)
-out = (C.c_ulonglong * 4)()
-for refill, thr, imin in ((0, 20, 0), (1, 20, 0), (1, 20, 8), (1, 20, 16), (1, 20, 24), (1, 20, 32), (1, 8, 24), (1, 32, 24)):
-  rt.set_option("refill", refill); rt.set_option("refill_threshold", thr); rt.set_option("inner_min", imin)
-  rt.mipt.mipt_debug_simd_profile(out, 1)
-  rt.render()
-  rt.mipt.mipt_debug_simd_profile(out, 1)
-  st = rt.stats()
-  print("refill", refill, "threshold", thr, "inner_min", imin, "extend ms %.2f shadow ms %.2f" % (st["traverse_ms"], st["shadow_ms"]))
-  print("inner: wave-iters %d mean active lanes %.1f ; leaf: wave-iters %d mean active lanes %.1f" % (out[0], out[1]/max(1,out[0]), out[2], out[3]/max(1,out[2])))
-  print("rays", st["rays_closest"], st["rays_shadow"], "inner steps/ray %.1f leaf steps/ray %.2f" % (out[1]/(st["rays_closest"]+st["rays_shadow"]), out[3]/(st["rays_closest"]+st["rays_shadow"])))
-
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); rt.set_option(k, int(v))
+out = (C.c_ulonglong * 16)()
+rt.mipt.mipt_debug_simd_profile(out, 1)
+rt.render()
+rt.mipt.mipt_debug_simd_profile(out, 1)
+st = rt.stats()
+o = list(out)
+rays = st["rays_closest"] + st["rays_shadow"]
+print(text, sys.argv[2:], "extend ms %.2f shadow ms %.2f (instrumented build)" % (st["traverse_ms"], st["shadow_ms"]))
+names = {0: "inner step", 2: "leaf phase", 4: "leaf triangle iteration", 6: "object-loop pass", 8: "outer iteration (lanes alive)", 10: "refill"}
+for k, nm in names.items():
+    print("  %-32s wave events %12d  mean active lanes %5.1f  lane events per ray %6.2f" % (nm, o[k], o[k + 1] / max(1, o[k]), o[k + 1] / rays))
+tot = o[12] + o[13] + o[14]
+print("  wave cycles: refill+objects %.1f%%  inner %.1f%%  leaf %.1f%%" % (100 * o[12] / tot, 100 * o[13] / tot, 100 * o[14] / tot))
