@@ -9,8 +9,9 @@ Workload (config.workload): the configuration BASELINE.json's metric is quoted o
 4096x2048 environment map, Phong BRDF, 1920x1080, depth 4, default loadScene() light and camera; it
 fits one GPU.  --workload c1 / c3 / c4 select the other configs (c1 = 133 128-triangle diffuse blob).
 One STEP = one pass of the hot path (camera rays -> getColor -> splat) over the whole frame at
---spp-per-step samples per pixel; the default K = 128 steps x 8 spp is exactly the 1024 spp of the
-config.  With N GPUs the frame's
+--spp-per-step samples per pixel (default 32: 66 M paths, ~11 GB of path state in flight — sized for
+288 GB of HBM; the per-launch ramp and drain of the persistent kernels is amortised over a large batch);
+the default K = 32 steps x 32 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
 32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
 the per-rank accumulators are summed by ONE all-reduce at the end (RCCL), so the total work is
 fixed: "scaling": "strong".
@@ -37,13 +38,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_STEP = 8
+SPP_PER_STEP = 32
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
@@ -198,12 +199,13 @@ def main():
     launches = sh_launches = 0
     rays_c = rays_s = 0
     pipeline = -1
+    merged = 0
     for s in range(args.warmup, args.warmup + args.steps):
         st = step(s)
         rays_c += st["rays_closest"]; rays_s += st["rays_shadow"]; paths += st["paths"]
         kern_ms += st["traverse_ms"]; launches += st["traverse_launches"]
         sh_ms += st["shadow_ms"]; sh_launches += st["shadow_launches"]; shade_ms += st["shade_ms"]
-        pipeline = st["pipeline"]
+        pipeline = st["pipeline"]; merged = st["traverse_merged"]
     if world > 1:                                        # the framebuffer reduce (RCCL over xGMI)
         if on_device:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)
@@ -234,7 +236,7 @@ def main():
             "host_bvh_build_s": t_build, "prepare_s": t_prepare, "finite": finite,
         }
         if world == 1 and args.pmc and pipeline == 1:
-            out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
+            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
         if world == 1 and not args.pmc:
             ob = oracle_bytes_per_ray(mesh, mat, cfg)
             my_launches = max(1, launches)
@@ -242,18 +244,21 @@ def main():
             if pipeline == 0:     # one kernel casts both kinds of rays
                 kernel = "k_render_paths"
                 bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
+            elif merged:          # dominant kernel = the traversal kernel, whose launches serve closest-hit and any-hit queues
+                kernel = "k_wf_traverse (closest-hit and any-hit queues; shadow(b) + extend(b+1) share a launch)"
+                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
             else:                 # dominant kernel = closest-hit traversal
-                kernel = "k_wf_traverse<false> (closest-hit / extend stage)"
+                kernel = "k_wf_traverse<0> (closest-hit / extend stage)"
                 bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": None, "kernel": kernel,
                                "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
                                "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],
-                               "rays_per_launch": (rays_c if pipeline else rays_c + rays_s) / my_launches}
+                               "rays_per_launch": (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches}
             try:   # HBM bytes per launch of the dominant kernel from the committed PMC run (same workload)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))[args.workload]
-                tr = tj["kernels"]["k_wf_traverse<false>" if pipeline == 1 else "k_render_paths"]
+                tr = tj["kernels"]["k_wf_traverse" if merged else ("k_wf_traverse<false>" if pipeline == 1 else "k_render_paths")]
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_high"]
                 out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of this kernel on this workload, " + tj["source"]
             except Exception:
@@ -262,7 +267,7 @@ def main():
                 sh_ach = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
                 out["roofline_shadow_kernel"] = {"kernel": "k_wf_traverse<true> (any-hit / shadow stage)", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,
                                                  "launches": int(sh_launches)}
-                out["stage_ms_per_step"] = {"extend": kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
+            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(mesh, mat, cfg, ob["rays_per_path"])
         print(json.dumps(out))

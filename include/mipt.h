@@ -165,13 +165,17 @@ typedef struct mipt_stats {
 	uint64_t mesh_casts_shadow;   /* TriMesh::intersection_shadow calls */
 	double   render_ms;           /* HIP-event time of the whole call on its stream */
 	double   traverse_ms;         /* HIP-event time summed over the launches of the dominant kernel:
-	                                 pipeline 0: the per-path kernel; pipeline 1: the closest-hit (extend) kernel */
-	double   shadow_ms;           /* pipeline 1: summed over the any-hit (shadow) kernel launches */
+	                                 pipeline 0: the per-path kernel; pipeline 1: the traversal kernel — closest-hit
+	                                 launches only when traverse_merged == 0, every traversal launch (closest-hit,
+	                                 any-hit and the merged any-hit(b) + closest-hit(b+1) launches) when it is 1 */
+	double   shadow_ms;           /* pipeline 1, traverse_merged == 0: summed over the any-hit (shadow) launches */
 	double   shade_ms;            /* pipeline 1: summed over generate + shade launches */
 	uint32_t traverse_launches;
 	uint32_t shadow_launches;
 	uint32_t passes;
 	uint32_t pipeline;            /* pipeline that produced these numbers */
+	uint32_t traverse_merged;     /* 1 = option "merge_traverse" was in effect (see traverse_ms) */
+	uint32_t reserved;
 } mipt_stats;
 
 typedef void (*mipt_progress_cb)(void* user, int samples_done, int samples_total);
@@ -229,6 +233,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
 /* Tunables (name/value); unknown names return MIPT_ERR_INVALID.
  *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default)
  *   "refill"          pipeline 1: 1 = traversal stages refill idle lanes from the queue (default), 0 = one ray per lane
+ *   "merge_traverse"  pipeline 1: 1 = the shadow rays of depth b and the closest-hit rays of depth b+1 share one
+ *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
  *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again

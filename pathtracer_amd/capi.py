@@ -35,7 +35,8 @@ class MiptStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("mesh_casts_closest", C.c_uint64), ("mesh_casts_shadow", C.c_uint64),
                 ("render_ms", C.c_double), ("traverse_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
-                ("traverse_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("passes", C.c_uint32), ("pipeline", C.c_uint32)]
+                ("traverse_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("passes", C.c_uint32), ("pipeline", C.c_uint32),
+                ("traverse_merged", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MiptHit(C.Structure):

@@ -39,6 +39,7 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v
 // ... and the block's LDS slab (+ global spill columns) for the persistent traversal kernels
 #define MIPT_DECLARE_LDS_STACK(stk, spill_buf) \
 	__shared__ uint2 lds_stack_[MIPT_LDS_STACK * MIPT_BLOCK]; \
+	__shared__ unsigned char lds_leafmap_[4 * MIPT_BLOCK];   /* per wave: owner lane + triangle slot of each packed leaf test */ \
 	LdsStack stk; stk.base = (lds_uint2*)lds_stack_ + threadIdx.x; stk.stride = MIPT_BLOCK; \
 	stk.spill = (glb_uint2*)(spill_buf) + (size_t)blockIdx.x * MIPT_BLOCK + threadIdx.x; stk.spill_stride = (int)(gridDim.x * MIPT_BLOCK);
 
@@ -195,6 +196,7 @@ struct mipt_ctx {
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
+	unsigned grid_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of: traverse<0,1,2>, shade<0,1,2>, extend, shadow
 	int n_mesh_objects = 0;
 	uint64_t host_paths = 0;
 	bool has_scene = false;
@@ -219,6 +221,7 @@ struct mipt_ctx {
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
+	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_paths_per_pass = 1 << 24;
@@ -282,6 +285,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
+	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
@@ -445,6 +449,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 			if (d.nuvs > 0 && o.n_alphamap > 0) {
 				for (int k = 0; k < o.n_alphamap; k++) if (o.alphamap[k].W > 0 || o.alphamap[k].multiplier[0] < 0.5f) d.alpha_test = 1;
 			}
+			if (d.alpha_test) H.any_alpha = 1;
 			c->n_mesh_objects++;
 		} else return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: type %d is outside the hot path", i, o.type);
 	}
@@ -702,6 +707,17 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	};
 	auto timed_end = [&]() -> int { int r = hipEventRecord(c->kev[2 * nev + 1], st) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP; nev++; return r; };
 	const unsigned persistent_blocks = (unsigned)c->n_cus * 8u;   // >= resident capacity of every stage kernel
+	// a persistent stage kernel is launched with exactly the blocks that can be resident (its waves take their first
+	// chunk statically: a block that only starts when another one has finished would hold its chunk back until then)
+	if (c->grid_stage[0] == 0) {
+		const void* kern[8] = {(const void*)k_wf_traverse<0>, (const void*)k_wf_traverse<1>, (const void*)k_wf_traverse<2>, (const void*)k_wf_shade<0>,
+		                       (const void*)k_wf_shade<1>, (const void*)k_wf_shade<2>, (const void*)k_wf_extend, (const void*)k_wf_shadow};
+		for (int k = 0; k < 8; k++) {
+			int nb = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+			c->grid_stage[k] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
+		}
+	}
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
@@ -718,23 +734,30 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, R, P, wf, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
-			const unsigned grid_p = std::min(persistent_blocks, grid_all);
+			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], grid_all)); };
+			const bool merge = c->opt_refill && c->opt_merge_traverse;
+			const float4* d_nodes = (const float4*)c->d_all_nodes;
+			const int thr = (int)c->opt_refill_threshold, imin = (int)c->opt_inner_min;
 			for (int b = 0; b < p->nb_bounces; b++) {
-				if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, (const float4*)c->d_all_nodes, c->d_all_tris, wf, b, (unsigned)total, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
-				else hipLaunchKernelGGL(k_wf_extend, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
-				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				if (!merge || b == 0) {                                  // closest hits of depth b (merged mode: done by the launch of depth b-1)
+					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+					else hipLaunchKernelGGL(k_wf_extend, G(6), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				}
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_fast_shade) {
-					hipLaunchKernelGGL(k_wf_shade<1>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					hipLaunchKernelGGL(k_wf_shade<2>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-				} else hipLaunchKernelGGL(k_wf_shade<0>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, (const float4*)c->d_all_nodes, c->d_all_tris, wf, b, 0u, (int)c->opt_refill_threshold, (int)c->opt_inner_min);
-				else hipLaunchKernelGGL(k_wf_shadow, dim3(grid_p), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
+				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
+				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
+				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
+			c->stats.traverse_merged = merge ? 1u : 0u;
 		}
 		if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());

@@ -13,7 +13,12 @@
 #pragma once
 
 #define MIPT_REFILL_THRESHOLD 20        // refill as soon as this many lanes are idle
+#ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 1024u           // ids reserved per global atomic (sub-allocated wave-locally)
+#endif
+#ifndef MIPT_PULL_DIV
+#define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
+#endif
 
 struct LaneState {
 	f3 org, d, invd;        // ray in the current mesh's frame
@@ -64,17 +69,22 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 #ifndef MIPT_TRAVERSE_WAVES
 #define MIPT_TRAVERSE_WAVES 4
 #endif
+// One queue of one depth: SHADOW = false the closest-hit rays of depth b (Scene::intersection), SHADOW = true the
+// light-sample rays of depth b (Scene::intersection_shadow).  Called by every wave of the grid; returns when the
+// queue is drained and all rays this wave fetched are finished.
 template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
-	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
+__device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
+                                               int b, unsigned n0, int refill_threshold, int inner_min, LdsStack& stk, unsigned char* leafmap) {
 	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
 	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
 	const bool identity = !SHADOW && b == 0;
 	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
-	// ids reserved per global atomic: large enough to keep the same-address atomic rate low, small
-	// enough that every wave of the grid gets several chunks (tail balance)
-	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_BLOCK / 64) * 8u)) & ~63u));
+	// ids reserved per global atomic: large enough to keep the same-address atomic rate low (one costs ~11 ns
+	// chip-wide), small enough that every wave of the grid gets several chunks (tail balance)
+	const unsigned nwaves = gridDim.x * (MIPT_BLOCK / 64), wave_id = blockIdx.x * (MIPT_BLOCK / 64) + (threadIdx.x >> 6);
+	bool first_pull = true;
+	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u));
 	const unsigned lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -86,6 +96,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
 	bool drained = false;
 	const int nobj = sc->nobj;
+	const bool any_alpha = sc->any_alpha != 0;
 
 	auto pop_next = [&]() -> uint32_t {
 		while (st.sp > 0) {
@@ -105,8 +116,12 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		int nidle = __popcll(idle);
 		if (!drained && nidle >= refill_threshold) {
 			if (chunk_next >= chunk_end) {
+				// The first chunk of every wave is assigned statically (chunk number = wave number), later ones come
+				// from the shared counter: 8192 waves hitting one address at launch cost ~90 us (one same-address
+				// atomic ~11 ns), and a queue shorter than the grid's first chunks needs no atomic at all.
 				unsigned base = 0;
-				if (lane == 0) base = atomicAdd(head, pull_chunk);
+				if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
+				else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
 				base = __builtin_amdgcn_readfirstlane(base);
 				if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
 				else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
@@ -202,35 +217,105 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		}
 		MIPT_PROF_CLOCK(c2);
 		MIPT_PROF_CYCLES(13, c1, c2)
-		// ---- leaf phase
-		if (alive && st.cur != MIPT_NONE && (st.cur & MIPT_LEAF_BIT)) {
-			MIPT_PROF_COUNT(2)
-			int first = (int)(st.cur & MIPT_LEAF_FIRST_MASK);
-			int count = (int)((st.cur >> 26) & 31u) + 1;
-			bool decided = false;
-			for (int i = first; i < first + count; i++) {
-				MIPT_PROF_COUNT(4)
-				float lt, lb, lg;
-				if (tri_test(tris + i, st.org, st.d, lt, lb, lg)) {
-					bool accept = lt < st.t;
-					int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
-					if (accept) {
-						const DObject& o = sc->obj[st.obj];
-						local = i - (int)o.tri_base;
-						if (o.alpha_test) accept = !alpha_rejects(o, local, 1 - lb - lg, lb, lg);
-					}
-					if (accept) {
-						st.t = lt;
-						if (SHADOW) {
-							if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
-						} else {
-							st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg;
+		// ---- leaf phase.  The (ray, triangle) tests of all lanes that hold a leaf are packed densely over the
+		//      wave: a leaf has at most 4 triangles and typically a quarter of the lanes hold one, so the per-lane
+		//      loop would run 4 rounds at ~15 of 64 lanes (measured).  Test j of the packed list runs on lane j:
+		//      it fetches its owner's ray with ds_bpermute, and each owner then walks the results of ITS triangles
+		//      in leaf order with the reference's strict '<' (TriangleMesh.cpp:1198), so the accepted triangle is
+		//      the one the sequential loop accepts.  Leaves with more triangles (degenerate splits) and scenes with
+		//      alpha-tested meshes take the per-lane loop below.
+		{
+			const bool leaf = alive && st.cur != MIPT_NONE && (st.cur & MIPT_LEAF_BIT);
+			const int first = (int)(st.cur & MIPT_LEAF_FIRST_MASK);
+			const int count = leaf ? (int)((st.cur >> 26) & 31u) + 1 : 0;
+			bool per_lane = leaf;
+			if (leaf) MIPT_PROF_COUNT(2)
+			if (!any_alpha) {
+				const int cnt = count <= 4 ? count : 0;
+				const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
+				if (b1 != 0) {
+					const int prefix = __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below) + __popcll(b4 & below);
+					const int total = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
+					for (int k = 0; k < 4; k++) if (k < cnt) leafmap[prefix + k] = (unsigned char)(lane | ((unsigned)k << 6));
+					__builtin_amdgcn_wave_barrier();
+					float cur_t = st.t, wb = 0.f, wg = 0.f;
+					int win = -1;
+					bool decided = false;
+					for (int base = 0; base < total; base += 64) {
+						const int j = base + (int)lane;
+						const unsigned m = j < total ? (unsigned)leafmap[j] : 0u;
+						const int src = (int)((m & 63u) << 2), slot = (int)(m >> 6);
+						const int f = __builtin_amdgcn_ds_bpermute(src, first);
+						f3 ro, rd;
+						ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.x)));
+						ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.y)));
+						ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.z)));
+						rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.x)));
+						rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.y)));
+						rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.z)));
+						float lt = __int_as_float(0x7f800000), lb = 0.f, lg = 0.f;
+						if (j < total) {
+							MIPT_PROF_COUNT(4)
+							float a, bb, gg;
+							if (tri_test(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
 						}
+						int wj = 0;
+						bool upd = false;
+#pragma unroll
+						for (int k = 0; k < 4; k++) {
+							const int jj = prefix + k - base;
+							const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(min(max(jj, 0), 63) << 2, __float_as_int(lt)));
+							if (k < cnt && jj >= 0 && jj < 64 && v < cur_t) {
+								cur_t = v; win = k; wj = jj; upd = true;
+								if (SHADOW && ((double)v < (double)st.dist * 0.999)) decided = true;               // TriangleMesh.cpp:1309
+							}
+						}
+						if (!SHADOW) {
+							const float vb = __int_as_float(__builtin_amdgcn_ds_bpermute(wj << 2, __float_as_int(lb)));
+							const float vg = __int_as_float(__builtin_amdgcn_ds_bpermute(wj << 2, __float_as_int(lg)));
+							if (upd) { wb = vb; wg = vg; }
+						}
+					}
+					if (cnt > 0) {
+						per_lane = false;
+						if (win >= 0) {
+							st.t = cur_t;
+							if (!SHADOW) {
+								const int local = first + win - (int)sc->obj[st.obj].tri_base;
+								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg;
+							}
+						}
+						if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
+						else st.cur = pop_next();
 					}
 				}
 			}
-			if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
-			else st.cur = pop_next();
+			if (per_lane) {
+				bool decided = false;
+				for (int i = first; i < first + count; i++) {
+					MIPT_PROF_COUNT(4)
+					float lt, lb, lg;
+					if (tri_test(tris + i, st.org, st.d, lt, lb, lg)) {
+						bool accept = lt < st.t;
+						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
+						if (accept) {
+							const DObject& o = sc->obj[st.obj];
+							local = i - (int)o.tri_base;
+							if (o.alpha_test) accept = !alpha_rejects(o, local, 1 - lb - lg, lb, lg);
+						}
+						if (accept) {
+							st.t = lt;
+							if (SHADOW) {
+								if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
+							} else {
+								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg;
+							}
+						}
+					}
+				}
+				if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
+				else st.cur = pop_next();
+			}
 		}
 		MIPT_PROF_CLOCK(c3);
 		MIPT_PROF_CYCLES(14, c2, c3)
@@ -241,4 +326,17 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
 		}
 	}
+}
+
+// MODE 0: closest-hit queue of depth b.  MODE 1: shadow queue of depth b.  MODE 2: shadow queue of depth b, then the
+// closest-hit queue of depth b + 1 — both were filled by shade(b) and are independent of each other, so one launch serves
+// both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
+// second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
+template <int MODE>
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
+	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
+	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min, stk, leafmap);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min, stk, leafmap);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min, stk, leafmap);
 }

@@ -69,7 +69,8 @@ struct DObject {
 
 struct DScene {
 	int nobj;
-	int _pad[3];
+	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)
+	int _pad[2];
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

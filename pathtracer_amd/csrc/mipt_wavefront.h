@@ -44,16 +44,25 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 // One same-address atomic costs ~11 ns chip-wide (MI355X_MICROARCH.md "dequeue": one word saturates at
 // ~88 ops/us), so queue traffic is batched: a wave pulls MIPT_WF_UNROLL*64 entries per atomic and
 // appends the survivors of all its sub-chunks with one atomic per destination queue.
+#ifndef MIPT_WF_UNROLL
 #define MIPT_WF_UNROLL 4
+#endif
 #define MIPT_WF_CHUNK (64u * MIPT_WF_UNROLL)
 
-// next chunk of a queue of n entries; returns false when the queue is drained
-__device__ __forceinline__ bool queue_pull(unsigned* __restrict__ head, unsigned n, unsigned& base) {
-	unsigned b = 0;
-	if (lane_id() == 0) b = atomicAdd(head, MIPT_WF_CHUNK);
-	base = __builtin_amdgcn_readfirstlane(b);
-	return base < n;
-}
+// Chunks of a queue of n entries for one wave.  The first chunk is static (chunk number = wave number): all waves
+// of a launch hitting one counter at start is ~90 us even for an empty queue.  Later chunks come from the shared
+// counter, and the atomic for chunk i+1 is issued when chunk i is handed out, so its round trip (a few us, comparable
+// to the work of one chunk) overlaps with the work instead of stalling the wave between chunks.
+struct QueuePuller {
+	unsigned next;        // lane 0: base of the chunk to hand out next
+	__device__ __forceinline__ void init() { next = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * MIPT_WF_CHUNK; }
+	__device__ __forceinline__ bool pull(unsigned* __restrict__ head, unsigned n, unsigned& base) {
+		base = __builtin_amdgcn_readfirstlane(next);
+		if (base >= n) return false;
+		if (lane_id() == 0) next = atomicAdd(head, MIPT_WF_CHUNK) + gridDim.x * (blockDim.x >> 6) * MIPT_WF_CHUNK;
+		return true;
+	}
+};
 
 // wave-aggregated append for the lanes whose bit u of `bits` is set (sub-chunk u of the chunk at
 // `base` of the source list; src == nullptr means the identity list): one atomic for all sub-chunks
@@ -119,7 +128,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 	unsigned* head = &wf.counters[4 * b + 1];
 	const unsigned* __restrict__ list = wf.list[b & 1];
 	unsigned base;
-	while (queue_pull(head, n, base)) {
+	QueuePuller q; q.init();
+	while (q.pull(head, n, base)) {
 #pragma unroll 1
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
 			unsigned idx = base + 64u * u + lane_id();
@@ -139,8 +149,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 // shade: material of the hit, emission, next-event-estimation request, continuation sampling.
 // TIER 0: every vertex with the general code.  TIER 1: fast tier over the same queue; vertices it cannot
 // handle go to list_slow.  TIER 2: the general code over list_slow.
+#ifndef MIPT_SHADE_WAVES
+#define MIPT_SHADE_WAVES 3
+#endif
 template <int TIER>
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : 2))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
 	const unsigned n = TIER == 2 ? wf.counters[MIPT_WF_CNT_NSLOW + b] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[(TIER == 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b];
 	const unsigned* __restrict__ list = TIER == 2 ? wf.list_slow : wf.list[b & 1];
@@ -148,7 +161,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shade(const DScene* __restric
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
-	while (queue_pull(head, n, base)) {
+	QueuePuller q; q.init();
+	while (q.pull(head, n, base)) {
 		unsigned cont_bits = 0, cast_bits = 0, slow_bits = 0;
 #pragma unroll 1
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
@@ -219,7 +233,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restri
 	unsigned* head = &wf.counters[4 * b + 3];
 	const unsigned* __restrict__ list = wf.list_sh;
 	unsigned base;
-	while (queue_pull(head, n, base)) {
+	QueuePuller q; q.init();
+	while (q.pull(head, n, base)) {
 #pragma unroll 1
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
 			unsigned idx = base + 64u * u + lane_id();

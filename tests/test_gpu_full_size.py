@@ -59,14 +59,18 @@ def test_oracle_subset_of_full_frame(c1):
 def test_pipelines_agree_full_frame(c1):
     mesh, cfg = c1
     rt0, img0, cnt0 = render(mesh, cfg, pipeline=0)
-    rt1, img1, cnt1 = render(mesh, cfg, pipeline=1)
+    rt1, img1, cnt1 = render(mesh, cfg, pipeline=1, merge_traverse=1)
     rt2, img2, cnt2 = render(mesh, cfg, pipeline=1, refill=0)
-    s0, s1, s2 = rt0.stats(), rt1.stats(), rt2.stats()
+    rt3, img3, cnt3 = render(mesh, cfg, pipeline=1, merge_traverse=0, refill_threshold=8, inner_min=40)
+    s0, s1, s2, s3 = rt0.stats(), rt1.stats(), rt2.stats(), rt3.stats()
     for k in ("paths", "rays_closest", "rays_shadow"):
-        assert s0[k] == s1[k] == s2[k], k
+        assert s0[k] == s1[k] == s2[k] == s3[k], k
     assert s0["paths"] == cfg.W * cfg.H * SPP
+    assert s1["traverse_merged"] == 1 and s3["traverse_merged"] == 0
+    assert s1["traverse_launches"] == cfg.nb_bounces + 1 and s3["traverse_launches"] == cfg.nb_bounces == s3["shadow_launches"]
     assert_bits(img1, img0, "image: wavefront vs per-path")
     assert_bits(img2, img0, "image: wavefront without refill vs per-path")
+    assert_bits(img3, img0, "image: wavefront, one launch per queue, other scheduling parameters vs per-path")
     assert_bits(cnt1, cnt0, "weights")
     assert np.isfinite(img0).all()   # (negative terms exist in the reference too: J is not clamped, Raytracer.cpp:545)
     assert 0.01 < (img0 / cnt0[..., None]).mean() / WHITE < 1.0
@@ -84,3 +88,27 @@ def test_light_linearity_and_weights(c1):
     # interior pixels receive the full 3x3 filter mass of SPP samples each from 9 sources
     _, img3, cnt3 = render(scenes.cornell_mesh(), cfg)
     assert_bits(cnt3, cnt, "splat weights do not depend on the scene")
+
+
+def test_c2_workload_oracle_subset():
+    """configs[2] at reduced tessellation (80 000 triangles so the oracle builds in seconds), full-size
+    textures, env map and frame: oracle on a random subset of (pixel, sample) pairs; L-inf tolerance of the
+    north star (acosf / atan2f of the env-map lookup are the device library's)."""
+    from oracle.binding import Oracle
+    mesh, cfg, mat, _ = scenes.workload("c2", spp=SPP, grid=200)
+    rng = np.random.default_rng(12)
+    pix = np.stack([rng.integers(0, cfg.H, 1500), rng.integers(0, cfg.W, 1500)], 1).astype(np.int32)
+    O = Oracle()
+    O.apply_config(cfg)
+    scenes.install(O, mesh, mat)
+    O.prepare()
+    want, want_j = O.getcolor_samples(pix, 0, SPP)
+    rt = capi.HostRaytracer(device=0)
+    rt.apply_config(cfg)
+    scenes.install(rt, mesh, mat)
+    rt.prepare()
+    got, got_j = rt.sample_radiance(pix, 0, SPP)
+    assert_bits(got_j, want_j, "jitter")
+    err = np.abs(got.astype(np.float64) - want).max() / WHITE
+    assert err < 1e-4, err                                   # north-star tolerance: per-pixel L-inf < 1e-4 on radiance / 196964.7
+    assert bits_equal(got, want).mean() > 0.95
