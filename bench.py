@@ -9,12 +9,13 @@ Workload (config.workload): the configuration BASELINE.json's metric is quoted o
 4096x2048 environment map, Phong BRDF, 1920x1080, depth 4, default loadScene() light and camera; it
 fits one GPU.  --workload c1 / c3 / c4 select the other configs (c1 = 133 128-triangle diffuse blob).
 One STEP = one pass of the hot path (camera rays -> getColor -> splat) over the whole frame at
---spp-per-step samples per pixel (default 32: 66 M paths, ~11 GB of path state in flight — sized for
+--spp-per-step samples per pixel (default 64: 133 M paths, ~21 GB of path state in flight — sized for
 288 GB of HBM; the per-launch ramp and drain of the persistent kernels is amortised over a large batch);
-the default K = 32 steps x 32 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
-32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
-the per-rank accumulators are summed by ONE all-reduce at the end (RCCL), so the total work is
-fixed: "scaling": "strong".
+the default K = 16 steps x 64 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
+32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated), a step
+renders N x --spp-per-step samples per pixel so that every rank keeps the same number of paths in
+flight per pass as the single-GPU run ("scaling": "weak": per-GPU work per step is fixed), and the
+per-rank accumulators are summed by ONE all-reduce at the end (RCCL).
 
 value = rays (closest-hit + shadow, counted like the oracle counts them) of all ranks / wall time
 of the K timed steps (+ the final reduce), inputs resident in HBM, barrier + synchronize on both
@@ -38,13 +39,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_STEP = 32
+SPP_PER_STEP = 64
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
@@ -151,7 +152,7 @@ def main():
         dist.barrier()
     from pathtracer_amd import capi, scenes
 
-    SPS = args.spp_per_step
+    SPS = args.spp_per_step * world     # weak scaling: a rank owns 1/world of the pixels and renders world x the samples per step
     total_spp = SPS * (args.steps + args.warmup)
     mesh, cfg, mat, wl_text = scenes.workload(args.workload, args.width, args.height, total_spp, args.grid)
     args.width, args.height = cfg.W, cfg.H
@@ -228,7 +229,7 @@ def main():
             "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
                        "parallelism": f"tiles32x{world}", "pipeline": int(pipeline)},

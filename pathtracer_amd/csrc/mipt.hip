@@ -224,7 +224,7 @@ struct mipt_ctx {
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
-	int64_t opt_paths_per_pass = 1 << 24;
+	int64_t opt_paths_per_pass = 1 << 27;   // 134 M paths (64 spp at 1080p), ~21 GB of path state
 };
 
 static int fail(mipt_ctx* c, int code, const char* fmt, ...) {
@@ -353,8 +353,10 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		int rc;
 		if ((rc = child_ref(l, f.lref))) return rc;
 		if ((rc = child_ref(r, f.rref))) return rc;
-		memcpy(f.lmin, m->nodes[l].bbox_min, 12); memcpy(f.lmax, m->nodes[l].bbox_max, 12);
-		memcpy(f.rmin, m->nodes[r].bbox_min, 12); memcpy(f.rmax, m->nodes[r].bbox_max, 12);
+		for (int k = 0; k < 3; k++) {
+			f.l[k][0] = m->nodes[l].bbox_min[k]; f.l[k][1] = m->nodes[l].bbox_max[k];
+			f.r[k][0] = m->nodes[r].bbox_min[k]; f.r[k][1] = m->nodes[r].bbox_max[k];
+		}
 	}
 	int rc;
 	if ((rc = child_ref(0, d.root_ref))) return rc;

@@ -21,7 +21,8 @@
 #endif
 
 struct LaneState {
-	f3 org, d, invd;        // ray in the current mesh's frame
+	mipt_f2 o_xy, i_xy, oz_iz;   // ray in the current mesh's frame: (org.x, org.y), (invd.x, invd.y), (org.z, invd.z) as register pairs
+	f3 d;                        // for the packed slab test (box_test_pairs)
 	float t;                // closest: best t over the objects visited so far; shadow: t of the current mesh
 	float beta, gamma;      // closest: barycentrics of the best triangle
 	float dist;             // shadow: dist_light
@@ -60,14 +61,14 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 	if (enter && t_root > cur_best_t) enter = false;
 	if (SHADOW && enter && t_root > st.dist) enter = false;
 	if (!enter) return false;
-	st.org = org; st.d = d; st.invd = invd;
+	st.o_xy = (mipt_f2){org.x, org.y}; st.i_xy = (mipt_f2){invd.x, invd.y}; st.oz_iz = (mipt_f2){org.z, invd.z}; st.d = d;
 	if (SHADOW) st.t = cur_best_t;
 	st.cur = o.root_ref; st.sp = 0;
 	return true;
 }
 
 #ifndef MIPT_TRAVERSE_WAVES
-#define MIPT_TRAVERSE_WAVES 4
+#define MIPT_TRAVERSE_WAVES 7
 #endif
 // One queue of one depth: SHADOW = false the closest-hit rays of depth b (Scene::intersection), SHADOW = true the
 // light-sample rays of depth b (Scene::intersection_shadow).  Called by every wave of the grid; returns when the
@@ -90,7 +91,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 
 	LaneState st;
 	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0;
-	st.org = mk3(0, 0, 0); st.d = mk3(0, 0, 0); st.invd = mk3(0, 0, 0);
+	st.o_xy = (mipt_f2){0.f, 0.f}; st.i_xy = (mipt_f2){0.f, 0.f}; st.oz_iz = (mipt_f2){0.f, 0.f}; st.d = mk3(0, 0, 0);
 	bool alive = false;                  // the lane holds a ray that is inside a mesh traversal
 	bool need = false;                   // the lane holds a ray that must visit its next object(s)
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
@@ -185,7 +186,12 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		//      (the phase also ends when fewer than inner_min lanes are still descending while others
 		//      already wait with a leaf: the stragglers simply resume in the next round)
 		{
-			const bool sx = st.invd.x >= 0, sy = st.invd.y >= 0, sz = st.invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
+			const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
+			const bool sx = s_invd.x >= 0, sy = s_invd.y >= 0, sz = s_invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
+			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
+			// together with them) use the literal early-out chain
+			const float inf = __int_as_float(0x7f800000);
+			const bool literal = alive && (fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
 			for (;;) {
 				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
 				const unsigned long long mi = __ballot(inner);
@@ -195,18 +201,21 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				MIPT_PROF_COUNT(0)
 				const float4* q = nodes + 4 * (size_t)st.cur;
 				float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-				f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
-				f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
 				uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 				float tl, tr;
 				bool goleft, goright;
-				if (SHADOW) {
-					goleft = box_test<false>(lmin, lmax, st.org, st.invd, sx, sy, sz, tl) && (tl < st.t) && (tl < st.dist);
-					goright = box_test<false>(rmin, rmax, st.org, st.invd, sx, sy, sz, tr) && (tr < st.t) && (tr < st.dist);
+				if (__ballot(literal) != 0) {
+					f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
+					f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
+					goleft = box_test<!SHADOW>(lmin, lmax, s_org, s_invd, sx, sy, sz, tl);
+					goright = box_test<!SHADOW>(rmin, rmax, s_org, s_invd, sx, sy, sz, tr);
 				} else {
-					goleft = box_test<true>(lmin, lmax, st.org, st.invd, sx, sy, sz, tl) && (tl < st.t);
-					goright = box_test<true>(rmin, rmax, st.org, st.invd, sx, sy, sz, tr) && (tr < st.t);
+					const mipt_f2 LX = {q0.x, q0.y}, LY = {q0.z, q0.w}, LZ = {q1.x, q1.y}, RX = {q1.z, q1.w}, RY = {q2.x, q2.y}, RZ = {q2.z, q2.w};
+					goleft = box_test_pairs<!SHADOW>(LX, LY, LZ, st.o_xy, st.i_xy, st.oz_iz, sx, sy, sz, tl);
+					goright = box_test_pairs<!SHADOW>(RX, RY, RZ, st.o_xy, st.i_xy, st.oz_iz, sx, sy, sz, tr);
 				}
+				goleft = goleft && (tl < st.t); goright = goright && (tr < st.t);
+				if (SHADOW) { goleft = goleft && (tl < st.dist); goright = goright && (tr < st.dist); }
 				if (goleft && goright) {
 					if (tl < tr) { stk.push(st.sp, rref, tr); st.sp++; st.cur = lref; }
 					else { stk.push(st.sp, lref, tl); st.sp++; st.cur = rref; }
@@ -247,9 +256,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						const int src = (int)((m & 63u) << 2), slot = (int)(m >> 6);
 						const int f = __builtin_amdgcn_ds_bpermute(src, first);
 						f3 ro, rd;
-						ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.x)));
-						ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.y)));
-						ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.org.z)));
+						ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.o_xy.x)));
+						ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.o_xy.y)));
+						ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.oz_iz.x)));
 						rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.x)));
 						rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.y)));
 						rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(st.d.z)));
@@ -295,7 +304,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				for (int i = first; i < first + count; i++) {
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
-					if (tri_test(tris + i, st.org, st.d, lt, lb, lg)) {
+					if (tri_test(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
 						bool accept = lt < st.t;
 						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 						if (accept) {

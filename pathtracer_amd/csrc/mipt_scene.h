@@ -30,9 +30,9 @@ struct DTex {              // Texture (BRDF.h:252-426)
 	const float* values;
 };
 
-struct DFatNode {          // 64 B, 64-B aligned
-	float lmin[3], lmax[3];
-	float rmin[3], rmax[3];
+struct DFatNode {          // 64 B, 64-B aligned.  Slabs are stored per axis as (min, max) pairs so that one packed
+	float l[3][2];         // fp32 instruction (v_pk_add_f32 / v_pk_mul_f32) handles both planes of an axis
+	float r[3][2];
 	uint32_t lref, rref;
 	uint32_t _pad[2];
 };

@@ -76,6 +76,38 @@ MIPT_DEV bool box_test(f3 bmin, f3 bmax, f3 o, f3 invd, bool sx, bool sy, bool s
 	return !rej;
 }
 
+// The same slab test for the persistent traversal kernels, on a DFatNode's (min, max) pairs: both planes of an axis
+// go through one packed subtract and one packed multiply — the SAME fp32 operations on the same operands as
+// intersection_invd / _positive_x / _negative_x — and the reference's chain of early-outs is evaluated in closed
+// form.  With near_k <= far_k on every axis (monotone rounding of (plane - o) * invd) the chain
+//     far_x < 0 | far_y < 0 | near_y > far_x | far_y < near_x | far_z < 0 | max(near_x, near_y) > far_z | near_z > min(far_x, far_y)
+// is exactly  min(far) < 0 | max(near) > min(far)  and the returned t is max(near, 0); the x-split variants test the
+// sign of the un-multiplied (far_x - o.x) instead of far_x < 0 (Geometry.h:146-204), which is kept literally.
+// NOT valid when a product is NaN (0 * inf: a direction component is exactly 0 and the origin lies on a slab
+// plane): callers route rays with an infinite invd component through box_test above.
+typedef float mipt_f2 __attribute__((ext_vector_type(2)));
+// The ray comes as register pairs (o.x, o.y), (invd.x, invd.y), (o.z, invd.z): the packed instructions broadcast
+// one half of a pair through op_sel, so no duplicated operands are needed.
+template <bool XSPLIT>
+MIPT_DEV bool box_test_pairs(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mipt_f2 i_xy, mipt_f2 oz_iz, bool sx, bool sy, bool sz, float& t_out) {
+	const mipt_f2 rx = X - __builtin_shufflevector(o_xy, o_xy, 0, 0), ry = Y - __builtin_shufflevector(o_xy, o_xy, 1, 1), rz = Z - __builtin_shufflevector(oz_iz, oz_iz, 0, 0);
+	const mipt_f2 tx = rx * __builtin_shufflevector(i_xy, i_xy, 0, 0), ty = ry * __builtin_shufflevector(i_xy, i_xy, 1, 1), tz = rz * __builtin_shufflevector(oz_iz, oz_iz, 1, 1);
+	const float nx = sx ? tx.x : tx.y, fx = sx ? tx.y : tx.x;
+	const float ny = sy ? ty.x : ty.y, fy = sy ? ty.y : ty.x;
+	const float nz = sz ? tz.x : tz.y, fz = sz ? tz.y : tz.x;
+	const float t_enter = fmaxf(fmaxf(nx, ny), nz);
+	const float t_exit = fminf(fminf(fx, fy), fz);
+	bool ok = !(t_enter > t_exit);
+	if (XSPLIT) {
+		const bool rejx = (sx & (rx.y < 0)) | (!sx & (rx.x > 0));
+		ok = ok & !rejx & !(fminf(fy, fz) < 0);
+	} else {
+		ok = ok & !(t_exit < 0);
+	}
+	t_out = t_enter < 0 ? 0.f : t_enter;
+	return ok;
+}
+
 // ---------------------------------------------------------------- Triangle::intersection (TriangleMesh.h:82-104)
 MIPT_DEV bool tri_test(const DTriIsect* __restrict__ T, f3 o, f3 d, float& t, float& beta, float& gamma) {
 	const float4* q = reinterpret_cast<const float4*>(T);
@@ -245,8 +277,8 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 			MIPT_PROF_COUNT(0)
 			const float4* q = nodes + 4 * (size_t)cur;
 			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-			f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
-			f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
+			f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);      // DFatNode: (min, max) pairs per axis
+			f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
 			uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 			float tl, tr;
 			bool goleft, goright;

@@ -30,6 +30,25 @@ struct DWave {
 	unsigned* counters;         // per depth b: [4b] n_extend, [4b+1] extend head, [4b+2] n_shadow, [4b+3] shadow head; then shade heads
 	DSamples out;
 };
+// Path state is written once and read once per depth, 10 GB per pass: it is accessed with the non-temporal
+// (streaming) cache policy so that it does not displace the BVH from L2 / Infinity Cache.
+#ifndef MIPT_STREAM_STATE
+#define MIPT_STREAM_STATE 1
+#endif
+typedef float mipt_v4f __attribute__((ext_vector_type(4)));
+typedef float mipt_v2f __attribute__((ext_vector_type(2)));
+typedef unsigned mipt_v2u __attribute__((ext_vector_type(2)));
+#if MIPT_STREAM_STATE
+__device__ __forceinline__ float4 wf_ld(const float4* p) { mipt_v4f v = __builtin_nontemporal_load((const mipt_v4f*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 wf_ld(const uint2* p) { mipt_v2u v = __builtin_nontemporal_load((const mipt_v2u*)p); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ float2 wf_ld(const float2* p) { mipt_v2f v = __builtin_nontemporal_load((const mipt_v2f*)p); return make_float2(v.x, v.y); }
+__device__ __forceinline__ void wf_st(float4* p, float4 a) { mipt_v4f v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, (mipt_v4f*)p); }
+__device__ __forceinline__ void wf_st(uint2* p, uint2 a) { mipt_v2u v = {a.x, a.y}; __builtin_nontemporal_store(v, (mipt_v2u*)p); }
+__device__ __forceinline__ void wf_st(float2* p, float2 a) { mipt_v2f v = {a.x, a.y}; __builtin_nontemporal_store(v, (mipt_v2f*)p); }
+#else
+template <class T> __device__ __forceinline__ T wf_ld(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void wf_st(T* p, T a) { *p = a; }
+#endif
 #define MIPT_WF_MAX_DEPTH 255
 // counters layout: [4b..4b+3] per depth (see DWave), then per depth: fast-shade head, then n_slow, then slow head
 #define MIPT_WF_CNT_SHADE_HEAD (4 * (MIPT_WF_MAX_DEPTH + 2))
@@ -96,7 +115,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	bool valid = false, alive = false;
-	if (tid < total) wf.wgt[tid] = make_float4(0.f, 0.f, 0.f, 0.f);      // not a live path until proven otherwise
+	if (tid < total) wf_st(&wf.wgt[tid], make_float4(0.f, 0.f, 0.f, 0.f));      // not a live path until proven otherwise
 	if (tid < total) {
 		int kk = (int)(tid / ps.npix_slots);
 		int slot = (int)(tid % ps.npix_slots);
@@ -106,14 +125,14 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 			valid = true;
 			PathState p; float dx, dy;
 			path_begin(R, i, j, ps.k0 + kk, p, dx, dy);
-			wf.out.col[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-			wf.out.dxdy[tid] = make_float2(dx, dy);
+			wf_st(&wf.out.col[tid], make_float4(0.f, 0.f, 0.f, 0.f));
+			wf_st(&wf.out.dxdy[tid], make_float2(dx, dy));
 			alive = path_alive(p);
 			if (alive) {
-				wf.ray_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
-				wf.ray_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
-				wf.wgt[tid] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
-				wf.rng[tid] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
+				wf_st(&wf.ray_o[tid], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f));
+				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
+				wf_st(&wf.wgt[tid], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
+				wf_st(&wf.rng[tid], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 		}
 	}
@@ -135,13 +154,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 			unsigned idx = base + 64u * u + lane_id();
 			if (idx >= n) continue;
 			unsigned id = b == 0 ? idx : list[idx];
-			if (b == 0 && !(__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID)) continue;
-			float4 o = wf.ray_o[id], d = wf.ray_d[id];
+			if (b == 0 && !(__float_as_uint(wf_ld(&wf.wgt[id]).w) & MIPT_WF_VALID)) continue;
+			float4 o = wf_ld(&wf.ray_o[id]), d = wf_ld(&wf.ray_d[id]);
 			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
 			Hit h;
 			bool hit = scene_closest(sc, r, h, stk);
 			unsigned packed = hit ? (((unsigned)h.obj << 27) | (h.tri < 0 ? MIPT_HIT_NOTRI : (unsigned)h.tri)) : MIPT_HIT_MISS;
-			wf.hit[id] = make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed));
+			wf_st(&wf.hit[id], make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed)));
 		}
 	}
 }
@@ -169,11 +188,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			unsigned idx = base + 64u * u + lane_id();
 			if (idx >= n) continue;
 			unsigned id = identity ? idx : list[idx];
-			float4 w = wf.wgt[id];
+			float4 w = wf_ld(&wf.wgt[id]);
 			unsigned fl = __float_as_uint(w.w);
 			if (identity && !(fl & MIPT_WF_VALID)) continue;
-			float4 o = wf.ray_o[id], d = wf.ray_d[id], hr = wf.hit[id], col = wf.out.col[id];
-			uint2 rs = wf.rng[id];
+			float4 o = wf_ld(&wf.ray_o[id]), d = wf_ld(&wf.ray_d[id]), hr = wf_ld(&wf.hit[id]), col = wf_ld(&wf.out.col[id]);
+			uint2 rs = wf_ld(&wf.rng[id]);
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
 			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
@@ -199,20 +218,20 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				c = r == VERTEX_CONTINUE;
 			} else c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
-			wf.out.col[id] = make_float4(p.color.x, p.color.y, p.color.z, 0.f);
+			wf_st(&wf.out.col[id], make_float4(p.color.x, p.color.y, p.color.z, 0.f));
 			if (sh.diffuse && sh.cast) {
 				cast_bits |= 1u << u; n_shadow++;
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
-				wf.sh_o[id] = make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist);
-				wf.sh_d[id] = make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f);
-				wf.sh_c[id] = make_float4(pc.x, pc.y, pc.z, 0.f);
+				wf_st(&wf.sh_o[id], make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist));
+				wf_st(&wf.sh_d[id], make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f));
+				wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
 			}
 			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
 			if (c) {
-				wf.ray_o[id] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f);
-				wf.ray_d[id] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
-				wf.wgt[id] = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
-				wf.rng[id] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
+				wf_st(&wf.ray_o[id], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f));
+				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
+				wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
+				wf_st(&wf.rng[id], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 			if (c) cont_bits |= 1u << u;
 		}
@@ -240,11 +259,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restri
 			unsigned idx = base + 64u * u + lane_id();
 			if (idx >= n) continue;
 			unsigned id = list[idx];
-			float4 o = wf.sh_o[id], d = wf.sh_d[id];
+			float4 o = wf_ld(&wf.sh_o[id]), d = wf_ld(&wf.sh_d[id]);
 			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
 			if (!scene_occluded(sc, r, o.w, stk)) {
-				float4 c = wf.out.col[id], pc = wf.sh_c[id];
-				wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+				float4 c = wf_ld(&wf.out.col[id]), pc = wf_ld(&wf.sh_c[id]);
+				wf_st(&wf.out.col[id], make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f));    // Raytracer.cpp:566
 			}
 		}
 	}

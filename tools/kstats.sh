@@ -2,7 +2,7 @@
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kstats_$tag -- python3 $R/bench.py --steps 8 --warmup 1 --pmc "$@" > $R/gpurun_out/kstats_$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kstats_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --pmc "$@" > $R/gpurun_out/kstats_$tag.log 2>&1
 f=$(ls $R/gpurun_out/kstats_$tag/*/*kernel_stats.csv | head -1)
 cp $f $R/gpurun_out/kstats_$tag.csv
 python3 - $f <<'PY'

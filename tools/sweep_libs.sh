@@ -2,7 +2,7 @@
 for cfg in "$@"; do
   set -- $cfg; lib=$1; shift
   if [ "$lib" = "-" ]; then unset MIPT_LIB_OVERRIDE; else export MIPT_LIB_OVERRIDE=$PWD/pathtracer_amd/libmipt_$lib.so; fi
-  python bench.py --steps 8 --warmup 1 --pmc "$@" > /tmp/b.json 2>/tmp/b.err || tail -3 /tmp/b.err
+  python bench.py --steps 3 --warmup 1 --pmc "$@" > /tmp/b.json 2>/tmp/b.err || tail -3 /tmp/b.err
   python - "$cfg" <<'PY'
 import json,sys
 d=json.load(open('/tmp/b.json'))
