@@ -259,7 +259,7 @@ def main():
                                "rays_per_launch": (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches}
             try:   # HBM bytes per launch of the dominant kernel from the committed PMC run (same workload)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))[args.workload]
-                tr = tj["kernels"]["k_wf_traverse" if merged else ("k_wf_traverse<false>" if pipeline == 1 else "k_render_paths")]
+                tr = tj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_high"]
                 out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of this kernel on this workload, " + tj["source"]
             except Exception:
