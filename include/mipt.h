@@ -237,6 +237,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
  *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
+ *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
+ *                     every ray (normally only for rays with a zero direction component)
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
  *   "paths_per_pass"  upper bound on paths in flight per pass */
 int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);

@@ -75,7 +75,9 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 // queue is drained and all rays this wave fetched are finished.
 template <bool SHADOW>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               int b, unsigned n0, int refill_threshold, int inner_min, LdsStack& stk, unsigned char* leafmap) {
+                                               int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
+	const int inner_min = inner_min_flags & 0xffff;
+	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
 	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
 	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
@@ -191,7 +193,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
 			// together with them) use the literal early-out chain
 			const float inf = __int_as_float(0x7f800000);
-			const bool literal = alive && (fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
+			const bool literal = alive && (force_literal || fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
 			for (;;) {
 				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
 				const unsigned long long mi = __ballot(inner);
@@ -342,10 +344,10 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
 template <int MODE>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min) {
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min, stk, leafmap);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min, stk, leafmap);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min, stk, leafmap);
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min_flags, stk, leafmap);
 }

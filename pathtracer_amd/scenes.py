@@ -110,6 +110,17 @@ def blob_mesh(n: int, fine_detail: bool = False, with_uv: bool = False) -> MeshD
     return MeshData(verts, norms, uvs, f, f.copy(), ft, f"blob{n}" + ("f" if fine_detail else ""))
 
 
+def fat_leaf_mesh(n: int = 20) -> MeshData:
+    """Blob with every 7th face repeated six times with OTHER vertex normals: coincident centroids cannot be
+    split, so the BVH gets leaves with more than 4 triangles, and the copies tie exactly in t — the reference
+    keeps the first one in leaf order (strict '<'), which is visible in the shading normal."""
+    m = blob_mesh(n)
+    sel = np.arange(0, m.ntri, 7)
+    fv = np.concatenate([m.faces_v] + [m.faces_v[sel]] * 6)
+    fn = np.concatenate([m.faces_n] + [np.roll(m.faces_n[sel], k + 1, axis=0) for k in range(6)])
+    return MeshData(m.vertices, m.normals, None, np.ascontiguousarray(fv, np.int32), np.ascontiguousarray(fn, np.int32), None, "fatleaf%d" % n)
+
+
 def write_obj(mesh: MeshData, path: str) -> None:
     """OBJ text with ``vn`` and ``f a//a`` (or ``a/t/n``) faces.  SURVEY.md §4 pitfall 1: an OBJ
     without ``vn`` renders black in the reference, so normals are always written."""

@@ -174,3 +174,26 @@ def test_error_paths():
         rt.set_option("no_such_option", 1)
     with pytest.raises(capi.MiptError):
         rt.sample_radiance(np.array([[10 ** 6, 0]], np.int32), 0, 1)   # pixel outside the image
+
+
+def test_two_meshes_fat_leaves_ties_and_literal_slab():
+    from oracle.binding import Oracle
+    cfg = scenes.config_c1(96, 64, 6)
+    cfg.nb_bounces = 5
+    fat, small = scenes.fat_leaf_mesh(), scenes.blob_mesh(24, fine_detail=True)
+    O, G = Oracle(), capi.HostRaytracer(device=0)
+    for X in (O, G):
+        X.apply_config(cfg)
+        a = X.add_mesh(fat, scale=30.0)
+        X.add_mesh(small, scale=14.0)          # a second mesh behind the first in the object list
+        X.prepare()
+    d = G.mesh_dump(a)
+    leaves = d["nodes_i"][d["nodes_i"][:, 0] == 1]
+    assert (leaves[:, 2] - leaves[:, 1]).max() > 4
+    pix = all_pixels(cfg)
+    want = O.getcolor_samples(pix, 0, cfg.spp)[0]
+    for opts in ({"pipeline": 1}, {"pipeline": 1, "literal_slab": 1}, {"pipeline": 1, "refill": 0}, {"pipeline": 0}):
+        for k, v in opts.items():
+            G.set_option(k, v)
+        assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, f"per-sample radiance {opts}")
+        G.set_option("literal_slab", 0); G.set_option("refill", 1)

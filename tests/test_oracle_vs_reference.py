@@ -49,6 +49,27 @@ def test_random_scene_radiance(seed, n, W, H, spp, depth):
     assert_bits(out[0][1], out[1][1], "jitter")
 
 
+def test_two_meshes_fat_leaves_and_ties():
+    """Leaves with more than 4 triangles (degenerate splits), exact ties in t between coincident triangles with
+    different shading normals, and a second mesh behind the first in the object list."""
+    cfg = scenes.config_c1(64, 40, 4)
+    cfg.nb_bounces = 5
+    fat, small = scenes.fat_leaf_mesh(), scenes.blob_mesh(24, fine_detail=True)
+    out, dumps = [], []
+    for X in (binding.Ref(), binding.Oracle()):
+        X.apply_config(cfg)
+        a = X.add_mesh(fat, scale=30.0)
+        X.add_mesh(small, scale=14.0)
+        X.prepare()
+        dumps.append(X.mesh_dump(a))
+        out.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp))
+    for key in ("perm", "nodes_i", "nodes_bb"):
+        assert_bits(dumps[0][key], dumps[1][key], "mesh." + key)
+    leaves = dumps[1]["nodes_i"][dumps[1]["nodes_i"][:, 0] == 1]
+    assert (leaves[:, 2] - leaves[:, 1]).max() > 4
+    assert_bits(out[0][0], out[1][0], "per-sample radiance")
+
+
 def test_mirror_and_glass():
     mesh = scenes.blob_mesh(20)
     cfg = scenes.config_c1(48, 27, 8)
