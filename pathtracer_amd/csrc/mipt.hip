@@ -375,6 +375,8 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		memcpy(ts[i].normals, T.normals, 36);
 		if (has_uv) memcpy(ts[i].uvs, T.uvs, 24); else memset(ts[i].uvs, 0, 24);
 		ts[i].group = m->indices[i].group;
+		if (ts[i].group > MIPT_GROUP_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "material group index above 2^30");
+		if (ts[i].group >= 0 && has_uv && m->indices[i].uvi >= 0 && m->indices[i].uvi < m->n_uvs) ts[i].group |= MIPT_GROUP_UV_OK;
 		if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
 	}
 	d.node_base = node_base; d.tri_base = tri_base;
@@ -401,6 +403,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	DScene& H = hs[0];
 	memset(&H, 0, sizeof H);
 	H.nobj = s->n_objects;
+	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
@@ -454,6 +457,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 				for (int k = 0; k < o.n_alphamap; k++) if (o.alphamap[k].W > 0 || o.alphamap[k].multiplier[0] < 0.5f) d.alpha_test = 1;
 			}
 			if (d.alpha_test) H.any_alpha = 1;
+			if (i < H.first_mesh) H.first_mesh = i;
 			c->n_mesh_objects++;
 		} else return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: type %d is outside the hot path", i, o.type);
 	}
@@ -736,7 +740,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		} else {
 			HIPCHK(c, hipMemsetAsync(wf.counters, 0, MIPT_WF_COUNTERS * sizeof(unsigned), st));
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, R, P, wf, c->d_cnt);
+			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], grid_all)); };
 			const bool merge = c->opt_refill && c->opt_merge_traverse;

@@ -12,7 +12,7 @@
 // ordered stack traversal per mesh, same pruning); only WHICH lane runs it and WHEN changes.
 #pragma once
 
-#define MIPT_REFILL_THRESHOLD 20        // refill as soon as this many lanes are idle
+#define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
 #ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 1024u           // ids reserved per global atomic (sub-allocated wave-locally)
 #endif
@@ -43,11 +43,10 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 	f3 d = xf_dir(o.inv, rd);
 	f3 org = xf_point(o.inv, ro);
 	if (o.type != 0) {
+		if (SHADOW) return false;                         // spheres / planes were tested when the request was made
 		float t;
 		bool hit = (o.type == 1) ? sphere_test(o, org, d, t) : plane_test(o, org, d, t);
-		if (SHADOW) {
-			if (hit && ((double)t < (double)st.dist * 0.999)) st.best = 1;                            // Geometry.cpp:736-740
-		} else {
+		{
 			if (hit && t < st.t) { st.t = t; st.best = (int)(((unsigned)i << 27) | MIPT_HIT_NOTRI); st.beta = 0; st.gamma = 0; }
 		}
 		return false;
@@ -78,8 +77,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
                                                int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
-	const unsigned n = SHADOW ? wf.counters[4 * b + 2] : (b == 0 ? n0 : wf.counters[4 * b]);
-	unsigned* head = &wf.counters[4 * b + (SHADOW ? 3 : 1)];
+	const unsigned n = SHADOW ? MIPT_N_SHADOW(wf, b) : MIPT_N_EXTEND(wf, b, n0);
+	unsigned* head = &wf.counters[SHADOW ? MIPT_CNT_SH_HEAD(b) : MIPT_CNT_EXT_HEAD(b)];
 	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
 	const bool identity = !SHADOW && b == 0;
 	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
@@ -98,7 +97,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	bool need = false;                   // the lane holds a ray that must visit its next object(s)
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
 	bool drained = false;
-	const int nobj = sc->nobj;
+	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
 	const bool any_alpha = sc->any_alpha != 0;
 
 	auto pop_next = [&]() -> uint32_t {
@@ -139,9 +138,12 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					if (identity) valid = (__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID) != 0;
 					if (valid) {
 						MIPT_PROF_COUNT(10)
-						st.id = id; st.obj = 0; need = true;
+						// the stage that created the ray has already visited the analytic objects (mipt_wavefront.h):
+						// closest-hit rays arrive with the (t, object) found in front of the first mesh, shadow rays
+						// arrive only if no sphere / plane occludes them
+						st.id = id; st.obj = first_mesh; need = true;
 						if (SHADOW) { st.dist = wf.sh_o[id].w; st.best = 0; }
-						else { st.t = __int_as_float(0x7f800000); st.best = (int)MIPT_HIT_MISS; st.beta = 0; st.gamma = 0; }
+						else { const float4 h0 = wf.hit[id]; st.t = h0.x; st.best = (int)__float_as_uint(h0.w); st.beta = 0; st.gamma = 0; }
 					}
 				}
 			}
@@ -157,7 +159,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
 			}
 			if (need) MIPT_PROF_COUNT(6)
-			for (int i = 0; i < nobj; i++) {
+			for (int i = first_mesh; i < nobj; i++) {
 				if (need && st.obj == i) {
 					if (visit_object<SHADOW>(sc->obj[i], i, ro, rd, st)) { need = false; alive = true; }
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided

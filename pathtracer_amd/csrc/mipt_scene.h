@@ -38,7 +38,9 @@ struct DFatNode {          // 64 B, 64-B aligned.  Slabs are stored per axis as 
 };
 
 struct DTriIsect { float A[3], u[3], v[3], N[3]; float m11, m12, m22, invdetm; };   // 64 B
-struct DTriShade { float normals[9]; float uvs[6]; int group; };                    // 64 B
+#define MIPT_GROUP_UV_OK 0x40000000      // DTriShade::group bit: indices[tri].uvi is a valid UV index
+#define MIPT_GROUP_MASK 0x3fffffff
+struct DTriShade { float normals[9]; float uvs[6]; int group; };                    // 64 B (group: material group | MIPT_GROUP_UV_OK)
 
 struct DObject {
 	int type, miroir, flip_normals, interp_normals;
@@ -70,7 +72,8 @@ struct DObject {
 struct DScene {
 	int nobj;
 	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)
-	int _pad[2];
+	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
+	int _pad[1];
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

@@ -169,6 +169,7 @@ MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& m
 // 7.2 mis-scheduling described at the call sites)
 __device__ __attribute__((noinline)) bool alpha_rejects(const DObject& o, int i, float alpha, float beta, float gamma) {
 	int group = o.shade[i].group;
+	if (group >= 0) group &= MIPT_GROUP_MASK;
 	const int* ix = o.uvidx + 3 * (size_t)i;
 	if ((unsigned)o.ntex[MT_ALPHA] > (unsigned)group && ix[0] >= 0 && ix[1] >= 0 && ix[2] >= 0) {
 		const float* a = o.uvs + 3 * (size_t)ix[0];
@@ -352,10 +353,13 @@ MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, 
 	float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 	f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
 	float uv00 = q2.y, uv01 = q2.z, uv10 = q2.w, uv11 = q3.x, uv20 = q3.y, uv21 = q3.z;
-	int group = __float_as_int(q3.w);
+	// group word: bit 30 = "the first UV index of the triangle is valid" (TriangleMesh.cpp:934), set at upload so that
+	// the test needs no extra (dependent, random) fetch from the index array
+	const int graw = __float_as_int(q3.w);
+	const int group = graw >= 0 ? (graw & MIPT_GROUP_MASK) : graw;
 	float u = 0, v = 0;
 	bool has_uv = false;
-	if (o.nuvs != 0 && group >= 0 && o.uvidx != nullptr && o.uvidx[3 * (size_t)tri] >= 0 && (unsigned)o.uvidx[3 * (size_t)tri] < (unsigned)o.nuvs) {
+	if (o.nuvs != 0 && graw >= 0 && (graw & MIPT_GROUP_UV_OK)) {
 		u = (uv00 * alpha + uv10 * beta + uv20 * gamma);
 		v = (uv01 * alpha + uv11 * beta + uv21 * gamma);
 		has_uv = true;
@@ -432,8 +436,7 @@ MIPT_DEV bool scene_closest(const DScene* __restrict__ sc, Ray r, Hit& h, STK& s
 
 // World-space hit point and MaterialValues of the winning object (tail of Scene::intersection,
 // Geometry.cpp:668-684, plus the winner's own material code).
-MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f3& P, Mat& mat) {
-	const DObject& o = sc->obj[h.obj];
+MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat) {
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
 	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
@@ -454,6 +457,9 @@ MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f
 	P = xf_point(o.trans, Pl);
 	mat.shadingN = fast_normalize(xf_rot(o.rot, mat.shadingN));
 }
+MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f3& P, Mat& mat) { hit_material_obj(sc->obj[h.obj], r, h, P, mat); }
+// (A wave-uniform loop over the objects, with scalar loads of the description, was measured slower in the shade stage:
+// the material chains of the distinct objects in a wave then run one after the other.)
 
 template <class STK>
 MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat, STK& stk) {

@@ -27,7 +27,7 @@ struct DWave {
 	unsigned* list_sh;          // path ids with a pending shadow ray
 	unsigned* list_slow;        // path ids whose vertex the fast shade tier deferred to the general one
 	uint2* spill;               // traversal-stack overflow columns (persistent kernels)
-	unsigned* counters;         // per depth b: [4b] n_extend, [4b+1] extend head, [4b+2] n_shadow, [4b+3] shadow head; then shade heads
+	unsigned* counters;         // queue sizes and heads, one per 128-byte line (MIPT_CNT_* below)
 	DSamples out;
 };
 // Path state is written once and read once per depth, 10 GB per pass: it is accessed with the non-temporal
@@ -54,7 +54,21 @@ template <class T> __device__ __forceinline__ void wf_st(T* p, T a) { *p = a; }
 #define MIPT_WF_CNT_SHADE_HEAD (4 * (MIPT_WF_MAX_DEPTH + 2))
 #define MIPT_WF_CNT_NSLOW (MIPT_WF_CNT_SHADE_HEAD + (MIPT_WF_MAX_DEPTH + 2))
 #define MIPT_WF_CNT_SLOW_HEAD (MIPT_WF_CNT_NSLOW + (MIPT_WF_MAX_DEPTH + 2))
-#define MIPT_WF_COUNTERS (MIPT_WF_CNT_SLOW_HEAD + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_NCOUNTERS (MIPT_WF_CNT_SLOW_HEAD + (MIPT_WF_MAX_DEPTH + 2))
+// every counter sits on its own 128-byte line: atomics on one line are serialised (~11 ns each chip-wide), and a shade
+// launch appends to two queues (shadow requests, continuing paths) once per chunk each
+#ifndef MIPT_CNT_STRIDE
+#define MIPT_CNT_STRIDE 32
+#endif
+#define MIPT_CNT(i) ((i) * MIPT_CNT_STRIDE)
+// per depth b: line 4b holds the PAIR {n_shadow(b), n_extend(b+1)} — the two queues shade(b) appends to — as one 64-bit
+// word so that one atomic reserves space in both; line 4b+1 = extend head, 4b+2 = shadow head
+#define MIPT_CNT_PAIR(b) MIPT_CNT(4 * (b))
+#define MIPT_CNT_EXT_HEAD(b) MIPT_CNT(4 * (b) + 1)
+#define MIPT_CNT_SH_HEAD(b) MIPT_CNT(4 * (b) + 2)
+#define MIPT_N_SHADOW(wf, b) ((wf).counters[MIPT_CNT_PAIR(b)])
+#define MIPT_N_EXTEND(wf, b, n0) ((b) == 0 ? (n0) : (wf).counters[MIPT_CNT_PAIR((b) - 1) + 1])
+#define MIPT_WF_COUNTERS (MIPT_WF_NCOUNTERS * MIPT_CNT_STRIDE)
 #define MIPT_HIT_MISS 0xffffffffu
 #define MIPT_HIT_NOTRI 0x07ffffffu
 
@@ -107,11 +121,74 @@ __device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned
 	}
 }
 
+// The analytic part of Scene::intersection / intersection_shadow is evaluated by the stage that CREATES a ray
+// (generate / shade, all lanes busy) instead of by the traversal kernels, where a refill serves few lanes:
+//  * closest hit: the objects in front of the first mesh of the object list (light sphere, env sphere, ground plane in
+//    every loadScene() scene) are tested in list order with the reference's strict '<' and the running (t, object)
+//    is stored in the path's hit record; the traversal continues from the first mesh with that bound, exactly as the
+//    object loop of Geometry.cpp:600-650 would have arrived there;
+//  * shadow ray: occlusion is an OR over the objects (Geometry.cpp:700-741), so every sphere / plane is tested here
+//    whatever its position in the list; an occluded request is dropped, the others only traverse the meshes.
+// Same device functions (xf_dir / xf_point / sphere_test / plane_test) as the in-kernel object loop: bit-identical.
+MIPT_DEV void analytic_prefix_closest(const DScene* __restrict__ sc, f3 ro, f3 rd, float& t, unsigned& best) {
+	t = __int_as_float(0x7f800000); best = MIPT_HIT_MISS;
+	const int n = sc->first_mesh;
+	for (int i = 0; i < n; i++) {
+		const DObject& o = sc->obj[i];
+		f3 d = xf_dir(o.inv, rd);
+		f3 org = xf_point(o.inv, ro);
+		float tt;
+		bool hit = (o.type == 1) ? sphere_test(o, org, d, tt) : plane_test(o, org, d, tt);
+		if (hit && tt < t) { t = tt; best = ((unsigned)i << 27) | MIPT_HIT_NOTRI; }
+	}
+}
+MIPT_DEV bool analytic_occluded(const DScene* __restrict__ sc, f3 ro, f3 rd, float dist) {
+	const int n = sc->nobj;
+	bool occ = false;
+	for (int i = 0; i < n; i++) {
+		const DObject& o = sc->obj[i];
+		if (o.type == 0) continue;
+		f3 d = xf_dir(o.inv, rd);
+		f3 org = xf_point(o.inv, ro);
+		float tt;
+		bool hit = (o.type == 1) ? sphere_test(o, org, d, tt) : plane_test(o, org, d, tt);
+		if (hit && ((double)tt < (double)dist * 0.999)) occ = true;                                       // Geometry.cpp:736-740
+	}
+	return occ;
+}
+
+// the same for two destination queues whose sizes share one 64-bit word (low: list_a, high: list_b): one atomic
+__device__ __forceinline__ void queue_push2(unsigned* __restrict__ list_a, unsigned* __restrict__ list_b, unsigned long long* __restrict__ count2,
+                                            unsigned bits_a, unsigned bits_b, const unsigned* __restrict__ src, unsigned src_base) {
+	unsigned long long ma[MIPT_WF_UNROLL], mb[MIPT_WF_UNROLL];
+	unsigned total_a = 0, total_b = 0;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+		ma[u] = __ballot((bits_a >> u) & 1u); total_a += (unsigned)__popcll(ma[u]);
+		mb[u] = __ballot((bits_b >> u) & 1u); total_b += (unsigned)__popcll(mb[u]);
+	}
+	if ((total_a | total_b) == 0) return;
+	unsigned lane = lane_id();
+	unsigned long long base2 = 0;
+	if (lane == 0) base2 = atomicAdd(count2, (unsigned long long)total_a | ((unsigned long long)total_b << 32));
+	unsigned base_a = __builtin_amdgcn_readfirstlane((unsigned)base2), base_b = __builtin_amdgcn_readfirstlane((unsigned)(base2 >> 32));
+	unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+		unsigned idx = src_base + 64u * u + lane;
+		unsigned id = 0;
+		if (((bits_a | bits_b) >> u) & 1u) id = src ? src[idx] : idx;
+		if ((bits_a >> u) & 1u) list_a[base_a + (unsigned)__popcll(ma[u] & below)] = id;
+		if ((bits_b >> u) & 1u) list_b[base_b + (unsigned)__popcll(mb[u] & below)] = id;
+		base_a += (unsigned)__popcll(ma[u]); base_b += (unsigned)__popcll(mb[u]);
+	}
+}
+
 // bit 31 of wgt.w marks a path slot that holds a live path (slots of 8x8 blocks that stick out of
 // the image never do); depth 0 of a pass uses the identity list, so generation needs no queue.
 #define MIPT_WF_VALID 0x80000000u
 
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt) {
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	bool valid = false, alive = false;
@@ -133,6 +210,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
 				wf_st(&wf.wgt[tid], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
 				wf_st(&wf.rng[tid], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
+				float t0; unsigned best0;
+				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
+				wf_st(&wf.hit[tid], make_float4(t0, 0.f, 0.f, __uint_as_float(best0)));
 			}
 		}
 	}
@@ -143,8 +223,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(DRender R, DPass ps,
 // Depth 0 walks the identity list of all n0 path slots and skips the dead ones.
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restrict__ sc, DWave wf, int b, unsigned n0) {
 	MIPT_DECLARE_STACK(stk);
-	const unsigned n = b == 0 ? n0 : wf.counters[4 * b];
-	unsigned* head = &wf.counters[4 * b + 1];
+	const unsigned n = MIPT_N_EXTEND(wf, b, n0);
+	unsigned* head = &wf.counters[MIPT_CNT_EXT_HEAD(b)];
 	const unsigned* __restrict__ list = wf.list[b & 1];
 	unsigned base;
 	QueuePuller q; q.init();
@@ -173,26 +253,46 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #endif
 template <int TIER>
 __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : 2))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
-	const unsigned n = TIER == 2 ? wf.counters[MIPT_WF_CNT_NSLOW + b] : (b == 0 ? n0 : wf.counters[4 * b]);
-	unsigned* head = &wf.counters[(TIER == 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b];
+	const unsigned n = TIER == 2 ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
+	unsigned* head = &wf.counters[MIPT_CNT((TIER == 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
 	const unsigned* __restrict__ list = TIER == 2 ? wf.list_slow : wf.list[b & 1];
 	const bool identity = TIER != 2 && b == 0;
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
 	QueuePuller q; q.init();
+	// Software pipeline over the sub-chunks of a chunk: the path ids of all sub-chunks are read first, and the state
+	// of sub-chunk u+1 is requested before sub-chunk u is shaded — with 3 waves per SIMD the stage is bound by its
+	// three dependent HBM round trips per vertex (state, shading record, texel), this hides the first one.
+	struct In { float4 w, o, d, hr, col; uint2 rs; };
+	auto fetch = [&](unsigned id, bool ok, In& in) {
+		if (ok) {
+			in.w = wf_ld(&wf.wgt[id]); in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); in.hr = wf_ld(&wf.hit[id]);
+			in.col = wf_ld(&wf.out.col[id]); in.rs = wf_ld(&wf.rng[id]);
+		}
+	};
 	while (q.pull(head, n, base)) {
 		unsigned cont_bits = 0, cast_bits = 0, slow_bits = 0;
-#pragma unroll 1
+		unsigned ids[MIPT_WF_UNROLL];
+#pragma unroll
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
-			unsigned idx = base + 64u * u + lane_id();
-			if (idx >= n) continue;
-			unsigned id = identity ? idx : list[idx];
-			float4 w = wf_ld(&wf.wgt[id]);
+			const unsigned idx = base + 64u * u + lane_id();
+			ids[u] = idx < n ? (identity ? idx : list[idx]) : 0xffffffffu;
+		}
+		In cur, nxt;
+		cur.w = cur.o = cur.d = cur.hr = cur.col = make_float4(0.f, 0.f, 0.f, 0.f); cur.rs = make_uint2(0u, 0u); nxt = cur;
+		fetch(ids[0], ids[0] != 0xffffffffu, cur);
+#pragma unroll
+		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+			const unsigned id = ids[u];
+			if (u + 1 < MIPT_WF_UNROLL) fetch(ids[u + 1], ids[u + 1] != 0xffffffffu, nxt);
+			const In sin = cur;
+			cur = nxt;
+			if (id == 0xffffffffu) continue;
+			const float4 w = sin.w, o = sin.o, d = sin.d, hr = sin.hr, col = sin.col;
+			const uint2 rs = sin.rs;
 			unsigned fl = __float_as_uint(w.w);
 			if (identity && !(fl & MIPT_WF_VALID)) continue;
-			float4 o = wf_ld(&wf.ray_o[id]), d = wf_ld(&wf.ray_d[id]), hr = wf_ld(&wf.hit[id]), col = wf_ld(&wf.out.col[id]);
-			uint2 rs = wf_ld(&wf.rng[id]);
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
 			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
@@ -219,8 +319,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			} else c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
 			wf_st(&wf.out.col[id], make_float4(p.color.x, p.color.y, p.color.z, 0.f));
-			if (sh.diffuse && sh.cast) {
-				cast_bits |= 1u << u; n_shadow++;
+			if (sh.diffuse && sh.cast) n_shadow++;                         // counted like the reference counts intersection_shadow calls
+			if (sh.diffuse && sh.cast && !analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
+				cast_bits |= 1u << u;
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
 				wf_st(&wf.sh_o[id], make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist));
 				wf_st(&wf.sh_d[id], make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f));
@@ -232,13 +333,15 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
 				wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
 				wf_st(&wf.rng[id], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
+				float t0; unsigned best0;
+				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
+				wf_st(&wf.hit[id], make_float4(t0, 0.f, 0.f, __uint_as_float(best0)));
 			}
 			if (c) cont_bits |= 1u << u;
 		}
 		const unsigned* src = identity ? nullptr : list;
-		queue_push(wf.list_sh, &wf.counters[4 * b + 2], cast_bits, src, base);
-		queue_push(next, &wf.counters[4 * (b + 1)], cont_bits, src, base);
-		if (TIER == 1) queue_push(wf.list_slow, &wf.counters[MIPT_WF_CNT_NSLOW + b], slow_bits, src, base);
+		queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);
+		if (TIER == 1) queue_push(wf.list_slow, &wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)], slow_bits, src, base);
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);
@@ -248,8 +351,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 // shadow: Scene::intersection_shadow; a visible light sample adds weight*contrib to the path colour
 __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restrict__ sc, DWave wf, int b) {
 	MIPT_DECLARE_STACK(stk);
-	const unsigned n = wf.counters[4 * b + 2];
-	unsigned* head = &wf.counters[4 * b + 3];
+	const unsigned n = MIPT_N_SHADOW(wf, b);
+	unsigned* head = &wf.counters[MIPT_CNT_SH_HEAD(b)];
 	const unsigned* __restrict__ list = wf.list_sh;
 	unsigned base;
 	QueuePuller q; q.init();
