@@ -276,6 +276,27 @@ class Ref(_Base):
         self.cdll.ref_time_render_nopreviz.restype = C.c_double
         self.cdll.ref_time_render_image.restype = C.c_double
 
+    def add_mesh_obj(self, path, scale=30.0, center=True):
+        """The reference's own TriMesh(&scene, path, ...): readOBJ + MTL + stb_image."""
+        return self.lib.ref_add_mesh(self.ctx, str(path).encode(), _f(scale), 1 if center else 0)
+
+    def group_materials(self, obj):
+        out = []
+        for g in range(self.lib.ref_num_groups(self.ctx, obj)):
+            m = np.zeros(12, np.float32); wh = np.zeros(8, np.int32)
+            self.lib.ref_get_group_material(self.ctx, obj, g, _p(m, _f), _p(wh, _i))
+            out.append((m, wh.reshape(4, 2)))
+        return out
+
+    def group_texture(self, obj, grp, slot):
+        m, wh = self.group_materials(obj)[grp]
+        W, H = int(wh[slot][0]), int(wh[slot][1])
+        if W == 0:
+            return None
+        self.lib.ref_group_texture_values.restype = C.POINTER(_f)
+        p = self.lib.ref_group_texture_values(self.ctx, obj, grp, slot)
+        return np.ctypeslib.as_array(p, shape=(H, W, 3)).copy()
+
     def add_mesh(self, mesh, scale=30.0, center=True, tmpdir=None):
         """Writes the mesh as OBJ text and lets the reference's own readOBJ parse it."""
         import tempfile

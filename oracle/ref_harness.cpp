@@ -207,6 +207,21 @@ void ref_get_object_matrices(RefCtx* c, int obj, float* trans12, float* inv12, f
 	memcpy(rot9, o->rot_matrix, 9 * sizeof(float));
 }
 
+// material lists of one group as readOBJ / the MTL parser left them: multipliers of Kd, Ks, Ne (3 each), alpha, refr,
+// transp (1 each); W, H of the Kd / Ks / normal / alpha images; and the decoded float image of one slot
+int ref_num_groups(RefCtx* c, int obj) { return (int)c->rt->s.objects[obj]->textures.size(); }
+void ref_get_group_material(RefCtx* c, int obj, int grp, float* out12, int* wh8) {
+	Object* o = c->rt->s.objects[obj];
+	for (int k = 0; k < 3; k++) { out12[k] = o->textures[grp].multiplier[k]; out12[3 + k] = o->specularmap[grp].multiplier[k]; out12[6 + k] = o->roughnessmap[grp].multiplier[k]; }
+	out12[9] = o->alphamap[grp].multiplier[0]; out12[10] = o->refr_index_map[grp].multiplier[0]; out12[11] = o->transparent_map[grp].multiplier[0];
+	const Texture* t[4] = {&o->textures[grp], &o->specularmap[grp], &o->normal_map[grp], &o->alphamap[grp]};
+	for (int k = 0; k < 4; k++) { wh8[2 * k] = (int)t[k]->W; wh8[2 * k + 1] = (int)t[k]->H; }
+}
+const float* ref_group_texture_values(RefCtx* c, int obj, int grp, int slot) {
+	Object* o = c->rt->s.objects[obj];
+	const Texture* t[4] = {&o->textures[grp], &o->specularmap[grp], &o->normal_map[grp], &o->alphamap[grp]};
+	return t[slot]->values.empty() ? (const float*)0 : &t[slot]->values[0];
+}
 void ref_mesh_counts(RefCtx* c, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs) {
 	TriMesh* g = c->rt->s.castToMesh[obj];
 	*ntri = (int)g->indices.size(); *nnodes = (int)g->bvh.nodes.size();

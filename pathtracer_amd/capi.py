@@ -156,6 +156,32 @@ class HostRaytracer:
         self.set_light(cfg.light_center, cfg.light_radius, cfg.light_scale)
         self.set_envmap_intensity(cfg.envmap_intensity)
 
+    def add_mesh_obj(self, path, scale=30.0, center=True):
+        """TriMesh(&scene, path, ...) of the reference: OBJ + MTL (+ PPM textures) read by the host mirror."""
+        self.host.mh_add_mesh_obj.restype = C.c_int
+        rid = self.host.mh_add_mesh_obj(self.h, str(path).encode(), _f(scale), 1 if center else 0)
+        if rid < 0:
+            raise MiptError("TriMesh(%s): %s" % (path, self.host.mh_last_error(self.h).decode()))
+        return rid
+
+    def group_materials(self, obj):
+        """Per material group: multipliers (Kd, Ks, Ne, alpha, refr, transp) and the image sizes of Kd / Ks / normal / alpha."""
+        out = []
+        for g in range(self.host.mh_num_groups(self.h, obj)):
+            m = np.zeros(12, np.float32); wh = np.zeros(8, np.int32)
+            self.host.mh_get_group_material(self.h, obj, g, m.ctypes.data_as(C.POINTER(_f)), wh.ctypes.data_as(C.POINTER(C.c_int)))
+            out.append((m, wh.reshape(4, 2)))
+        return out
+
+    def group_texture(self, obj, grp, slot):
+        m, wh = self.group_materials(obj)[grp]
+        W, H = int(wh[slot][0]), int(wh[slot][1])
+        if W == 0:
+            return None
+        self.host.mh_group_texture_values.restype = C.POINTER(_f)
+        p = self.host.mh_group_texture_values(self.h, obj, grp, slot)
+        return np.ctypeslib.as_array(p, shape=(H, W, 3)).copy()
+
     def add_mesh(self, mesh, scale=30.0, center=True, tmpdir=None):
         v = np.ascontiguousarray(mesh.vertices, np.float32)
         n = np.ascontiguousarray(mesh.normals, np.float32)

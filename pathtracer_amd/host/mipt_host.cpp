@@ -6,8 +6,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <thread>
 
 #ifndef M_PI
@@ -116,9 +119,22 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 		t.group = 0;   // no usemtl: every face in group 0, "Default" (TriangleMesh.cpp:462-467)
 		t.showEdges[0] = t.showEdges[1] = t.showEdges[2] = 1;
 	}
-	// readOBJ's per-group default material lists (TriangleMesh.cpp:470-480)
-	add_col_texture(Vector(0.5f, 0.5f, 0.5f)); add_col_specular(Vector(0, 0, 0)); add_col_roughness(Vector(0, 0, 0));
-	add_null_normalmap(); add_col_alpha(1.f); add_col_refr(1.3f); add_col_transp(1.f); add_col_subsurface(Vector(0, 0, 0));
+	groupNames["Default"] = 0;
+	add_default_group_materials(1);
+	finish_init(center);
+}
+
+// readOBJ's per-group default material lists (TriangleMesh.cpp:470-480)
+void TriMesh::add_default_group_materials(int ngroups) {
+	for (int g = 0; g < ngroups; g++) {
+		add_col_texture(Vector(0.5f, 0.5f, 0.5f)); add_col_specular(Vector(0, 0, 0)); add_col_roughness(Vector(0, 0, 0));
+		add_null_normalmap(); add_col_alpha(1.f); add_col_refr(1.3f); add_col_transp(1.f); add_col_subsurface(Vector(0, 0, 0));
+	}
+}
+
+// TriMesh::init after the file has been read (TriangleMesh.cpp:742-841), scaling = 1, offset = 0, preserve_input = false
+void TriMesh::finish_init(bool center) {
+	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
 	for (auto& v : vertices) { std::swap(v[0], v[2]); v[0] = -v[0]; }
 	for (auto& v : normals) { std::swap(v[0], v[2]); v[0] = -v[0]; }
@@ -157,6 +173,189 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 	}
 	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
 	if (nt != 0) setup_tangents();
+}
+
+// ---------------------------------------------------------------- OBJ / MTL ingestion
+// Same file semantics as TriMesh::readOBJ (TriangleMesh.cpp:240-569), written as a small scanner instead of sscanf
+// cascades.  What is reproduced, because it decides which triangles / materials come out:
+//  * physical lines are cut at 254 characters (fgets(line, 255)); only the first two characters select the record;
+//  * "v x y z [r g b]" (colours ignored here), "vn", "vt u v", "usemtl name" (groups numbered by first appearance),
+//    "mtllib file";
+//  * a face corner is v/t/n, v/t, v or v//n — the form of the FIRST three corners is tried in that order and applies
+//    to the whole line — with 1-based or negative (relative) indices; polygons are fanned as (c0, c_{k-1}, c_k);
+//  * no usemtl anywhere: every face in group 0 ("Default");
+//  * MTL: records are recognised at column 0 only ("Kd", "Ks", "Ns", "map_Kd", "map_Ks", "map_Bump", "map_d",
+//    "newmtl"), "Ns" with one value is replicated, a material name the OBJ never used lands in group 0
+//    (std::map::operator[] default), illum is never evaluated.
+// Images: binary PPM (P6, maxval 255) — the one format of the reference's decoder (stb_image) that needs no codec;
+// anything else is reported through load_error and leaves the constant colour in place.
+namespace {
+struct Corner { int v, t, n; bool has_t, has_n; };
+// one corner starting at p; returns the end pointer or nullptr.  `%u` of the reference accepts a sign.
+const char* scan_int(const char* p, int& out) {
+	while (*p == ' ' || *p == '\t') p++;
+	char* e;
+	long long v = strtoll(p, &e, 10);
+	if (e == p) return nullptr;
+	out = (int)(unsigned)v;
+	return e;
+}
+const char* scan_corner(const char* p, Corner& c) {
+	c.has_t = c.has_n = false; c.t = c.n = 0;
+	p = scan_int(p, c.v);
+	if (!p) return nullptr;
+	if (*p != '/') return p;
+	p++;
+	if (*p == '/') {                                  // v//n
+		const char* q = scan_int(p + 1, c.n);
+		if (!q || p[1] == ' ') return nullptr;
+		c.has_n = true;
+		return q;
+	}
+	if (*p == ' ' || *p == '\t') return nullptr;
+	const char* q = scan_int(p, c.t);
+	if (!q) return nullptr;
+	c.has_t = true;
+	if (*q != '/') return q;
+	if (q[1] == ' ' || q[1] == '\t') return nullptr;
+	const char* r = scan_int(q + 1, c.n);
+	if (!r) return nullptr;
+	c.has_n = true;
+	return r;
+}
+std::string dir_of(const std::string& path) { size_t k = path.find_last_of("/\\"); return path.substr(0, k + 1); }   // extractFilePathWithEndingSlash
+std::string rest_of_line(const char* line, size_t skip) {   // sscanf(line, "keyword %[^\n]"): blanks after the keyword are skipped
+	const char* p = line + std::min(skip - 1, strlen(line));
+	while (*p == ' ' || *p == '\t') p++;
+	std::string r(p);
+	size_t k = r.find('\n');
+	if (k != std::string::npos) r.erase(k);
+	return r;
+}
+bool read_ppm(const std::string& file, std::vector<unsigned char>& rgb, int& W, int& H) {
+	FILE* f = fopen(file.c_str(), "rb");
+	if (!f) return false;
+	auto token = [&](int& out) {
+		int ch = fgetc(f);
+		for (;;) {
+			while (ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t') ch = fgetc(f);
+			if (ch == '#') { while (ch != '\n' && ch != EOF) ch = fgetc(f); continue; }
+			break;
+		}
+		if (ch < '0' || ch > '9') return false;
+		out = 0;
+		while (ch >= '0' && ch <= '9') { out = out * 10 + (ch - '0'); ch = fgetc(f); }
+		return true;                                 // the single whitespace after the token is consumed
+	};
+	bool ok = fgetc(f) == 'P' && fgetc(f) == '6';
+	int maxv = 0;
+	ok = ok && token(W) && token(H) && token(maxv) && maxv == 255 && W > 0 && H > 0;
+	if (ok) { rgb.resize((size_t)W * H * 3); ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size(); }
+	fclose(f);
+	return ok;
+}
+}  // namespace
+
+bool TriMesh::readOBJ(const char* obj) {
+	FILE* f = fopen(obj, "r");
+	if (!f) { load_error = std::string("cannot open ") + obj; return false; }
+	std::string matfile;
+	int curGroup = -1;
+	char line[255];
+	while (fgets(line, 255, f)) {
+		if (line[0] == 'u' && line[1] == 's') {
+			std::string grp = rest_of_line(line, 7);
+			auto it = groupNames.find(grp);
+			if (it != groupNames.end()) curGroup = it->second;
+			else { curGroup = (int)groupNames.size(); groupNames[grp] = curGroup; }
+		}
+		if (line[0] == 'm' && line[1] == 't' && line[2] == 'l') matfile = rest_of_line(line, 7);
+		if (line[0] == 'v' && line[1] == ' ') {
+			float x = 0, y = 0, z = 0, cr, cg, cb;
+			if (sscanf(line, "v %f %f %f %f %f %f", &x, &y, &z, &cr, &cg, &cb) == 6) {   // vertex colours feed getMaterial (TriangleMesh.cpp:980-1000): outside the hot path
+				fclose(f); load_error = "per-vertex colours are not supported"; return false;
+			}
+			vertices.push_back(Vector(x, y, z));
+		}
+		if (line[0] == 'v' && line[1] == 'n') { float x = 0, y = 0, z = 0; sscanf(line, "vn %f %f %f", &x, &y, &z); normals.push_back(Vector(x, y, z)); }
+		if (line[0] == 'v' && line[1] == 't') { float x = 0, y = 0; sscanf(line, "vt %f %f", &x, &y); uvs.push_back(Vector(x, y, 0)); }
+		if (line[0] == 'f') {
+			Corner c[3];
+			const char* p = line + 1;
+			bool ok = true;
+			for (int k = 0; k < 3 && ok; k++) { p = scan_corner(p, c[k]); ok = p != nullptr; }
+			if (!ok) continue;
+			// the form of the line is that of its first corners (the sscanf cascade of :327-383)
+			const bool form_t = c[0].has_t && c[1].has_t && c[2].has_t, form_n = c[0].has_n && c[1].has_n && c[2].has_n;
+			auto rel = [](int i, size_t n) { return i < 0 ? (int)n + i : i - 1; };
+			auto emit = [&](const Corner& a, const Corner& b, const Corner& d, bool first) {
+				mipt_triangle_indices t;
+				memset(&t, 0, sizeof t);
+				t.group = curGroup;
+				t.showEdges[0] = first; t.showEdges[1] = 1; t.showEdges[2] = 1;
+				t.vtxi = rel(a.v, vertices.size()); t.vtxj = rel(b.v, vertices.size()); t.vtxk = rel(d.v, vertices.size());
+				t.uvi = t.uvj = t.uvk = -1; t.ni = t.nj = t.nk = -1;
+				if (form_t) { t.uvi = rel(a.t, uvs.size()); t.uvj = rel(b.t, uvs.size()); t.uvk = rel(d.t, uvs.size()); }
+				if (form_n) { t.ni = rel(a.n, normals.size()); t.nj = rel(b.n, normals.size()); t.nk = rel(d.n, normals.size()); }
+				indices.push_back(t);
+			};
+			emit(c[0], c[1], c[2], true);
+			Corner last = c[2];
+			for (;;) {                                 // fan: (c0, previous, next)  (:391-457)
+				while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+				if (*p == '\n' || *p == '\0') break;
+				Corner nx;
+				const char* q = scan_corner(p, nx);
+				if (!q) { p++; continue; }
+				if (form_t && !nx.has_t) { p = q; continue; }
+				emit(c[0], last, nx, false);
+				last = nx;
+				p = q;
+			}
+		}
+	}
+	fclose(f);
+	if (groupNames.empty()) {
+		for (auto& t : indices) t.group = 0;
+		groupNames["Default"] = 0;
+	}
+	add_default_group_materials((int)groupNames.size());
+	if (matfile.empty()) return true;
+	FILE* m = fopen((dir_of(obj) + matfile).c_str(), "r");
+	if (!m) return true;                               // a missing MTL is not an error in the reference either
+	int grp = 0;
+	auto image = [&](Texture& tex, const std::string& file, bool normals_map) {
+		std::vector<unsigned char> rgb; int W = 0, H = 0;
+		if (!read_ppm(dir_of(obj) + file, rgb, W, H)) { load_error = "texture " + file + ": only binary PPM (P6, 8 bit) is decoded here"; return; }
+		if (normals_map) tex.loadNormalsRGB8(rgb.data(), W, H); else tex.loadColorsRGB8(rgb.data(), W, H);
+	};
+	while (fgets(line, 255, m)) {
+		if (line[0] == 'n' && line[1] == 'e' && line[2] == 'w') {
+			auto it = groupNames.find(rest_of_line(line, 7));
+			grp = it != groupNames.end() ? it->second : 0;
+		}
+		if (line[0] == 'm' && line[4] == 'K' && line[5] == 'd') image(textures[grp], rest_of_line(line, 7), false);
+		if (line[0] == 'm' && line[4] == 'K' && line[5] == 's') image(specularmap[grp], rest_of_line(line, 7), false);
+		if (line[0] == 'm' && line[4] == 'B' && line[5] == 'u') image(normal_map[grp], rest_of_line(line, 9), true);
+		if (line[0] == 'm' && line[1] == 'a' && line[4] == 'd') image(alphamap[grp], rest_of_line(line, 6), false);
+		if (line[0] == 'K' && line[1] == 'd') { Vector k; sscanf(line, "Kd %f %f %f", &k[0], &k[1], &k[2]); textures[grp].multiplier = k; }
+		if (line[0] == 'K' && line[1] == 's') { Vector k; sscanf(line, "Ks %f %f %f", &k[0], &k[1], &k[2]); specularmap[grp].multiplier = k; }
+		if (line[0] == 'N' && line[1] == 's') {
+			Vector k;
+			int got = sscanf(line, "Ns %f %f %f", &k[0], &k[1], &k[2]);
+			if (got == 1) k = Vector(k[0], k[0], k[0]);
+			roughnessmap[grp].multiplier = k;
+		}
+	}
+	fclose(m);
+	return true;
+}
+
+TriMesh::TriMesh(const char* obj, bool center) {
+	type = OT_TRIMESH; interp_normals = true; name = obj;
+	loaded = readOBJ(obj);
+	if (loaded && !indices.empty()) finish_init(center);
+	else loaded = false;
 }
 
 void TriMesh::build_bbox(int i0, int i1, float* o) const {   // :843-858
@@ -548,6 +747,29 @@ void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
 }
 void mh_set_envmap_intensity(mh_raytracer* h, float v) { h->rt.s.envmap_intensity = v; }
+int mh_add_mesh_obj(mh_raytracer* h, const char* obj_file, float scale, int center) {
+	Raytracer& r = h->rt;
+	TriMesh* g = new TriMesh(obj_file, center != 0);
+	if (!g->loaded) { r.set_error(g->load_error.empty() ? std::string("no faces in ") + obj_file : g->load_error); delete g; return -1; }
+	g->scale = scale;   // GUI placement, mainApp.cpp:2402-2410
+	g->max_translation = Vector(0, r.s.objects[2]->max_translation[1] - g->bbox[1] * g->scale, 0);
+	r.s.addObject(g);
+	return (int)r.s.objects.size() - 1;
+}
+// multipliers of one material group: Kd, Ks, Ne (3 each), alpha, refr, transp (1 each) + W, H of the Kd / Ks / normal / alpha images
+void mh_get_group_material(mh_raytracer* h, int obj, int grp, float* out12, int* wh8) {
+	Object* o = h->rt.s.objects[obj];
+	for (int k = 0; k < 3; k++) { out12[k] = o->textures[grp].multiplier[k]; out12[3 + k] = o->specularmap[grp].multiplier[k]; out12[6 + k] = o->roughnessmap[grp].multiplier[k]; }
+	out12[9] = o->alphamap[grp].multiplier[0]; out12[10] = o->refr_index_map[grp].multiplier[0]; out12[11] = o->transparent_map[grp].multiplier[0];
+	const Texture* t[4] = {&o->textures[grp], &o->specularmap[grp], &o->normal_map[grp], &o->alphamap[grp]};
+	for (int k = 0; k < 4; k++) { wh8[2 * k] = (int)t[k]->W; wh8[2 * k + 1] = (int)t[k]->H; }
+}
+int mh_num_groups(mh_raytracer* h, int obj) { return (int)h->rt.s.objects[obj]->textures.size(); }
+const float* mh_group_texture_values(mh_raytracer* h, int obj, int grp, int slot) {   // slot: 0 Kd, 1 Ks, 2 normal, 3 alpha
+	Object* o = h->rt.s.objects[obj];
+	const Texture* t[4] = {&o->textures[grp], &o->specularmap[grp], &o->normal_map[grp], &o->alphamap[grp]};
+	return t[slot]->values.empty() ? nullptr : t[slot]->values.data();
+}
 int mh_add_mesh(mh_raytracer* h, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs, int nf, const int* fv, const int* fn, const int* ft, float scale, int center) {
 	Raytracer& r = h->rt;
 	TriMesh* g = new TriMesh(nv, verts, nn, normals, nt, uvs, nf, fv, fn, ft, center != 0);

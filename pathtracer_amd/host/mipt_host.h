@@ -10,6 +10,7 @@
 // render_image / render_image_nopreviz, and Scene::intersection / intersection_shadow.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,12 @@ public:
 	// parsed): scaling = 1, offset = 0, preserve_input = false.
 	TriMesh(int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
 	        int nf, const int* fv, const int* fn, const int* ft, bool center);
+	// TriMesh(scene, obj, 1, (0,0,0), false, NULL, false, center) (TriangleMesh.cpp:714-716): readOBJ + MTL + init.
+	// `loaded` is false (and load_error says why) when the file cannot be read or holds no face.
+	TriMesh(const char* obj, bool center);
+	bool loaded = true;
+	std::string load_error;
+	std::map<std::string, int> groupNames;   // usemtl name -> material group (TriangleMesh.h:228)
 	std::vector<Vector> vertices, normals, uvs;
 	std::vector<mipt_triangle_indices> indices;
 	std::vector<mipt_triangle> triangleSoup;
@@ -96,6 +103,9 @@ public:
 	struct { float bbox[6]; std::vector<BVHNodes> nodes; } bvh;
 	float bbox[6];
 private:
+	bool readOBJ(const char* obj);
+	void add_default_group_materials(int ngroups);
+	void finish_init(bool center);
 	void build_bbox(int i0, int i1, float* out6) const;
 	void build_centers_bbox(int i0, int i1, float* out6) const;
 	float split_cost(int i0, int i1, int split_dim, float split_val) const;
@@ -140,6 +150,7 @@ public:
 	int open_device(int device_id);
 	void set_partition(int tile_size, int rank, int nranks) { tile_size_ = tile_size; tile_rank_ = rank; tile_nranks_ = nranks; }
 	const char* last_error() const;
+	void set_error(const std::string& e) { err_ = e; }
 
 	int W = 1000, H = 800;
 	int nrays = 100, last_nrays = -1;
@@ -188,6 +199,10 @@ void mh_set_render(mh_raytracer*, int W, int H, int nrays, int nb_bounces, float
 void mh_set_camera(mh_raytracer*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);
 void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_lumiere);
 void mh_set_envmap_intensity(mh_raytracer*, float v);
+int  mh_add_mesh_obj(mh_raytracer*, const char* obj_file, float scale, int center);   // TriMesh(&s, file, ...) + GUI placement; -1 on failure (mh_last_error)
+void mh_get_group_material(mh_raytracer*, int obj, int grp, float* out12, int* wh8);
+int  mh_num_groups(mh_raytracer*, int obj);
+const float* mh_group_texture_values(mh_raytracer*, int obj, int grp, int slot);
 int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
                  int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
 void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks

@@ -278,3 +278,60 @@ def install(X, mesh, mat):
         if "envmap" in mat:
             X.set_envmap(mat["envmap"])
     return oid
+
+
+# ---------------------------------------------------------------- an OBJ / MTL / PPM scene on disk
+def write_ppm(path: str, rgb8: np.ndarray) -> None:
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb8.shape[1], rgb8.shape[0]))
+        f.write(np.ascontiguousarray(rgb8, np.uint8).tobytes())
+
+
+def write_obj_scene(directory: str, n: int = 10) -> str:
+    """A blob written the way real OBJ files are: quads and a pentagon fan (polygon triangulation), 1-based and
+    negative (relative) indices, v/t/n and v//n corners, three usemtl groups, an MTL with Kd / Ks / Ns (one and three
+    values), map_Kd / map_Bump / map_d images (binary PPM), an indented record and a material the OBJ never uses.
+    Returns the path of the .obj."""
+    import os
+    m = blob_mesh(n, with_uv=True)
+    nv = m.vertices.shape[0]
+    L = ["# synthetic OBJ scene", "mtllib scene.mtl"]
+    L += ["v %.9g %.9g %.9g" % tuple(v) for v in m.vertices.tolist()]
+    L += ["vn %.9g %.9g %.9g" % tuple(v) for v in m.normals.tolist()]
+    L += ["vt %.9g %.9g" % tuple(v) for v in m.uvs.tolist()]
+    quad = lambda i, j: (i * (n + 1) + j, i * (n + 1) + j + 1, (i + 1) * (n + 1) + j + 1, (i + 1) * (n + 1) + j)
+    for i in range(n):
+        if i == 0:
+            L.append("usemtl skin")
+        elif i == n // 3:
+            L.append("usemtl   bumpy")          # blanks after the keyword are skipped by the reference's sscanf
+        elif i == 2 * n // 3:
+            L.append("usemtl plain")
+        j = 0
+        while j < n:
+            a, b, c, d = quad(i, j)
+            if i < n // 3:                      # quads, 1-based v/t/n
+                L.append("f " + " ".join("%d/%d/%d" % (k + 1, k + 1, k + 1) for k in (a, b, c, d)))
+                j += 1
+            elif i < 2 * n // 3:                # quads, negative indices (relative to the end of the arrays)
+                L.append("f " + " ".join("%d/%d/%d" % (k - nv, k - nv, k - nv) for k in (a, b, c, d)) + " ")
+                j += 1
+            elif j + 1 < n:                     # two quads merged into one hexagon fan, v//n corners
+                a2, b2, c2, d2 = quad(i, j + 1)
+                L.append("f " + " ".join("%d//%d" % (k + 1, k + 1) for k in (a, b, b2, c2, c, d)))
+                j += 2
+            else:
+                L.append("f " + " ".join("%d//%d" % (k + 1, k + 1) for k in (a, b, c, d)))
+                j += 1
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "scene.obj"), "w") as f:
+        f.write("\n".join(L) + "\n")
+    with open(os.path.join(directory, "scene.mtl"), "w") as f:
+        f.write("newmtl skin\nKd 0.9 0.8 0.7\nKs 0.2 0.2 0.1\nNs 35\nmap_Kd kd.ppm\n\tKd 9 9 9\n"
+                "newmtl bumpy\nKd 0.3 0.6 0.9\nNs 10 20 30\nmap_Bump bump.ppm\nmap_d alpha.ppm\n"
+                "newmtl plain\nKd 0.5 0.4 0.3\n"
+                "newmtl never_used\nKs 0.05 0.06 0.07\n")
+    write_ppm(os.path.join(directory, "kd.ppm"), checker_texture(32, 16, 3, 4))
+    write_ppm(os.path.join(directory, "bump.ppm"), bump_texture())
+    write_ppm(os.path.join(directory, "alpha.ppm"), alpha_texture())
+    return os.path.join(directory, "scene.obj")

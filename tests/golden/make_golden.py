@@ -141,6 +141,28 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"scene_{name}.npz"), **g)
         print(name, "mean radiance / white =", float(rgb.mean() / 196964.7))
 
+    # OBJ / MTL / PPM ingestion: the scene files are regenerated by scenes.write_obj_scene, the
+    # reference reads them with its own readOBJ + stb_image; what it made of them is the fixture
+    import tempfile
+    R = Ref()
+    cfg = scenes.config_c1(64, 36, 4)
+    R.apply_config(cfg)
+    oid = R.add_mesh_obj(scenes.write_obj_scene(tempfile.mkdtemp(prefix="ptref_objscene_")))
+    R.prepare()
+    d = R.mesh_dump(oid)
+    g = dict(perm=d["perm"], nodes_i=d["nodes_i"], nodes_bb=d["nodes_bb"], groups=d["groups"], root_bb=d["root_bb"],
+             soup16=d["soup"][:, :16], soup_normals=d["soup"][:, 22:31], soup_uvs=d["soup"][:, 16:22])
+    for k, (m, wh) in enumerate(R.group_materials(oid)):
+        g[f"mat{k}"], g[f"mat{k}_wh"] = m, wh
+        for slot in range(4):
+            t = R.group_texture(oid, k, slot)
+            if t is not None:
+                g[f"tex{k}_{slot}"] = t
+    rgb, dxdy = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+    g["sample_rgb"], g["sample_dxdy"] = rgb, dxdy
+    np.savez_compressed(os.path.join(OUT, "objscene.npz"), **g)
+    print("objscene mean radiance / white =", float(rgb.mean() / 196964.7))
+
     # (viii) full C0 image 256x256x64spp, stored normalised
     R = Ref()
     mesh, cfg, oid = setup(R, "c0full")
