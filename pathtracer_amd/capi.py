@@ -156,6 +156,12 @@ class HostRaytracer:
         self.set_light(cfg.light_center, cfg.light_radius, cfg.light_scale)
         self.set_envmap_intensity(cfg.envmap_intensity)
 
+    def set_brdf_merl_file(self, obj, path):
+        """objects[obj]->brdf = new IsoMERLBRDF(path): the MERL .binary file is read by the host mirror."""
+        self.host.mh_set_brdf_merl_file.restype = C.c_int
+        if self.host.mh_set_brdf_merl_file(self.h, obj, str(path).encode()) != 0:
+            raise MiptError(self.host.mh_last_error(self.h).decode())
+
     def add_mesh_obj(self, path, scale=30.0, center=True):
         """TriMesh(&scene, path, ...) of the reference: OBJ + MTL (+ PPM textures) read by the host mirror."""
         self.host.mh_add_mesh_obj.restype = C.c_int

@@ -803,6 +803,23 @@ void mh_set_group_texture(mh_raytracer* h, int obj, int grp, int slot, int W, in
 }
 void mh_set_envmap(mh_raytracer* h, int W, int H, const unsigned char* rgb) { static_cast<Sphere*>(h->rt.s.objects[1])->load_envmap_rgb8(rgb, W, H); }
 void mh_set_brdf_merl(mh_raytracer* h, int obj, const double* table) { h->rt.s.objects[obj]->merl_data.assign(table, table + (size_t)3 * 90 * 90 * 180); }
+// objects[obj]->brdf = new IsoMERLBRDF(file): the MERL ".binary" layout read like read_brdf (MERLBRDFRead.cpp:212-236):
+// three int32 dimensions whose product must be 90*90*180 (= BRDF_SAMPLING_RES_THETA_H * _THETA_D * _PHI_D / 2), then
+// 3 planes of that many doubles.  Returns 0, or -1 with mh_last_error set (the reference prints and carries on with no BRDF).
+int mh_set_brdf_merl_file(mh_raytracer* h, int obj, const char* file) {
+	FILE* f = fopen(file, "rb");
+	if (!f) { h->rt.set_error(std::string("cannot open ") + file); return -1; }
+	int dims[3] = {0, 0, 0};
+	const size_t n = (size_t)90 * 90 * 180;
+	bool ok = fread(dims, sizeof(int), 3, f) == 3 && (long long)dims[0] * dims[1] * dims[2] == (long long)n;
+	std::vector<double> data;
+	if (ok) { data.resize(3 * n); ok = fread(data.data(), sizeof(double), 3 * n, f) == 3 * n; }
+	fclose(f);
+	if (!ok) { h->rt.set_error(std::string("not a MERL .binary file (dimensions / length): ") + file); return -1; }
+	h->rt.s.objects[obj]->merl_data.swap(data);
+	return 0;
+}
+const double* mh_merl_data(mh_raytracer* h, int obj) { const auto& d = h->rt.s.objects[obj]->merl_data; return d.empty() ? nullptr : d.data(); }
 int mh_prepare(mh_raytracer* h, int upload) {
 	Raytracer& r = h->rt;
 	r.prepare_render((float)r.s.current_frame);

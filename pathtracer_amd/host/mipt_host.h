@@ -212,6 +212,8 @@ void mh_add_group_material(mh_raytracer*, int obj, const float* Kd, const float*
 void mh_set_group_texture(mh_raytracer*, int obj, int grp, int slot, int W, int H, const unsigned char* rgb);
 void mh_set_envmap(mh_raytracer*, int W, int H, const unsigned char* rgb);
 void mh_set_brdf_merl(mh_raytracer*, int obj, const double* table);   // objects[obj]->brdf = new IsoMERLBRDF(...) (mainApp.cpp:2436)
+int  mh_set_brdf_merl_file(mh_raytracer*, int obj, const char* merl_binary_file);   // IsoMERLBRDF(file): read_brdf (MERLBRDFRead.cpp:212-236)
+const double* mh_merl_data(mh_raytracer*, int obj);      // IsoMERLBRDF::data of the object, or null
 int  mh_prepare(mh_raytracer*, int upload);               // prepare_render; upload=0 skips the device (CPU tests)
 int  mh_render_image(mh_raytracer*);
 int  mh_render_image_nopreviz(mh_raytracer*);

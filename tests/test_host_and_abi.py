@@ -123,3 +123,35 @@ def test_parallel_bvh_build_gives_the_serial_tree():
     for who, fork, d in dumps[1:]:
         for key in ("perm", "nodes_i", "nodes_bb", "soup", "root_bb"):
             assert_bits(d[key], ref[key], f"{who} fork={fork} mesh.{key}")
+
+
+def test_merl_binary_file_reader(tmp_path):
+    """IsoMERLBRDF(file): three int32 dimensions + 3 x 90*90*180 doubles (MERLBRDFRead.cpp:212-236); a file with other
+    dimensions or a short payload is refused."""
+    import ctypes
+    mipt, host = capi.load()
+    table = scenes.synthetic_merl_table()
+    good = tmp_path / "m.binary"
+    with open(good, "wb") as f:
+        f.write(np.array([90, 90, 180], np.int32).tobytes()); f.write(np.ascontiguousarray(table, np.float64).tobytes())
+    H = capi.HostRaytracer()
+    H.apply_config(scenes.config_c1(8, 8, 1))
+    oid = H.add_mesh(scenes.blob_mesh(6))
+    H.set_brdf_merl_file(oid, good)
+    H.prepare()
+    # the table reaches the C-ABI description bit for bit
+    H2 = capi.HostRaytracer()
+    H2.apply_config(scenes.config_c1(8, 8, 1))
+    oid2 = H2.add_mesh(scenes.blob_mesh(6))
+    H2.set_brdf_merl(oid2, table)
+    host.mh_merl_data.restype = ctypes.POINTER(ctypes.c_double)
+    a = np.ctypeslib.as_array(host.mh_merl_data(H.h, oid), shape=(3 * 90 * 90 * 180,))
+    b = np.ctypeslib.as_array(host.mh_merl_data(H2.h, oid2), shape=(3 * 90 * 90 * 180,))
+    assert_bits(a, b, "MERL table read from the file")
+    bad = tmp_path / "bad.binary"
+    with open(bad, "wb") as f:
+        f.write(np.array([90, 90, 90], np.int32).tobytes()); f.write(np.zeros(10, np.float64).tobytes())
+    with pytest.raises(capi.MiptError):
+        H.set_brdf_merl_file(oid, bad)
+    with pytest.raises(capi.MiptError):
+        H.set_brdf_merl_file(oid, tmp_path / "missing.binary")
