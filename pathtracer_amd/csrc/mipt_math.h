@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mipt_sincos.h"
+#include "mipt_powf.h"
 
 #define MIPT_DEV __device__ __forceinline__
 
@@ -69,9 +70,14 @@ MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.
 MIPT_DEV float pt_sinf(float y) { return mipt_sincosf<false>(y); }
 MIPT_DEV float pt_cosf(float y) { return mipt_sincosf<true>(y); }
 
-// powf: exact for the cases the default materials produce (Ne = 0 -> 1, pow(1,y) = 1);
-// otherwise the device library's powf (<= 1 ulp from glibc's).
-__device__ __attribute__((noinline)) float powf_general(float x, float y) { return powf(x, y); }
+// powf: the host libm's algorithm, bit for bit (mipt_powf.h), for positive finite x and finite non-zero y; the exact
+// special values (pow(x,0) = 1, pow(1,y) = 1, zero / inf / NaN / negative bases) come from the device library.
+__device__ __attribute__((noinline)) float powf_special(float x, float y) { return powf(x, y); }
+__device__ __attribute__((noinline)) float powf_general(float x, float y) {
+	float r;
+	if (mipt_powf_main(x, y, r)) return r;
+	return powf_special(x, y);
+}
 MIPT_DEV float pt_powf(float x, float y) {
 	if (y == 0.f) return 1.f;
 	if (x == 1.f) return 1.f;

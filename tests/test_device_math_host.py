@@ -15,3 +15,15 @@ def test_sincos_bit_exact_with_libm(tmp_path):
     n, bad_sin, bad_cos = int(out[0]), int(out[1]), int(out[2])
     assert n > 1_000_000_000
     assert bad_sin == 0 and bad_cos == 0, (bad_sin, bad_cos)
+
+
+def test_powf_bit_exact_with_libm(tmp_path):
+    """csrc/mipt_powf.h against the host libm's powf: every float x in (0, 2] for the constant exponents 5.f
+    (Schlick) and 2.2f, plus 20 M random (x, y) pairs over a wide domain and over the Phong lobe's domain."""
+    exe = str(tmp_path / "powf_check")
+    subprocess.run(["g++", "-O2", "-fopenmp", "-ffp-contract=off", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "powf_check.cpp"), "-lm"], check=True)
+    out = subprocess.run([exe, "20000000", "1"], check=True, capture_output=True, text=True).stdout.split()
+    n, bad, unhandled = int(out[0]), int(out[1]), int(out[2])
+    assert n > 2_000_000_000
+    assert bad == 0 and unhandled == 0, (bad, unhandled)
