@@ -14,3 +14,5 @@ for n in ("default","c1"):
         print(n, 'Mrays/s %.0f frac %.3f'%(d['value'], d['roofline']['frac']), d.get('stage_ms_per_step'), 'ms/step %.2f'%d['ms_per_step'], d.get('cpu_baseline',{}).get('value'))
     except Exception as e: print(n, "failed", e)
 PY
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+bash tools/gpu_more.sh
