@@ -252,7 +252,12 @@ def main():
                 kernel = "k_wf_traverse<0> (closest-hit / extend stage)"
                 bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            try:
+                stream = rt.measure_stream_read(8 << 30, 5)      # achievable read bandwidth of this device
+            except Exception:
+                stream = None
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "peak_measured_stream_read": stream, "frac_of_measured": (achieved / stream) if stream else None,
                                "traffic": None, "kernel": kernel,
                                "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
                                "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],

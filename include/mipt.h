@@ -226,6 +226,10 @@ int mipt_sample_radiance(mipt_ctx* ctx, const mipt_render_params* p, const int32
  * W-pixel-wide image, or -1 for bad parameters.  Pure host function (no device needed). */
 int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j);
 
+/* Measurement aid (bench.py): achievable HBM read bandwidth of the context's device, a grid-stride sum over `bytes` of
+ * device memory with 16-byte loads, `repeats` launches timed with HIP events.  Not part of the reference's surface. */
+int mipt_measure_stream_read(mipt_ctx* ctx, uint64_t bytes, int repeats, double* gb_per_s);
+
 /* Statistics of the last render call (rays counted like the oracle does, kernel time from HIP
  * events on the render stream). */
 int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);

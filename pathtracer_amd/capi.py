@@ -25,7 +25,7 @@ MIPT_ERR_NO_DEVICE = 2
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
 
 _f = C.c_float
 _i = C.c_int
@@ -338,6 +338,12 @@ class HostRaytracer:
     def render_device(self, d_accum_ptr, stream=0):
         self._need_device()
         self._check(self.mipt.mipt_render_device(self.ctx, self.render_params, C.c_void_p(d_accum_ptr), C.c_void_p(stream)), "mipt_render_device")
+
+    def measure_stream_read(self, nbytes=8 << 30, repeats=5):
+        """Achievable HBM read bandwidth of the device in GB/s (mipt_measure_stream_read)."""
+        out = C.c_double(0.0)
+        self._check(self.mipt.mipt_measure_stream_read(self.ctx, C.c_uint64(nbytes), int(repeats), C.byref(out)), "mipt_measure_stream_read")
+        return out.value
 
     def stats(self):
         st = MiptStats()

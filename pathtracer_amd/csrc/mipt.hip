@@ -849,6 +849,37 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	return rc;
 }
 
+// Achievable HBM read bandwidth of this device, for the roofline's denominator (SURVEY.md §8d asks for the measured
+// figure beside the 8 TB/s data-sheet peak): a grid-stride sum over `bytes` of device memory with 16-byte loads.
+__global__ void __launch_bounds__(256) k_stream_read(const float4* __restrict__ src, size_t n4, float* __restrict__ sink) {
+	float acc = 0.f;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+		float4 v = src[i];
+		acc += v.x + v.y + v.z + v.w;
+	}
+	if (acc == 123.456f) *sink = acc;               // never true for the zero-filled buffer; keeps the loads alive
+}
+extern "C" int mipt_measure_stream_read(mipt_ctx* c, uint64_t bytes, int repeats, double* gb_per_s) {
+	if (!c || !gb_per_s || bytes < (1u << 20) || repeats < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	float4* buf = nullptr; float* sink = nullptr;
+	HIPCHK(c, hipMalloc(&buf, bytes));
+	if (hipMalloc(&sink, 4) != hipSuccess) { hipFree(buf); return fail(c, MIPT_ERR_HIP, "hipMalloc failed"); }
+	hipMemset(buf, 0, bytes);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const unsigned grid = (unsigned)c->n_cus * 8u;
+	hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, 0, buf, (size_t)(bytes / 16), sink);   // warm-up
+	hipEventRecord(e0, 0);
+	for (int r = 0; r < repeats; r++) hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, 0, buf, (size_t)(bytes / 16), sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipFree(sink);
+	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
+	*gb_per_s = (double)bytes * repeats / (ms * 1e-3) / 1e9;
+	return MIPT_OK;
+}
+
 #ifdef MIPT_PROFILE_SIMD
 extern "C" int mipt_debug_simd_profile(unsigned long long* out16, int reset) {
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_simd_prof), 128) != hipSuccess) return MIPT_ERR_HIP;
