@@ -200,8 +200,10 @@ int mipt_upload_scene(mipt_ctx* ctx, const mipt_scene_desc* scene);
  * Camera::generateDirection, getColor, Gaussian splat.  ADDS into the caller's host buffers
  * accum_rgb = Raytracer::imagedouble (W*H*3, row-flipped: pixel (i,j) at ((H-i-1)*W+j)*3) and
  * accum_w = Raytracer::sample_count (W*H); the caller zero-fills them as prepare_render does.
- * `cb` (may be NULL) is called after each pass; `cancel` (may be NULL) is polled between passes
- * like Raytracer::stopped (Raytracer.cpp:1452). */
+ * `cb` (may be NULL) is called after each pass, after the caller's buffers have received the sums so far (the
+ * reference's GUI thread reads them while render_image runs); `cancel` (may be NULL) is polled between passes like
+ * Raytracer::stopped (Raytracer.cpp:1452): the call then returns MIPT_ERR_CANCELLED with the finished passes in
+ * the buffers.  The pass size is min(option "paths_per_pass", remaining samples). */
 int mipt_render(mipt_ctx* ctx, const mipt_render_params* p, float* accum_rgb, float* accum_w,
                 mipt_progress_cb cb, void* cb_user, volatile int* cancel);
 

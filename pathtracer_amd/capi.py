@@ -22,6 +22,7 @@ LIBHOST = os.path.join(_HERE, "libmipt_host.so")
 
 MIPT_OK = 0
 MIPT_ERR_NO_DEVICE = 2
+MIPT_ERR_CANCELLED = 6
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
@@ -334,6 +335,25 @@ class HostRaytracer:
         return img, cnt
 
     render_seeded = render
+
+    def render_progressive(self, on_pass=None, cancel_after=None):
+        """mipt_render with a progress callback (and, optionally, the cancel flag raised after `cancel_after` passes).
+        Returns (status, imagedouble, sample_count, [(samples_done, samples_total, sum of sample_count at the call), ...])."""
+        self._need_device()
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        calls = []
+        cancel = C.c_int(0)
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+
+        def cb(user, done, total):
+            calls.append((done, total, float(cnt.sum(dtype=np.float64))))
+            if on_pass is not None:
+                on_pass(done, total, img, cnt)
+            if cancel_after is not None and len(calls) >= cancel_after:
+                cancel.value = 1
+        rc = self.mipt.mipt_render(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), CB(cb), None, C.byref(cancel))
+        return rc, img, cnt, calls
 
     def render_device(self, d_accum_ptr, stream=0):
         self._need_device()

@@ -837,13 +837,22 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	hipError_t e = hipMemcpy(d_acc, accum_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(d_acc + npx * 3, accum_w, npx * sizeof(float), hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(d_acc); return fail(c, MIPT_ERR_HIP, "upload of accumulators failed: %s", hipGetErrorString(e)); }
-	int rc = render_impl(c, p, d_acc, 0, cb, cb_user, cancel, nullptr);
+	// the caller's buffers receive the running sums before every progress call (the GUI thread of the reference reads
+	// imagedouble / sample_count while render_image is still running, mainApp.h:557-569) and at the end — also when
+	// the render was cancelled: the passes finished so far are complete sums, as after Raytracer::stopped
+	struct Publish { float *d_acc, *rgb, *w; size_t npx; mipt_progress_cb cb; void* user; bool failed; } pub = {d_acc, accum_rgb, accum_w, npx, cb, cb_user, false};
+	auto publish = [](Publish* q) {
+		hipError_t e2 = hipMemcpy(q->rgb, q->d_acc, q->npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e2 == hipSuccess) e2 = hipMemcpy(q->w, q->d_acc + q->npx * 3, q->npx * sizeof(float), hipMemcpyDeviceToHost);
+		if (e2 != hipSuccess) q->failed = true;
+	};
+	static auto trampoline = +[](void* u, int done, int total) { Publish* q = (Publish*)u; hipError_t e2 = hipMemcpy(q->rgb, q->d_acc, q->npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e2 == hipSuccess) e2 = hipMemcpy(q->w, q->d_acc + q->npx * 3, q->npx * sizeof(float), hipMemcpyDeviceToHost); if (e2 != hipSuccess) q->failed = true; q->cb(q->user, done, total); };
+	int rc = render_impl(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel, nullptr);
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
-	if (rc == MIPT_OK) {
-		e = hipMemcpy(accum_rgb, d_acc, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
-		if (e == hipSuccess) e = hipMemcpy(accum_w, d_acc + npx * 3, npx * sizeof(float), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed: %s", hipGetErrorString(e));
+	if (rc == MIPT_OK || rc == MIPT_ERR_CANCELLED) {
+		publish(&pub);
+		if (pub.failed) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed");
 	}
 	hipFree(d_acc);
 	return rc;

@@ -199,3 +199,27 @@ def test_two_meshes_fat_leaves_ties_and_literal_slab():
             G.set_option(k, v)
         assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, f"per-sample radiance {opts}")
         G.set_option("literal_slab", 0); G.set_option("refill", 1)
+
+
+def test_progress_callback_and_cancel():
+    """mipt_render's threading contract: the caller's buffers hold the running sums at every progress
+    call, and raising the cancel flag ends the render between passes with the finished passes in the buffers."""
+    rt, (mesh, cfg, oid) = gpu("blob32")
+    slots = ((cfg.W + 7) // 8) * ((cfg.H + 7) // 8) * 64             # path slots per sample: whole 8x8 pixel blocks
+    rt.set_option("paths_per_pass", 2 * slots)                     # 2 samples per pass -> spp / 2 passes
+    rc, img, cnt, calls = rt.render_progressive()
+    assert rc == capi.MIPT_OK
+    assert [c[0] for c in calls] == list(range(2, cfg.spp + 1, 2)) and all(c[1] == cfg.spp for c in calls)
+    sums = [c[2] for c in calls]
+    assert all(b > a for a, b in zip(sums, sums[1:])) and abs(sums[-1] - float(cnt.sum(dtype=np.float64))) < 1e-3 * sums[-1]
+    g = load_golden("scene_blob32.npz")
+    assert np.allclose(cnt, g["count"], rtol=1e-5, atol=0)         # several passes: same samples, other summation order
+    err = np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max()
+    assert err < TOL                                               # several passes: same samples, other summation order
+    # cancel after the first pass: status CANCELLED, buffers = exactly the first 2 samples
+    rc2, img2, cnt2, calls2 = rt.render_progressive(cancel_after=1)
+    assert rc2 == capi.MIPT_ERR_CANCELLED and len(calls2) == 1 and calls2[0][0] == 2
+    rt.params.sample_begin, rt.params.sample_end = 0, 2
+    img_ref, cnt_ref = rt.render()
+    assert_bits(img2, img_ref, "image after cancel == render of the finished samples")
+    assert_bits(cnt2, cnt_ref, "weights after cancel")
