@@ -1,0 +1,52 @@
+// mipt_render — a GUI-free front end on top of the host mirror, in the spirit of the reference's command line
+// (`pathtracer scene.scn out.png`, mainApp.cpp:38-49): the default loadScene() scene (light, environment sphere, ground
+// plane, camera) plus one OBJ/MTL mesh placed like a file dropped on the GUI (scale 30, bottom on the plane,
+// mainApp.cpp:2402-2410), rendered with Raytracer::render_image_nopreviz() on the GPU and written as a binary PPM.
+//
+//   mipt_render mesh.obj out.ppm [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+
+#include "mipt_host.h"
+
+using namespace mipt_host;
+
+int main(int argc, char** argv) {
+	if (argc < 3) { fprintf(stderr, "usage: %s mesh.obj out.ppm [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
+	int W = 1000, H = 800, spp = 100, bounces = 3, device = 0;
+	const char* merl = nullptr;
+	bool mirror = false;
+	for (int i = 3; i < argc; i++) {
+		if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { fprintf(stderr, "bad size\n"); return 2; } }
+		else if (!strcmp(argv[i], "-n") && i + 1 < argc) spp = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-b") && i + 1 < argc) bounces = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-d") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--merl") && i + 1 < argc) merl = argv[++i];
+		else if (!strcmp(argv[i], "--mirror")) mirror = true;
+		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+	}
+	mh_raytracer* h = mh_create();                                       // new Raytracer + loadScene()
+	int rc = mh_open_device(h, device);
+	if (rc != MIPT_OK) { fprintf(stderr, "cannot open GPU %d (status %d): %s\n", device, rc, mh_last_error(h)); return 1; }   // no CPU fallback
+	mh_set_render(h, W, H, spp, bounces, 0.5f);
+	auto t0 = std::chrono::steady_clock::now();
+	int obj = mh_add_mesh_obj(h, argv[1], 30.f, 1);
+	if (obj < 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+	if (mirror) mh_set_object_flags(h, obj, 1, 0);
+	if (merl && mh_set_brdf_merl_file(h, obj, merl) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+	auto t1 = std::chrono::steady_clock::now();
+	rc = mh_render_image_nopreviz(h);
+	auto t2 = std::chrono::steady_clock::now();
+	if (rc != MIPT_OK) { fprintf(stderr, "render failed (status %d): %s\n", rc, mh_last_error(h)); return 1; }
+	FILE* f = fopen(argv[2], "wb");
+	if (!f) { fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
+	fprintf(f, "P6\n%d %d\n255\n", W, H);
+	fwrite(mh_image(h), 1, (size_t)W * H * 3, f);
+	fclose(f);
+	auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+	fprintf(stderr, "%s: load + BVH %.2f s, render %dx%d x %d spp %.2f s -> %s\n", argv[1], secs(t0, t1), W, H, spp, secs(t1, t2), argv[2]);
+	mh_destroy(h);
+	return 0;
+}

@@ -112,3 +112,30 @@ def test_c2_workload_oracle_subset():
     err = np.abs(got.astype(np.float64) - want).max() / WHITE
     assert err < 1e-4, err                                   # north-star tolerance: per-pixel L-inf < 1e-4 on radiance / 196964.7
     assert bits_equal(got, want).mean() > 0.95
+
+
+@pytest.mark.parametrize("wl,grid", [("c3", 200), ("c4", 160)])
+def test_c3_c4_workloads_oracle_subset(wl, grid):
+    """configs[3] (dielectric, depth 12) and configs[4] (MERL table, thin-lens depth of field, 3840x2160) at reduced
+    tessellation but full frame size: oracle on a random subset of (pixel, sample) pairs, both schedulers, bit for bit
+    (Schlick's powf, sinf / cosf are the host libm's algorithms; the MERL evaluation is fp64 arithmetic and table reads)."""
+    from oracle.binding import Oracle
+    mesh, cfg, mat, _ = scenes.workload(wl, spp=SPP, grid=grid)
+    rng = np.random.default_rng(13)
+    pix = np.stack([rng.integers(0, cfg.H, 1200), rng.integers(0, cfg.W, 1200)], 1).astype(np.int32)
+    O = Oracle()
+    O.apply_config(cfg)
+    scenes.install(O, mesh, mat)
+    O.prepare()
+    want, want_j = O.getcolor_samples(pix, 0, SPP)
+    rt = capi.HostRaytracer(device=0)
+    rt.apply_config(cfg)
+    scenes.install(rt, mesh, mat)
+    rt.prepare()
+    for pipeline in (1, 0):
+        rt.set_option("pipeline", pipeline)
+        got, got_j = rt.sample_radiance(pix, 0, SPP)
+        assert_bits(got_j, want_j, "jitter")
+        err = np.abs(got.astype(np.float64) - want).max() / WHITE
+        assert err < 1e-4, (wl, pipeline, err)              # north-star tolerance
+        assert_bits(got, want, f"{wl}: per-sample radiance, pipeline {pipeline}")
