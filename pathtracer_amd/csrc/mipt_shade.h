@@ -90,13 +90,13 @@ __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ dat
 	f3 t2 = cross(t1, N);
 	f3 wil = mk3(dot(wi, t1), dot(wi, t2), dot(wi, N));
 	f3 wol = mk3(dot(wo, t1), dot(wo, t2), dot(wo, N));
-	float thetai = acosf(wil.z);
+	float thetai = mipt_acosf(wil.z);
 	if ((double)thetai >= MIPT_PI / 2) return mk3(0, 0, 0);
-	float thetao = acosf(wol.z);
+	float thetao = mipt_acosf(wol.z);
 	if ((double)thetao >= MIPT_PI / 2) return mk3(0, 0, 0);
-	float phio = atan2f(wol.y, wol.x);
+	float phio = mipt_atan2f(wol.y, wol.x);
 	if (phio < 0) phio = (float)((double)phio + 2 * MIPT_PI);
-	float phii = atan2f(wil.y, wil.x);
+	float phii = mipt_atan2f(wil.y, wil.x);
 	if (phii < 0) phii = (float)((double)phii + 2 * MIPT_PI);
 	// std_coords_to_half_diff_coords (:76-127)
 	double theta_in = thetai, fi_in = phii, theta_out = thetao, fi_out = phio;

@@ -394,8 +394,8 @@ MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
 	mat.Kd = mk3(0.5f, 0.5f, 0.5f); mat.Ks = mk3(0, 0, 0); mat.Ne = mk3(100, 100, 100); mat.transp = false; mat.refr_index = 0.f;
 	if (s.has_envmap) {
 		N = fast_normalize(N);
-		float theta = 1.f - acosf(N.y) / (float)MIPT_PI;
-		float phi = (float)(((double)atan2f(-N.z, N.x) + MIPT_PI) / (double)(2.f * (float)MIPT_PI));
+		float theta = 1.f - mipt_acosf(N.y) / (float)MIPT_PI;
+		float phi = (float)(((double)mipt_atan2f(-N.z, N.x) + MIPT_PI) / (double)(2.f * (float)MIPT_PI));
 		query_material(s, 0, theta, phi, mat);
 		mat.shadingN = -N;
 		int idx = 3 * ((int)(theta * ((float)s.envH - 1.f)) * s.envW + (int)(phi * ((float)s.envW - 1.f)));

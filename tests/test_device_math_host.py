@@ -27,3 +27,15 @@ def test_powf_bit_exact_with_libm(tmp_path):
     n, bad, unhandled = int(out[0]), int(out[1]), int(out[2])
     assert n > 2_000_000_000
     assert bad == 0 and unhandled == 0, (bad, unhandled)
+
+
+def test_acosf_atanf_atan2f_bit_exact_with_libm(tmp_path):
+    """csrc/mipt_invtrig.h against the host libm: acosf on every float in [-1, 1], atanf over all magnitudes, atan2f on
+    50 M random pairs (the env-map lookup's domain and a wide log-uniform one) and the special points."""
+    exe = str(tmp_path / "invtrig_check")
+    subprocess.run(["g++", "-O2", "-fopenmp", "-ffp-contract=off", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "invtrig_check.cpp"), "-lm"], check=True)
+    out = subprocess.run([exe, "50000000"], check=True, capture_output=True, text=True).stdout.split()
+    n, bad = int(out[0]), [int(v) for v in out[1:4]]
+    assert n > 4_000_000_000
+    assert bad == [0, 0, 0], bad
