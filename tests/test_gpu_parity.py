@@ -223,3 +223,24 @@ def test_progress_callback_and_cancel():
     img_ref, cnt_ref = rt.render()
     assert_bits(img2, img_ref, "image after cancel == render of the finished samples")
     assert_bits(cnt2, cnt_ref, "weights after cancel")
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_scene_without_mesh_and_tiny_images(pipeline):
+    """Edge cases of the queues: no TriMesh at all (every ray is decided by the analytic objects and nothing reaches the
+    traversal kernels), images smaller than one 8x8 pixel block, a single sample, depth 1."""
+    from oracle.binding import Oracle
+    for (W, H, spp, depth) in ((48, 32, 3, 4), (5, 3, 1, 1), (1, 1, 2, 3)):
+        cfg = scenes.config_c1(W, H, spp)
+        cfg.nb_bounces = depth
+        O, G = Oracle(), capi.HostRaytracer(device=0)
+        for X in (O, G):
+            X.apply_config(cfg)
+            X.prepare()
+        G.set_option("pipeline", pipeline)
+        pix = all_pixels(cfg)
+        assert_bits(G.getcolor_samples(pix, 0, spp)[0], O.getcolor_samples(pix, 0, spp)[0], f"no mesh, {W}x{H}x{spp}, depth {depth}")
+        img, cnt = G.render()
+        oimg, ocnt = O.render_seeded()
+        assert_bits(cnt, ocnt, "weights")
+        assert_bits(img, oimg, "image")
