@@ -276,6 +276,28 @@ class Ref(_Base):
         self.cdll.ref_time_render_nopreviz.restype = C.c_double
         self.cdll.ref_time_render_image.restype = C.c_double
 
+    # ---- .scn scene files (the reference's own Raytracer::save_scene / load_scene)
+    def save_scene(self, path):
+        self.lib.ref_save_scene(self.ctx, str(path).encode())
+
+    def load_scene(self, path):
+        self.lib.ref_load_scene(self.ctx, str(path).encode())
+        hdr = self.scene_header()
+        self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])
+
+    def num_objects(self):
+        return self.lib.ref_num_objects(self.ctx)
+
+    def scene_header(self):
+        o = np.zeros(32, np.float32)
+        self.lib.ref_get_scene_header(self.ctx, _p(o, _f))
+        return o
+
+    def object_state(self, obj):
+        o = np.zeros(24, np.float32); fl = np.zeros(8, np.int32)
+        self.lib.ref_get_object_state(self.ctx, obj, _p(o, _f), _p(fl, _i))
+        return o, fl
+
     def add_mesh_obj(self, path, scale=30.0, center=True):
         """The reference's own TriMesh(&scene, path, ...): readOBJ + MTL + stb_image."""
         return self.lib.ref_add_mesh(self.ctx, str(path).encode(), _f(scale), 1 if center else 0)

@@ -60,6 +60,39 @@ void ref_destroy(RefCtx* c) {
 	delete c;
 }
 
+// .scn scene files through the reference's own Raytracer::save_scene / load_scene (Raytracer.cpp:1096-1236)
+void ref_save_scene(RefCtx* c, const char* file) { c->rt->save_scene(file); }
+void ref_load_scene(RefCtx* c, const char* file) {
+	Raytracer* rt = c->rt;
+	rt->load_scene(file, NULL);
+	rt->last_nrays = -1; rt->lastfilter = -1; rt->randomPerPixel.clear();
+	rt->has_denoiser = false;
+}
+int ref_num_objects(RefCtx* c) { return (int)c->rt->s.objects.size(); }
+void ref_get_scene_header(RefCtx* c, float* o) {
+	Raytracer& r = *c->rt;
+	int k = 0;
+	o[k++] = (float)r.W; o[k++] = (float)r.H; o[k++] = (float)r.nrays; o[k++] = (float)r.nb_bounces;
+	for (int q = 0; q < 3; q++) o[k++] = r.cam.position[q];
+	for (int q = 0; q < 3; q++) o[k++] = r.cam.direction[q];
+	for (int q = 0; q < 3; q++) o[k++] = r.cam.up[q];
+	o[k++] = r.cam.fov; o[k++] = r.cam.focus_distance; o[k++] = r.cam.aperture; o[k++] = r.sigma_filter; o[k++] = r.gamma;
+	o[k++] = r.s.intensite_lumiere; o[k++] = r.s.envmap_intensity; o[k++] = r.s.double_frustum_start_t;
+	while (k < 32) o[k++] = 0.f;
+}
+void ref_get_object_state(RefCtx* c, int obj, float* o, int* fl) {
+	Object* ob = c->rt->s.objects[obj];
+	int k = 0;
+	for (int q = 0; q < 3; q++) o[k++] = ob->max_translation[q];
+	for (int q = 0; q < 9; q++) o[k++] = ob->mat_rotation[q];
+	for (int q = 0; q < 3; q++) o[k++] = ob->rotation_center[q];
+	o[k++] = ob->scale;
+	for (int q = 0; q < 8; q++) o[16 + q] = 0.f;
+	fl[0] = ob->type == OT_SPHERE ? 1 : (ob->type == OT_PLANE ? 2 : 0); fl[1] = ob->miroir; fl[2] = ob->ghost; fl[3] = ob->flip_normals; fl[4] = ob->interp_normals; fl[5] = 0; fl[6] = fl[7] = 0;
+	if (ob->type == OT_SPHERE) { Sphere* sp = dynamic_cast<Sphere*>(ob); for (int q = 0; q < 3; q++) o[16 + q] = sp->O[q]; o[19] = sp->R; fl[5] = sp->has_envmap; }
+	if (ob->type == OT_PLANE) { Plane* pl = dynamic_cast<Plane*>(ob); for (int q = 0; q < 3; q++) { o[16 + q] = pl->A[q]; o[19 + q] = pl->vecN[q]; } }
+}
+
 void ref_set_render(RefCtx* c, int W, int H, int nrays, int nb_bounces, float sigma_filter) {
 	Raytracer* rt = c->rt;
 	rt->W = W; rt->H = H; rt->nrays = nrays; rt->nb_bounces = nb_bounces; rt->sigma_filter = sigma_filter;

@@ -163,6 +163,32 @@ class HostRaytracer:
         if self.host.mh_set_brdf_merl_file(self.h, obj, str(path).encode()) != 0:
             raise MiptError(self.host.mh_last_error(self.h).decode())
 
+    # ---- .scn scene files (Raytracer::load_scene / save_scene of the host mirror)
+    def load_scene(self, path):
+        self.host.mh_load_scene.restype = C.c_int
+        if self.host.mh_load_scene(self.h, str(path).encode()) != 0:
+            raise MiptError("load_scene(%s): %s" % (path, self.host.mh_last_error(self.h).decode()))
+        hdr = self.scene_header()
+        self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])
+
+    def save_scene(self, path):
+        self.host.mh_save_scene.restype = C.c_int
+        if self.host.mh_save_scene(self.h, str(path).encode()) != 0:
+            raise MiptError("save_scene(%s) failed" % path)
+
+    def num_objects(self):
+        return self.host.mh_num_objects(self.h)
+
+    def scene_header(self):
+        o = np.zeros(32, np.float32)
+        self.host.mh_get_scene_header(self.h, o.ctypes.data_as(C.POINTER(_f)))
+        return o
+
+    def object_state(self, obj):
+        o = np.zeros(24, np.float32); fl = np.zeros(8, np.int32)
+        self.host.mh_get_object_state(self.h, obj, o.ctypes.data_as(C.POINTER(_f)), fl.ctypes.data_as(C.POINTER(C.c_int)))
+        return o, fl
+
     def add_mesh_obj(self, path, scale=30.0, center=True):
         """TriMesh(&scene, path, ...) of the reference: OBJ + MTL (+ PPM textures) read by the host mirror."""
         self.host.mh_add_mesh_obj.restype = C.c_int

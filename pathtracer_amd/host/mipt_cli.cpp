@@ -4,6 +4,7 @@
 // mainApp.cpp:2402-2410), rendered with Raytracer::render_image_nopreviz() on the GPU and written as a binary PPM.
 //
 //   mipt_render mesh.obj out.ppm [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]
+//   mipt_render scene.scn out.ppm [-s WxH] [-n spp] [-b bounces] [-d device]     (the reference's scene files; options override the file)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,12 +31,24 @@ int main(int argc, char** argv) {
 	mh_raytracer* h = mh_create();                                       // new Raytracer + loadScene()
 	int rc = mh_open_device(h, device);
 	if (rc != MIPT_OK) { fprintf(stderr, "cannot open GPU %d (status %d): %s\n", device, rc, mh_last_error(h)); return 1; }   // no CPU fallback
-	mh_set_render(h, W, H, spp, bounces, 0.5f);
 	auto t0 = std::chrono::steady_clock::now();
-	int obj = mh_add_mesh_obj(h, argv[1], 30.f, 1);
-	if (obj < 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
-	if (mirror) mh_set_object_flags(h, obj, 1, 0);
-	if (merl && mh_set_brdf_merl_file(h, obj, merl) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+	const size_t len = strlen(argv[1]);
+	if (len > 4 && !strcmp(argv[1] + len - 4, ".scn")) {                   // Raytracer::load_scene; explicit options override the file
+		if (mh_load_scene(h, argv[1]) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+		float hdr[32]; mh_get_scene_header(h, hdr);
+		bool sized = false, sampled = false, bounced = false;
+		for (int i = 3; i < argc; i++) { sized |= !strcmp(argv[i], "-s"); sampled |= !strcmp(argv[i], "-n"); bounced |= !strcmp(argv[i], "-b"); }
+		if (!sized) { W = (int)hdr[0]; H = (int)hdr[1]; }
+		if (!sampled) spp = (int)hdr[2];
+		if (!bounced) bounces = (int)hdr[3];
+		mh_set_render(h, W, H, spp, bounces, hdr[16]);
+	} else {
+		mh_set_render(h, W, H, spp, bounces, 0.5f);
+		int obj = mh_add_mesh_obj(h, argv[1], 30.f, 1);
+		if (obj < 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+		if (mirror) mh_set_object_flags(h, obj, 1, 0);
+		if (merl && mh_set_brdf_merl_file(h, obj, merl) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+	}
 	auto t1 = std::chrono::steady_clock::now();
 	rc = mh_render_image_nopreviz(h);
 	auto t2 = std::chrono::steady_clock::now();

@@ -256,7 +256,7 @@ bool read_ppm(const std::string& file, std::vector<unsigned char>& rgb, int& W, 
 }
 }  // namespace
 
-bool TriMesh::readOBJ(const char* obj) {
+bool TriMesh::readOBJ(const char* obj, bool load_textures) {
 	FILE* f = fopen(obj, "r");
 	if (!f) { load_error = std::string("cannot open ") + obj; return false; }
 	std::string matfile;
@@ -319,6 +319,7 @@ bool TriMesh::readOBJ(const char* obj) {
 		for (auto& t : indices) t.group = 0;
 		groupNames["Default"] = 0;
 	}
+	if (!load_textures) return true;                  // init(load_textures = false): the caller supplies the material lists (.scn files)
 	add_default_group_materials((int)groupNames.size());
 	if (matfile.empty()) return true;
 	FILE* m = fopen((dir_of(obj) + matfile).c_str(), "r");
@@ -328,6 +329,7 @@ bool TriMesh::readOBJ(const char* obj) {
 		std::vector<unsigned char> rgb; int W = 0, H = 0;
 		if (!read_ppm(dir_of(obj) + file, rgb, W, H)) { load_error = "texture " + file + ": only binary PPM (P6, 8 bit) is decoded here"; return; }
 		if (normals_map) tex.loadNormalsRGB8(rgb.data(), W, H); else tex.loadColorsRGB8(rgb.data(), W, H);
+		tex.filename = dir_of(obj) + file;              // Texture::filename, what save_scene writes
 	};
 	while (fgets(line, 255, m)) {
 		if (line[0] == 'n' && line[1] == 'e' && line[2] == 'w') {
@@ -351,9 +353,9 @@ bool TriMesh::readOBJ(const char* obj) {
 	return true;
 }
 
-TriMesh::TriMesh(const char* obj, bool center) {
-	type = OT_TRIMESH; interp_normals = true; name = obj;
-	loaded = readOBJ(obj);
+TriMesh::TriMesh(const char* obj, bool center, bool load_textures) {
+	type = OT_TRIMESH; interp_normals = true; name = obj; is_centered = center;
+	loaded = readOBJ(obj, load_textures);
 	if (loaded && !indices.empty()) finish_init(center);
 	else loaded = false;
 }
@@ -564,6 +566,271 @@ void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
 	cam.up = Vector(u[0], c * u[1] - sn * u[2], sn * u[1] + c * u[2]);
 }
 
+// ---------------------------------------------------------------- .scn scene files
+// The reference's own text format (Raytracer::save_scene / load_scene, Raytracer.cpp:1096-1236; Object::save_to_file /
+// load_from_file, Geometry.h:455-662; Sphere / Plane / TriMesh tails, Geometry.h:875-908, 1193-1213, TriangleMesh.h:
+// 132-162).  Values are written with "%f" (six decimals) and read back from those decimals, exactly like the reference,
+// so a scene loaded here and there is the same scene.  The optional / backward-compatible records of load_scene are
+// accepted.  What the hot path does not cover is refused loudly rather than dropped: lenticular / array cameras, a
+// background image, fog, key-framed transforms, PointSet objects, per-face colour files.
+namespace {
+struct ScnReader {
+	FILE* f;
+	std::string err;
+	char line[1024];
+	bool next() {                                       // next non-empty line, without its newline
+		while (fgets(line, sizeof line, f)) {
+			size_t n = strlen(line);
+			while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
+			const char* p = line;
+			while (*p == ' ' || *p == '\t') p++;
+			if (*p) { if (p != line) memmove(line, p, strlen(p) + 1); return true; }
+		}
+		return false;
+	}
+	bool starts(const char* key) const { return strncmp(line, key, strlen(key)) == 0; }
+	const char* after(const char* key) const { const char* p = line + strlen(key); while (*p == ' ') p++; return p; }
+	bool fail(const std::string& what) { if (err.empty()) err = what + " (at: \"" + line + "\")"; return false; }
+	bool expect(const char* key) { if (!next() || !starts(key)) return fail(std::string("expected \"") + key + "\""); return true; }
+	bool getu(const char* key, int& v) { if (!expect(key)) return false; v = (int)strtoul(after(key), nullptr, 10); return true; }
+	bool getf(const char* key, float& v) { if (!expect(key)) return false; v = strtof(after(key), nullptr); return true; }
+	bool floats(const char* p, float* out, int n) {      // n numbers separated by anything that is not part of a number
+		for (int k = 0; k < n; k++) {
+			while (*p && !(*p == '-' || *p == '+' || *p == '.' || (*p >= '0' && *p <= '9') || *p == 'n' || *p == 'i')) p++;
+			char* e; out[k] = strtof(p, &e);
+			if (e == p) return false;
+			p = e;
+		}
+		return true;
+	}
+};
+
+void scn_texture_list(ScnReader& R, const char* count_key, bool count_already_read, std::vector<Texture>& list, int kind, const std::string& dir, bool& ok) {
+	// kind: 0 colour image (gamma decoded), 2 normal map, 3 alpha (a bare number is a constant), 5 / 6 scalar multiplier "multiplier: %f)"
+	int n = 0;
+	if (!ok) return;
+	if (count_already_read) n = (int)strtoul(R.after(count_key), nullptr, 10);
+	else if (!R.getu(count_key, n)) { ok = false; return; }
+	for (int i = 0; i < n && ok; i++) {
+		if (!R.expect("texture:")) { ok = false; return; }
+		std::string name = R.after("texture:");
+		Texture t;
+		t.filename = name;
+		t.multiplier = (kind == 1) ? Vector(0, 0, 0) : (kind == 2 ? Vector(0, 0, 1) : Vector(1, 1, 1));
+		float col[3];
+		char* e = nullptr;
+		if ((kind == 0 || kind == 1 || kind == 4) && name.compare(0, 6, "Color:") == 0 && R.floats(name.c_str() + 6, col, 3)) {
+			t.multiplier = kind == 4 ? Vector(col[0], col[1], col[2]) : Vector(col[0] / 255.f, col[1] / 255.f, col[2] / 255.f);   // legacy "Color: (r, g, b)"
+		} else if (kind == 3 && (strtof(name.c_str(), &e), e != name.c_str())) {
+			float c = strtof(name.c_str(), nullptr); t.multiplier = Vector(c, c, c);
+		} else if (name != "Null" && !name.empty()) {
+			std::vector<unsigned char> rgb; int W = 0, H = 0;
+			std::string file = (name[0] == '/' ? name : dir + name);
+			FILE* probe = fopen(file.c_str(), "rb");
+			if (probe) {                                   // a missing file leaves the constant, as load_image returning false does
+				fclose(probe);
+				if (!read_ppm(file, rgb, W, H)) { R.fail("texture " + name + ": only binary PPM (P6, 8 bit) is decoded here"); ok = false; return; }
+				if (kind == 2) t.loadNormalsRGB8(rgb.data(), W, H); else t.loadColorsRGB8(rgb.data(), W, H);
+			}
+		}
+		if (!R.expect("multiplier:")) { ok = false; return; }
+		float m[3];
+		if (kind >= 5) { if (!R.floats(R.after("multiplier:"), m, 1)) { R.fail("bad multiplier"); ok = false; return; } t.multiplier[0] = m[0]; }
+		else { if (!R.floats(R.after("multiplier:"), m, 3)) { R.fail("bad multiplier"); ok = false; return; } t.multiplier = Vector(m[0], m[1], m[2]); }
+		list.push_back(t);
+	}
+}
+
+bool scn_object_common(ScnReader& R, Object* o, const std::string& dir) {      // Object::load_from_file
+	if (!R.expect("name:")) return false;
+	o->name = R.after("name:");
+	int b = 0;
+	if (!R.getu("miroir:", b)) return false;
+	o->miroir = b != 0;
+	if (!R.next()) return R.fail("truncated object");
+	if (R.starts("ghost:")) { o->ghost = strtoul(R.after("ghost:"), nullptr, 10) != 0; if (!R.expect("translation:")) return false; }
+	else if (!R.starts("translation:")) return R.fail("expected translation");
+	float v[9];
+	if (!R.floats(R.after("translation:"), v, 3)) return R.fail("bad translation");
+	o->max_translation = Vector(v[0], v[1], v[2]);
+	if (!R.expect("rotation:") || !R.floats(R.after("rotation:"), v, 9)) return R.fail("bad rotation");
+	for (int k = 0; k < 9; k++) o->mat_rotation[k] = v[k];
+	if (!R.expect("center:") || !R.floats(R.after("center:"), v, 3)) return R.fail("bad center");
+	o->rotation_center = Vector(v[0], v[1], v[2]);
+	if (!R.getf("scale:", o->scale)) return false;
+	if (!R.getu("display_edges:", b)) return false;
+	if (!R.getu("interp_normals:", b)) return false;
+	o->interp_normals = b != 0;
+	if (!R.getu("flip_normals:", b)) return false;
+	o->flip_normals = b != 0;
+	if (!R.next()) return R.fail("truncated object");
+	bool have_count = true;
+	if (R.starts("nb_transforms:")) {
+		if (strtoul(R.after("nb_transforms:"), nullptr, 10) != 0) return R.fail("key-framed transforms are outside the hot path");
+		have_count = false;
+	} else if (!R.starts("nb_textures:")) return R.fail("expected nb_textures");
+	bool ok = true;
+	scn_texture_list(R, "nb_textures:", have_count, o->textures, 0, dir, ok);
+	scn_texture_list(R, "nb_normalmaps:", false, o->normal_map, 2, dir, ok);
+	if (!ok) return false;
+	if (!R.next()) return R.fail("truncated object");
+	if (R.starts("nb_subsurfaces:")) { scn_texture_list(R, "nb_subsurfaces:", true, o->subsurface, 0, dir, ok); scn_texture_list(R, "nb_specularmaps:", false, o->specularmap, 1, dir, ok); }
+	else if (R.starts("nb_specularmaps:")) scn_texture_list(R, "nb_specularmaps:", true, o->specularmap, 1, dir, ok);
+	else return R.fail("expected nb_specularmaps");
+	scn_texture_list(R, "nb_alphamaps:", false, o->alphamap, 3, dir, ok);
+	scn_texture_list(R, "nb_expmaps:", false, o->roughnessmap, 4, dir, ok);
+	scn_texture_list(R, "nb_transpmaps:", false, o->transparent_map, 5, dir, ok);
+	scn_texture_list(R, "nb_refrindexmaps:", false, o->refr_index_map, 6, dir, ok);
+	return ok;
+}
+}  // namespace
+
+bool Raytracer::load_scene(const char* filename) {
+	ScnReader R; R.f = fopen(filename, "r");
+	if (!R.f) { err_ = std::string("cannot open ") + filename; return false; }
+	const std::string dir = dir_of(filename);
+	auto bail = [&](const std::string& why) { if (R.f) fclose(R.f); err_ = std::string(filename) + ": " + (why.empty() ? R.err : why); return false; };
+	for (Object* o : s.objects) delete o;
+	s.objects.clear(); s.lumiere = nullptr;
+	float v[9];
+	if (!R.expect("W,H:") || !R.floats(R.after("W,H:"), v, 2)) return bail("");
+	W = (int)v[0]; H = (int)v[1];
+	if (!R.getu("nrays:", nrays)) return bail("");
+	if (!R.next()) return bail("truncated header");
+	if (R.starts("nbframes:")) { if (!R.expect("Cam:")) return bail(""); }
+	else if (!R.starts("Cam:")) return bail("expected Cam");
+	if (!R.floats(R.after("Cam:"), v, 9)) return bail("bad Cam");
+	cam.position = Vector(v[0], v[1], v[2]); cam.direction = Vector(v[3], v[4], v[5]); cam.up = Vector(v[6], v[7], v[8]);
+	if (!R.getf("fov:", cam.fov) || !R.getf("focus:", cam.focus_distance) || !R.getf("aperture:", cam.aperture) || !R.getf("sigma_filter:", sigma_filter) || !R.getf("gamma:", gamma)) return bail("");
+	if (!R.next()) return bail("truncated header");
+	if (R.starts("is_lenticular:")) {
+		if (strtoul(R.after("is_lenticular:"), nullptr, 10) != 0) return bail("lenticular cameras are outside the hot path");
+		int u = 0; float fl = 0;
+		if (!R.getu("lenticular_nb_images:", u) || !R.getf("lenticular_max_angle:", fl) || !R.getu("lenticular_pixel_width:", u)) return bail("");
+		if (!R.getu("isArray:", u)) return bail("");
+		if (u != 0) return bail("camera arrays are outside the hot path");
+		if (!R.getu("nbviewX:", u) || !R.getu("nbviewY:", u) || !R.getf("maxSpacingX:", fl) || !R.getf("maxSpacingY:", fl)) return bail("");
+		if (!R.getu("bounces:", nb_bounces)) return bail("");
+	} else if (R.starts("bounces:")) nb_bounces = (int)strtoul(R.after("bounces:"), nullptr, 10);
+	else return bail("expected bounces");
+	if (!R.next()) return bail("truncated header");
+	if (R.starts("has_denoiser:")) { if (!R.getf("intensite_lum:", s.intensite_lumiere)) return bail(""); }
+	else if (R.starts("intensite_lum:")) s.intensite_lumiere = strtof(R.after("intensite_lum:"), nullptr);
+	else return bail("expected intensite_lum");
+	if (!R.getf("intensite_envmap:", s.envmap_intensity)) return bail("");
+	if (!R.next()) return bail("truncated header");
+	if (R.starts("background:")) return bail("background images are outside the hot path");
+	if (!R.starts("nbobjects:")) return bail("expected nbobjects");
+	const int nbo = (int)strtoul(R.after("nbobjects:"), nullptr, 10);
+	for (int i = 0; i < nbo; i++) {
+		if (!R.next()) return bail("truncated object list");
+		if (R.starts("NEW SPHERE")) {
+			Sphere* sp = new Sphere(Vector(0, 0, 0), 0);
+			s.addObject(sp);
+			if (!scn_object_common(R, sp, dir)) return bail("");
+			int has_env = 0;
+			if (!R.getu("is_envmap:", has_env) || !R.expect("envmapfilename:")) return bail("");
+			const std::string envfile = R.after("envmapfilename:");
+			if (!R.expect("O:") || !R.floats(R.after("O:"), v, 3)) return bail("bad O");
+			sp->O = Vector(v[0], v[1], v[2]);
+			if (!R.getf("R:", sp->R)) return bail("");
+			sp->rotation_center = sp->O; sp->name = "Sphere";           // Sphere::init (Geometry.h:856-873)
+			if (has_env) {
+				std::vector<unsigned char> rgb; int w = 0, h = 0;
+				if (!read_ppm(envfile[0] == '/' ? envfile : dir + envfile, rgb, w, h)) return bail("environment map " + envfile + ": only binary PPM (P6, 8 bit) is decoded here");
+				sp->load_envmap_rgb8(rgb.data(), w, h);
+				sp->envmapfilename = envfile;
+			}
+		} else if (R.starts("NEW PLANE")) {
+			Plane* pl = new Plane(Vector(0, 0, 0), Vector(0, 1, 0));
+			s.addObject(pl);
+			if (!scn_object_common(R, pl, dir)) return bail("");
+			if (!R.expect("Point:") || !R.floats(R.after("Point:"), v, 3)) return bail("bad Point");
+			pl->A = Vector(v[0], v[1], v[2]);
+			if (!R.expect("N:") || !R.floats(R.after("N:"), v, 3)) return bail("bad N");
+			pl->vecN = Vector(v[0], v[1], v[2]);
+			pl->name = "Plane";
+		} else if (R.starts("NEW MESH")) {
+			Object tmp;                                                   // Object::load_from_file runs before TriMesh::init
+			if (!scn_object_common(R, &tmp, dir)) return bail("");
+			if (!R.next()) return bail("truncated mesh");
+			bool centered = true;
+			int hascsv = 0;
+			if (R.starts("is_centered:")) { centered = strtoul(R.after("is_centered:"), nullptr, 10) == 1; if (!R.getu("has_csv:", hascsv)) return bail(""); }
+			else if (R.starts("has_csv:")) hascsv = (int)strtoul(R.after("has_csv:"), nullptr, 10);
+			else return bail("expected has_csv");
+			if (hascsv) return bail("per-face colour files are outside the hot path");
+			R.next();                                                     // "csv_file: "
+			const std::string file = tmp.name[0] == '/' ? tmp.name : dir + tmp.name;
+			TriMesh* g = new TriMesh(file.c_str(), centered, /*load_textures=*/false);
+			if (!g->loaded) { std::string why = g->load_error; delete g; return bail(why.empty() ? "no faces in " + file : why); }
+			// the transform and material lists of the file replace what init() derived (TriMesh::create_from_file: the
+			// lists were read first, init(load_textures = false) then keeps them; rot_center = the stored centre)
+			g->name = tmp.name; g->miroir = tmp.miroir; g->ghost = tmp.ghost; g->flip_normals = tmp.flip_normals; g->interp_normals = true;
+			g->scale = tmp.scale; g->max_translation = tmp.max_translation; g->rotation_center = tmp.rotation_center;
+			memcpy(g->mat_rotation, tmp.mat_rotation, sizeof tmp.mat_rotation);
+			g->textures = tmp.textures; g->normal_map = tmp.normal_map; g->subsurface = tmp.subsurface; g->specularmap = tmp.specularmap;
+			g->alphamap = tmp.alphamap; g->roughnessmap = tmp.roughnessmap; g->transparent_map = tmp.transparent_map; g->refr_index_map = tmp.refr_index_map;
+			s.addObject(g);
+		} else return bail("object kind outside the hot path");
+	}
+	float fog = 0;
+	if (R.next() && R.starts("fog_density:")) { fog = strtof(R.after("fog_density:"), nullptr); if (fog != 0.f) return bail("fog is outside the hot path"); }
+	while (R.next()) if (R.starts("double_frustum_start_t:")) s.double_frustum_start_t = strtof(R.after("double_frustum_start_t:"), nullptr);
+	fclose(R.f); R.f = nullptr;
+	if (s.objects.empty() || s.objects[0]->type != OT_SPHERE) { err_ = std::string(filename) + ": object 0 must be the light sphere"; return false; }
+	s.lumiere = static_cast<Sphere*>(s.objects[0]);
+	last_nrays = -1; lastfilter = -1; randomPerPixel.clear(); clear_image();
+	err_.clear();
+	return true;
+}
+
+bool Raytracer::save_scene(const char* filename) const {
+	FILE* f = fopen(filename, "w+");
+	if (!f) return false;
+	fprintf(f, "W,H: %u, %u\n", W, H);
+	fprintf(f, "nrays: %u\n", nrays);
+	fprintf(f, "nbframes: %u\n", 1u);
+	fprintf(f, "Cam: (%f, %f, %f), (%f, %f, %f), (%f, %f, %f)\n", cam.position[0], cam.position[1], cam.position[2], cam.direction[0], cam.direction[1], cam.direction[2], cam.up[0], cam.up[1], cam.up[2]);
+	fprintf(f, "fov: %f\nfocus: %f\naperture: %f\nsigma_filter: %f\ngamma: %f\n", cam.fov, cam.focus_distance, cam.aperture, sigma_filter, gamma);
+	fprintf(f, "is_lenticular: 0\nlenticular_nb_images: 10\nlenticular_max_angle: %f\nlenticular_pixel_width: 1\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n", (float)(35 * M_PI / 180. * 0.25), 0.f, 0.f);   // Camera defaults (Vector.h:720-730)
+	fprintf(f, "bounces: %u\nhas_denoiser: 0\n", nb_bounces);
+	fprintf(f, "intensite_lum: %f\nintensite_envmap: %f\n", s.intensite_lumiere, s.envmap_intensity);
+	fprintf(f, "nbobjects: %u\n", (unsigned)s.objects.size());
+	auto list3 = [&](const char* key, const std::vector<Texture>& l) {
+		fprintf(f, "%s: %u\n", key, (unsigned)l.size());
+		for (const Texture& t : l) fprintf(f, "texture: %s\nmultiplier: (%f, %f, %f)\n", t.filename.empty() ? "Null" : t.filename.c_str(), t.multiplier[0], t.multiplier[1], t.multiplier[2]);
+	};
+	auto list1 = [&](const char* key, const std::vector<Texture>& l) {
+		fprintf(f, "%s: %u\n", key, (unsigned)l.size());
+		for (const Texture& t : l) fprintf(f, "texture: %s\nmultiplier: %f)\n", t.filename.empty() ? "Null" : t.filename.c_str(), t.multiplier[0]);
+	};
+	for (const Object* o : s.objects) {
+		fprintf(f, o->type == OT_SPHERE ? "NEW SPHERE\n" : o->type == OT_PLANE ? "NEW PLANE\n" : "NEW MESH\n");
+		fprintf(f, "name: %s\nmiroir: %u\nghost: %u\n", o->name.c_str(), o->miroir ? 1 : 0, o->ghost ? 1 : 0);
+		fprintf(f, "translation: (%f, %f, %f)\n", o->max_translation[0], o->max_translation[1], o->max_translation[2]);
+		const float* m = o->mat_rotation;
+		fprintf(f, "rotation: (%f, %f, %f, %f, %f, %f, %f, %f, %f)\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]);
+		fprintf(f, "center: (%f, %f, %f)\n", o->rotation_center[0], o->rotation_center[1], o->rotation_center[2]);
+		fprintf(f, "scale: %f\ndisplay_edges: 0\ninterp_normals: %u\nflip_normals: %u\nnb_transforms: 0\n", o->scale, o->interp_normals ? 1 : 0, o->flip_normals ? 1 : 0);
+		list3("nb_textures", o->textures); list3("nb_normalmaps", o->normal_map); list3("nb_subsurfaces", o->subsurface); list3("nb_specularmaps", o->specularmap);
+		list3("nb_alphamaps", o->alphamap); list3("nb_expmaps", o->roughnessmap); list1("nb_transpmaps", o->transparent_map); list1("nb_refrindexmaps", o->refr_index_map);
+		if (o->type == OT_SPHERE) {
+			const Sphere* sp = static_cast<const Sphere*>(o);
+			fprintf(f, "is_envmap: %u\nenvmapfilename: %s\nO: (%f, %f, %f)\nR: %f\n", sp->has_envmap ? 1 : 0, sp->envmapfilename.c_str(), sp->O[0], sp->O[1], sp->O[2], sp->R);
+		} else if (o->type == OT_PLANE) {
+			const Plane* pl = static_cast<const Plane*>(o);
+			fprintf(f, "Point: (%f, %f, %f)\nN: (%f, %f, %f)\n", pl->A[0], pl->A[1], pl->A[2], pl->vecN[0], pl->vecN[1], pl->vecN[2]);
+		} else {
+			fprintf(f, "is_centered: %u\nhas_csv: 0\ncsv_file: \n", static_cast<const TriMesh*>(o)->is_centered ? 1 : 0);
+		}
+	}
+	fprintf(f, "fog_density: %f\nfog_absorption: %f\nfog_density_decay: %f\nfog_absorption_decay: %f\nfog_type: 0\nfog_phase_type: 0\n", 0.f, 0.f, 0.f, 0.f);
+	fprintf(f, "double_frustum_start_t: %f\n", s.double_frustum_start_t);
+	fclose(f);
+	return true;
+}
+
 void Raytracer::clear_image() {
 	image.assign((size_t)W * H * 3, 0);
 	imagedouble.assign((size_t)W * H * 3, 0.f);
@@ -747,6 +1014,32 @@ void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
 }
 void mh_set_envmap_intensity(mh_raytracer* h, float v) { h->rt.s.envmap_intensity = v; }
+int mh_load_scene(mh_raytracer* h, const char* scn) { return h->rt.load_scene(scn) ? 0 : -1; }
+int mh_save_scene(mh_raytracer* h, const char* scn) { return h->rt.save_scene(scn) ? 0 : -1; }
+int mh_num_objects(mh_raytracer* h) { return (int)h->rt.s.objects.size(); }
+void mh_get_scene_header(mh_raytracer* h, float* o) {
+	const Raytracer& r = h->rt;
+	int k = 0;
+	o[k++] = (float)r.W; o[k++] = (float)r.H; o[k++] = (float)r.nrays; o[k++] = (float)r.nb_bounces;
+	for (int c = 0; c < 3; c++) o[k++] = r.cam.position[c];
+	for (int c = 0; c < 3; c++) o[k++] = r.cam.direction[c];
+	for (int c = 0; c < 3; c++) o[k++] = r.cam.up[c];
+	o[k++] = r.cam.fov; o[k++] = r.cam.focus_distance; o[k++] = r.cam.aperture; o[k++] = r.sigma_filter; o[k++] = r.gamma;
+	o[k++] = r.s.intensite_lumiere; o[k++] = r.s.envmap_intensity; o[k++] = r.s.double_frustum_start_t;
+	while (k < 32) o[k++] = 0.f;
+}
+void mh_get_object_state(mh_raytracer* h, int obj, float* o, int* fl) {
+	const Object* ob = h->rt.s.objects[obj];
+	int k = 0;
+	for (int c = 0; c < 3; c++) o[k++] = ob->max_translation[c];
+	for (int c = 0; c < 9; c++) o[k++] = ob->mat_rotation[c];
+	for (int c = 0; c < 3; c++) o[k++] = ob->rotation_center[c];
+	o[k++] = ob->scale;
+	for (int c = 0; c < 8; c++) o[16 + c] = 0.f;
+	fl[0] = (int)ob->type; fl[1] = ob->miroir; fl[2] = ob->ghost; fl[3] = ob->flip_normals; fl[4] = ob->interp_normals; fl[5] = 0; fl[6] = fl[7] = 0;
+	if (ob->type == OT_SPHERE) { const Sphere* sp = static_cast<const Sphere*>(ob); for (int c = 0; c < 3; c++) o[16 + c] = sp->O[c]; o[19] = sp->R; fl[5] = sp->has_envmap; }
+	if (ob->type == OT_PLANE) { const Plane* pl = static_cast<const Plane*>(ob); for (int c = 0; c < 3; c++) { o[16 + c] = pl->A[c]; o[19 + c] = pl->vecN[c]; } }
+}
 int mh_add_mesh_obj(mh_raytracer* h, const char* obj_file, float scale, int center) {
 	Raytracer& r = h->rt;
 	TriMesh* g = new TriMesh(obj_file, center != 0);

@@ -29,6 +29,7 @@ struct Texture {                      // BRDF.h:252-426
 	Vector multiplier{1, 1, 1};
 	size_t W = 0, H = 0;
 	std::vector<float> values;
+	std::string filename;             // image the values came from ("" / "Null": constant), as written to .scn files
 	// Texture::loadColors on an 8-bit RGB image given top row first (what stb_image returns):
 	// load_image's row flip (utils.cpp:112-118), /255.f and powf(.,2.2f) (BRDF.h:393-404).
 	void loadColorsRGB8(const unsigned char* rgb, int w, int h);
@@ -75,6 +76,7 @@ public:
 	void load_envmap_rgb8(const unsigned char* rgb, int w, int h);   // Sphere::load_envmap (:912-916), rows as in the file
 	Vector O; float R = 0; bool has_envmap = false;
 	std::vector<unsigned char> envtex; int envW = 0, envH = 0;
+	std::string envmapfilename;
 };
 
 class Plane : public Object {         // Geometry.h:1127-1217
@@ -91,7 +93,8 @@ public:
 	        int nf, const int* fv, const int* fn, const int* ft, bool center);
 	// TriMesh(scene, obj, 1, (0,0,0), false, NULL, false, center) (TriangleMesh.cpp:714-716): readOBJ + MTL + init.
 	// `loaded` is false (and load_error says why) when the file cannot be read or holds no face.
-	TriMesh(const char* obj, bool center);
+	TriMesh(const char* obj, bool center, bool load_textures = true);
+	bool is_centered = true;
 	bool loaded = true;
 	std::string load_error;
 	std::map<std::string, int> groupNames;   // usemtl name -> material group (TriangleMesh.h:228)
@@ -103,7 +106,7 @@ public:
 	struct { float bbox[6]; std::vector<BVHNodes> nodes; } bvh;
 	float bbox[6];
 private:
-	bool readOBJ(const char* obj);
+	bool readOBJ(const char* obj, bool load_textures);
 	void add_default_group_materials(int ngroups);
 	void finish_init(bool center);
 	void build_bbox(int i0, int i1, float* out6) const;
@@ -141,6 +144,8 @@ public:
 	Raytracer();
 	~Raytracer();
 	void loadScene();                 // Raytracer.cpp:1238-1274
+	bool load_scene(const char* filename);         // Raytracer.cpp:1148-1236 (.scn text format); false + last_error() on refusal
+	bool save_scene(const char* filename) const;   // Raytracer.cpp:1096-1145
 	void prepare_render(float time);  // Raytracer.cpp:1321-1391 + scene upload
 	void render_image();              // Raytracer.cpp:1424-1563: progressive, one pass per sample
 	void render_image_nopreviz();     // Raytracer.cpp:1565-1718: offline, image divided by sample_count
@@ -199,6 +204,11 @@ void mh_set_render(mh_raytracer*, int W, int H, int nrays, int nb_bounces, float
 void mh_set_camera(mh_raytracer*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);
 void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_lumiere);
 void mh_set_envmap_intensity(mh_raytracer*, float v);
+int  mh_load_scene(mh_raytracer*, const char* scn_file);   // Raytracer::load_scene; 0 or -1 (mh_last_error)
+int  mh_save_scene(mh_raytracer*, const char* scn_file);   // Raytracer::save_scene
+int  mh_num_objects(mh_raytracer*);
+void mh_get_scene_header(mh_raytracer*, float* out32);     // W,H,nrays,bounces, cam pos/dir/up, fov, focus, aperture, sigma, gamma, intensite_lum, intensite_envmap, frustum t
+void mh_get_object_state(mh_raytracer*, int obj, float* out24, int* flags8);   // translation 3, rotation 9, center 3, scale, sphere O 3 + R / plane A 3 + N 3 ; type, miroir, ghost, flip, interp, has_envmap
 int  mh_add_mesh_obj(mh_raytracer*, const char* obj_file, float scale, int center);   // TriMesh(&s, file, ...) + GUI placement; -1 on failure (mh_last_error)
 void mh_get_group_material(mh_raytracer*, int obj, int grp, float* out12, int* wh8);
 int  mh_num_groups(mh_raytracer*, int obj);

@@ -163,6 +163,34 @@ def main():
     np.savez_compressed(os.path.join(OUT, "objscene.npz"), **g)
     print("objscene mean radiance / white =", float(rgb.mean() / 196964.7))
 
+    # .scn scene files: the reference SAVES the OBJ scene with a changed camera / depth, that text is
+    # the fixture (tests/golden/objscene.scn); a second reference instance LOADS it and renders: expected state + radiance
+    d = tempfile.mkdtemp(prefix="ptref_scn_")
+    cwd = os.getcwd()
+    os.chdir(d)                      # the reference resolves the relative file names of a .scn against the working directory
+    try:
+        scenes.write_obj_scene(d)
+        R = Ref()
+        cfg = scenes.config_c1(64, 36, 4)
+        cfg.aperture, cfg.nb_bounces = 0.25, 5
+        R.apply_config(cfg)
+        R.add_mesh_obj("scene.obj")
+        R.save_scene("objscene.scn")
+        text = open("objscene.scn").read()
+        R2 = Ref()
+        R2.load_scene("objscene.scn")
+        R2.prepare()
+        g = dict(header=R2.scene_header())
+        for k in range(R2.num_objects()):
+            g[f"obj{k}_state"], g[f"obj{k}_flags"] = R2.object_state(k)
+        rgb, dxdy = R2.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+        g["sample_rgb"], g["sample_dxdy"] = rgb, dxdy
+    finally:
+        os.chdir(cwd)
+    open(os.path.join(OUT, "objscene.scn"), "w").write(text)
+    np.savez_compressed(os.path.join(OUT, "objscene_scn.npz"), **g)
+    print("objscene.scn mean radiance / white =", float(rgb.mean() / 196964.7))
+
     # (viii) full C0 image 256x256x64spp, stored normalised
     R = Ref()
     mesh, cfg, oid = setup(R, "c0full")
