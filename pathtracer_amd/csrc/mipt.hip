@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mipt.h"
@@ -368,16 +369,27 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	std::vector<int> uvidx;
 	const bool has_uv = m->n_uvs > 0 && m->uvs;
 	if (has_uv) uvidx.resize((size_t)nt * 3);
-	for (int i = 0; i < nt; i++) {
-		const mipt_triangle& T = m->triangleSoup[i];
-		memcpy(ti[i].A, T.A, 12); memcpy(ti[i].u, T.u, 12); memcpy(ti[i].v, T.v, 12); memcpy(ti[i].N, T.N, 12);
-		ti[i].m11 = T.m11; ti[i].m12 = T.m12; ti[i].m22 = T.m22; ti[i].invdetm = T.invdetm;
-		memcpy(ts[i].normals, T.normals, 36);
-		if (has_uv) memcpy(ts[i].uvs, T.uvs, 24); else memset(ts[i].uvs, 0, 24);
-		ts[i].group = m->indices[i].group;
-		if (ts[i].group > MIPT_GROUP_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "material group index above 2^30");
-		if (ts[i].group >= 0 && has_uv && m->indices[i].uvi >= 0 && m->indices[i].uvi < m->n_uvs) ts[i].group |= MIPT_GROUP_UV_OK;
-		if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
+	// the per-triangle records: independent iterations, on the host's hardware threads for multi-million-triangle meshes
+	{
+		const int nthreads = std::max(1, std::min((int)std::thread::hardware_concurrency(), nt / 65536));
+		std::vector<int> bad(nthreads, 0);
+		auto work = [&](int t) {
+			const int i0 = (int)((long long)nt * t / nthreads), i1 = (int)((long long)nt * (t + 1) / nthreads);
+			for (int i = i0; i < i1; i++) {
+				const mipt_triangle& T = m->triangleSoup[i];
+				memcpy(ti[i].A, T.A, 12); memcpy(ti[i].u, T.u, 12); memcpy(ti[i].v, T.v, 12); memcpy(ti[i].N, T.N, 12);
+				ti[i].m11 = T.m11; ti[i].m12 = T.m12; ti[i].m22 = T.m22; ti[i].invdetm = T.invdetm;
+				memcpy(ts[i].normals, T.normals, 36);
+				if (has_uv) memcpy(ts[i].uvs, T.uvs, 24); else memset(ts[i].uvs, 0, 24);
+				ts[i].group = m->indices[i].group;
+				if (ts[i].group > MIPT_GROUP_MASK) bad[t] = 1;
+				if (ts[i].group >= 0 && has_uv && m->indices[i].uvi >= 0 && m->indices[i].uvi < m->n_uvs) ts[i].group |= MIPT_GROUP_UV_OK;
+				if (has_uv) { uvidx[3 * (size_t)i] = m->indices[i].uvi; uvidx[3 * (size_t)i + 1] = m->indices[i].uvj; uvidx[3 * (size_t)i + 2] = m->indices[i].uvk; }
+			}
+		};
+		if (nthreads == 1) work(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+		for (int b : bad) if (b) return fail(c, MIPT_ERR_UNSUPPORTED, "material group index above 2^30");
 	}
 	d.node_base = node_base; d.tri_base = tri_base;
 	stg.fat.insert(stg.fat.end(), fat.begin(), fat.end());

@@ -124,6 +124,16 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 	finish_init(center);
 }
 
+// contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
+template <class F>
+static void parallel_for(int n, F f) {
+	const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
+	if (nt <= 1) { f(0, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) th.emplace_back([=] { f((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+	for (auto& x : th) x.join();
+}
+
 // readOBJ's per-group default material lists (TriangleMesh.cpp:470-480)
 void TriMesh::add_default_group_materials(int ngroups) {
 	for (int g = 0; g < ngroups; g++) {
@@ -154,7 +164,8 @@ void TriMesh::finish_init(bool center) {
 	build_bbox(0, nf, bbox);
 	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
 	triangleSoup.resize(nf);
-	for (int i = 0; i < nf; i++) {
+	parallel_for(nf, [&](int i0, int i1) {
+	for (int i = i0; i < i1; i++) {
 		mipt_triangle& T = triangleSoup[i];
 		memset(&T, 0, sizeof T);
 		const Vector &A = vertices[indices[i].vtxi], &B = vertices[indices[i].vtxj], &C = vertices[indices[i].vtxk];
@@ -171,6 +182,7 @@ void TriMesh::finish_init(bool center) {
 			for (int k = 0; k < 3; k++) { T.uvs[k][0] = uvs[tidx[k]][0]; T.uvs[k][1] = uvs[tidx[k]][1]; }
 		}
 	}
+	});
 	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
 	if (nt != 0) setup_tangents();
 }
