@@ -243,6 +243,7 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
  *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
+ *   "lane_limit"      measurement probe: the persistent traversal hands rays to the first N lanes of a wave only (0 = all 64)
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
  *                     every ray (normally only for rays with a zero direction component)
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again

@@ -77,6 +77,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
                                                int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
+	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
 	const unsigned n = SHADOW ? MIPT_N_SHADOW(wf, b) : MIPT_N_EXTEND(wf, b, n0);
 	unsigned* head = &wf.counters[SHADOW ? MIPT_CNT_SH_HEAD(b) : MIPT_CNT_EXT_HEAD(b)];
 	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
@@ -114,7 +115,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		MIPT_PROF_CLOCK(c0);
 		if (alive) MIPT_PROF_COUNT(8)
 		// ---- refill idle lanes from the queue
-		unsigned long long idle = __ballot(!alive && !need);
+		unsigned long long idle = __ballot(!alive && !need && lane < lane_limit);
 		int nidle = __popcll(idle);
 		if (!drained && nidle >= refill_threshold) {
 			if (chunk_next >= chunk_end) {
@@ -129,7 +130,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
 			}
 			unsigned take = min((unsigned)nidle, chunk_end - chunk_next);
-			if (!alive && !need) {
+			if (!alive && !need && lane < lane_limit) {
 				unsigned prefix = (unsigned)__popcll(idle & below);
 				if (prefix < take) {
 					unsigned idx = chunk_next + prefix;
@@ -181,7 +182,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		{
 			const int nalive = __popcll(__ballot(alive));
 			if (nalive == 0) { if (drained) break; else continue; }
-			if (!drained && 64 - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
+			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
 		}
 		MIPT_PROF_CLOCK(c1);
 		MIPT_PROF_CYCLES(12, c0, c1)
