@@ -1473,6 +1473,8 @@ static v3 sample_radiance(const o_ctx* c, int i, int j, int k, float* dx_out, fl
 }
 
 void o_getcolor_samples(o_ctx* c, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy) {
+	/* samples are independent (own pcg32 stream each): large requests run on all host threads */
+	#pragma omp parallel for schedule(dynamic, 256) if(npix >= 4096)
 	for (int q = 0; q < npix; q++) for (int k = k0; k < k1; k++) {
 		float dx, dy;
 		v3 col = sample_radiance(c, ij[2 * q], ij[2 * q + 1], k, &dx, &dy, NULL);
@@ -1480,6 +1482,7 @@ void o_getcolor_samples(o_ctx* c, int npix, const int* ij, int k0, int k1, float
 		out_rgb[3 * o] = col.x; out_rgb[3 * o + 1] = col.y; out_rgb[3 * o + 2] = col.z;
 		if (out_dxdy) { out_dxdy[2 * o] = dx; out_dxdy[2 * o + 1] = dy; }
 	}
+	#pragma omp parallel
 	cnt_flush();
 }
 

@@ -139,3 +139,27 @@ def test_c3_c4_workloads_oracle_subset(wl, grid):
         err = np.abs(got.astype(np.float64) - want).max() / WHITE
         assert err < 1e-4, (wl, pipeline, err)              # north-star tolerance
         assert_bits(got, want, f"{wl}: per-sample radiance, pipeline {pipeline}")
+
+
+@pytest.mark.parametrize("wl", ["c1", "c2", "c3"])
+def test_every_pixel_of_the_full_size_frame(wl):
+    """configs[1..3] at FULL size (c2: 2 508 800 triangles, 2048x2048 Kd texture, 4096x2048 env map, 1920x1080; c3: the
+    same mesh as a dielectric, depth 12) — one sample of EVERY pixel through the oracle (all host threads) against the
+    HIP path, bit for bit (2.07 M paths each)."""
+    from oracle.binding import Oracle
+    mesh, cfg, mat, _ = scenes.workload(wl, spp=1)
+    O = Oracle()
+    O.apply_config(cfg)
+    scenes.install(O, mesh, mat)
+    O.prepare()
+    pix = np.stack(np.meshgrid(np.arange(cfg.H), np.arange(cfg.W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+    want, want_j = O.getcolor_samples(pix, 0, 1)
+    rt = capi.HostRaytracer(device=0)
+    rt.apply_config(cfg)
+    scenes.install(rt, mesh, mat)
+    rt.prepare()
+    got, got_j = rt.sample_radiance(pix, 0, 1)
+    assert_bits(got_j, want_j, "jitter")
+    assert np.abs(got.astype(np.float64) - want).max() / WHITE < 1e-4
+    assert_bits(got, want, "per-sample radiance of all 2 073 600 pixels")
+    assert 0.01 < want.mean() / WHITE < 1.0
