@@ -1,0 +1,69 @@
+"""Differential fuzzing of the HIP path against the oracle: random scenes (tessellation, one or two meshes, scales,
+camera, light, aperture, depth, materials incl. glossy / mirror / dielectric / textures / MERL), per-sample radiance
+compared bit for bit on both pipelines.  usage: python tools/fuzz_parity.py [n_scenes] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from helpers import bits_equal, WHITE
+from pathtracer_amd import capi, scenes
+from oracle.binding import Oracle
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for it in range(n_scenes):
+    W, H, spp = int(rng.integers(8, 97)), int(rng.integers(8, 65)), int(rng.integers(1, 5))
+    cfg = scenes.config_c1(W, H, spp)
+    cfg.nb_bounces = int(rng.integers(1, 9))
+    cfg.aperture = float(rng.choice([0.0, 0.1, 0.5, 2.0]))
+    cfg.light_center = tuple(float(x) for x in rng.uniform(-30, 40, 3))
+    cfg.light_radius = float(rng.uniform(2, 15))
+    if rng.random() < 0.5:
+        ang = rng.uniform(-0.6, 0.2)
+        cfg.cam_pos = (float(rng.uniform(-20, 20)), float(rng.uniform(-10, 20)), float(rng.uniform(30, 70)))
+        cfg.cam_dir = (0.0, float(np.sin(ang)), float(-np.cos(ang)))
+        cfg.cam_up = (0.0, float(np.cos(ang)), float(np.sin(ang)))
+    kind = rng.choice(["diffuse", "glossy", "mirror", "glass", "textured", "merl", "two", "fat"])
+    n = int(rng.integers(6, 70))
+    mesh = scenes.blob_mesh(n, fine_detail=bool(rng.integers(0, 2)), with_uv=(kind == "textured"))
+    if kind == "fat":
+        mesh = scenes.fat_leaf_mesh(int(rng.integers(8, 30)))
+    scale = float(rng.choice([30.0, 5.0, 0.5, 80.0]))
+    out = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        X.apply_config(cfg)
+        oid = X.add_mesh(mesh, scale=scale)
+        out.append((X, oid))
+    # materials must be identical on both sides: draw once, apply twice
+    Kd, Ks, Ne = rng.uniform(0, 1, 3), rng.uniform(0, 0.9, 3), rng.uniform(0, 300, 3)
+    for X, oid in out:
+        if kind == "glossy":
+            X.set_group_material(oid, 0, Kd, Ks, Ne)
+            X.add_group_material(2, Kd[::-1], Ks * 0.5, Ne)
+        elif kind == "mirror":
+            X.set_object_flags(oid, True, False)
+        elif kind == "glass":
+            X.set_group_material(oid, 0, Kd, (0, 0, 0), (0, 0, 0), 0.0, float(1.0 + Ks[0]))
+        elif kind == "textured":
+            X.set_group_material(oid, 0, (1, 1, 1), Ks * 0.4, Ne * 0.2)
+            X.set_group_texture(oid, 0, 0, scenes.checker_texture(32, 16, 5, 4))
+            X.set_envmap(scenes.sky_envmap(64, 32))
+        elif kind == "merl":
+            X.set_brdf_merl(oid, scenes.synthetic_merl_table())
+        elif kind == "two":
+            X.add_mesh(scenes.blob_mesh(12), scale=scale * 0.4)
+        X.prepare()
+    O, G = out[0][0], out[1][0]
+    pix = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+    want = O.getcolor_samples(pix, 0, spp)[0]
+    line = "%2d %-8s n=%-3d scale %-5g %3dx%-3d spp %d depth %d aperture %-4g" % (it, kind, n, scale, W, H, spp, cfg.nb_bounces, cfg.aperture)
+    for pipeline in (1, 0):
+        G.set_option("pipeline", pipeline)
+        got = G.getcolor_samples(pix, 0, spp)[0]
+        same = bits_equal(got, want).all(-1).mean()
+        err = np.abs(got.astype(np.float64) - want).max() / WHITE
+        line += "  p%d: identical %.6f max|err|/white %.2g" % (pipeline, same, err)
+        if same < 1.0:
+            bad += 1
+    print(line, flush=True)
+print("scenes with any differing sample:", bad)
