@@ -144,7 +144,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						// arrive only if no sphere / plane occludes them
 						st.id = id; st.obj = first_mesh; need = true;
 						if (SHADOW) { st.dist = wf.sh_o[id].w; st.best = 0; }
-						else { const float4 h0 = wf.hit[id]; st.t = h0.x; st.best = (int)__float_as_uint(h0.w); st.beta = 0; st.gamma = 0; }
+						else { st.beta = 0; st.gamma = 0; }                          // st.t / st.best arrive with the ray (object loop below)
 					}
 				}
 			}
@@ -158,6 +158,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
 				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+				if (!SHADOW && st.obj == first_mesh) { st.t = o4.w; st.best = (int)__float_as_uint(d4.w); }      // a fresh ray: what the analytic objects left
 			}
 			if (need) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {

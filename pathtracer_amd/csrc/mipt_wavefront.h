@@ -125,7 +125,7 @@ __device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned
 // (generate / shade, all lanes busy) instead of by the traversal kernels, where a refill serves few lanes:
 //  * closest hit: the objects in front of the first mesh of the object list (light sphere, env sphere, ground plane in
 //    every loadScene() scene) are tested in list order with the reference's strict '<' and the running (t, object)
-//    is stored in the path's hit record; the traversal continues from the first mesh with that bound, exactly as the
+//    is stored with the ray (the .w of its origin / direction float4s); the traversal continues from the first mesh with that bound, exactly as the
 //    object loop of Geometry.cpp:600-650 would have arrived there;
 //  * shadow ray: occlusion is an OR over the objects (Geometry.cpp:700-741), so every sphere / plane is tested here
 //    whatever its position in the list; an occluded request is dropped, the others only traverse the meshes.
@@ -206,13 +206,12 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __rest
 			wf_st(&wf.out.dxdy[tid], make_float2(dx, dy));
 			alive = path_alive(p);
 			if (alive) {
-				wf_st(&wf.ray_o[tid], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f));
-				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
+				float t0; unsigned best0;
+				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);       // rides in the unused .w of the ray's two float4s
+				wf_st(&wf.ray_o[tid], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
+				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
 				wf_st(&wf.wgt[tid], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
 				wf_st(&wf.rng[tid], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
-				float t0; unsigned best0;
-				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
-				wf_st(&wf.hit[tid], make_float4(t0, 0.f, 0.f, __uint_as_float(best0)));
 			}
 		}
 	}
@@ -329,13 +328,12 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			}
 			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
 			if (c) {
-				wf_st(&wf.ray_o[id], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f));
-				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f));
+				float t0; unsigned best0;
+				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);       // rides in the unused .w of the ray's two float4s
+				wf_st(&wf.ray_o[id], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
+				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
 				wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
 				wf_st(&wf.rng[id], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
-				float t0; unsigned best0;
-				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
-				wf_st(&wf.hit[id], make_float4(t0, 0.f, 0.f, __uint_as_float(best0)));
 			}
 			if (c) cont_bits |= 1u << u;
 		}
