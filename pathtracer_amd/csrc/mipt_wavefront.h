@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	auto fetch = [&](unsigned id, bool ok, In& in) {
 		if (ok) {
 			in.w = wf_ld(&wf.wgt[id]); in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); in.hr = wf_ld(&wf.hit[id]);
-			in.col = wf_ld(&wf.out.col[id]); in.rs = wf_ld(&wf.rng[id]);
+			if (TIER != 1) in.col = wf_ld(&wf.out.col[id]);          // the fast tier touches the colour only when a vertex adds to it
+			in.rs = wf_ld(&wf.rng[id]);
 		}
 	};
 	while (q.pull(head, n, base)) {
@@ -317,7 +318,14 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				c = r == VERTEX_CONTINUE;
 			} else c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
-			wf_st(&wf.out.col[id], make_float4(p.color.x, p.color.y, p.color.z, 0.f));
+			if (TIER == 1) {
+				// the vertex ran with colour 0, so p.color is exactly the term it adds (0 + x = x); on a non-emissive surface
+				// that term is 0 and colour + 0 = colour: the path's colour is neither read nor written (it is never -0)
+				if (p.color.x != 0.f || p.color.y != 0.f || p.color.z != 0.f) {
+					const float4 c0 = wf_ld(&wf.out.col[id]);
+					wf_st(&wf.out.col[id], make_float4(c0.x + p.color.x, c0.y + p.color.y, c0.z + p.color.z, 0.f));
+				}
+			} else wf_st(&wf.out.col[id], make_float4(p.color.x, p.color.y, p.color.z, 0.f));
 			if (sh.diffuse && sh.cast) n_shadow++;                         // counted like the reference counts intersection_shadow calls
 			if (sh.diffuse && sh.cast && !analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
 				cast_bits |= 1u << u;
