@@ -1,5 +1,5 @@
 """profiles/hbm_traffic.json from PMC summaries (tools/pmc.sh): HBM bytes per launch of each kernel.
-usage: python tools/pmc_traffic.py c1=profiles/r1_f_c1_pmc_summary.txt c2=profiles/r1_f_c2_pmc_summary.txt"""
+usage: python tools/pmc_traffic.py c1=profiles/r1_g_c1_pmc_summary.txt c2=profiles/r1_g_c2_pmc_summary.txt"""
 import json, re, sys
 out = {}
 for arg in sys.argv[1:]:
