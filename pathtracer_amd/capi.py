@@ -23,6 +23,7 @@ LIBHOST = os.path.join(_HERE, "libmipt_host.so")
 MIPT_OK = 0
 MIPT_ERR_NO_DEVICE = 2
 MIPT_ERR_CANCELLED = 6
+MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
@@ -38,6 +39,34 @@ class MiptStats(C.Structure):
                 ("render_ms", C.c_double), ("traverse_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("traverse_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("passes", C.c_uint32), ("pipeline", C.c_uint32),
                 ("traverse_merged", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class MiptTexture(C.Structure):
+    _fields_ = [("multiplier", _f * 3), ("W", C.c_int32), ("H", C.c_int32), ("values", C.POINTER(_f))]
+
+
+class MiptBvhNode(C.Structure):
+    """mipt_bvh_node == BVHNodesT<float> (36 bytes)."""
+    _fields_ = [("isleaf", C.c_uint8), ("_pad", C.c_uint8 * 3), ("fg", C.c_int32), ("fd", C.c_int32), ("bbox_min", _f * 3), ("bbox_max", _f * 3)]
+
+
+class MiptMesh(C.Structure):
+    _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_uvs", C.c_int32), ("nodes", C.POINTER(MiptBvhNode)),
+                ("bvh_bbox_min", _f * 3), ("bvh_bbox_max", _f * 3), ("triangleSoup", C.c_void_p), ("indices", C.c_void_p),
+                ("uvs", C.POINTER(_f)), ("tangentSoup", C.POINTER(_f))]
+
+
+class MiptObject(C.Structure):
+    _fields_ = [("type", C.c_int32), ("miroir", C.c_int32), ("ghost", C.c_int32), ("flip_normals", C.c_int32), ("interp_normals", C.c_int32),
+                ("trans_matrix", _f * 12), ("inv_trans_matrix", _f * 12), ("rot_matrix", _f * 9),
+                ("brdf_kind", C.c_int32), ("merl_data", C.POINTER(C.c_double)),
+                ("n_lists", C.c_int32 * 8), ("lists", C.POINTER(MiptTexture) * 8),
+                ("O", _f * 3), ("R", _f), ("has_envmap", C.c_int32), ("envW", C.c_int32), ("envH", C.c_int32), ("envtex", C.POINTER(C.c_uint8)),
+                ("A", _f * 3), ("vecN", _f * 3), ("mesh", C.POINTER(MiptMesh))]
+
+
+class MiptSceneDesc(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(MiptObject))]
 
 
 class MiptHit(C.Structure):

@@ -349,6 +349,24 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		ref = MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (tri_base + (uint32_t)n.fg);
 		return MIPT_OK;
 	};
+	// the traversal stack holds at most one pending far child per inner node on the current root-to-leaf path: refuse
+	// trees deeper than the stack instead of overrunning it (the reference's own fixed 50-entry stack is UB there,
+	// TriangleMesh.cpp:1153).  Children follow their parent in the node array, so one forward pass gives the depths.
+	{
+		std::vector<unsigned char> depth(nn, 0);
+		depth[0] = 1;
+		int deepest = 1;
+		for (int i = 0; i < nn; i++) {
+			if (m->nodes[i].isleaf) continue;
+			const int l = m->nodes[i].fg, r = m->nodes[i].fd;
+			if (l <= i || l >= nn || r <= i || r >= nn) return fail(c, MIPT_ERR_INVALID, "BVH child index out of order");
+			const int dchild = depth[i] + 1;
+			if (dchild > 250) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH deeper than 250 levels");
+			depth[l] = depth[r] = (unsigned char)dchild;
+			deepest = std::max(deepest, (int)depth[i]);
+		}
+		if (deepest > MIPT_STACK_DEPTH) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH with %d levels of inner nodes: the traversal stack holds %d", deepest, MIPT_STACK_DEPTH);
+	}
 	std::vector<DFatNode> fat(nfat > 0 ? nfat : 1);
 	memset(fat.data(), 0, fat.size() * sizeof(DFatNode));
 	for (int i = 0; i < nn; i++) {

@@ -244,3 +244,36 @@ def test_scene_without_mesh_and_tiny_images(pipeline):
         oimg, ocnt = O.render_seeded()
         assert_bits(cnt, ocnt, "weights")
         assert_bits(img, oimg, "image")
+
+
+def test_degenerate_deep_bvh_is_refused_not_overrun():
+    """A chain-shaped BVH deeper than the traversal stack (hand-built node array through the C ABI) must be refused at
+    upload; the reference's own fixed-size stack is undefined behaviour there (TriangleMesh.cpp:1153)."""
+    import ctypes as C
+    rt = capi.HostRaytracer(device=0)
+    rt.apply_config(scenes.config_c1(8, 8, 1))
+    oid = rt.add_mesh(scenes.blob_mesh(8))
+    rt.prepare()                                              # a valid upload first
+    # now hand the ABI a 60-level chain: node i = inner(i+1, leaf), built over the first triangles of the same mesh
+    desc = C.cast(rt.host.mh_scene_desc(rt.h), C.POINTER(capi.MiptSceneDesc)).contents
+    mesh = desc.objects[oid].mesh.contents
+    depth = 60
+    nodes = (capi.MiptBvhNode * (2 * depth + 1))()
+    for i in range(depth):
+        nodes[2 * i].isleaf = 0; nodes[2 * i].fg = 2 * i + 1; nodes[2 * i].fd = 2 * i + 2
+        nodes[2 * i + 1].isleaf = 1; nodes[2 * i + 1].fg = i % 4; nodes[2 * i + 1].fd = i % 4 + 1
+        for k in range(3):
+            nodes[2 * i].bbox_min[k] = nodes[2 * i + 1].bbox_min[k] = -1.0
+            nodes[2 * i].bbox_max[k] = nodes[2 * i + 1].bbox_max[k] = 1.0
+    last = nodes[2 * depth]
+    last.isleaf = 1; last.fg = 0; last.fd = 1
+    for k in range(3):
+        last.bbox_min[k], last.bbox_max[k] = -1.0, 1.0
+    old_nodes, old_n = mesh.nodes, mesh.n_nodes
+    mesh.nodes, mesh.n_nodes = C.cast(nodes, type(mesh.nodes)), 2 * depth + 1
+    try:
+        rc = rt.mipt.mipt_upload_scene(rt.ctx, C.byref(desc))
+        assert rc == capi.MIPT_ERR_UNSUPPORTED, rc
+        assert b"traversal stack" in rt.mipt.mipt_last_error(rt.ctx)
+    finally:
+        mesh.nodes, mesh.n_nodes = old_nodes, old_n

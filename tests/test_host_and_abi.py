@@ -155,3 +155,19 @@ def test_merl_binary_file_reader(tmp_path):
         H.set_brdf_merl_file(oid, bad)
     with pytest.raises(capi.MiptError):
         H.set_brdf_merl_file(oid, tmp_path / "missing.binary")
+
+
+def test_scene_desc_ctypes_layout_matches_header():
+    """The ctypes mirror of mipt_object / mipt_mesh / mipt_bvh_node (used by tests that hand-build descriptions) has the
+    layout the C compiler gives include/mipt.h."""
+    import subprocess, tempfile, os, ctypes
+    src = "\n".join(['#include <stdio.h>', '#include <stddef.h>', '#include "mipt.h"',
+                     'int main(){printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(mipt_bvh_node), sizeof(mipt_mesh), sizeof(mipt_object),',
+                     '  offsetof(mipt_object, mesh), offsetof(mipt_object, O), offsetof(mipt_mesh, nodes), sizeof(mipt_scene_desc));return 0;}', ''])
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "t.c"), "w").write(src)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")], check=True)
+    got = [int(x) for x in subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(capi.MiptBvhNode), ctypes.sizeof(capi.MiptMesh), ctypes.sizeof(capi.MiptObject), capi.MiptObject.mesh.offset,
+            capi.MiptObject.O.offset, capi.MiptMesh.nodes.offset, ctypes.sizeof(capi.MiptSceneDesc)]
+    assert got == want, (got, want)
