@@ -291,7 +291,36 @@ MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, P
 		return VERTEX_END;
 	}
 	const DObject& obj = sc->obj[h.obj];
-	const bool plain = !obj.miroir && !mat.transp && obj.merl == nullptr &&
+	if (obj.miroir || mat.transp) {                                      // mirror (:413-436) / Fresnel dielectric (:438-489): no NEE, no shadow ray
+		ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;  // :411
+		if (obj.miroir) {
+			ps.ray.o = P + 0.001f * N;
+			ps.ray.d = reflect(rayDirection, N);
+			ps.depth--;
+			return VERTEX_CONTINUE;
+		}
+		float n1 = 1.f, n2 = mat.refr_index;
+		f3 nt = N;
+		bool entering = true;
+		if (dot(rayDirection, N) > 0) { n1 = mat.refr_index; n2 = 1; nt = -N; entering = false; }
+		float radical = 1.f - sqr(n1 / n2) * (1.f - sqr(dot(nt, rayDirection)));
+		Ray nr;
+		if (radical > 0) {
+			f3 refr = (n1 / n2) * (rayDirection - dot(rayDirection, nt) * nt) - nt * sqrtf(radical);
+			float R0 = sqr((n1 - n2) / (n1 + n2));
+			float Rf;
+			if (entering) Rf = R0 + (1 - R0) * pt_powf(1.f + dot(rayDirection, N), 5.f);
+			else Rf = R0 + (1 - R0) * pt_powf(1.f - dot(refr, N), 5.f);
+			if (pcg_uniform(ps.rng) < Rf) { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
+			else { nr.o = P - 0.001f * nt; nr.d = refr; }
+		} else {
+			nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N);
+		}
+		ps.ray = nr;
+		ps.depth--;
+		return VERTEX_CONTINUE;
+	}
+	const bool plain = obj.merl == nullptr &&
 	                   mat.Ks.x == 0.f && mat.Ks.y == 0.f && mat.Ks.z == 0.f && mat.Ne.x >= 0.f && mat.Ne.y >= 0.f && mat.Ne.z >= 0.f;
 	if (!plain) return VERTEX_DEFER;
 	uint64_t rng = ps.rng;
