@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c1g", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)

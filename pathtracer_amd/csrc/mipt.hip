@@ -196,6 +196,7 @@ struct mipt_ctx {
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
+	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
 	unsigned grid_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of: traverse<0,1,2>, shade<0,1,2>, extend, shadow
 	int n_mesh_objects = 0;
@@ -437,6 +438,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
+	bool scene_merl = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -448,7 +450,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 		d.type = o.type; d.miroir = o.miroir; d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
 		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
 		d.brdf_kind = o.brdf_kind; d.merl = nullptr;
-		if (o.brdf_kind == MIPT_BRDF_MERL) { int rc = upload(c, o.merl_data, (size_t)3 * 90 * 90 * 180, &d.merl); if (rc) return rc; }
+		if (o.brdf_kind == MIPT_BRDF_MERL) { int rc = upload(c, o.merl_data, (size_t)3 * 90 * 90 * 180, &d.merl); if (rc) return rc; scene_merl = true; }
 		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
 		lists[MT_KD] = o.textures; counts[MT_KD] = o.n_textures;
 		lists[MT_KS] = o.specularmap; counts[MT_KS] = o.n_specularmap;
@@ -509,6 +511,8 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->d_scene = const_cast<DScene*>(dsc);
 	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
+	c->scene_has_merl = scene_merl;
+	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	return MIPT_OK;
 }
 
@@ -751,7 +755,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	// chunk statically: a block that only starts when another one has finished would hold its chunk back until then)
 	if (c->grid_stage[0] == 0) {
 		const void* kern[8] = {(const void*)k_wf_traverse<0>, (const void*)k_wf_traverse<1>, (const void*)k_wf_traverse<2>, (const void*)k_wf_shade<0>,
-		                       (const void*)k_wf_shade<1>, (const void*)k_wf_shade<2>, (const void*)k_wf_extend, (const void*)k_wf_shadow};
+		                       (const void*)k_wf_shade<1>, (const void*)(c->scene_has_merl ? k_wf_shade<3> : k_wf_shade<2>), (const void*)k_wf_extend, (const void*)k_wf_shadow};
 		for (int k = 0; k < 8; k++) {
 			int nb = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
@@ -788,7 +792,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_fast_shade) {
 					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					if (c->scene_has_merl) hipLaunchKernelGGL(k_wf_shade<3>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					else hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");

@@ -176,6 +176,9 @@ struct ShadowRequest {
 // estimation (shadow request), samples the continuation ray and updates weight/depth.
 // Returns true while the path continues.  `weight_at_vertex` is the weight the direct term must
 // be multiplied with once the shadow query is resolved (color += pathWeight*currentContrib).
+// MERL = false: the scene has no measured BRDF (the caller knows from the upload): the fp64 table evaluation is not
+// compiled into the kernel, which is what its register count is otherwise sized for.
+template <bool MERL = true>
 MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathState& ps, bool has_inter, const Hit& h, f3 P, const Mat& mat,
                           int pix, int sampleID, ShadowRequest& sh, f3& weight_at_vertex) {
 	sh.diffuse = false;
@@ -195,6 +198,7 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 		return false;
 	}
 	const DObject& obj = sc->obj[h.obj];
+	const double* const merl = MERL ? obj.merl : nullptr;
 	ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
 	if (obj.miroir) {                                                    // :413-436
 		ps.ray.o = P + 0.001f * N;
@@ -235,7 +239,7 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	f3 wi = fast_normalize(pt_l - P);
 	float d_light2 = norm2(pt_l - P);
 	if (!(dot(mat.shadingN, wi) < 0)) {
-		f3 brdf = obj.merl ? merl_eval(obj.merl, wi, -rayDirection, N) : phong_eval(mat, wi, -rayDirection, N);
+		f3 brdf = merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(mat, wi, -rayDirection, N);
 		float J = dot(dir_l, -wi) / d_light2;
 		float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
 		if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
@@ -250,12 +254,12 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
 	float pdf;
 	f3 dir;
-	if (obj.merl) {                                   // IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw
+	if (merl) {                                       // IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw
 		dir = random_cos(N, r1, r2);
 		pdf = (float)((double)dot(N, dir) / (MIPT_PI));
 	} else dir = phong_sample(mat, -rayDirection, N, pdf, r1, r2, ps.rng);
 	if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) return false;   // :593
-	f3 brdf_i = obj.merl ? merl_eval(obj.merl, dir, -rayDirection, N) : phong_eval(mat, dir, -rayDirection, N);
+	f3 brdf_i = merl ? merl_eval(merl, dir, -rayDirection, N) : phong_eval(mat, dir, -rayDirection, N);
 	ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);            // :611
 	ps.ray.o = P + 0.01f * dir;
 	ps.ray.d = dir;

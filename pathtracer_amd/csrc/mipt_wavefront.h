@@ -246,16 +246,19 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 
 // shade: material of the hit, emission, next-event-estimation request, continuation sampling.
 // TIER 0: every vertex with the general code.  TIER 1: fast tier over the same queue; vertices it cannot
-// handle go to list_slow.  TIER 2: the general code over list_slow.
+// handle go to list_slow.  TIER 2: the general code over list_slow for scenes without a measured BRDF, TIER 3: with.
 #ifndef MIPT_SHADE_WAVES
 #define MIPT_SHADE_WAVES 3
 #endif
+#ifndef MIPT_SHADE2_WAVES
+#define MIPT_SHADE2_WAVES 2
+#endif
 template <int TIER>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : 2))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
-	const unsigned n = TIER == 2 ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
-	unsigned* head = &wf.counters[MIPT_CNT((TIER == 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
-	const unsigned* __restrict__ list = TIER == 2 ? wf.list_slow : wf.list[b & 1];
-	const bool identity = TIER != 2 && b == 0;
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : 2)))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+	const unsigned n = TIER >= 2 ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
+	unsigned* head = &wf.counters[MIPT_CNT((TIER >= 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
+	const unsigned* __restrict__ list = TIER >= 2 ? wf.list_slow : wf.list[b & 1];
+	const bool identity = TIER < 2 && b == 0;
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				int r = path_vertex_fast(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 				if (r == VERTEX_DEFER) { slow_bits |= 1u << u; continue; }
 				c = r == VERTEX_CONTINUE;
-			} else c = path_vertex(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			} else c = path_vertex<TIER != 2>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
 			if (TIER == 1) {
 				// the vertex ran with colour 0, so p.color is exactly the term it adds (0 + x = x); on a non-emissive surface

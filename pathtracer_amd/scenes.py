@@ -243,6 +243,11 @@ def workload(name: str, width: int = None, height: int = None, spp: int = None, 
         g = grid or 258
         cfg = config_c1(width or 1920, height or 1080, spp or 256)
         return blob_mesh(g), cfg, None, f"configs[1]: {2 * g * g}-triangle diffuse blob, Phong BRDF"
+    if name == "c1g":     # configs[1] with a glossy Phong lobe on the mesh (not a BASELINE config: exercises the general shade tier)
+        g = grid or 258
+        cfg = config_c1(width or 1920, height or 1080, spp or 256)
+        mat = dict(Kd=(0.5, 0.4, 0.3), Ks=(0.3, 0.3, 0.3), Ne=(50.0, 50.0, 50.0))
+        return blob_mesh(g), cfg, mat, f"configs[1] with a glossy lobe: {2 * g * g}-triangle blob, Phong Ks 0.3 Ne 50"
     if name == "c2":      # 2.5M triangles, Kd texture, env map, 1024 spp
         g = grid or 1120
         cfg = config_c1(width or 1920, height or 1080, spp or 1024)
