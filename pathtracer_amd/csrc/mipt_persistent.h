@@ -8,8 +8,9 @@
 // ray of the queue as soon as enough lanes are idle (active-lane compaction by __ballot / popcount
 // prefix), so the 64-wide traversal steps stay populated.
 //
-// Every ray still performs exactly the reference's sequence of operations (objects in index order,
-// ordered stack traversal per mesh, same pruning); only WHICH lane runs it and WHEN changes.
+// Every ray still performs exactly the reference's sequence of operations (objects in index order —
+// the analytic ones in front of the first mesh already by the stage that created the ray —, ordered
+// stack traversal per mesh, same pruning); only WHICH lane runs it and WHEN changes.
 #pragma once
 
 #define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)

@@ -9,8 +9,8 @@
 //
 // Path state lives in HBM as float4-packed arrays indexed by path id (a path keeps its id for the
 // whole pass, only the id lists are compacted); every stage is a persistent kernel whose waves pull
-// 64-entry chunks from a device-side counter, so the launch geometry does not depend on queue sizes
-// that only the device knows.
+// chunks of ids (the first one statically, later ones from a device-side counter), so the launch
+// geometry does not depend on queue sizes that only the device knows.
 //
 // Float semantics: every stage calls the same device functions as the per-path kernel; the
 // additions into a path's colour happen in the reference's order (emission of vertex b, direct
