@@ -60,6 +60,15 @@ void ref_destroy(RefCtx* c) {
 	delete c;
 }
 
+// the reference's image decoder as Texture::loadColors calls it (utils.cpp:98-165: stb_image, 3 channels, rows flipped)
+int ref_load_image(const char* file, unsigned char* out, int capacity, int* W, int* H) {
+	std::vector<unsigned char> val; size_t w = 0, h = 0;
+	if (!load_image(file, val, w, h, false)) return -1;
+	if ((int)val.size() > capacity) return -2;
+	memcpy(out, &val[0], val.size()); *W = (int)w; *H = (int)h;
+	return 0;
+}
+
 // .scn scene files through the reference's own Raytracer::save_scene / load_scene (Raytracer.cpp:1096-1236)
 void ref_save_scene(RefCtx* c, const char* file) { c->rt->save_scene(file); }
 void ref_load_scene(RefCtx* c, const char* file) {

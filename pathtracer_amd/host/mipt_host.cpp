@@ -12,6 +12,7 @@
 #include <limits>
 #include <map>
 #include <thread>
+#include <zlib.h>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -266,6 +267,101 @@ bool read_ppm(const std::string& file, std::vector<unsigned char>& rgb, int& W, 
 	fclose(f);
 	return ok;
 }
+
+// PNG as the reference's decoder (stb_image, asked for 3 channels) delivers it: non-interlaced, bit depth 1 / 2 / 4 / 8;
+// grey levels below 8 bits are scaled to 0..255, grey is replicated to RGB, a palette is expanded, alpha (channel or tRNS)
+// is dropped.  Decompression by zlib's inflate, the five scanline filters undone here.  16-bit and Adam7 files are refused.
+bool read_png(const std::string& file, std::vector<unsigned char>& rgb, int& W, int& H, std::string& why) {
+	FILE* f = fopen(file.c_str(), "rb");
+	if (!f) { why = "cannot open"; return false; }
+	std::vector<unsigned char> buf;
+	{ unsigned char tmp[65536]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n); }
+	fclose(f);
+	static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	if (buf.size() < 33 || memcmp(buf.data(), sig, 8) != 0) { why = "not a PNG file"; return false; }
+	auto be32 = [&](size_t o) { return ((unsigned)buf[o] << 24) | ((unsigned)buf[o + 1] << 16) | ((unsigned)buf[o + 2] << 8) | (unsigned)buf[o + 3]; };
+	int depth = 0, ctype = 0, interlace = 0;
+	std::vector<unsigned char> idat, plte;
+	size_t o = 8;
+	bool seen_end = false;
+	while (o + 12 <= buf.size() && !seen_end) {
+		const unsigned len = be32(o);
+		const char* tag = (const char*)&buf[o + 4];
+		if (o + 12 + (size_t)len > buf.size()) { why = "truncated chunk"; return false; }
+		const unsigned char* d = &buf[o + 8];
+		if (!memcmp(tag, "IHDR", 4)) {
+			if (len != 13) { why = "bad IHDR"; return false; }
+			W = (int)be32(o + 8); H = (int)be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12];
+			if (d[10] != 0 || d[11] != 0) { why = "unknown compression / filter method"; return false; }
+		} else if (!memcmp(tag, "PLTE", 4)) plte.assign(d, d + len);
+		else if (!memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+		else if (!memcmp(tag, "IEND", 4)) seen_end = true;
+		o += 12 + (size_t)len;
+	}
+	if (W <= 0 || H <= 0 || idat.empty()) { why = "no image data"; return false; }
+	if (interlace != 0) { why = "Adam7-interlaced PNG is not decoded here"; return false; }
+	if (depth == 16) { why = "16-bit PNG (the reference reads it through CImg) is not decoded here"; return false; }
+	int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+	if (!chans || !(depth == 8 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) { why = "unsupported colour type / bit depth"; return false; }
+	if (ctype == 3 && plte.size() < 3) { why = "palette image without PLTE"; return false; }
+	const size_t row_bytes = ((size_t)W * chans * depth + 7) / 8, bpp = std::max<size_t>(1, (size_t)chans * depth / 8);
+	std::vector<unsigned char> raw((row_bytes + 1) * (size_t)H);
+	{
+		z_stream zs; memset(&zs, 0, sizeof zs);
+		if (inflateInit(&zs) != Z_OK) { why = "zlib init failed"; return false; }
+		zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size(); zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
+		const int rc = inflate(&zs, Z_FINISH);
+		const bool complete = zs.total_out == raw.size();
+		inflateEnd(&zs);
+		if ((rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) || !complete) { why = "corrupt image data"; return false; }
+	}
+	std::vector<unsigned char> prev(row_bytes, 0), cur(row_bytes);
+	rgb.assign((size_t)W * H * 3, 0);
+	for (int y = 0; y < H; y++) {
+		const unsigned char* in = &raw[(row_bytes + 1) * (size_t)y];
+		const int ft = in[0];
+		if (ft > 4) { why = "bad scanline filter"; return false; }
+		for (size_t x = 0; x < row_bytes; x++) {
+			const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+			int v = in[1 + x];
+			if (ft == 1) v += a;
+			else if (ft == 2) v += b;
+			else if (ft == 3) v += (a + b) >> 1;
+			else if (ft == 4) { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+			cur[x] = (unsigned char)v;
+		}
+		unsigned char* out = &rgb[(size_t)y * W * 3];
+		static const int scale[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};      // grey levels to 0..255 (not applied to palette indices)
+		for (int x = 0; x < W; x++) {
+			auto sample = [&](int k) -> int {                  // k-th sample of the row
+				if (depth == 8) return cur[k];
+				const int per = 8 / depth, byte = cur[k / per], shift = 8 - depth * (k % per + 1);
+				return (byte >> shift) & ((1 << depth) - 1);
+			};
+			if (ctype == 0 || ctype == 4) { const int g = sample(x * chans) * (ctype == 0 ? scale[depth] : 1); out[3 * x] = out[3 * x + 1] = out[3 * x + 2] = (unsigned char)g; }
+			else if (ctype == 3) {
+				const size_t idx = (size_t)sample(x);
+				if (3 * idx + 2 >= plte.size()) { why = "palette index out of range"; return false; }
+				out[3 * x] = plte[3 * idx]; out[3 * x + 1] = plte[3 * idx + 1]; out[3 * x + 2] = plte[3 * idx + 2];
+			} else { out[3 * x] = cur[(size_t)x * chans]; out[3 * x + 1] = cur[(size_t)x * chans + 1]; out[3 * x + 2] = cur[(size_t)x * chans + 2]; }
+		}
+		prev.swap(cur);
+	}
+	return true;
+}
+
+// an 8-bit RGB image by content: binary PPM or PNG (what the reference reads through stb_image without a lossy codec)
+bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, int& W, int& H, std::string& why) {
+	FILE* f = fopen(file.c_str(), "rb");
+	if (!f) { why = "cannot open"; return false; }
+	unsigned char magic[4] = {0, 0, 0, 0};
+	const size_t got = fread(magic, 1, 4, f);
+	fclose(f);
+	if (got >= 2 && magic[0] == 'P' && magic[1] == '6') { if (read_ppm(file, rgb, W, H)) return true; why = "malformed binary PPM (P6, maxval 255 expected)"; return false; }
+	if (got == 4 && magic[0] == 0x89 && magic[1] == 'P' && magic[2] == 'N' && magic[3] == 'G') return read_png(file, rgb, W, H, why);
+	why = "only binary PPM and PNG images are decoded here (JPEG / BMP / TGA / HDR need the reference's codecs)";
+	return false;
+}
 }  // namespace
 
 bool TriMesh::readOBJ(const char* obj, bool load_textures) {
@@ -339,7 +435,8 @@ bool TriMesh::readOBJ(const char* obj, bool load_textures) {
 	int grp = 0;
 	auto image = [&](Texture& tex, const std::string& file, bool normals_map) {
 		std::vector<unsigned char> rgb; int W = 0, H = 0;
-		if (!read_ppm(dir_of(obj) + file, rgb, W, H)) { load_error = "texture " + file + ": only binary PPM (P6, 8 bit) is decoded here"; return; }
+		std::string why;
+		if (!read_image_rgb8(dir_of(obj) + file, rgb, W, H, why)) { load_error = "texture " + file + ": " + why; return; }
 		if (normals_map) tex.loadNormalsRGB8(rgb.data(), W, H); else tex.loadColorsRGB8(rgb.data(), W, H);
 		tex.filename = dir_of(obj) + file;              // Texture::filename, what save_scene writes
 	};
@@ -641,7 +738,8 @@ void scn_texture_list(ScnReader& R, const char* count_key, bool count_already_re
 			FILE* probe = fopen(file.c_str(), "rb");
 			if (probe) {                                   // a missing file leaves the constant, as load_image returning false does
 				fclose(probe);
-				if (!read_ppm(file, rgb, W, H)) { R.fail("texture " + name + ": only binary PPM (P6, 8 bit) is decoded here"); ok = false; return; }
+				std::string why;
+				if (!read_image_rgb8(file, rgb, W, H, why)) { R.fail("texture " + name + ": " + why); ok = false; return; }
 				if (kind == 2) t.loadNormalsRGB8(rgb.data(), W, H); else t.loadColorsRGB8(rgb.data(), W, H);
 			}
 		}
@@ -749,7 +847,8 @@ bool Raytracer::load_scene(const char* filename) {
 			sp->rotation_center = sp->O; sp->name = "Sphere";           // Sphere::init (Geometry.h:856-873)
 			if (has_env) {
 				std::vector<unsigned char> rgb; int w = 0, h = 0;
-				if (!read_ppm(envfile[0] == '/' ? envfile : dir + envfile, rgb, w, h)) return bail("environment map " + envfile + ": only binary PPM (P6, 8 bit) is decoded here");
+				std::string why;
+				if (!read_image_rgb8(envfile[0] == '/' ? envfile : dir + envfile, rgb, w, h, why)) return bail("environment map " + envfile + ": " + why);
 				sp->load_envmap_rgb8(rgb.data(), w, h);
 				sp->envmapfilename = envfile;
 			}
@@ -1026,6 +1125,14 @@ void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
 }
 void mh_set_envmap_intensity(mh_raytracer* h, float v) { h->rt.s.envmap_intensity = v; }
+// decode an image file the way Texture::loadColors' load_image does (stb_image, 3 channels, rows as in the file): for tests
+int mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W, int* H, char* err, int errlen) {
+	std::vector<unsigned char> rgb; std::string why;
+	if (!read_image_rgb8(file, rgb, *W, *H, why)) { if (err && errlen > 0) { strncpy(err, why.c_str(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+	if ((int)rgb.size() > capacity) return -2;
+	memcpy(rgb_out, rgb.data(), rgb.size());
+	return 0;
+}
 int mh_load_scene(mh_raytracer* h, const char* scn) { return h->rt.load_scene(scn) ? 0 : -1; }
 int mh_save_scene(mh_raytracer* h, const char* scn) { return h->rt.save_scene(scn) ? 0 : -1; }
 int mh_num_objects(mh_raytracer* h) { return (int)h->rt.s.objects.size(); }

@@ -204,6 +204,7 @@ void mh_set_render(mh_raytracer*, int W, int H, int nrays, int nb_bounces, float
 void mh_set_camera(mh_raytracer*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);
 void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_lumiere);
 void mh_set_envmap_intensity(mh_raytracer*, float v);
+int  mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W, int* H, char* err, int errlen);   // PPM / PNG as stb_image delivers them (3 channels)
 int  mh_load_scene(mh_raytracer*, const char* scn_file);   // Raytracer::load_scene; 0 or -1 (mh_last_error)
 int  mh_save_scene(mh_raytracer*, const char* scn_file);   // Raytracer::save_scene
 int  mh_num_objects(mh_raytracer*);

@@ -1,0 +1,118 @@
+"""PNG / PPM decoding of the host mirror (used for MTL textures, .scn textures and environment maps): every colour type and
+bit depth stb_image handles without a lossy codec, every scanline filter, against the pixels the file was made from and,
+where the compiled reference is present, against the reference's own load_image (stb_image)."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi
+
+
+def png_bytes(arr, ctype, depth, palette=None, filters=(0, 1, 2, 3, 4)):
+    """arr: (H, W, channels) samples already in the file's value range.  Rows get the filters in turn."""
+    H, W, ch = arr.shape
+    bits = ch * depth
+    rows = []
+    for y in range(H):
+        if depth == 8:
+            rows.append(arr[y].astype(np.uint8).tobytes())
+        else:
+            v = arr[y].reshape(-1).astype(np.uint8)
+            per = 8 // depth
+            pad = (-len(v)) % per
+            v = np.concatenate([v, np.zeros(pad, np.uint8)]).reshape(-1, per)
+            byte = np.zeros(len(v), np.uint16)
+            for k in range(per):
+                byte = (byte << depth) | v[:, k]
+            rows.append(byte.astype(np.uint8).tobytes())
+    bpp = max(1, bits // 8)
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)]
+        out = bytearray(len(row))
+        for x in range(len(row)):
+            a = row[x - bpp] if x >= bpp else 0
+            b = prev[x]
+            c = prev[x - bpp] if x >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[x] = (row[x] - pred) & 255
+        raw.append(ft); raw += out
+        prev = row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    z = zlib.compress(bytes(raw), 6)
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        body += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    half = len(z) // 2                      # two IDAT chunks: the stream must be concatenated
+    body += chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+    return b"\x89PNG\r\n\x1a\n" + body
+
+
+CASES = [(0, 8), (0, 4), (0, 2), (0, 1), (2, 8), (3, 8), (3, 4), (3, 2), (3, 1), (4, 8), (6, 8)]
+
+
+def make_case(ctype, depth, rng):
+    W, H = 37, 23
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    arr = rng.integers(0, 1 << depth, (H, W, ch))
+    palette = rng.integers(0, 256, ((1 << depth), 3)) if ctype == 3 else None
+    scale = {1: 255, 2: 85, 4: 17, 8: 1}[depth]
+    if ctype == 0: rgb = np.repeat(arr[..., :1] * scale, 3, -1)
+    elif ctype == 4: rgb = np.repeat(arr[..., :1], 3, -1)
+    elif ctype == 3: rgb = palette[arr[..., 0]]
+    else: rgb = arr[..., :3]
+    return png_bytes(arr, ctype, depth, palette), rgb.astype(np.uint8)
+
+
+def host_read(path):
+    mipt, host = capi.load()
+    W, H = C.c_int(0), C.c_int(0)
+    buf = (C.c_ubyte * (1 << 22))()
+    err = C.create_string_buffer(256)
+    rc = host.mh_read_image(str(path).encode(), buf, len(buf), C.byref(W), C.byref(H), err, 256)
+    if rc != 0:
+        raise capi.MiptError(err.value.decode())
+    return np.frombuffer(buf, np.uint8, W.value * H.value * 3).reshape(H.value, W.value, 3).copy()
+
+
+@pytest.mark.parametrize("ctype,depth", CASES)
+def test_png_decoding(tmp_path, ctype, depth):
+    data, want = make_case(ctype, depth, np.random.default_rng(100 * ctype + depth))
+    p = tmp_path / f"t_{ctype}_{depth}.png"
+    p.write_bytes(data)
+    assert np.array_equal(host_read(p), want)
+    from oracle import binding
+    if binding.ref_available():                      # the reference's own load_image (stb_image; it flips the rows)
+        R = binding.Ref()
+        W, H = C.c_int(0), C.c_int(0)
+        buf = (C.c_ubyte * (1 << 22))()
+        assert R.lib.ref_load_image(str(p).encode(), buf, len(buf), C.byref(W), C.byref(H)) == 0
+        ref = np.frombuffer(buf, np.uint8, W.value * H.value * 3).reshape(H.value, W.value, 3)[::-1]
+        assert np.array_equal(ref, want)
+
+
+def test_undecodable_images_are_refused(tmp_path):
+    data, _ = make_case(2, 8, np.random.default_rng(1))
+    (tmp_path / "cut.png").write_bytes(data[: len(data) // 2])
+    with pytest.raises(capi.MiptError):
+        host_read(tmp_path / "cut.png")
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))
+    with pytest.raises(capi.MiptError, match="PPM and PNG"):
+        host_read(tmp_path / "x.jpg")
+    ihdr16 = data.replace(struct.pack(">IIBB", 37, 23, 8, 2), struct.pack(">IIBB", 37, 23, 16, 2), 1)
+    (tmp_path / "deep.png").write_bytes(ihdr16)
+    with pytest.raises(capi.MiptError, match="16-bit"):
+        host_read(tmp_path / "deep.png")
