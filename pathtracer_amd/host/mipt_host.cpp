@@ -350,7 +350,44 @@ bool read_png(const std::string& file, std::vector<unsigned char>& rgb, int& W, 
 	return true;
 }
 
-// an 8-bit RGB image by content: binary PPM or PNG (what the reference reads through stb_image without a lossy codec)
+// Windows BMP, the uncompressed kinds (BI_RGB): 24 / 32 bits per pixel and 8-bit palettes, bottom-up or top-down rows;
+// delivered top row first like stb_image does.  Compressed, bit-field and 16-bit files are refused.
+bool read_bmp(const std::string& file, std::vector<unsigned char>& rgb, int& W, int& H, std::string& why) {
+	FILE* f = fopen(file.c_str(), "rb");
+	if (!f) { why = "cannot open"; return false; }
+	std::vector<unsigned char> b;
+	{ unsigned char tmp[65536]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) b.insert(b.end(), tmp, tmp + n); }
+	fclose(f);
+	auto le32 = [&](size_t o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8) | ((unsigned)b[o + 2] << 16) | ((unsigned)b[o + 3] << 24); };
+	auto le16 = [&](size_t o) { return (unsigned)b[o] | ((unsigned)b[o + 1] << 8); };
+	if (b.size() < 54 || b[0] != 'B' || b[1] != 'M') { why = "not a BMP file"; return false; }
+	const unsigned offset = le32(10), hsz = le32(14);
+	if (hsz < 40) { why = "OS/2 BMP headers are not decoded here"; return false; }
+	W = (int)le32(18);
+	int h = (int)le32(22);
+	const bool flip = h > 0;                                   // positive height: rows stored bottom-up
+	H = h < 0 ? -h : h;
+	const unsigned bpp = le16(28), comp = le32(30);
+	if (comp != 0 || !(bpp == 24 || bpp == 32 || bpp == 8)) { why = "only uncompressed 8 / 24 / 32-bit BMP is decoded here"; return false; }
+	if (W <= 0 || H <= 0) { why = "bad BMP size"; return false; }
+	const size_t stride = (((size_t)W * bpp + 31) / 32) * 4;
+	if ((size_t)offset + stride * H > b.size()) { why = "truncated BMP"; return false; }
+	const unsigned char* pal = &b[14 + hsz];
+	unsigned ncol = le32(46); if (bpp == 8 && ncol == 0) ncol = 256;
+	if (bpp == 8 && 14 + (size_t)hsz + 4 * (size_t)ncol > b.size()) { why = "truncated BMP palette"; return false; }
+	rgb.resize((size_t)W * H * 3);
+	for (int y = 0; y < H; y++) {
+		const unsigned char* row = &b[offset + stride * (size_t)(flip ? H - 1 - y : y)];
+		unsigned char* out = &rgb[(size_t)y * W * 3];
+		for (int x = 0; x < W; x++) {
+			if (bpp == 8) { const unsigned i = row[x]; if (i >= ncol) { why = "BMP palette index out of range"; return false; } out[3 * x] = pal[4 * i + 2]; out[3 * x + 1] = pal[4 * i + 1]; out[3 * x + 2] = pal[4 * i]; }
+			else { const unsigned char* px = row + (size_t)x * (bpp / 8); out[3 * x] = px[2]; out[3 * x + 1] = px[1]; out[3 * x + 2] = px[0]; }
+		}
+	}
+	return true;
+}
+
+// an 8-bit RGB image by content: binary PPM, PNG or uncompressed BMP (what the reference reads through stb_image without a lossy codec)
 bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, int& W, int& H, std::string& why) {
 	FILE* f = fopen(file.c_str(), "rb");
 	if (!f) { why = "cannot open"; return false; }
@@ -359,7 +396,8 @@ bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, i
 	fclose(f);
 	if (got >= 2 && magic[0] == 'P' && magic[1] == '6') { if (read_ppm(file, rgb, W, H)) return true; why = "malformed binary PPM (P6, maxval 255 expected)"; return false; }
 	if (got == 4 && magic[0] == 0x89 && magic[1] == 'P' && magic[2] == 'N' && magic[3] == 'G') return read_png(file, rgb, W, H, why);
-	why = "only binary PPM and PNG images are decoded here (JPEG / BMP / TGA / HDR need the reference's codecs)";
+	if (got >= 2 && magic[0] == 'B' && magic[1] == 'M') return read_bmp(file, rgb, W, H, why);
+	why = "only binary PPM, PNG and uncompressed BMP images are decoded here (JPEG / TGA / HDR need the reference's codecs)";
 	return false;
 }
 }  // namespace

@@ -110,9 +110,41 @@ def test_undecodable_images_are_refused(tmp_path):
     with pytest.raises(capi.MiptError):
         host_read(tmp_path / "cut.png")
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))
-    with pytest.raises(capi.MiptError, match="PPM and PNG"):
+    with pytest.raises(capi.MiptError, match="PPM, PNG"):
         host_read(tmp_path / "x.jpg")
     ihdr16 = data.replace(struct.pack(">IIBB", 37, 23, 8, 2), struct.pack(">IIBB", 37, 23, 16, 2), 1)
     (tmp_path / "deep.png").write_bytes(ihdr16)
     with pytest.raises(capi.MiptError, match="16-bit"):
         host_read(tmp_path / "deep.png")
+
+
+@pytest.mark.parametrize("bpp,topdown", [(24, False), (32, False), (24, True), (8, False)])
+def test_bmp_decoding(tmp_path, bpp, topdown):
+    rng = np.random.default_rng(bpp + topdown)
+    W, H = 29, 17                                       # 29 * 3 bytes is not a multiple of 4: rows are padded
+    if bpp == 8:
+        pal = rng.integers(0, 256, (256, 3))
+        idx = rng.integers(0, 256, (H, W))
+        want = pal[idx].astype(np.uint8)
+        pix = idx.astype(np.uint8)[..., None]
+    else:
+        want = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        pix = want[..., ::-1]
+        if bpp == 32:
+            pix = np.concatenate([pix, np.full((H, W, 1), 255, np.uint8)], -1)
+    stride = ((W * bpp + 31) // 32) * 4
+    rows = [pix[y].tobytes().ljust(stride, b"\0") for y in (range(H) if topdown else range(H - 1, -1, -1))]
+    palbytes = b"".join(bytes([int(c[2]), int(c[1]), int(c[0]), 0]) for c in pal) if bpp == 8 else b""
+    offset = 54 + len(palbytes)
+    hdr = b"BM" + struct.pack("<IHHI", offset + stride * H, 0, 0, offset) + struct.pack("<IiiHHIIiiII", 40, W, -H if topdown else H, 1, bpp, 0, stride * H, 2835, 2835, 256 if bpp == 8 else 0, 0)
+    p = tmp_path / "t.bmp"
+    p.write_bytes(hdr + palbytes + b"".join(rows))
+    assert np.array_equal(host_read(p), want)
+    from oracle import binding
+    if binding.ref_available():
+        R = binding.Ref()
+        Wc, Hc = C.c_int(0), C.c_int(0)
+        buf = (C.c_ubyte * (1 << 22))()
+        assert R.lib.ref_load_image(str(p).encode(), buf, len(buf), C.byref(Wc), C.byref(Hc)) == 0
+        ref = np.frombuffer(buf, np.uint8, Wc.value * Hc.value * 3).reshape(Hc.value, Wc.value, 3)[::-1]
+        assert np.array_equal(ref, want)
