@@ -232,6 +232,22 @@ int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j);
  * device memory with 16-byte loads, `repeats` launches timed with HIP events.  Not part of the reference's surface. */
 int mipt_measure_stream_read(mipt_ctx* ctx, uint64_t bytes, int repeats, double* gb_per_s);
 
+/* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
+ * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes
+ * compare equal as floats; a coordinate that is +0 in some vertices and -0 in others may come out with the other sign).
+ *   vertices          nverts x 3 floats, as TriMesh::init leaves them (axis swap, centering) before build_bvh
+ *   tri_vtx, stride   the three vertex indices of triangle i are the ints at tri_vtx + i*tri_stride_bytes: pass
+ *                     &indices[0].vtxi and sizeof(TriangleIndices) (44)
+ *   out_nodes         room for node_capacity nodes (2*ntri always suffices); *out_n_nodes receives the count
+ *   out_perm          ntri ints: position i of the reordered mesh holds input triangle out_perm[i]; the caller applies
+ *                     it to `indices` (and to permuted_triangle_index) exactly as the reference's swaps would have
+ *   out_seconds       optional: device time of the build (HIP events), without the transfers
+ * No context is needed (the scene does not exist yet when TriMesh::init runs); the text of a failure is
+ * mipt_build_bvh_error() (thread local).  MIPT_ERR_NO_DEVICE without a GPU: there is no CPU build behind this entry. */
+int mipt_build_bvh(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri,
+                   mipt_bvh_node* out_nodes, int node_capacity, int* out_n_nodes, int32_t* out_perm, double* out_seconds);
+const char* mipt_build_bvh_error(void);
+
 /* Statistics of the last render call (rays counted like the oracle does, kernel time from HIP
  * events on the render stream). */
 int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);

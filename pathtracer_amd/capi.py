@@ -27,7 +27,8 @@ MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option"]
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
+                "mipt_build_bvh", "mipt_build_bvh_error"]
 
 _f = C.c_float
 _i = C.c_int
@@ -108,6 +109,7 @@ def load():
         getattr(mipt, s)
     mipt.mipt_last_error.restype = C.c_char_p
     mipt.mipt_last_error.argtypes = [C.c_void_p]
+    mipt.mipt_build_bvh_error.restype = C.c_char_p
     host.mh_create.restype = C.c_void_p
     host.mh_last_error.restype = C.c_char_p
     for name in ("mh_ctx", "mh_scene_desc", "mh_render_params", "mh_imagedouble", "mh_sample_count", "mh_image"):
@@ -118,6 +120,30 @@ def load():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def set_bvh_builder(mode, device=0):
+    """Which builder the host mirror's TriMesh::init uses: 'host' (the recursion), 'gpu' (mipt_build_bvh; an error
+    without a device) or 'auto' (GPU when a device is present; default)."""
+    load()[1].mh_set_bvh_builder({"host": 0, "gpu": 1, "auto": 2}[mode], int(device))
+
+
+def build_bvh(vertices, tri_vtx, device=0):
+    """mipt_build_bvh on raw arrays: (nodes_i [n,3] = isleaf/fg/fd, nodes_bb [n,6], perm [ntri], device seconds)."""
+    mipt = load()[0]
+    v = np.ascontiguousarray(vertices, np.float32)
+    t = np.ascontiguousarray(tri_vtx, np.int32)
+    ntri = t.shape[0]
+    nodes = np.zeros((2 * ntri, 9), np.uint32)
+    perm = np.zeros(ntri, np.int32)
+    nn, sec = C.c_int(0), C.c_double(0)
+    rc = mipt.mipt_build_bvh(int(device), _p(v, _f), v.shape[0], t.ctypes.data_as(C.c_void_p), 12, ntri,
+                             nodes.ctypes.data_as(C.c_void_p), nodes.shape[0], C.byref(nn), _p(perm, _i), C.byref(sec))
+    if rc != 0:
+        raise MiptError(rc, mipt.mipt_build_bvh_error().decode())
+    nodes = nodes[: nn.value]
+    nodes_i = np.stack([nodes[:, 0] & 0xff, nodes[:, 1], nodes[:, 2]], 1).astype(np.int32)
+    return nodes_i, nodes[:, 3:9].copy().view(np.float32), perm, sec.value
 
 
 def light_intensity(R, scale=1.0):
@@ -307,6 +333,12 @@ class HostRaytracer:
         t, inv, r = np.zeros(12, np.float32), np.zeros(12, np.float32), np.zeros(9, np.float32)
         self.host.mh_get_object_matrices(self.h, obj, _p(t, _f), _p(inv, _f), _p(r, _f))
         return t, inv, r
+
+    def mesh_bvh_builder(self, obj):
+        """('gpu' | 'host', seconds TriMesh::init spent in build_bvh, device seconds of the GPU build)."""
+        a, b = C.c_double(0), C.c_double(0)
+        who = self.host.mh_mesh_bvh_builder(self.h, obj, C.byref(a), C.byref(b))
+        return ("gpu" if who == 1 else "host"), a.value, b.value
 
     def mesh_dump(self, obj):
         c = [_i(0) for _ in range(5)]

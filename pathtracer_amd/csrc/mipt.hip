@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 
 #include "mipt_wavefront.h"
 #include "mipt_persistent.h"
+#include "mipt_build.h"
 
 // =====================================================================================
 // host side: context, upload, C-ABI
@@ -923,6 +924,154 @@ extern "C" int mipt_measure_stream_read(mipt_ctx* c, uint64_t bytes, int repeats
 	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipFree(sink);
 	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
 	*gb_per_s = (double)bytes * repeats / (ms * 1e-3) / 1e9;
+	return MIPT_OK;
+}
+
+// =====================================================================================
+// BVH construction on the device (mipt_build.h): same nodes, same positions, same triangle order as
+// TriMesh::build_bvh (TriangleMesh.cpp:878-885, 1029-1130)
+// =====================================================================================
+static thread_local std::string g_build_err;
+extern "C" const char* mipt_build_bvh_error(void) { return g_build_err.c_str(); }
+
+namespace {
+struct DevPool {     // device allocations of one build, released on every exit path
+	std::vector<void*> p;
+	~DevPool() { for (void* q : p) hipFree(q); }
+	template <class T> bool get(T** out, size_t count) {
+		void* q = nullptr;
+		if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
+		p.push_back(q); *out = (T*)q; return true;
+	}
+};
+int build_fail(int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	g_build_err = buf;
+	return code;
+}
+}
+#define BHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return build_fail(MIPT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri,
+                              mipt_bvh_node* out_nodes, int node_capacity, int* out_n_nodes, int32_t* out_perm, double* out_seconds) {
+	using namespace bvhb;
+	static_assert(sizeof(ONode) == sizeof(mipt_bvh_node), "node layout");
+	g_build_err.clear();
+	if (!vertices || nverts <= 0 || !tri_vtx || tri_stride_bytes < 12 || ntri <= 0 || !out_nodes || !out_n_nodes || !out_perm) return build_fail(MIPT_ERR_INVALID, "bad arguments");
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return build_fail(MIPT_ERR_NO_DEVICE, "no usable HIP device");
+	BHIP(hipSetDevice(device_id));
+	const int n = ntri;
+	// vertex indices of the triangles, packed (the reference's TriangleIndices records are 44 bytes apart)
+	std::vector<int> tv((size_t)n * 3);
+	{
+		const int nthreads = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
+		std::vector<int> bad(nthreads, 0);
+		auto work = [&](int t) {
+			const int i0 = (int)((long long)n * t / nthreads), i1 = (int)((long long)n * (t + 1) / nthreads);
+			for (int i = i0; i < i1; i++) {
+				const int* q = (const int*)((const char*)tri_vtx + (size_t)i * tri_stride_bytes);
+				for (int k = 0; k < 3; k++) { if (q[k] < 0 || q[k] >= nverts) bad[t] = 1; tv[3 * (size_t)i + k] = q[k]; }
+			}
+		};
+		if (nthreads == 1) work(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+		for (int b : bad) if (b) return build_fail(MIPT_ERR_INVALID, "triangle vertex index out of range");
+	}
+	hipEvent_t e0, e1;
+	BHIP(hipEventCreate(&e0)); BHIP(hipEventCreate(&e1));
+	struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
+	DevPool pool;
+	const int maxseg = n / (BVHB_SMALL + 1) + 2;
+	float* d_vtx; int* d_tv; float4* d_rec; uint32_t *d_order[2], *d_S, *d_tpos, *d_acc, *d_bins, *d_bsum; int* d_segof[2]; uint8_t* d_pf;
+	Seg* d_segs[2]; float* d_planes; LNode* d_ln; int* d_smalls; Counters* d_cnt; ONode *d_sn, *d_out;
+	const int nscanblk = (n + BVHB_SCAN_TILE - 1) / BVHB_SCAN_TILE;
+	bool ok = pool.get(&d_vtx, (size_t)nverts * 3) && pool.get(&d_tv, (size_t)n * 3) && pool.get(&d_rec, (size_t)n * 3)
+	       && pool.get(&d_order[0], n) && pool.get(&d_order[1], n) && pool.get(&d_segof[0], n) && pool.get(&d_segof[1], n)
+	       && pool.get(&d_S, (size_t)n + 1) && pool.get(&d_tpos, n) && pool.get(&d_pf, n) && pool.get(&d_bsum, nscanblk)
+	       && pool.get(&d_segs[0], maxseg) && pool.get(&d_segs[1], maxseg) && pool.get(&d_acc, (size_t)maxseg * 12)
+	       && pool.get(&d_bins, (size_t)maxseg * BVHB_BINWORDS) && pool.get(&d_planes, (size_t)maxseg * (BVHB_NPLANES + 2))
+	       && pool.get(&d_ln, (size_t)2 * n + 2) && pool.get(&d_smalls, (size_t)n + 1) && pool.get(&d_cnt, 1)
+	       && pool.get(&d_sn, (size_t)2 * n + 2) && pool.get(&d_out, (size_t)2 * n + 2);
+	if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for a %d-triangle build", n);
+	BHIP(hipMemcpy(d_vtx, vertices, (size_t)nverts * 12, hipMemcpyHostToDevice));
+	BHIP(hipMemcpy(d_tv, tv.data(), (size_t)n * 12, hipMemcpyHostToDevice));
+	BHIP(hipEventRecord(e0, 0));
+	const bool large_root = n > BVHB_SMALL;
+	const unsigned pos_blocks = (unsigned)((n + 255) / 256);
+	hipLaunchKernelGGL(k_prepare, dim3(pos_blocks), dim3(256), 0, 0, d_vtx, d_tv, n, d_rec, d_order[0], d_segof[0], large_root ? 0 : -1);
+	{
+		LNode root; memset(&root, 0, sizeof root);
+		root.i0 = 0; root.i1 = n; root.left = root.right = -1; root.kind = large_root ? K_PENDING : K_SMALL;
+		BHIP(hipMemcpyAsync(d_ln, &root, sizeof root, hipMemcpyHostToDevice, 0));
+		Seg s0; memset(&s0, 0, sizeof s0); s0.node = 0; s0.i0 = 0; s0.i1 = n;
+		BHIP(hipMemcpyAsync(d_segs[0], &s0, sizeof s0, hipMemcpyHostToDevice, 0));
+		Counters c0 = {1, 0, large_root ? 0 : 1, 0};
+		BHIP(hipMemcpyAsync(d_cnt, &c0, sizeof c0, hipMemcpyHostToDevice, 0));
+		if (!large_root) { int z = 0; BHIP(hipMemcpyAsync(d_smalls, &z, 4, hipMemcpyHostToDevice, 0)); }
+		BHIP(hipStreamSynchronize(0));   // the staging variables go out of scope
+	}
+	// level-synchronous phase
+	std::vector<int> level_begin{0};       // LNode id ranges per level
+	int nseg = large_root ? 1 : 0, ln_count = 1, nsmall = large_root ? 0 : 1, cur = 0, levels = 0;
+	const int gpw = std::max(1, std::min(64, n / (64 * 8192)));
+	const unsigned wave_blocks = (unsigned)(((long long)n + 64LL * gpw - 1) / (64LL * gpw));
+	while (nseg > 0) {
+		if (++levels > 100000) return build_fail(MIPT_ERR_UNSUPPORTED, "degenerate mesh: more than 100000 BVH levels");
+		const unsigned seg_blocks = (unsigned)((nseg + 127) / 128);
+		const size_t init_n = (size_t)nseg * BVHB_BINWORDS;
+		Seg* segs = d_segs[cur]; Seg* next = d_segs[cur ^ 1];
+		hipLaunchKernelGGL(k_lvl_init, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, 0, nseg, d_acc, d_bins);
+		hipLaunchKernelGGL(k_lvl_bounds, dim3(wave_blocks), dim3(64), 0, 0, d_rec, d_order[cur], d_segof[cur], n, gpw, d_acc);
+		hipLaunchKernelGGL(k_lvl_planes, dim3(seg_blocks), dim3(128), 0, 0, nseg, segs, d_acc, d_ln, d_planes);
+		hipLaunchKernelGGL(k_lvl_bin, dim3(wave_blocks), dim3(64), 0, 0, d_rec, d_order[cur], d_segof[cur], n, gpw, segs, d_planes, d_bins);
+		hipLaunchKernelGGL(k_lvl_choose, dim3(seg_blocks), dim3(128), 0, 0, nseg, segs, d_bins, d_planes);
+		hipLaunchKernelGGL(k_scan_sums, dim3(nscanblk), dim3(256), 0, 0, d_rec, d_order[cur], d_segof[cur], n, segs, d_pf, d_bsum);
+		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, 0, d_bsum, nscanblk);
+		hipLaunchKernelGGL(k_scan_apply, dim3(nscanblk), dim3(256), 0, 0, d_pf, n, d_bsum, d_S);
+		hipLaunchKernelGGL(k_lvl_scatter_true, dim3(pos_blocks), dim3(256), 0, 0, d_order[cur], d_segof[cur], n, segs, d_pf, d_S, d_order[cur ^ 1], d_tpos);
+		hipLaunchKernelGGL(k_lvl_scatter_false, dim3(pos_blocks), dim3(256), 0, 0, d_order[cur], d_segof[cur], n, segs, d_pf, d_S, d_order[cur ^ 1], d_tpos, &d_cnt->unresolved);
+		hipLaunchKernelGGL(k_lvl_children, dim3(seg_blocks), dim3(128), 0, 0, nseg, segs, d_S, d_ln, next, d_smalls, d_cnt);
+		hipLaunchKernelGGL(k_lvl_resegment, dim3(pos_blocks), dim3(256), 0, 0, d_segof[cur], n, segs, d_segof[cur ^ 1]);
+		Counters h;
+		BHIP(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
+		for (int round = 0; h.unresolved; round++) {   // long jump chains: double the jump table and walk again
+			if (round > 40) return build_fail(MIPT_ERR_HIP, "partition did not converge");
+			hipLaunchKernelGGL(k_lvl_double, dim3(pos_blocks), dim3(256), 0, 0, d_segof[cur], n, segs, d_S, d_tpos);
+			BHIP(hipMemsetAsync(&d_cnt->unresolved, 0, 4, 0));
+			hipLaunchKernelGGL(k_lvl_scatter_false, dim3(pos_blocks), dim3(256), 0, 0, d_order[cur], d_segof[cur], n, segs, d_pf, d_S, d_order[cur ^ 1], d_tpos, &d_cnt->unresolved);
+			BHIP(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
+		}
+		level_begin.push_back(ln_count);
+		ln_count = h.ln_count; nsmall = h.nsmall; nseg = h.nseg_next;
+		if (nseg > maxseg) return build_fail(MIPT_ERR_HIP, "segment list overflow");
+		BHIP(hipMemsetAsync(&d_cnt->nseg_next, 0, 4, 0));
+		cur ^= 1;
+	}
+	level_begin.push_back(ln_count);
+	if (nsmall > 0) hipLaunchKernelGGL(k_small_subtrees, dim3((unsigned)((nsmall + 63) / 64)), dim3(64), 0, 0, nsmall, d_smalls, d_ln, d_rec, d_order[cur], d_sn);
+	const int nlev = (int)level_begin.size() - 1;
+	for (int L = nlev - 1; L >= 0; L--) {
+		const int b = level_begin[L], e = level_begin[L + 1];
+		if (e > b) hipLaunchKernelGGL(k_sizes, dim3((unsigned)((e - b + 255) / 256)), dim3(256), 0, 0, d_ln, b, e);
+	}
+	for (int L = 0; L < nlev; L++) {
+		const int b = level_begin[L], e = level_begin[L + 1];
+		if (e > b) hipLaunchKernelGGL(k_preorder, dim3((unsigned)((e - b + 255) / 256)), dim3(256), 0, 0, d_ln, b, e);
+	}
+	hipLaunchKernelGGL(k_emit, dim3((unsigned)((ln_count + 127) / 128)), dim3(128), 0, 0, d_ln, ln_count, d_sn, d_out);
+	BHIP(hipEventRecord(e1, 0));
+	LNode root;
+	BHIP(hipMemcpy(&root, d_ln, sizeof root, hipMemcpyDeviceToHost));
+	BHIP(hipGetLastError());
+	const int total = root.size;
+	if (total <= 0 || total > 2 * n) return build_fail(MIPT_ERR_HIP, "inconsistent node count %d", total);
+	if (total > node_capacity) return build_fail(MIPT_ERR_INVALID, "node_capacity %d is too small for %d nodes", node_capacity, total);
+	BHIP(hipMemcpy(out_nodes, d_out, (size_t)total * sizeof(ONode), hipMemcpyDeviceToHost));
+	BHIP(hipMemcpy(out_perm, d_order[cur], (size_t)n * 4, hipMemcpyDeviceToHost));
+	*out_n_nodes = total;
+	if (out_seconds) { float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); *out_seconds = ms * 1e-3; }
 	return MIPT_OK;
 }
 

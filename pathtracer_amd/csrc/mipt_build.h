@@ -1,0 +1,510 @@
+// mipt_build.h — construction of the reference's BVH on the GPU.
+//
+// The tree is the one TriMesh::build_bvh / build_bvh_recur make (TriangleMesh.cpp:878-885, 1029-1130):
+//   node box = box of the vertices of triangles [i0,i1); split axis = longest axis of the box of the centroids
+//   ((A+B)+C)/3.f; 16 candidate planes at cb + diag*(t+1)/17; cost = area(L)*n_L + area(R)*n_R with a triangle on the
+//   left when centroid <= plane; first strict minimum wins; in-place partition; leaf when one side is empty or
+//   i1 <= i0+4; nodes pushed in preorder.
+// Everything except the partition is a min/max/count reduction, so it does not depend on the order triangles are
+// visited in and maps onto level-synchronous data-parallel passes.  The partition is order dependent:
+//     pivot = i0-1; for i in [i0,i1): if pred(i) { pivot++; swap(a[i], a[pivot]); }
+// keeps the pred-true elements in their order, but the pred-false ones behave like a FIFO whose front is moved to the
+// back by every true element that arrives while it is non-empty.  Closed form used here: with T[k] the position of the
+// k-th true element, the true element at x ends at i0 + rank(x), and a false element at x keeps jumping
+// x -> T[x - i0] while x - i0 < n_true (it is the one sitting at the pivot slot when that true element arrives).
+//
+// Segments larger than BVHB_SMALL triangles are processed level by level, all segments of a level at once (one pass
+// over the triangle positions per step, atomics into per-segment accumulators with per-wave run aggregation).
+// Segments of at most BVHB_SMALL triangles are finished by one thread each, which runs the reference's serial recursion
+// literally on its own index range.  Node numbers are assigned afterwards from subtree sizes (preorder = the
+// reference's push_back order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BVHB_SMALL 32          // subtrees of at most this many triangles are built by one thread
+#define BVHB_NPLANES 16
+#define BVHB_NBINS 17
+#define BVHB_BINWORDS (BVHB_NBINS * 7)
+#define BVHB_WALK_CAP 64       // jumps a false element may take before the pointer-doubling fallback is used
+
+namespace bvhb {
+
+enum { K_PENDING = 0, K_INNER = 1, K_LEAF = 2, K_SMALL = 3 };
+
+struct LNode {                 // node of the level-synchronous phase (level order)
+	float bb[6];
+	int i0, i1;
+	int left, right;           // LNode ids of the children (K_INNER)
+	int kind;
+	int size;                  // nodes in the subtree
+	int pre;                   // preorder number = index in the reference's node vector
+	int _pad;
+};
+
+struct Seg {                   // a segment of the current level
+	int node;                  // LNode id
+	int i0, i1;
+	int dim;
+	float split;
+	int ntrue;
+	int lseg, rseg;            // segment ids of the children in the next level (-1: not a large segment)
+};
+
+struct ONode { uint8_t isleaf; uint8_t _pad[3]; int32_t fg, fd; float bmin[3], bmax[3]; };   // = mipt_bvh_node
+
+// order-preserving float <-> uint32 map for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t fenc(float f) { uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float fdec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }
+__device__ __forceinline__ float fmin_ref(float o, float v) { return (v < o) ? v : o; }   // std::min(o, v)
+__device__ __forceinline__ float fmax_ref(float o, float v) { return (o < v) ? v : o; }   // std::max(o, v)
+
+// Per-triangle record: centroid + box of the three vertices, 48 B.
+//   r0 = (cx, cy, cz, minx), r1 = (miny, minz, maxx, maxy), r2 = (maxz, -, -, -)
+struct TriRec { float c[3], mn[3], mx[3]; };
+__device__ __forceinline__ TriRec load_rec(const float4* __restrict__ rec, uint32_t id) {
+	const float4 a = rec[3 * (size_t)id], b = rec[3 * (size_t)id + 1], c = rec[3 * (size_t)id + 2];
+	TriRec r;
+	r.c[0] = a.x; r.c[1] = a.y; r.c[2] = a.z; r.mn[0] = a.w; r.mn[1] = b.x; r.mn[2] = b.y; r.mx[0] = b.z; r.mx[1] = b.w; r.mx[2] = c.x;
+	return r;
+}
+__device__ __forceinline__ float load_centroid(const float4* __restrict__ rec, uint32_t id, int dim) {
+	const float4 a = rec[3 * (size_t)id];
+	return dim == 0 ? a.x : (dim == 1 ? a.y : a.z);
+}
+
+__global__ void k_prepare(const float* __restrict__ vtx, const int* __restrict__ tv, int n, float4* __restrict__ rec,
+                          uint32_t* __restrict__ order, int* __restrict__ segof, int rootseg) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int a = tv[3 * (size_t)i], b = tv[3 * (size_t)i + 1], c = tv[3 * (size_t)i + 2];
+	float cen[3], mn[3], mx[3];
+	for (int k = 0; k < 3; k++) {
+		const float A = vtx[3 * (size_t)a + k], B = vtx[3 * (size_t)b + k], C = vtx[3 * (size_t)c + k];
+		cen[k] = ((A + B) + C) / 3.f;
+		mn[k] = fmin_ref(fmin_ref(A, B), C);
+		mx[k] = fmax_ref(fmax_ref(A, B), C);
+	}
+	rec[3 * (size_t)i] = make_float4(cen[0], cen[1], cen[2], mn[0]);
+	rec[3 * (size_t)i + 1] = make_float4(mn[1], mn[2], mx[0], mx[1]);
+	rec[3 * (size_t)i + 2] = make_float4(mx[2], 0.f, 0.f, 0.f);
+	order[i] = (uint32_t)i;
+	segof[i] = rootseg;
+}
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+// ---- step A: box of the vertices and box of the centroids of every segment ----------------------------------------
+// One wave per block; a wave walks `gpw` groups of 64 consecutive positions.  While all 64 positions of a group belong
+// to the segment of the current run the lanes accumulate privately; the run is flushed (wave reduction + 12 atomics)
+// when the segment changes.  Groups that straddle segments fall back to per-lane atomics.
+__global__ __launch_bounds__(64) void k_lvl_bounds(const float4* __restrict__ rec, const uint32_t* __restrict__ order, const int* __restrict__ segof,
+                                                   int n, int gpw, uint32_t* __restrict__ acc) {
+	const int lane = threadIdx.x;
+	const long long base = (long long)blockIdx.x * gpw * 64;
+	int run = -1;
+	float mn[3], mx[3], cmn[3], cmx[3];
+	auto reset = [&] { for (int k = 0; k < 3; k++) { mn[k] = cmn[k] = INFINITY; mx[k] = cmx[k] = -INFINITY; } };
+	auto flush = [&] {
+		if (run < 0) return;
+		uint32_t* a = acc + 12 * (size_t)run;
+		for (int k = 0; k < 3; k++) {
+			const float v0 = wave_min(mn[k]), v1 = wave_max(mx[k]), v2 = wave_min(cmn[k]), v3 = wave_max(cmx[k]);
+			if (lane == 0) { atomicMin(a + k, fenc(v0)); atomicMax(a + 3 + k, fenc(v1)); atomicMin(a + 6 + k, fenc(v2)); atomicMax(a + 9 + k, fenc(v3)); }
+		}
+	};
+	reset();
+	for (int g = 0; g < gpw; g++) {
+		const long long x = base + (long long)g * 64 + lane;
+		const int s = (x < n) ? segof[x] : -1;
+		const int s0 = __builtin_amdgcn_readfirstlane(s);
+		if (__all(s == s0)) {
+			if (s0 != run) { flush(); reset(); run = s0; }
+			if (s0 >= 0) {
+				const TriRec r = load_rec(rec, order[x]);
+				for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], r.mn[k]); mx[k] = fmaxf(mx[k], r.mx[k]); cmn[k] = fminf(cmn[k], r.c[k]); cmx[k] = fmaxf(cmx[k], r.c[k]); }
+			}
+		} else {
+			flush(); reset(); run = -1;
+			if (s >= 0) {
+				const TriRec r = load_rec(rec, order[x]);
+				uint32_t* a = acc + 12 * (size_t)s;
+				for (int k = 0; k < 3; k++) { atomicMin(a + k, fenc(r.mn[k])); atomicMax(a + 3 + k, fenc(r.mx[k])); atomicMin(a + 6 + k, fenc(r.c[k])); atomicMax(a + 9 + k, fenc(r.c[k])); }
+			}
+		}
+	}
+	flush();
+}
+
+__global__ void k_lvl_init(int nseg, uint32_t* __restrict__ acc, uint32_t* __restrict__ bins) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < (size_t)nseg * 12) acc[i] = ((i % 12) % 6 < 3) ? 0xffffffffu : 0u;
+	if (i < (size_t)nseg * BVHB_BINWORDS) {
+		const int w = (int)(i % 7);   // 0..2 min, 3..5 max, 6 count; the reference starts from +-1E10 (TriangleMesh.cpp:1061-1064)
+		bins[i] = w < 3 ? fenc(1E10f) : (w < 6 ? fenc(-1E10f) : 0u);
+	}
+}
+
+// ---- step B: node box, split axis and the 16 candidate planes of every segment -------------------------------------
+__global__ void k_lvl_planes(int nseg, Seg* __restrict__ segs, const uint32_t* __restrict__ acc, LNode* __restrict__ ln, float* __restrict__ planes) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	const uint32_t* a = acc + 12 * (size_t)s;
+	LNode& nd = ln[segs[s].node];
+	for (int k = 0; k < 6; k++) nd.bb[k] = fdec(a[k]);
+	float cb[6];
+	for (int k = 0; k < 6; k++) cb[k] = fdec(a[6 + k]);
+	const float diag[3] = {cb[3] - cb[0], cb[4] - cb[1], cb[5] - cb[2]};
+	int dim;
+	if (diag[0] >= diag[1] && diag[0] >= diag[2]) dim = 0;
+	else if (diag[1] >= diag[0] && diag[1] >= diag[2]) dim = 1;
+	else dim = 2;
+	segs[s].dim = dim;
+	float* p = planes + (size_t)s * (BVHB_NPLANES + 2);
+	for (int t = 0; t < BVHB_NPLANES; t++) p[t] = cb[dim] + diag[dim] * ((t + 1) / (float)(BVHB_NPLANES + 1));
+	p[BVHB_NPLANES] = cb[dim];
+	p[BVHB_NPLANES + 1] = diag[dim];
+}
+
+// ---- step C: triangles binned by the number of planes their centroid lies beyond ----------------------------------
+// centroid <= plane[t] is monotone in t (planes are non-decreasing), so the left set of plane t is bins 0..t.
+__global__ __launch_bounds__(64) void k_lvl_bin(const float4* __restrict__ rec, const uint32_t* __restrict__ order, const int* __restrict__ segof,
+                                                int n, int gpw, const Seg* __restrict__ segs, const float* __restrict__ planes, uint32_t* __restrict__ bins) {
+	__shared__ uint32_t lb[BVHB_BINWORDS];
+	const int lane = threadIdx.x;
+	const long long base = (long long)blockIdx.x * gpw * 64;
+	int run = -1, dim = 0;
+	float sv[BVHB_NPLANES];
+	auto init_lds = [&] {
+		for (int i = lane; i < BVHB_BINWORDS; i += 64) { const int w = i % 7; lb[i] = w < 3 ? fenc(1E10f) : (w < 6 ? fenc(-1E10f) : 0u); }
+		__syncthreads();
+	};
+	auto flush = [&] {
+		if (run < 0) return;
+		__syncthreads();
+		uint32_t* b = bins + (size_t)run * BVHB_BINWORDS;
+		for (int i = lane; i < BVHB_BINWORDS; i += 64) {
+			const int w = i % 7;
+			const uint32_t v = lb[i];
+			if (w < 3) { if (v != fenc(1E10f)) atomicMin(b + i, v); }
+			else if (w < 6) { if (v != fenc(-1E10f)) atomicMax(b + i, v); }
+			else if (v) atomicAdd(b + i, v);
+		}
+		__syncthreads();
+		init_lds();
+	};
+	init_lds();
+	for (int g = 0; g < gpw; g++) {
+		const long long x = base + (long long)g * 64 + lane;
+		const int s = (x < n) ? segof[x] : -1;
+		const int s0 = __builtin_amdgcn_readfirstlane(s);
+		if (__all(s == s0)) {
+			if (s0 != run) {
+				flush(); run = s0;
+				if (s0 >= 0) { dim = segs[s0].dim; for (int t = 0; t < BVHB_NPLANES; t++) sv[t] = planes[(size_t)s0 * (BVHB_NPLANES + 2) + t]; }
+			}
+			if (s0 >= 0) {
+				const TriRec r = load_rec(rec, order[x]);
+				const float c = dim == 0 ? r.c[0] : (dim == 1 ? r.c[1] : r.c[2]);
+				int b = 0;
+				for (int t = 0; t < BVHB_NPLANES; t++) b += (c <= sv[t]) ? 0 : 1;
+				uint32_t* q = lb + b * 7;
+				for (int k = 0; k < 3; k++) { atomicMin(q + k, fenc(r.mn[k])); atomicMax(q + 3 + k, fenc(r.mx[k])); }
+				atomicAdd(q + 6, 1u);
+			}
+		} else {
+			flush(); run = -1;
+			if (s >= 0) {
+				const TriRec r = load_rec(rec, order[x]);
+				const int d = segs[s].dim;
+				const float c = d == 0 ? r.c[0] : (d == 1 ? r.c[1] : r.c[2]);
+				const float* p = planes + (size_t)s * (BVHB_NPLANES + 2);
+				int b = 0;
+				for (int t = 0; t < BVHB_NPLANES; t++) b += (c <= p[t]) ? 0 : 1;
+				uint32_t* q = bins + (size_t)s * BVHB_BINWORDS + b * 7;
+				for (int k = 0; k < 3; k++) { atomicMin(q + k, fenc(r.mn[k])); atomicMax(q + 3 + k, fenc(r.mx[k])); }
+				atomicAdd(q + 6, 1u);
+			}
+		}
+	}
+	flush();
+}
+
+__device__ __forceinline__ float box_area(const float* mn, const float* mx) {
+	const float s0 = mx[0] - mn[0], s1 = mx[1] - mn[1], s2 = mx[2] - mn[2];
+	return 2 * (s0 * s1 + s0 * s2 + s1 * s2);
+}
+
+// ---- step D: cost of the 16 planes from the bins, first strict minimum (TriangleMesh.cpp:1052-1090) ----------------
+__global__ void k_lvl_choose(int nseg, Seg* __restrict__ segs, const uint32_t* __restrict__ bins, const float* __restrict__ planes) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	const uint32_t* b = bins + (size_t)s * BVHB_BINWORDS;
+	const float* p = planes + (size_t)s * (BVHB_NPLANES + 2);
+	float best_factor = 0.5f, best = INFINITY;   // 1E50 narrowed to float
+	for (int t = 0; t < BVHB_NPLANES; t++) {
+		float lmn[3] = {1E10f, 1E10f, 1E10f}, lmx[3] = {-1E10f, -1E10f, -1E10f}, rmn[3] = {1E10f, 1E10f, 1E10f}, rmx[3] = {-1E10f, -1E10f, -1E10f};
+		int nl = 0, nr = 0;
+		for (int j = 0; j < BVHB_NBINS; j++) {
+			const uint32_t* q = b + j * 7;
+			if (j <= t) { for (int k = 0; k < 3; k++) { lmn[k] = fminf(lmn[k], fdec(q[k])); lmx[k] = fmaxf(lmx[k], fdec(q[3 + k])); } nl += (int)q[6]; }
+			else        { for (int k = 0; k < 3; k++) { rmn[k] = fminf(rmn[k], fdec(q[k])); rmx[k] = fmaxf(rmx[k], fdec(q[3 + k])); } nr += (int)q[6]; }
+		}
+		const float cost = box_area(lmn, lmx) * nl + box_area(rmn, rmx) * nr;
+		if (cost < best) { best = cost; best_factor = (t + 1) / (float)(BVHB_NPLANES + 1); }
+	}
+	segs[s].split = p[BVHB_NPLANES] + p[BVHB_NPLANES + 1] * best_factor;
+}
+
+// ---- step E/F: pred (centroid <= split) and its exclusive prefix sum over all positions ---------------------------
+#define BVHB_SCAN_ROWS 16
+#define BVHB_SCAN_TILE (256 * BVHB_SCAN_ROWS)
+
+__global__ __launch_bounds__(256) void k_scan_sums(const float4* __restrict__ rec, const uint32_t* __restrict__ order, const int* __restrict__ segof, int n,
+                                                   const Seg* __restrict__ segs, uint8_t* __restrict__ pf, uint32_t* __restrict__ bsum) {
+	__shared__ uint32_t ws[4];
+	const size_t base = (size_t)blockIdx.x * BVHB_SCAN_TILE;
+	uint32_t cnt = 0;
+	for (int j = 0; j < BVHB_SCAN_ROWS; j++) {
+		const size_t x = base + (size_t)j * 256 + threadIdx.x;
+		if (x >= (size_t)n) break;
+		const int s = segof[x];
+		uint8_t p = 0;
+		if (s >= 0) p = load_centroid(rec, order[x], segs[s].dim) <= segs[s].split ? 1 : 0;
+		pf[x] = p;
+		cnt += p;
+	}
+	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+	__syncthreads();
+	if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ bsum, int nb) {   // exclusive scan of the block sums, one block
+	__shared__ uint32_t ws[16];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = 0; base < nb; base += 1024) {
+		const int i = base + threadIdx.x;
+		const uint32_t v = i < nb ? bsum[i] : 0;
+		uint32_t incl = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += t; }
+		if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += ws[w];
+		const uint32_t c = carry;
+		if (i < nb) bsum[i] = c + woff + incl - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = c + woff + incl;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint8_t* __restrict__ pf, int n, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ S) {
+	__shared__ uint32_t ws[4];
+	const size_t base = (size_t)blockIdx.x * BVHB_SCAN_TILE;
+	uint32_t carry = bsum[blockIdx.x];
+	for (int j = 0; j < BVHB_SCAN_ROWS; j++) {
+		const size_t x = base + (size_t)j * 256 + threadIdx.x;
+		const uint32_t v = x < (size_t)n ? pf[x] : 0;
+		uint32_t incl = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += t; }
+		if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += ws[w];
+		const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
+		if (x < (size_t)n) {
+			S[x] = carry + woff + incl - v;
+			if (x == (size_t)n - 1) S[n] = carry + woff + incl;
+		}
+		carry += total;
+		__syncthreads();
+	}
+}
+
+// ---- step G/H: the reference's in-place partition as a scatter -----------------------------------------------------
+__global__ void k_lvl_scatter_true(const uint32_t* __restrict__ order, const int* __restrict__ segof, int n, const Seg* __restrict__ segs,
+                                   const uint8_t* __restrict__ pf, const uint32_t* __restrict__ S, uint32_t* __restrict__ order2, uint32_t* __restrict__ tpos) {
+	const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= (size_t)n) return;
+	const int s = segof[x];
+	if (s < 0) { order2[x] = order[x]; return; }
+	if (!pf[x]) return;
+	const int i0 = segs[s].i0;
+	const uint32_t d = (uint32_t)i0 + (S[x] - S[i0]);
+	order2[d] = order[x];
+	tpos[d] = (uint32_t)x;
+}
+
+__global__ void k_lvl_scatter_false(const uint32_t* __restrict__ order, const int* __restrict__ segof, int n, const Seg* __restrict__ segs,
+                                    const uint8_t* __restrict__ pf, const uint32_t* __restrict__ S, uint32_t* __restrict__ order2,
+                                    const uint32_t* __restrict__ tpos, int* __restrict__ unresolved) {
+	const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= (size_t)n) return;
+	const int s = segof[x];
+	if (s < 0 || pf[x]) return;
+	const uint32_t lim = (uint32_t)segs[s].i0 + (S[segs[s].i1] - S[segs[s].i0]);
+	uint32_t y = (uint32_t)x;
+	for (int step = 0; y < lim; step++) {
+		if (step == BVHB_WALK_CAP) { atomicOr(unresolved, 1); return; }
+		y = tpos[y];
+	}
+	order2[y] = order[x];
+}
+
+// pointer doubling over the jump table (fallback for long chains: a few false elements in front of many true ones)
+__global__ void k_lvl_double(const int* __restrict__ segof, int n, const Seg* __restrict__ segs, const uint32_t* __restrict__ S, uint32_t* __restrict__ tpos) {
+	const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= (size_t)n) return;
+	const int s = segof[x];
+	if (s < 0) return;
+	const uint32_t lim = (uint32_t)segs[s].i0 + (S[segs[s].i1] - S[segs[s].i0]);
+	if (x >= lim) return;
+	const uint32_t y = tpos[x];
+	if (y < lim && y != x) tpos[x] = tpos[y];   // any value read here is a later point of the same chain
+}
+
+// ---- step I/J: leaf test, children, next level's segments ---------------------------------------------------------
+struct Counters { int ln_count, nseg_next, nsmall, unresolved; };
+
+__global__ void k_lvl_children(int nseg, Seg* __restrict__ segs, const uint32_t* __restrict__ S, LNode* __restrict__ ln, Seg* __restrict__ next,
+                               int* __restrict__ smalls, Counters* __restrict__ cnt) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	Seg& g = segs[s];
+	const int nt = (int)(S[g.i1] - S[g.i0]), n = g.i1 - g.i0;
+	g.ntrue = nt; g.lseg = g.rseg = -1;
+	LNode& nd = ln[g.node];
+	if (nt == 0 || nt == n || n <= 4) { nd.kind = K_LEAF; nd.size = 1; return; }   // pivot < i0 || pivot >= i1-1 || i1 <= i0+4
+	nd.kind = K_INNER;
+	const int l = atomicAdd(&cnt->ln_count, 2);
+	nd.left = l; nd.right = l + 1;
+	for (int c = 0; c < 2; c++) {
+		const int a = c ? g.i0 + nt : g.i0, b = c ? g.i1 : g.i0 + nt;
+		LNode& ch = ln[l + c];
+		ch.i0 = a; ch.i1 = b; ch.left = ch.right = -1; ch.size = 0; ch.pre = 0;
+		if (b - a > BVHB_SMALL) {
+			ch.kind = K_PENDING;
+			const int q = atomicAdd(&cnt->nseg_next, 1);
+			next[q].node = l + c; next[q].i0 = a; next[q].i1 = b;
+			if (c) g.rseg = q; else g.lseg = q;
+		} else {
+			ch.kind = K_SMALL;
+			smalls[atomicAdd(&cnt->nsmall, 1)] = l + c;
+		}
+	}
+}
+
+__global__ void k_lvl_resegment(const int* __restrict__ segof, int n, const Seg* __restrict__ segs, int* __restrict__ segof2) {
+	const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= (size_t)n) return;
+	const int s = segof[x];
+	int r = -1;
+	if (s >= 0) r = ((int)x < segs[s].i0 + segs[s].ntrue) ? segs[s].lseg : segs[s].rseg;
+	segof2[x] = r;
+}
+
+// ---- small subtrees: the reference's recursion, one thread per subtree --------------------------------------------
+__global__ void k_small_subtrees(int nsmall, const int* __restrict__ smalls, LNode* __restrict__ ln, const float4* __restrict__ rec,
+                                 uint32_t* __restrict__ order, ONode* __restrict__ sn) {
+	const int q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nsmall) return;
+	LNode& root = ln[smalls[q]];
+	ONode* out = sn + 2 * (size_t)root.i0;         // a subtree over m triangles has at most 2m-1 nodes
+	int count = 0;
+	int stk[BVHB_SMALL + 2][3];                     // (i0, i1, parent << 1 | side)
+	int sp = 0;
+	stk[0][0] = root.i0; stk[0][1] = root.i1; stk[0][2] = -1; sp = 1;
+	while (sp > 0) {
+		sp--;
+		const int i0 = stk[sp][0], i1 = stk[sp][1], link = stk[sp][2];
+		const int node = count++;
+		if (link >= 0) { if (link & 1) out[link >> 1].fd = node; else out[link >> 1].fg = node; }
+		// build_bbox + build_centers_bbox (TriangleMesh.cpp:843-875)
+		float bmn[3], bmx[3], cmn[3], cmx[3];
+		{
+			const TriRec r = load_rec(rec, order[i0]);
+			for (int k = 0; k < 3; k++) { bmn[k] = r.mn[k]; bmx[k] = r.mx[k]; cmn[k] = cmx[k] = r.c[k]; }
+		}
+		for (int i = i0 + 1; i < i1; i++) {
+			const TriRec r = load_rec(rec, order[i]);
+			for (int k = 0; k < 3; k++) { bmn[k] = fmin_ref(bmn[k], r.mn[k]); bmx[k] = fmax_ref(bmx[k], r.mx[k]); cmn[k] = fmin_ref(cmn[k], r.c[k]); cmx[k] = fmax_ref(cmx[k], r.c[k]); }
+		}
+		ONode o;
+		o.isleaf = 1; o._pad[0] = o._pad[1] = o._pad[2] = 0; o.fg = i0; o.fd = i1;
+		for (int k = 0; k < 3; k++) { o.bmin[k] = bmn[k]; o.bmax[k] = bmx[k]; }
+		const float diag[3] = {cmx[0] - cmn[0], cmx[1] - cmn[1], cmx[2] - cmn[2]};
+		int dim;
+		if (diag[0] >= diag[1] && diag[0] >= diag[2]) dim = 0;
+		else if (diag[1] >= diag[0] && diag[1] >= diag[2]) dim = 1;
+		else dim = 2;
+		const float cb = dim == 0 ? cmn[0] : (dim == 1 ? cmn[1] : cmn[2]);
+		const float dg = dim == 0 ? diag[0] : (dim == 1 ? diag[1] : diag[2]);
+		float best_factor = 0.5f, best = INFINITY;
+		for (int t = 0; t < BVHB_NPLANES; t++) {
+			const float factor = (t + 1) / (float)(BVHB_NPLANES + 1);
+			const float sv = cb + dg * factor;
+			float lmn[3] = {1E10f, 1E10f, 1E10f}, lmx[3] = {-1E10f, -1E10f, -1E10f}, rmn[3] = {1E10f, 1E10f, 1E10f}, rmx[3] = {-1E10f, -1E10f, -1E10f};
+			int nl = 0, nr = 0;
+			for (int i = i0; i < i1; i++) {
+				const TriRec r = load_rec(rec, order[i]);
+				const float c = dim == 0 ? r.c[0] : (dim == 1 ? r.c[1] : r.c[2]);
+				if (c <= sv) { for (int k = 0; k < 3; k++) { lmn[k] = fmin_ref(lmn[k], r.mn[k]); lmx[k] = fmax_ref(lmx[k], r.mx[k]); } nl++; }
+				else         { for (int k = 0; k < 3; k++) { rmn[k] = fmin_ref(rmn[k], r.mn[k]); rmx[k] = fmax_ref(rmx[k], r.mx[k]); } nr++; }
+			}
+			const float cost = box_area(lmn, lmx) * nl + box_area(rmn, rmx) * nr;
+			if (cost < best) { best = cost; best_factor = factor; }
+		}
+		const float split = cb + dg * best_factor;
+		int pivot = i0 - 1;
+		for (int i = i0; i < i1; i++) {
+			const uint32_t id = order[i];
+			if (load_centroid(rec, id, dim) <= split) { pivot++; const uint32_t o2 = order[pivot]; order[pivot] = id; order[i] = o2; }
+		}
+		if (!(pivot < i0 || pivot >= i1 - 1 || i1 <= i0 + 4)) {
+			o.isleaf = 0;
+			stk[sp][0] = pivot + 1; stk[sp][1] = i1; stk[sp][2] = (node << 1) | 1; sp++;   // right is popped after the whole left subtree
+			stk[sp][0] = i0; stk[sp][1] = pivot + 1; stk[sp][2] = (node << 1); sp++;
+		}
+		out[node] = o;
+	}
+	root.size = count;
+}
+
+// ---- node numbering: subtree sizes bottom-up, preorder numbers top-down, emission ---------------------------------
+__global__ void k_sizes(LNode* __restrict__ ln, int begin, int end) {
+	const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= end) return;
+	if (ln[i].kind == K_INNER) ln[i].size = 1 + ln[ln[i].left].size + ln[ln[i].right].size;
+}
+__global__ void k_preorder(LNode* __restrict__ ln, int begin, int end) {
+	const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= end) return;
+	if (ln[i].kind == K_INNER) { ln[ln[i].left].pre = ln[i].pre + 1; ln[ln[i].right].pre = ln[i].pre + 1 + ln[ln[i].left].size; }
+}
+__global__ void k_emit(const LNode* __restrict__ ln, int nln, const ONode* __restrict__ sn, ONode* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nln) return;
+	const LNode& nd = ln[i];
+	if (nd.kind == K_SMALL) {
+		const ONode* src = sn + 2 * (size_t)nd.i0;
+		for (int j = 0; j < nd.size; j++) {
+			ONode o = src[j];
+			if (!o.isleaf) { o.fg += nd.pre; o.fd += nd.pre; }
+			out[nd.pre + j] = o;
+		}
+		return;
+	}
+	ONode o;
+	o._pad[0] = o._pad[1] = o._pad[2] = 0;
+	for (int k = 0; k < 3; k++) { o.bmin[k] = nd.bb[k]; o.bmax[k] = nd.bb[3 + k]; }
+	if (nd.kind == K_INNER) { o.isleaf = 0; o.fg = ln[nd.left].pre; o.fd = ln[nd.right].pre; }
+	else { o.isleaf = 1; o.fg = nd.i0; o.fd = nd.i1; }
+	out[nd.pre] = o;
+}
+
+}   // namespace bvhb

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <chrono>
 #include <thread>
 #include <zlib.h>
 
@@ -125,6 +126,11 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 	finish_init(center);
 }
 
+// which builder TriMesh::init uses: 0 = host recursion, 1 = GPU (an error if there is no device), 2 = GPU when a device
+// is present, host recursion otherwise (default)
+static int g_bvh_builder_mode = 2, g_bvh_builder_device = 0;
+extern "C" void mh_set_bvh_builder(int mode, int device) { g_bvh_builder_mode = mode; g_bvh_builder_device = device; }
+
 // contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
 template <class F>
 static void parallel_for(int n, F f) {
@@ -158,10 +164,19 @@ void TriMesh::finish_init(bool center) {
 	}
 	permuted_triangle_index.resize(nf);
 	for (int i = 0; i < nf; i++) permuted_triangle_index[i] = i;
-	// build_bvh (:878-885)
+	// build_bvh (:878-885): on the GPU (mipt_build_bvh, same tree and triangle order) or with the host recursion below
 	build_bbox(0, nf, bvh.bbox);
-	bvh.nodes.reserve((size_t)nf * 2);
-	build_bvh_recur(bvh.nodes, 0, nf, 0);
+	const auto t_build = std::chrono::steady_clock::now();
+	bvh_builder = 0;
+	if (g_bvh_builder_mode != 0 && !build_bvh_gpu()) {
+		if (g_bvh_builder_mode == 1 || !bvh_gpu_unavailable) { loaded = false; return; }   // forced, or a real failure: say so
+	}
+	if (!bvh_builder) {
+		bvh.nodes.clear();
+		bvh.nodes.reserve((size_t)nf * 2);
+		build_bvh_recur(bvh.nodes, 0, nf, 0);
+	}
+	bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
 	build_bbox(0, nf, bbox);
 	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
 	triangleSoup.resize(nf);
@@ -533,6 +548,31 @@ void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
 // references relative to that vector) and spliced behind the left subtree afterwards — preorder
 // positions are then exactly what the serial push_back order gives.  The 16 candidate planes of a
 // large node are evaluated concurrently as well (the first minimum in plane order wins, as in the loop).
+// mipt_build_bvh (include/mipt.h) in place of the recursion: the device returns the node vector and the permutation
+// the reference's swaps produce; it is applied to `indices` / `permuted_triangle_index` here.
+bool TriMesh::build_bvh_gpu() {
+	const int nf = (int)indices.size();
+	std::vector<BVHNodes> nodes((size_t)nf * 2);
+	std::vector<int32_t> perm(nf);
+	int nn = 0;
+	double dev_s = 0;
+	const int rc = mipt_build_bvh(g_bvh_builder_device, &vertices[0][0], (int)vertices.size(), &indices[0].vtxi, (int)sizeof(mipt_triangle_indices), nf,
+	                              reinterpret_cast<mipt_bvh_node*>(nodes.data()), (int)nodes.size(), &nn, perm.data(), &dev_s);
+	if (rc != MIPT_OK) {
+		bvh_gpu_unavailable = (rc == MIPT_ERR_NO_DEVICE);
+		load_error = std::string("mipt_build_bvh: ") + mipt_build_bvh_error();
+		return false;
+	}
+	nodes.resize(nn);
+	bvh.nodes.swap(nodes);
+	std::vector<mipt_triangle_indices> src(indices);
+	parallel_for(nf, [&](int i0, int i1) { for (int i = i0; i < i1; i++) { indices[i] = src[perm[i]]; permuted_triangle_index[i] = perm[i]; } });
+	bvh_builder = 1;
+	bvh_device_seconds = dev_s;
+	load_error.clear();
+	return true;
+}
+
 namespace {
 int kParallelSubtree = 1 << 15;      // ranges above this many triangles fork
 int kParallelPlanes = 1 << 18;       // ranges above this evaluate the candidate planes on threads
@@ -1223,6 +1263,7 @@ const float* mh_group_texture_values(mh_raytracer* h, int obj, int grp, int slot
 int mh_add_mesh(mh_raytracer* h, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs, int nf, const int* fv, const int* fn, const int* ft, float scale, int center) {
 	Raytracer& r = h->rt;
 	TriMesh* g = new TriMesh(nv, verts, nn, normals, nt, uvs, nf, fv, fn, ft, center != 0);
+	if (!g->loaded) { r.set_error(g->load_error); delete g; return -1; }
 	g->scale = scale;   // GUI placement, mainApp.cpp:2402-2410
 	g->max_translation = Vector(0, r.s.objects[2]->max_translation[1] - g->bbox[1] * g->scale, 0);
 	r.s.addObject(g);
@@ -1302,6 +1343,12 @@ void mh_get_object_matrices(mh_raytracer* h, int obj, float* t, float* inv, floa
 void mh_mesh_counts(mh_raytracer* h, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs) {
 	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
 	*ntri = (int)g->indices.size(); *nnodes = (int)g->bvh.nodes.size(); *nverts = (int)g->vertices.size(); *nnormals = (int)g->normals.size(); *nuvs = (int)g->uvs.size();
+}
+int mh_mesh_bvh_builder(mh_raytracer* h, int obj, double* seconds, double* device_seconds) {
+	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
+	if (seconds) *seconds = g->bvh_build_seconds;
+	if (device_seconds) *device_seconds = g->bvh_device_seconds;
+	return g->bvh_builder;
 }
 void mh_mesh_dump(mh_raytracer* h, int obj, int* perm, int* nodes_i, float* nodes_bb, float* soup, int* groups, float* root_bb) {
 	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);

@@ -105,7 +105,11 @@ public:
 	std::vector<int> permuted_triangle_index;
 	struct { float bbox[6]; std::vector<BVHNodes> nodes; } bvh;
 	float bbox[6];
+	int bvh_builder = 0;                 // who built bvh.nodes: 0 = the host recursion, 1 = mipt_build_bvh on the GPU
+	double bvh_build_seconds = 0, bvh_device_seconds = 0;
 private:
+	bool bvh_gpu_unavailable = false;
+	bool build_bvh_gpu();
 	bool readOBJ(const char* obj, bool load_textures);
 	void add_default_group_materials(int ngroups);
 	void finish_init(bool center);
@@ -216,6 +220,8 @@ int  mh_num_groups(mh_raytracer*, int obj);
 const float* mh_group_texture_values(mh_raytracer*, int obj, int grp, int slot);
 int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
                  int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
+void mh_set_bvh_builder(int mode, int device);              // 0 host recursion, 1 GPU, 2 GPU if present else host (default)
+int  mh_mesh_bvh_builder(mh_raytracer*, int obj, double* seconds, double* device_seconds);   // 0 host / 1 GPU built this mesh
 void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks
 void mh_set_object_flags(mh_raytracer*, int obj, int miroir, int flip_normals);
 void mh_set_group_material(mh_raytracer*, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
