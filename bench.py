@@ -161,8 +161,9 @@ def main():
     rt.apply_config(cfg)
     rt.set_partition(32, rank, world)
     t0 = time.time()
-    scenes.install(rt, mesh, mat)
+    mesh_obj = scenes.install(rt, mesh, mat)
     t_build = time.time() - t0
+    bvh_who, bvh_s, bvh_dev_s = rt.mesh_bvh_builder(mesh_obj)
     t0 = time.time()
     rt.prepare()
     t_prepare = time.time() - t0
@@ -234,7 +235,9 @@ def main():
             "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
                        "parallelism": f"tiles32x{world}", "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
-            "host_bvh_build_s": t_build, "prepare_s": t_prepare, "finite": finite,
+            "host_bvh_build_s": t_build,   # TriMesh::init as a whole (axis swap, BVH, triangle soup, tangents)
+            "bvh_build": {"builder": bvh_who, "seconds": round(bvh_s, 4), "device_seconds": round(bvh_dev_s, 4), "triangles": int(mesh.ntri)},
+            "prepare_s": t_prepare, "finite": finite,
         }
         if world == 1 and args.pmc and pipeline == 1:
             out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -937,7 +939,8 @@ extern "C" const char* mipt_build_bvh_error(void) { return g_build_err.c_str(); 
 namespace {
 struct DevPool {     // device allocations of one build, released on every exit path
 	std::vector<void*> p;
-	~DevPool() { for (void* q : p) hipFree(q); }
+	~DevPool() { release(); }
+	void release() { for (void* q : p) hipFree(q); p.clear(); }
 	template <class T> bool get(T** out, size_t count) {
 		void* q = nullptr;
 		if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
@@ -958,36 +961,30 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	using namespace bvhb;
 	static_assert(sizeof(ONode) == sizeof(mipt_bvh_node), "node layout");
 	g_build_err.clear();
-	if (!vertices || nverts <= 0 || !tri_vtx || tri_stride_bytes < 12 || ntri <= 0 || !out_nodes || !out_n_nodes || !out_perm) return build_fail(MIPT_ERR_INVALID, "bad arguments");
+	const bool trace = getenv("MIPT_BUILD_TRACE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char* what) {
+		if (!trace) return;
+		hipDeviceSynchronize();
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[mipt_build_bvh] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
+	if (!vertices || nverts <= 0 || !tri_vtx || tri_stride_bytes < 12 || (tri_stride_bytes & 3) || ntri <= 0 || !out_nodes || !out_n_nodes || !out_perm) return build_fail(MIPT_ERR_INVALID, "bad arguments");
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return build_fail(MIPT_ERR_NO_DEVICE, "no usable HIP device");
 	BHIP(hipSetDevice(device_id));
 	const int n = ntri;
-	// vertex indices of the triangles, packed (the reference's TriangleIndices records are 44 bytes apart)
-	std::vector<int> tv((size_t)n * 3);
-	{
-		const int nthreads = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
-		std::vector<int> bad(nthreads, 0);
-		auto work = [&](int t) {
-			const int i0 = (int)((long long)n * t / nthreads), i1 = (int)((long long)n * (t + 1) / nthreads);
-			for (int i = i0; i < i1; i++) {
-				const int* q = (const int*)((const char*)tri_vtx + (size_t)i * tri_stride_bytes);
-				for (int k = 0; k < 3; k++) { if (q[k] < 0 || q[k] >= nverts) bad[t] = 1; tv[3 * (size_t)i + k] = q[k]; }
-			}
-		};
-		if (nthreads == 1) work(0);
-		else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
-		for (int b : bad) if (b) return build_fail(MIPT_ERR_INVALID, "triangle vertex index out of range");
-	}
+	phase("pack indices");
 	hipEvent_t e0, e1;
 	BHIP(hipEventCreate(&e0)); BHIP(hipEventCreate(&e1));
 	struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
 	DevPool pool;
 	const int maxseg = n / (BVHB_SMALL + 1) + 2;
-	float* d_vtx; int* d_tv; float4* d_rec; uint32_t *d_order[2], *d_S, *d_tpos, *d_acc, *d_bins, *d_bsum; int* d_segof[2]; uint8_t* d_pf;
+	float* d_vtx; char* d_tv; float4* d_rec; int* d_bad; uint32_t *d_order[2], *d_S, *d_tpos, *d_acc, *d_bins, *d_bsum; int* d_segof[2]; uint8_t* d_pf;
 	Seg* d_segs[2]; float* d_planes; LNode* d_ln; int* d_smalls; Counters* d_cnt; ONode *d_sn, *d_out;
 	const int nscanblk = (n + BVHB_SCAN_TILE - 1) / BVHB_SCAN_TILE;
-	bool ok = pool.get(&d_vtx, (size_t)nverts * 3) && pool.get(&d_tv, (size_t)n * 3) && pool.get(&d_rec, (size_t)n * 3)
+	bool ok = pool.get(&d_vtx, (size_t)nverts * 3) && pool.get(&d_tv, (size_t)n * tri_stride_bytes) && pool.get(&d_bad, 1) && pool.get(&d_rec, (size_t)n * 3)
 	       && pool.get(&d_order[0], n) && pool.get(&d_order[1], n) && pool.get(&d_segof[0], n) && pool.get(&d_segof[1], n)
 	       && pool.get(&d_S, (size_t)n + 1) && pool.get(&d_tpos, n) && pool.get(&d_pf, n) && pool.get(&d_bsum, nscanblk)
 	       && pool.get(&d_segs[0], maxseg) && pool.get(&d_segs[1], maxseg) && pool.get(&d_acc, (size_t)maxseg * 12)
@@ -995,12 +992,15 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	       && pool.get(&d_ln, (size_t)2 * n + 2) && pool.get(&d_smalls, (size_t)n + 1) && pool.get(&d_cnt, 1)
 	       && pool.get(&d_sn, (size_t)2 * n + 2) && pool.get(&d_out, (size_t)2 * n + 2);
 	if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for a %d-triangle build", n);
+	phase("hipMalloc");
 	BHIP(hipMemcpy(d_vtx, vertices, (size_t)nverts * 12, hipMemcpyHostToDevice));
-	BHIP(hipMemcpy(d_tv, tv.data(), (size_t)n * 12, hipMemcpyHostToDevice));
+	BHIP(hipMemcpy(d_tv, tri_vtx, (size_t)(n - 1) * tri_stride_bytes + 12, hipMemcpyHostToDevice));   // the records as they are (TriangleIndices: 44 bytes apart)
+	BHIP(hipMemsetAsync(d_bad, 0, 4, 0));
+	phase("upload");
 	BHIP(hipEventRecord(e0, 0));
 	const bool large_root = n > BVHB_SMALL;
 	const unsigned pos_blocks = (unsigned)((n + 255) / 256);
-	hipLaunchKernelGGL(k_prepare, dim3(pos_blocks), dim3(256), 0, 0, d_vtx, d_tv, n, d_rec, d_order[0], d_segof[0], large_root ? 0 : -1);
+	hipLaunchKernelGGL(k_prepare, dim3(pos_blocks), dim3(256), 0, 0, d_vtx, nverts, d_tv, tri_stride_bytes, n, d_rec, d_order[0], d_segof[0], large_root ? 0 : -1, d_bad);
 	{
 		LNode root; memset(&root, 0, sizeof root);
 		root.i0 = 0; root.i1 = n; root.left = root.right = -1; root.kind = large_root ? K_PENDING : K_SMALL;
@@ -1010,7 +1010,9 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 		Counters c0 = {1, 0, large_root ? 0 : 1, 0};
 		BHIP(hipMemcpyAsync(d_cnt, &c0, sizeof c0, hipMemcpyHostToDevice, 0));
 		if (!large_root) { int z = 0; BHIP(hipMemcpyAsync(d_smalls, &z, 4, hipMemcpyHostToDevice, 0)); }
-		BHIP(hipStreamSynchronize(0));   // the staging variables go out of scope
+		int bad = 0;
+		BHIP(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));   // also: the staging variables go out of scope
+		if (bad) return build_fail(MIPT_ERR_INVALID, "triangle vertex index out of range");
 	}
 	// level-synchronous phase
 	std::vector<int> level_begin{0};       // LNode id ranges per level
@@ -1050,7 +1052,9 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 		cur ^= 1;
 	}
 	level_begin.push_back(ln_count);
+	phase("levels");
 	if (nsmall > 0) hipLaunchKernelGGL(k_small_subtrees, dim3((unsigned)((nsmall + 63) / 64)), dim3(64), 0, 0, nsmall, d_smalls, d_ln, d_rec, d_order[cur], d_sn);
+	phase("small subtrees");
 	const int nlev = (int)level_begin.size() - 1;
 	for (int L = nlev - 1; L >= 0; L--) {
 		const int b = level_begin[L], e = level_begin[L + 1];
@@ -1070,6 +1074,9 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	if (total > node_capacity) return build_fail(MIPT_ERR_INVALID, "node_capacity %d is too small for %d nodes", node_capacity, total);
 	BHIP(hipMemcpy(out_nodes, d_out, (size_t)total * sizeof(ONode), hipMemcpyDeviceToHost));
 	BHIP(hipMemcpy(out_perm, d_order[cur], (size_t)n * 4, hipMemcpyDeviceToHost));
+	phase("numbering + download");
+	pool.release();
+	phase("hipFree");
 	*out_n_nodes = total;
 	if (out_seconds) { float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); *out_seconds = ms * 1e-3; }
 	return MIPT_OK;

@@ -73,11 +73,13 @@ __device__ __forceinline__ float load_centroid(const float4* __restrict__ rec, u
 	return dim == 0 ? a.x : (dim == 1 ? a.y : a.z);
 }
 
-__global__ void k_prepare(const float* __restrict__ vtx, const int* __restrict__ tv, int n, float4* __restrict__ rec,
-                          uint32_t* __restrict__ order, int* __restrict__ segof, int rootseg) {
+__global__ void k_prepare(const float* __restrict__ vtx, int nverts, const char* __restrict__ tri_vtx, int stride, int n, float4* __restrict__ rec,
+                          uint32_t* __restrict__ order, int* __restrict__ segof, int rootseg, int* __restrict__ bad) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const int a = tv[3 * (size_t)i], b = tv[3 * (size_t)i + 1], c = tv[3 * (size_t)i + 2];
+	const int* q = (const int*)(tri_vtx + (size_t)i * stride);
+	int a = q[0], b = q[1], c = q[2];
+	if ((unsigned)a >= (unsigned)nverts || (unsigned)b >= (unsigned)nverts || (unsigned)c >= (unsigned)nverts) { atomicOr(bad, 1); a = b = c = 0; }
 	float cen[3], mn[3], mx[3];
 	for (int k = 0; k < 3; k++) {
 		const float A = vtx[3 * (size_t)a + k], B = vtx[3 * (size_t)b + k], C = vtx[3 * (size_t)c + k];
@@ -126,11 +128,29 @@ __global__ __launch_bounds__(64) void k_lvl_bounds(const float4* __restrict__ re
 				for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], r.mn[k]); mx[k] = fmaxf(mx[k], r.mx[k]); cmn[k] = fminf(cmn[k], r.c[k]); cmx[k] = fmaxf(cmx[k], r.c[k]); }
 			}
 		} else {
+			// several segments in the group: segmented inclusive scan over the runs of equal segment, the last lane of a
+			// run holds the run's boxes and issues the atomics
 			flush(); reset(); run = -1;
+			const int prev = __shfl_up(s, 1), nxt = __shfl_down(s, 1);
+			const bool head = lane == 0 || prev != s, tail = lane == 63 || nxt != s;
+			const unsigned long long heads = __ballot(head);
+			const int start = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+			float lo[6], hi[6];
+			for (int k = 0; k < 6; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
 			if (s >= 0) {
 				const TriRec r = load_rec(rec, order[x]);
+				for (int k = 0; k < 3; k++) { lo[k] = r.mn[k]; hi[k] = r.mx[k]; lo[3 + k] = hi[3 + k] = r.c[k]; }
+			}
+			for (int o = 1; o < 64; o <<= 1) {
+				const bool take = lane - o >= start;
+				for (int k = 0; k < 6; k++) {
+					const float a = __shfl_up(lo[k], o), b = __shfl_up(hi[k], o);
+					if (take) { lo[k] = fminf(lo[k], a); hi[k] = fmaxf(hi[k], b); }
+				}
+			}
+			if (tail && s >= 0) {
 				uint32_t* a = acc + 12 * (size_t)s;
-				for (int k = 0; k < 3; k++) { atomicMin(a + k, fenc(r.mn[k])); atomicMax(a + 3 + k, fenc(r.mx[k])); atomicMin(a + 6 + k, fenc(r.c[k])); atomicMax(a + 9 + k, fenc(r.c[k])); }
+				for (int k = 0; k < 3; k++) { atomicMin(a + k, fenc(lo[k])); atomicMax(a + 3 + k, fenc(hi[k])); atomicMin(a + 6 + k, fenc(lo[3 + k])); atomicMax(a + 9 + k, fenc(hi[3 + k])); }
 			}
 		}
 	}
@@ -169,32 +189,37 @@ __global__ void k_lvl_planes(int nseg, Seg* __restrict__ segs, const uint32_t* _
 
 // ---- step C: triangles binned by the number of planes their centroid lies beyond ----------------------------------
 // centroid <= plane[t] is monotone in t (planes are non-decreasing), so the left set of plane t is bins 0..t.
+#define BVHB_SLOTS 3           // a group of 64 positions meets at most 3 segments of more than BVHB_SMALL (>= 33) triangles
 __global__ __launch_bounds__(64) void k_lvl_bin(const float4* __restrict__ rec, const uint32_t* __restrict__ order, const int* __restrict__ segof,
                                                 int n, int gpw, const Seg* __restrict__ segs, const float* __restrict__ planes, uint32_t* __restrict__ bins) {
-	__shared__ uint32_t lb[BVHB_BINWORDS];
+	__shared__ uint32_t lb[BVHB_SLOTS][BVHB_BINWORDS];
+	__shared__ int slot_seg[BVHB_SLOTS];
 	const int lane = threadIdx.x;
 	const long long base = (long long)blockIdx.x * gpw * 64;
 	int run = -1, dim = 0;
 	float sv[BVHB_NPLANES];
-	auto init_lds = [&] {
-		for (int i = lane; i < BVHB_BINWORDS; i += 64) { const int w = i % 7; lb[i] = w < 3 ? fenc(1E10f) : (w < 6 ? fenc(-1E10f) : 0u); }
+	auto init_lds = [&](int nslots) {
+		for (int i = lane; i < nslots * BVHB_BINWORDS; i += 64) { const int w = i % 7; (&lb[0][0])[i] = w < 3 ? fenc(1E10f) : (w < 6 ? fenc(-1E10f) : 0u); }
 		__syncthreads();
 	};
-	auto flush = [&] {
-		if (run < 0) return;
-		__syncthreads();
-		uint32_t* b = bins + (size_t)run * BVHB_BINWORDS;
+	auto flush_slot = [&](int slot, int seg) {     // LDS bins of one run -> the segment's bins
+		uint32_t* b = bins + (size_t)seg * BVHB_BINWORDS;
 		for (int i = lane; i < BVHB_BINWORDS; i += 64) {
 			const int w = i % 7;
-			const uint32_t v = lb[i];
+			const uint32_t v = lb[slot][i];
 			if (w < 3) { if (v != fenc(1E10f)) atomicMin(b + i, v); }
 			else if (w < 6) { if (v != fenc(-1E10f)) atomicMax(b + i, v); }
 			else if (v) atomicAdd(b + i, v);
 		}
-		__syncthreads();
-		init_lds();
 	};
-	init_lds();
+	auto flush = [&] {
+		if (run < 0) return;
+		__syncthreads();
+		flush_slot(0, run);
+		__syncthreads();
+		init_lds(1);
+	};
+	init_lds(BVHB_SLOTS);
 	for (int g = 0; g < gpw; g++) {
 		const long long x = base + (long long)g * 64 + lane;
 		const int s = (x < n) ? segof[x] : -1;
@@ -209,12 +234,19 @@ __global__ __launch_bounds__(64) void k_lvl_bin(const float4* __restrict__ rec, 
 				const float c = dim == 0 ? r.c[0] : (dim == 1 ? r.c[1] : r.c[2]);
 				int b = 0;
 				for (int t = 0; t < BVHB_NPLANES; t++) b += (c <= sv[t]) ? 0 : 1;
-				uint32_t* q = lb + b * 7;
+				uint32_t* q = &lb[0][b * 7];
 				for (int k = 0; k < 3; k++) { atomicMin(q + k, fenc(r.mn[k])); atomicMax(q + 3 + k, fenc(r.mx[k])); }
 				atomicAdd(q + 6, 1u);
 			}
 		} else {
+			// several segments in the group: every run of an active segment gets an LDS slot
 			flush(); run = -1;
+			const int prev = __shfl_up(s, 1);
+			const bool head = (lane == 0 || prev != s) && s >= 0;
+			const unsigned long long heads = __ballot(head);
+			const int slot = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
+			const int nslots = __popcll(heads);
+			if (head && slot < BVHB_SLOTS) slot_seg[slot] = s;
 			if (s >= 0) {
 				const TriRec r = load_rec(rec, order[x]);
 				const int d = segs[s].dim;
@@ -222,10 +254,15 @@ __global__ __launch_bounds__(64) void k_lvl_bin(const float4* __restrict__ rec, 
 				const float* p = planes + (size_t)s * (BVHB_NPLANES + 2);
 				int b = 0;
 				for (int t = 0; t < BVHB_NPLANES; t++) b += (c <= p[t]) ? 0 : 1;
-				uint32_t* q = bins + (size_t)s * BVHB_BINWORDS + b * 7;
+				uint32_t* q = slot < BVHB_SLOTS ? &lb[slot][b * 7] : bins + (size_t)s * BVHB_BINWORDS + b * 7;
 				for (int k = 0; k < 3; k++) { atomicMin(q + k, fenc(r.mn[k])); atomicMax(q + 3 + k, fenc(r.mx[k])); }
 				atomicAdd(q + 6, 1u);
 			}
+			__syncthreads();
+			const int used = nslots < BVHB_SLOTS ? nslots : BVHB_SLOTS;
+			for (int k = 0; k < used; k++) flush_slot(k, slot_seg[k]);
+			__syncthreads();
+			init_lds(used);
 		}
 	}
 	flush();
@@ -409,8 +446,14 @@ __global__ void k_lvl_resegment(const int* __restrict__ segof, int n, const Seg*
 }
 
 // ---- small subtrees: the reference's recursion, one thread per subtree --------------------------------------------
-__global__ void k_small_subtrees(int nsmall, const int* __restrict__ smalls, LNode* __restrict__ ln, const float4* __restrict__ rec,
-                                 uint32_t* __restrict__ order, ONode* __restrict__ sn) {
+// Nodes of more than BVHB_LITERAL triangles cost their 16 planes from 17 bins kept in LDS (one column per thread, so
+// the records are read three times per node instead of eighteen); smaller nodes run the reference's loops as they are.
+#define BVHB_LITERAL 8
+__global__ __launch_bounds__(64) void k_small_subtrees(int nsmall, const int* __restrict__ smalls, LNode* __restrict__ ln, const float4* __restrict__ rec,
+                                                       uint32_t* __restrict__ order, ONode* __restrict__ sn) {
+	__shared__ float sbox[BVHB_NBINS * 6][64];
+	__shared__ int scnt[BVHB_NBINS][64];
+	const int lane = threadIdx.x;
 	const int q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= nsmall) return;
 	LNode& root = ln[smalls[q]];
@@ -445,19 +488,64 @@ __global__ void k_small_subtrees(int nsmall, const int* __restrict__ smalls, LNo
 		const float cb = dim == 0 ? cmn[0] : (dim == 1 ? cmn[1] : cmn[2]);
 		const float dg = dim == 0 ? diag[0] : (dim == 1 ? diag[1] : diag[2]);
 		float best_factor = 0.5f, best = INFINITY;
-		for (int t = 0; t < BVHB_NPLANES; t++) {
-			const float factor = (t + 1) / (float)(BVHB_NPLANES + 1);
-			const float sv = cb + dg * factor;
-			float lmn[3] = {1E10f, 1E10f, 1E10f}, lmx[3] = {-1E10f, -1E10f, -1E10f}, rmn[3] = {1E10f, 1E10f, 1E10f}, rmx[3] = {-1E10f, -1E10f, -1E10f};
-			int nl = 0, nr = 0;
+		if (i1 - i0 <= BVHB_LITERAL) {
+			for (int t = 0; t < BVHB_NPLANES; t++) {
+				const float factor = (t + 1) / (float)(BVHB_NPLANES + 1);
+				const float sv = cb + dg * factor;
+				float lmn[3] = {1E10f, 1E10f, 1E10f}, lmx[3] = {-1E10f, -1E10f, -1E10f}, rmn[3] = {1E10f, 1E10f, 1E10f}, rmx[3] = {-1E10f, -1E10f, -1E10f};
+				int nl = 0, nr = 0;
+				for (int i = i0; i < i1; i++) {
+					const TriRec r = load_rec(rec, order[i]);
+					const float c = dim == 0 ? r.c[0] : (dim == 1 ? r.c[1] : r.c[2]);
+					if (c <= sv) { for (int k = 0; k < 3; k++) { lmn[k] = fmin_ref(lmn[k], r.mn[k]); lmx[k] = fmax_ref(lmx[k], r.mx[k]); } nl++; }
+					else         { for (int k = 0; k < 3; k++) { rmn[k] = fmin_ref(rmn[k], r.mn[k]); rmx[k] = fmax_ref(rmx[k], r.mx[k]); } nr++; }
+				}
+				const float cost = box_area(lmn, lmx) * nl + box_area(rmn, rmx) * nr;
+				if (cost < best) { best = cost; best_factor = factor; }
+			}
+		} else {
+			float sv[BVHB_NPLANES];
+#pragma unroll
+			for (int t = 0; t < BVHB_NPLANES; t++) sv[t] = cb + dg * ((t + 1) / (float)(BVHB_NPLANES + 1));
+			for (int j = 0; j < BVHB_NBINS; j++) {
+				for (int k = 0; k < 3; k++) { sbox[j * 6 + k][lane] = 1E10f; sbox[j * 6 + 3 + k][lane] = -1E10f; }
+				scnt[j][lane] = 0;
+			}
 			for (int i = i0; i < i1; i++) {
 				const TriRec r = load_rec(rec, order[i]);
 				const float c = dim == 0 ? r.c[0] : (dim == 1 ? r.c[1] : r.c[2]);
-				if (c <= sv) { for (int k = 0; k < 3; k++) { lmn[k] = fmin_ref(lmn[k], r.mn[k]); lmx[k] = fmax_ref(lmx[k], r.mx[k]); } nl++; }
-				else         { for (int k = 0; k < 3; k++) { rmn[k] = fmin_ref(rmn[k], r.mn[k]); rmx[k] = fmax_ref(rmx[k], r.mx[k]); } nr++; }
+				int b = 0;
+#pragma unroll
+				for (int t = 0; t < BVHB_NPLANES; t++) b += (c <= sv[t]) ? 0 : 1;
+				for (int k = 0; k < 3; k++) {
+					sbox[b * 6 + k][lane] = fmin_ref(sbox[b * 6 + k][lane], r.mn[k]);
+					sbox[b * 6 + 3 + k][lane] = fmax_ref(sbox[b * 6 + 3 + k][lane], r.mx[k]);
+				}
+				scnt[b][lane]++;
 			}
-			const float cost = box_area(lmn, lmx) * nl + box_area(rmn, rmx) * nr;
-			if (cost < best) { best = cost; best_factor = factor; }
+			float cl[BVHB_NPLANES];
+			{
+				float mn[3] = {1E10f, 1E10f, 1E10f}, mx[3] = {-1E10f, -1E10f, -1E10f};
+				int cnt = 0;
+#pragma unroll
+				for (int t = 0; t < BVHB_NPLANES; t++) {     // left set of plane t = bins 0..t
+					for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], sbox[t * 6 + k][lane]); mx[k] = fmaxf(mx[k], sbox[t * 6 + 3 + k][lane]); }
+					cnt += scnt[t][lane];
+					cl[t] = box_area(mn, mx) * cnt;
+				}
+			}
+			{
+				float mn[3] = {1E10f, 1E10f, 1E10f}, mx[3] = {-1E10f, -1E10f, -1E10f};
+				int cnt = 0;
+#pragma unroll
+				for (int t = BVHB_NPLANES - 1; t >= 0; t--) {   // right set of plane t = bins t+1..16
+					for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], sbox[(t + 1) * 6 + k][lane]); mx[k] = fmaxf(mx[k], sbox[(t + 1) * 6 + 3 + k][lane]); }
+					cnt += scnt[t + 1][lane];
+					cl[t] = cl[t] + box_area(mn, mx) * cnt;
+				}
+			}
+#pragma unroll
+			for (int t = 0; t < BVHB_NPLANES; t++) if (cl[t] < best) { best = cl[t]; best_factor = (t + 1) / (float)(BVHB_NPLANES + 1); }
 		}
 		const float split = cb + dg * best_factor;
 		int pivot = i0 - 1;

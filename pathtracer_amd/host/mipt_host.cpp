@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <chrono>
 #include <thread>
 #include <zlib.h>
@@ -540,6 +541,42 @@ void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
 	}
 }
 
+// mipt_build_bvh (include/mipt.h) in place of the recursion: the device returns the node vector and the permutation
+// the reference's swaps produce; it is applied to `indices` / `permuted_triangle_index` here.
+bool TriMesh::build_bvh_gpu() {
+	const int nf = (int)indices.size();
+	const bool trace = getenv("MIPT_BUILD_TRACE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char* what) {
+		if (!trace) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[build_bvh_gpu] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
+	bvh.nodes.resize((size_t)nf * 2);            // not zeroed (PodVec): pages are touched by the download only
+	std::vector<int32_t> perm(nf);
+	int nn = 0;
+	double dev_s = 0;
+	const int rc = mipt_build_bvh(g_bvh_builder_device, &vertices[0][0], (int)vertices.size(), &indices[0].vtxi, (int)sizeof(mipt_triangle_indices), nf,
+	                              reinterpret_cast<mipt_bvh_node*>(bvh.nodes.data()), nf * 2, &nn, perm.data(), &dev_s);
+	phase("mipt_build_bvh");
+	if (rc != MIPT_OK) {
+		bvh_gpu_unavailable = (rc == MIPT_ERR_NO_DEVICE);
+		load_error = std::string("mipt_build_bvh: ") + mipt_build_bvh_error();
+		bvh.nodes.clear();
+		return false;
+	}
+	bvh.nodes.resize(nn);
+	PodVec<mipt_triangle_indices> dst(nf);
+	parallel_for(nf, [&](int i0, int i1) { for (int i = i0; i < i1; i++) { dst[i] = indices[perm[i]]; permuted_triangle_index[i] = perm[i]; } });
+	indices.swap(dst);
+	phase("permute indices");
+	bvh_builder = 1;
+	bvh_device_seconds = dev_s;
+	load_error.clear();
+	return true;
+}
+
 // build_bvh_recur (TriangleMesh.cpp:1029-1130): longest centroid axis, 16 candidate planes,
 // cost area_L*n_L + area_R*n_R, in-place partition, <= 4 triangles per leaf, nodes in preorder.
 //
@@ -548,31 +585,6 @@ void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
 // references relative to that vector) and spliced behind the left subtree afterwards — preorder
 // positions are then exactly what the serial push_back order gives.  The 16 candidate planes of a
 // large node are evaluated concurrently as well (the first minimum in plane order wins, as in the loop).
-// mipt_build_bvh (include/mipt.h) in place of the recursion: the device returns the node vector and the permutation
-// the reference's swaps produce; it is applied to `indices` / `permuted_triangle_index` here.
-bool TriMesh::build_bvh_gpu() {
-	const int nf = (int)indices.size();
-	std::vector<BVHNodes> nodes((size_t)nf * 2);
-	std::vector<int32_t> perm(nf);
-	int nn = 0;
-	double dev_s = 0;
-	const int rc = mipt_build_bvh(g_bvh_builder_device, &vertices[0][0], (int)vertices.size(), &indices[0].vtxi, (int)sizeof(mipt_triangle_indices), nf,
-	                              reinterpret_cast<mipt_bvh_node*>(nodes.data()), (int)nodes.size(), &nn, perm.data(), &dev_s);
-	if (rc != MIPT_OK) {
-		bvh_gpu_unavailable = (rc == MIPT_ERR_NO_DEVICE);
-		load_error = std::string("mipt_build_bvh: ") + mipt_build_bvh_error();
-		return false;
-	}
-	nodes.resize(nn);
-	bvh.nodes.swap(nodes);
-	std::vector<mipt_triangle_indices> src(indices);
-	parallel_for(nf, [&](int i0, int i1) { for (int i = i0; i < i1; i++) { indices[i] = src[perm[i]]; permuted_triangle_index[i] = perm[i]; } });
-	bvh_builder = 1;
-	bvh_device_seconds = dev_s;
-	load_error.clear();
-	return true;
-}
-
 namespace {
 int kParallelSubtree = 1 << 15;      // ranges above this many triangles fork
 int kParallelPlanes = 1 << 18;       // ranges above this evaluate the candidate planes on threads
@@ -597,7 +609,7 @@ float TriMesh::split_cost(int i0, int i1, int split_dim, float split_val) const 
 	return area(lmin, lmax) * nl + area(rmin, rmax) * nr;
 }
 
-void TriMesh::build_bvh_recur(std::vector<BVHNodes>& out, int i0, int i1, int depth) {
+void TriMesh::build_bvh_recur(PodVec<BVHNodes>& out, int i0, int i1, int depth) {
 	const int node = (int)out.size();
 	BVHNodes n;
 	build_bbox(i0, i1, n.bbox);
@@ -636,7 +648,7 @@ void TriMesh::build_bvh_recur(std::vector<BVHNodes>& out, int i0, int i1, int de
 	if (pivot < i0 || pivot >= i1 - 1 || i1 <= i0 + 4) return;
 	out[node].isleaf = false;
 	if (i1 - (pivot + 1) >= kParallelSubtree && pivot + 1 - i0 >= kParallelSubtree) {
-		std::vector<BVHNodes> right;
+		PodVec<BVHNodes> right;
 		std::thread worker([&] { build_bvh_recur(right, pivot + 1, i1, depth + 1); });
 		out[node].fg = (int)out.size();
 		build_bvh_recur(out, i0, pivot + 1, depth + 1);

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,15 @@ struct Texture {                      // BRDF.h:252-426
 };
 
 struct BVHNodes { bool isleaf; int fg, fd; float bbox[6]; };   // TriangleMesh.h:6-13 (36 bytes)
+
+// std::vector whose resize() leaves new POD elements uninitialised: the node / index vectors of a 23.7 M-triangle mesh
+// are gigabytes that the GPU build fills right away, zeroing them first costs more than the build
+template <class T> struct default_init_allocator : std::allocator<T> {
+	template <class U> struct rebind { using other = default_init_allocator<U>; };
+	template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+	template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using PodVec = std::vector<T, default_init_allocator<T>>;
 static_assert(sizeof(BVHNodes) == sizeof(mipt_bvh_node), "BVH node layout");
 
 enum ObjectType { OT_TRIMESH = MIPT_OBJ_TRIMESH, OT_SPHERE = MIPT_OBJ_SPHERE, OT_PLANE = MIPT_OBJ_PLANE };
@@ -99,11 +109,11 @@ public:
 	std::string load_error;
 	std::map<std::string, int> groupNames;   // usemtl name -> material group (TriangleMesh.h:228)
 	std::vector<Vector> vertices, normals, uvs;
-	std::vector<mipt_triangle_indices> indices;
+	PodVec<mipt_triangle_indices> indices;
 	std::vector<mipt_triangle> triangleSoup;
 	std::vector<Vector> tangentSoup;
 	std::vector<int> permuted_triangle_index;
-	struct { float bbox[6]; std::vector<BVHNodes> nodes; } bvh;
+	struct { float bbox[6]; PodVec<BVHNodes> nodes; } bvh;
 	float bbox[6];
 	int bvh_builder = 0;                 // who built bvh.nodes: 0 = the host recursion, 1 = mipt_build_bvh on the GPU
 	double bvh_build_seconds = 0, bvh_device_seconds = 0;
@@ -116,7 +126,7 @@ private:
 	void build_bbox(int i0, int i1, float* out6) const;
 	void build_centers_bbox(int i0, int i1, float* out6) const;
 	float split_cost(int i0, int i1, int split_dim, float split_val) const;
-	void build_bvh_recur(std::vector<BVHNodes>& out, int i0, int i1, int depth);
+	void build_bvh_recur(PodVec<BVHNodes>& out, int i0, int i1, int depth);
 	void setup_tangents();
 };
 
