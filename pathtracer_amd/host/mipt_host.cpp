@@ -130,6 +130,7 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 // which builder TriMesh::init uses: 0 = host recursion, 1 = GPU (an error if there is no device), 2 = GPU when a device
 // is present, host recursion otherwise (default)
 static int g_bvh_builder_mode = 2, g_bvh_builder_device = 0;
+extern "C" void mh_set_obj_slicing(int slice_bytes, int max_slices);   // test hook: how readOBJ cuts the text into concurrently parsed slices
 extern "C" void mh_set_bvh_builder(int mode, int device) { g_bvh_builder_mode = mode; g_bvh_builder_device = device; }
 
 // contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
@@ -210,8 +211,9 @@ void TriMesh::finish_init(bool center) {
 //  * physical lines are cut at 254 characters (fgets(line, 255)); only the first two characters select the record;
 //  * "v x y z [r g b]" (colours ignored here), "vn", "vt u v", "usemtl name" (groups numbered by first appearance),
 //    "mtllib file";
-//  * a face corner is v/t/n, v/t, v or v//n — the form of the FIRST three corners is tried in that order and applies
-//    to the whole line — with 1-based or negative (relative) indices; polygons are fanned as (c0, c_{k-1}, c_k);
+//  * a face corner is v/t/n, v/t, v or v//n with 1-based or negative (relative) indices — the first three corners must
+//    share one form (tried in that order), further corners are matched one by one (v/t/n, v/t, v//n, v) — and
+//    polygons are fanned as (c0, c_{k-1}, c_k); the text is split into slices that are parsed concurrently;
 //  * no usemtl anywhere: every face in group 0 ("Default");
 //  * MTL: records are recognised at column 0 only ("Kd", "Ks", "Ns", "map_Kd", "map_Ks", "map_Bump", "map_d",
 //    "newmtl"), "Ns" with one value is replicated, a material name the OBJ never used lands in group 0
@@ -219,39 +221,6 @@ void TriMesh::finish_init(bool center) {
 // Images: binary PPM (P6, maxval 255) — the one format of the reference's decoder (stb_image) that needs no codec;
 // anything else is reported through load_error and leaves the constant colour in place.
 namespace {
-struct Corner { int v, t, n; bool has_t, has_n; };
-// one corner starting at p; returns the end pointer or nullptr.  `%u` of the reference accepts a sign.
-const char* scan_int(const char* p, int& out) {
-	while (*p == ' ' || *p == '\t') p++;
-	char* e;
-	long long v = strtoll(p, &e, 10);
-	if (e == p) return nullptr;
-	out = (int)(unsigned)v;
-	return e;
-}
-const char* scan_corner(const char* p, Corner& c) {
-	c.has_t = c.has_n = false; c.t = c.n = 0;
-	p = scan_int(p, c.v);
-	if (!p) return nullptr;
-	if (*p != '/') return p;
-	p++;
-	if (*p == '/') {                                  // v//n
-		const char* q = scan_int(p + 1, c.n);
-		if (!q || p[1] == ' ') return nullptr;
-		c.has_n = true;
-		return q;
-	}
-	if (*p == ' ' || *p == '\t') return nullptr;
-	const char* q = scan_int(p, c.t);
-	if (!q) return nullptr;
-	c.has_t = true;
-	if (*q != '/') return q;
-	if (q[1] == ' ' || q[1] == '\t') return nullptr;
-	const char* r = scan_int(q + 1, c.n);
-	if (!r) return nullptr;
-	c.has_n = true;
-	return r;
-}
 std::string dir_of(const std::string& path) { size_t k = path.find_last_of("/\\"); return path.substr(0, k + 1); }   // extractFilePathWithEndingSlash
 std::string rest_of_line(const char* line, size_t skip) {   // sscanf(line, "keyword %[^\n]"): blanks after the keyword are skipped
 	const char* p = line + std::min(skip - 1, strlen(line));
@@ -418,65 +387,176 @@ bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, i
 }
 }  // namespace
 
-bool TriMesh::readOBJ(const char* obj, bool load_textures) {
-	FILE* f = fopen(obj, "r");
-	if (!f) { load_error = std::string("cannot open ") + obj; return false; }
-	std::string matfile;
-	int curGroup = -1;
+namespace {
+// What one slice of the OBJ text contributes.  Slices start after a newline, so the 254-character record cutting of
+// fgets(line, 255) falls the same way as in a front-to-back read; everything that depends on what came before the
+// slice (relative indices, the current usemtl group) is recorded symbolically and resolved when the slices are joined.
+// sscanf restricted to what the face records need: in `fmt`, 'u' is %u (leading white space skipped, optional sign,
+// decimal digits), 'n' is %n, a blank matches any amount of white space, anything else must match literally.
+// Returns the number of %u conversions (-1 when the input ends before the first one).
+int scan_units(const char* s, const char* fmt, int* out, int* consumed) {
+	const char* p = s;
+	int n = 0;
+	auto space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+	for (; *fmt; fmt++) {
+		if (*fmt == 'u') {
+			while (space(*p)) p++;
+			if (*p == 0) return n ? n : -1;
+			const char* d = p;
+			if (*d == '+' || *d == '-') d++;
+			if (*d < '0' || *d > '9') return n;
+			char* e;
+			out[n++] = (int)(unsigned)strtoul(p, &e, 10);
+			p = e;
+		} else if (*fmt == 'n') *consumed = (int)(p - s);
+		else if (*fmt == ' ') { while (space(*p)) p++; }
+		else { if (*p != *fmt) return n; p++; }
+	}
+	return n;
+}
+
+int g_obj_slice_bytes = 1 << 20, g_obj_max_slices = 0;
+struct ObjSlice {
+	std::vector<Vector> v, vn, vt;
+	PodVec<mipt_triangle_indices> faces;       // indices local to the slice where the bit in `relmask` is set
+	std::vector<uint16_t> relmask;             // bit k: field k of (vtxi,vtxj,vtxk,uvi,uvj,uvk,ni,nj,nk) is relative to the running count
+	std::vector<int> face_group;               // index into `usemtl` of the group in force (-1: the one inherited from the previous slice)
+	std::vector<std::string> usemtl;           // names in order of appearance
+	std::string matfile; bool has_matfile = false;
+	bool vertex_colours = false;
+};
+
+void parse_obj_slice(const char* p, const char* end, ObjSlice& o) {
 	char line[255];
-	while (fgets(line, 255, f)) {
-		if (line[0] == 'u' && line[1] == 's') {
-			std::string grp = rest_of_line(line, 7);
-			auto it = groupNames.find(grp);
-			if (it != groupNames.end()) curGroup = it->second;
-			else { curGroup = (int)groupNames.size(); groupNames[grp] = curGroup; }
-		}
-		if (line[0] == 'm' && line[1] == 't' && line[2] == 'l') matfile = rest_of_line(line, 7);
+	while (p < end) {
+		size_t len = 0;                            // fgets(line, 255, f)
+		while (p < end && len < 254) { const char ch = *p++; line[len++] = ch; if (ch == '\n') break; }
+		line[len] = 0;
+		if (line[0] == 'u' && line[1] == 's') o.usemtl.push_back(rest_of_line(line, 7));
+		if (line[0] == 'm' && line[1] == 't' && line[2] == 'l') { o.matfile = rest_of_line(line, 7); o.has_matfile = true; }
 		if (line[0] == 'v' && line[1] == ' ') {
 			float x = 0, y = 0, z = 0, cr, cg, cb;
-			if (sscanf(line, "v %f %f %f %f %f %f", &x, &y, &z, &cr, &cg, &cb) == 6) {   // vertex colours feed getMaterial (TriangleMesh.cpp:980-1000): outside the hot path
-				fclose(f); load_error = "per-vertex colours are not supported"; return false;
-			}
-			vertices.push_back(Vector(x, y, z));
+			if (sscanf(line, "v %f %f %f %f %f %f", &x, &y, &z, &cr, &cg, &cb) == 6) { o.vertex_colours = true; return; }   // vertex colours feed getMaterial (TriangleMesh.cpp:980-1000): outside the hot path
+			o.v.push_back(Vector(x, y, z));
 		}
-		if (line[0] == 'v' && line[1] == 'n') { float x = 0, y = 0, z = 0; sscanf(line, "vn %f %f %f", &x, &y, &z); normals.push_back(Vector(x, y, z)); }
-		if (line[0] == 'v' && line[1] == 't') { float x = 0, y = 0; sscanf(line, "vt %f %f", &x, &y); uvs.push_back(Vector(x, y, 0)); }
+		if (line[0] == 'v' && line[1] == 'n') { float x = 0, y = 0, z = 0; sscanf(line, "vn %f %f %f", &x, &y, &z); o.vn.push_back(Vector(x, y, z)); }
+		if (line[0] == 'v' && line[1] == 't') { float x = 0, y = 0; sscanf(line, "vt %f %f", &x, &y); o.vt.push_back(Vector(x, y, 0)); }
 		if (line[0] == 'f') {
-			Corner c[3];
-			const char* p = line + 1;
-			bool ok = true;
-			for (int k = 0; k < 3 && ok; k++) { p = scan_corner(p, c[k]); ok = p != nullptr; }
-			if (!ok) continue;
-			// the form of the line is that of its first corners (the sscanf cascade of :327-383)
-			const bool form_t = c[0].has_t && c[1].has_t && c[2].has_t, form_n = c[0].has_n && c[1].has_n && c[2].has_n;
-			auto rel = [](int i, size_t n) { return i < 0 ? (int)n + i : i - 1; };
-			auto emit = [&](const Corner& a, const Corner& b, const Corner& d, bool first) {
+			// the sscanf cascades of TriangleMesh.cpp:327-457, form by form.  The first three corners must share one
+			// form (v/t/n, v/t, v, v//n — tried in that order); every further corner is matched on its own, again in the
+			// order v/t/n, v/t, v//n, v, so that e.g. the tail "44/" that the 254-character cut leaves of "44//1" still
+			// yields the vertex 44, exactly as in the reference.
+			const char* q = line + 1;
+			int a[9], off = 0;
+			bool form_t = false, form_n = false;
+			int i0, i2, j0 = 0, j2 = 0, k0 = 0, k2 = 0, i1, j1 = 0, k1 = 0;
+			if (scan_units(q, "u/u/u u/u/u u/u/un", a, &off) == 9) { form_t = form_n = true; i0 = a[0]; j0 = a[1]; k0 = a[2]; i1 = a[3]; j1 = a[4]; k1 = a[5]; i2 = a[6]; j2 = a[7]; k2 = a[8]; }
+			else if (scan_units(q, "u/u u/u u/un", a, &off) == 6) { form_t = true; i0 = a[0]; j0 = a[1]; i1 = a[2]; j1 = a[3]; i2 = a[4]; j2 = a[5]; }
+			else if (scan_units(q, "u u un", a, &off) == 3) { i0 = a[0]; i1 = a[1]; i2 = a[2]; }
+			else if (scan_units(q, "u//u u//u u//un", a, &off) == 6) { form_n = true; i0 = a[0]; k0 = a[1]; i1 = a[2]; k1 = a[3]; i2 = a[4]; k2 = a[5]; }
+			else continue;   // the reference goes on with whatever its variables hold (undefined); such lines are dropped here
+			auto emit = [&](bool first, int vi, int vj, int vk, bool with_t, int ti, int tj, int tk, bool with_n, int ni, int nj, int nk, const char* after) {
 				mipt_triangle_indices t;
 				memset(&t, 0, sizeof t);
-				t.group = curGroup;
-				t.showEdges[0] = first; t.showEdges[1] = 1; t.showEdges[2] = 1;
-				t.vtxi = rel(a.v, vertices.size()); t.vtxj = rel(b.v, vertices.size()); t.vtxk = rel(d.v, vertices.size());
+				t.showEdges[0] = first; t.showEdges[1] = 1;
+				t.showEdges[2] = (after[0] == '\n') || (after[0] == ' ' && after[1] == '\n');
+				unsigned mask = 0;
+				auto rel = [&](int i, size_t n, int bit) { if (i < 0) { mask |= 1u << bit; return (int)n + i; } return i - 1; };
+				t.vtxi = rel(vi, o.v.size(), 0); t.vtxj = rel(vj, o.v.size(), 1); t.vtxk = rel(vk, o.v.size(), 2);
 				t.uvi = t.uvj = t.uvk = -1; t.ni = t.nj = t.nk = -1;
-				if (form_t) { t.uvi = rel(a.t, uvs.size()); t.uvj = rel(b.t, uvs.size()); t.uvk = rel(d.t, uvs.size()); }
-				if (form_n) { t.ni = rel(a.n, normals.size()); t.nj = rel(b.n, normals.size()); t.nk = rel(d.n, normals.size()); }
-				indices.push_back(t);
+				if (with_t) { t.uvi = rel(ti, o.vt.size(), 3); t.uvj = rel(tj, o.vt.size(), 4); t.uvk = rel(tk, o.vt.size(), 5); }
+				if (with_n) { t.ni = rel(ni, o.vn.size(), 6); t.nj = rel(nj, o.vn.size(), 7); t.nk = rel(nk, o.vn.size(), 8); }
+				o.faces.push_back(t);
+				o.relmask.push_back((uint16_t)mask);
+				o.face_group.push_back((int)o.usemtl.size() - 1);
 			};
-			emit(c[0], c[1], c[2], true);
-			Corner last = c[2];
+			emit(true, i0, i1, i2, form_t, j0, j1, j2, form_n, k0, k1, k2, q + off);
+			q += off;
 			for (;;) {                                 // fan: (c0, previous, next)  (:391-457)
-				while (*p == ' ' || *p == '\t' || *p == '\r') p++;
-				if (*p == '\n' || *p == '\0') break;
-				Corner nx;
-				const char* q = scan_corner(p, nx);
-				if (!q) { p++; continue; }
-				if (form_t && !nx.has_t) { p = q; continue; }
-				emit(c[0], last, nx, false);
-				last = nx;
-				p = q;
+				if (*q == '\n' || *q == '\0') break;
+				if (scan_units(q, "u/u/un", a, &off) == 3) { emit(false, i0, i2, a[0], true, j0, j2, a[1], true, k0, k2, a[2], q + off); q += off; i2 = a[0]; j2 = a[1]; k2 = a[2]; }
+				else if (scan_units(q, "u/un", a, &off) == 2) { emit(false, i0, i2, a[0], true, j0, j2, a[1], false, 0, 0, 0, q + off); q += off; i2 = a[0]; j2 = a[1]; }
+				else if (scan_units(q, "u//un", a, &off) == 2) { emit(false, i0, i2, a[0], false, 0, 0, 0, true, k0, k2, a[1], q + off); q += off; i2 = a[0]; k2 = a[1]; }
+				else if (scan_units(q, "un", a, &off) == 1) { emit(false, i0, i2, a[0], false, 0, 0, 0, false, 0, 0, 0, q + off); q += off; i2 = a[0]; }
+				else q++;
 			}
 		}
 	}
-	fclose(f);
+}
+}   // namespace
+extern "C" void mh_set_obj_slicing(int slice_bytes, int max_slices) { g_obj_slice_bytes = std::max(1, slice_bytes); g_obj_max_slices = max_slices; }
+
+bool TriMesh::readOBJ(const char* obj, bool load_textures) {
+	std::vector<char> text;
+	{
+		FILE* f = fopen(obj, "rb");
+		if (!f) { load_error = std::string("cannot open ") + obj; return false; }
+		fseek(f, 0, SEEK_END);
+		const long sz = ftell(f);
+		fseek(f, 0, SEEK_SET);
+		text.resize(sz > 0 ? (size_t)sz : 0);
+		const size_t got = text.empty() ? 0 : fread(text.data(), 1, text.size(), f);
+		fclose(f);
+		text.resize(got);
+	}
+	// slices of about equal size, each starting right after a newline, parsed on the host's hardware threads
+	const int nslices = std::max(1, std::min(g_obj_max_slices > 0 ? g_obj_max_slices : (int)std::thread::hardware_concurrency(), (int)(text.size() / (size_t)g_obj_slice_bytes)));
+	std::vector<size_t> cut(nslices + 1, text.size());
+	cut[0] = 0;
+	for (int k = 1; k < nslices; k++) {
+		size_t c = std::max(cut[k - 1], text.size() * k / nslices);
+		while (c < text.size() && c > 0 && text[c - 1] != '\n') c++;
+		cut[k] = c;
+	}
+	std::vector<ObjSlice> sl(nslices);
+	{
+		std::vector<std::thread> th;
+		for (int k = 1; k < nslices; k++) th.emplace_back([&, k] { parse_obj_slice(text.data() + cut[k], text.data() + cut[k + 1], sl[k]); });
+		parse_obj_slice(text.data() + cut[0], text.data() + cut[1], sl[0]);
+		for (auto& x : th) x.join();
+	}
+	for (const ObjSlice& o : sl) if (o.vertex_colours) { load_error = "per-vertex colours are not supported"; return false; }
+	// join: running counts for relative indices, groups numbered by first appearance, the last mtllib wins
+	std::string matfile;
+	std::vector<size_t> bv(nslices + 1, 0), bt(nslices + 1, 0), bn(nslices + 1, 0), bf(nslices + 1, 0);
+	std::vector<std::vector<int>> group_id(nslices);
+	std::vector<int> inherited(nslices, -1);
+	int curGroup = -1;
+	for (int k = 0; k < nslices; k++) {
+		const ObjSlice& o = sl[k];
+		bv[k + 1] = bv[k] + o.v.size(); bt[k + 1] = bt[k] + o.vt.size(); bn[k + 1] = bn[k] + o.vn.size(); bf[k + 1] = bf[k] + o.faces.size();
+		inherited[k] = curGroup;
+		for (const std::string& grp : o.usemtl) {
+			auto it = groupNames.find(grp);
+			if (it != groupNames.end()) curGroup = it->second;
+			else { curGroup = (int)groupNames.size(); groupNames[grp] = curGroup; }
+			group_id[k].push_back(curGroup);
+		}
+		if (o.has_matfile) matfile = o.matfile;
+	}
+	vertices.resize(bv[nslices]); uvs.resize(bt[nslices]); normals.resize(bn[nslices]); indices.resize(bf[nslices]);
+	{
+		auto join = [&](int k) {
+			const ObjSlice& o = sl[k];
+			std::copy(o.v.begin(), o.v.end(), vertices.begin() + bv[k]);
+			std::copy(o.vt.begin(), o.vt.end(), uvs.begin() + bt[k]);
+			std::copy(o.vn.begin(), o.vn.end(), normals.begin() + bn[k]);
+			for (size_t i = 0; i < o.faces.size(); i++) {
+				mipt_triangle_indices t = o.faces[i];
+				const unsigned m = o.relmask[i];
+				if (m) {
+					int* fld[9] = {&t.vtxi, &t.vtxj, &t.vtxk, &t.uvi, &t.uvj, &t.uvk, &t.ni, &t.nj, &t.nk};
+					for (int b = 0; b < 9; b++) if (m & (1u << b)) *fld[b] += (int)(b < 3 ? bv[k] : (b < 6 ? bt[k] : bn[k]));
+				}
+				t.group = o.face_group[i] < 0 ? inherited[k] : group_id[k][o.face_group[i]];
+				indices[bf[k] + i] = t;
+			}
+		};
+		std::vector<std::thread> th;
+		for (int k = 1; k < nslices; k++) th.emplace_back(join, k);
+		join(0);
+		for (auto& x : th) x.join();
+	}
 	if (groupNames.empty()) {
 		for (auto& t : indices) t.group = 0;
 		groupNames["Default"] = 0;
@@ -487,6 +567,7 @@ bool TriMesh::readOBJ(const char* obj, bool load_textures) {
 	FILE* m = fopen((dir_of(obj) + matfile).c_str(), "r");
 	if (!m) return true;                               // a missing MTL is not an error in the reference either
 	int grp = 0;
+	char line[255];
 	auto image = [&](Texture& tex, const std::string& file, bool normals_map) {
 		std::vector<unsigned char> rgb; int W = 0, H = 0;
 		std::string why;
@@ -1042,6 +1123,7 @@ int Raytracer::open_device(int device_id) {
 	if (ctx) { mipt_destroy(ctx); ctx = nullptr; }
 	last_status = mipt_create(&device_id, 1, &ctx);
 	if (last_status != MIPT_OK) err_ = "mipt_create failed (no usable HIP device: this library has no CPU path)";
+	else g_bvh_builder_device = device_id;   // meshes loaded by this process build their BVH on the GPU it renders on
 	return last_status;
 }
 const char* Raytracer::last_error() const { return (ctx && last_status != MIPT_OK && err_.empty()) ? mipt_last_error(ctx) : err_.c_str(); }

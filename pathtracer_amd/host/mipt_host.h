@@ -230,6 +230,7 @@ int  mh_num_groups(mh_raytracer*, int obj);
 const float* mh_group_texture_values(mh_raytracer*, int obj, int grp, int slot);
 int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,
                  int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
+void mh_set_obj_slicing(int slice_bytes, int max_slices);    // test hook: readOBJ parses slices of the file concurrently (default 1 MiB, one per hardware thread)
 void mh_set_bvh_builder(int mode, int device);              // 0 host recursion, 1 GPU, 2 GPU if present else host (default)
 int  mh_mesh_bvh_builder(mh_raytracer*, int obj, double* seconds, double* device_seconds);   // 0 host / 1 GPU built this mesh
 void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks
