@@ -11,6 +11,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <array>
+#include <mutex>
 #include <memory>
 #include <chrono>
 #include <thread>
@@ -105,23 +107,36 @@ void Sphere::load_envmap_rgb8(const unsigned char* rgb, int w, int h) {
 Plane::Plane(const Vector& A_, const Vector& N) { type = OT_PLANE; A = A_; vecN = N; name = "Plane"; }
 
 // ---------------------------------------------------------------- TriMesh
+// contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
+template <class F>
+static void parallel_for(int n, F f) {
+	const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
+	if (nt <= 1) { f(0, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) th.emplace_back([=] { f((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+	for (auto& x : th) x.join();
+}
+
 TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt, const float* uv,
                  int nf, const int* fv, const int* fn, const int* ft, bool center) {
 	type = OT_TRIMESH; interp_normals = true; name = "mesh";
 	vertices.resize(nv); normals.resize(nn); uvs.resize(nt);
-	for (int i = 0; i < nv; i++) vertices[i] = Vector(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
-	for (int i = 0; i < nn; i++) normals[i] = Vector(norms[3 * i], norms[3 * i + 1], norms[3 * i + 2]);
+	parallel_for(nv, [&](int a, int b) { for (int i = a; i < b; i++) vertices[i] = Vector(verts[3 * (size_t)i], verts[3 * (size_t)i + 1], verts[3 * (size_t)i + 2]); });
+	parallel_for(nn, [&](int a, int b) { for (int i = a; i < b; i++) normals[i] = Vector(norms[3 * (size_t)i], norms[3 * (size_t)i + 1], norms[3 * (size_t)i + 2]); });
 	for (int i = 0; i < nt; i++) uvs[i] = Vector(uv[2 * i], uv[2 * i + 1], 0);
 	indices.resize(nf);
-	for (int i = 0; i < nf; i++) {
+	parallel_for(nf, [&](int a, int b) {
+	for (int i = a; i < b; i++) {
+		const size_t j = 3 * (size_t)i;
 		mipt_triangle_indices& t = indices[i];
 		memset(&t, 0, sizeof t);
-		t.vtxi = fv[3 * i]; t.vtxj = fv[3 * i + 1]; t.vtxk = fv[3 * i + 2];
-		t.ni = fn ? fn[3 * i] : -1; t.nj = fn ? fn[3 * i + 1] : -1; t.nk = fn ? fn[3 * i + 2] : -1;
-		t.uvi = ft ? ft[3 * i] : -1; t.uvj = ft ? ft[3 * i + 1] : -1; t.uvk = ft ? ft[3 * i + 2] : -1;
+		t.vtxi = fv[j]; t.vtxj = fv[j + 1]; t.vtxk = fv[j + 2];
+		t.ni = fn ? fn[j] : -1; t.nj = fn ? fn[j + 1] : -1; t.nk = fn ? fn[j + 2] : -1;
+		t.uvi = ft ? ft[j] : -1; t.uvj = ft ? ft[j + 1] : -1; t.uvk = ft ? ft[j + 2] : -1;
 		t.group = 0;   // no usemtl: every face in group 0, "Default" (TriangleMesh.cpp:462-467)
 		t.showEdges[0] = t.showEdges[1] = t.showEdges[2] = 1;
 	}
+	});
 	groupNames["Default"] = 0;
 	add_default_group_materials(1);
 	finish_init(center);
@@ -132,16 +147,6 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 static int g_bvh_builder_mode = 2, g_bvh_builder_device = 0;
 extern "C" void mh_set_obj_slicing(int slice_bytes, int max_slices);   // test hook: how readOBJ cuts the text into concurrently parsed slices
 extern "C" void mh_set_bvh_builder(int mode, int device) { g_bvh_builder_mode = mode; g_bvh_builder_device = device; }
-
-// contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
-template <class F>
-static void parallel_for(int n, F f) {
-	const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
-	if (nt <= 1) { f(0, n); return; }
-	std::vector<std::thread> th;
-	for (int t = 0; t < nt; t++) th.emplace_back([=] { f((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
-	for (auto& x : th) x.join();
-}
 
 // readOBJ's per-group default material lists (TriangleMesh.cpp:470-480)
 void TriMesh::add_default_group_materials(int ngroups) {
@@ -155,17 +160,28 @@ void TriMesh::add_default_group_materials(int ngroups) {
 void TriMesh::finish_init(bool center) {
 	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
-	for (auto& v : vertices) { std::swap(v[0], v[2]); v[0] = -v[0]; }
-	for (auto& v : normals) { std::swap(v[0], v[2]); v[0] = -v[0]; }
+	const int nvtx = (int)vertices.size();
+	parallel_for(nvtx, [&](int a, int b) { for (int i = a; i < b; i++) { Vector& v = vertices[i]; std::swap(v[0], v[2]); v[0] = -v[0]; } });
+	parallel_for(nn, [&](int a, int b) { for (int i = a; i < b; i++) { Vector& v = normals[i]; std::swap(v[0], v[2]); v[0] = -v[0]; } });
 	float bmin[3] = {1E9f, 1E9f, 1E9f}, bmax[3] = {-1E9f, -1E9f, -1E9f};
-	for (const auto& v : vertices) for (int k = 0; k < 3; k++) { bmin[k] = std::min(bmin[k], v[k]); bmax[k] = std::max(bmax[k], v[k]); }
+	{   // min / max over chunks, joined in chunk order: std::min / std::max keep the earlier of equal values either way
+		std::mutex mu;
+		std::map<int, std::array<float, 6>> part;
+		parallel_for(nvtx, [&](int a, int b) {
+			std::array<float, 6> q = {1E9f, 1E9f, 1E9f, -1E9f, -1E9f, -1E9f};
+			for (int i = a; i < b; i++) for (int k = 0; k < 3; k++) { q[k] = std::min(q[k], vertices[i][k]); q[3 + k] = std::max(q[3 + k], vertices[i][k]); }
+			std::lock_guard<std::mutex> g(mu);
+			part[a] = q;
+		});
+		for (const auto& kv : part) for (int k = 0; k < 3; k++) { bmin[k] = std::min(bmin[k], kv.second[k]); bmax[k] = std::max(bmax[k], kv.second[3 + k]); }
+	}
 	if (center) {   // :760-770 with scaling = 1, offset = 0
 		float s = std::max(bmax[0] - bmin[0], std::max(bmax[1] - bmin[1], bmax[2] - bmin[2]));
 		float c[3] = {(bmin[0] + bmax[0]) * 0.5f, (bmin[1] + bmax[1]) * 0.5f, (bmin[2] + bmax[2]) * 0.5f};
-		for (auto& v : vertices) for (int k = 0; k < 3; k++) v[k] = (v[k] - c[k]) / s * 1.f + 0.f;
+		parallel_for(nvtx, [&](int a, int b) { for (int i = a; i < b; i++) for (int k = 0; k < 3; k++) vertices[i][k] = (vertices[i][k] - c[k]) / s * 1.f + 0.f; });
 	}
 	permuted_triangle_index.resize(nf);
-	for (int i = 0; i < nf; i++) permuted_triangle_index[i] = i;
+	parallel_for(nf, [&](int a, int b) { for (int i = a; i < b; i++) permuted_triangle_index[i] = i; });
 	// build_bvh (:878-885): on the GPU (mipt_build_bvh, same tree and triangle order) or with the host recursion below
 	build_bbox(0, nf, bvh.bbox);
 	const auto t_build = std::chrono::steady_clock::now();
@@ -607,10 +623,24 @@ TriMesh::TriMesh(const char* obj, bool center, bool load_textures) {
 void TriMesh::build_bbox(int i0, int i1, float* o) const {   // :843-858
 	const Vector& f = vertices[indices[i0].vtxi];
 	for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[k]; }
-	for (int i = i0; i < i1; i++) {
-		const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
-		for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) { o[k] = std::min(o[k], vertices[vi[c]][k]); o[3 + k] = std::max(o[3 + k], vertices[vi[c]][k]); }
-	}
+	auto range = [&](int a, int b, float* q) {
+		for (int i = a; i < b; i++) {
+			const int vi[3] = {indices[i].vtxi, indices[i].vtxj, indices[i].vtxk};
+			for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) { q[k] = std::min(q[k], vertices[vi[c]][k]); q[3 + k] = std::max(q[3 + k], vertices[vi[c]][k]); }
+		}
+	};
+	if (i1 - i0 < (1 << 18)) { range(i0, i1, o); return; }
+	// whole-mesh boxes (build_bvh, the object's bbox): chunks on threads, joined in chunk order (same result: min / max
+	// keep the earlier of equal values either way)
+	std::mutex mu;
+	std::map<int, std::array<float, 6>> part;
+	parallel_for(i1 - i0, [&](int a, int b) {
+		std::array<float, 6> q = {o[0], o[1], o[2], o[3], o[4], o[5]};
+		range(i0 + a, i0 + b, q.data());
+		std::lock_guard<std::mutex> g(mu);
+		part[a] = q;
+	});
+	for (const auto& kv : part) for (int k = 0; k < 3; k++) { o[k] = std::min(o[k], kv.second[k]); o[3 + k] = std::max(o[3 + k], kv.second[3 + k]); }
 }
 void TriMesh::build_centers_bbox(int i0, int i1, float* o) const {   // :861-875
 	auto center = [&](int i) { return divs(add(add(vertices[indices[i].vtxi], vertices[indices[i].vtxj]), vertices[indices[i].vtxk]), 3.f); };
