@@ -224,6 +224,18 @@ int mipt_trace_shadow(mipt_ctx* ctx, const mipt_ray* rays, const float* dist_lig
 int mipt_sample_radiance(mipt_ctx* ctx, const mipt_render_params* p, const int32_t* pixels_ij, int npix,
                          int k0, int k1, float* out_rgb, float* out_dxdy);
 
+/* The has_denoiser branch of render_image_nopreviz (Raytracer.cpp:1631-1645, 1676-1683): no splat — every sample adds
+ * its colour to its own pixel and 1 to the sample count — plus the two auxiliary images of the denoiser: the sums of
+ * getColor's albedoValue (Kd of the first hit) and normalValue (its shading normal), (0,0,0) for a sample that hits
+ * nothing (Raytracer.cpp:255-258, 1628).  All four arrays are in the reference's layout (idx = ((H-i-1)*W+j)*3) and are
+ * added to, like mipt_render's.  The caller divides by the count / normalises as Raytracer.cpp:1689-1696 does; note
+ * that the reference fills normalImage from imagedoublethreads (:1680), this entry returns the normals. */
+int mipt_render_denoiser_inputs(mipt_ctx* ctx, const mipt_render_params* p, float* accum_rgb, float* accum_w, float* albedo_rgb, float* normal_xyz);
+
+/* Test aid beside mipt_sample_radiance: getColor's three outputs (colour, normalValue, albedoValue) per (pixel, sample). */
+int mipt_sample_denoiser_inputs(mipt_ctx* ctx, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1,
+                                float* out_rgb, float* out_normal, float* out_albedo);
+
 /* Work partition used by mipt_render*: the rank in [0, tile_nranks) that renders pixel (i, j) of a
  * W-pixel-wide image, or -1 for bad parameters.  Pure host function (no device needed). */
 int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j);

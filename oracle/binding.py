@@ -256,6 +256,21 @@ class _Base:
         self.lib.ref_getcolor_samples(self.ctx, n, _p(ij, _i), k0, k1, _p(rgb, _f), _p(dxdy, _f))
         return rgb, dxdy
 
+    def getcolor_samples_aov(self, ij, k0, k1):
+        """(rgb, normal, albedo) per sample: getColor's colour and its normalValue / albedoValue outputs."""
+        ij = np.ascontiguousarray(ij, np.int32)
+        n = ij.shape[0]
+        out = [np.zeros((n, k1 - k0, 3), np.float32) for _ in range(3)]
+        self.lib.ref_getcolor_samples_aov(self.ctx, n, _p(ij, _i), k0, k1, *[_p(a, _f) for a in out])
+        return tuple(out)
+
+    def render_denoiser_inputs(self):
+        """(imagedouble, sample_count, albedo sums, normal sums) of the has_denoiser accumulation (no splat)."""
+        img, alb, nrm = (np.zeros((self.H, self.W, 3), np.float32) for _ in range(3))
+        cnt = np.zeros((self.H, self.W), np.float32)
+        self.lib.ref_render_denoiser_inputs(self.ctx, _p(img, _f), _p(cnt, _f), _p(alb, _f), _p(nrm, _f))
+        return img, cnt, alb, nrm
+
     def render_seeded(self):
         img = np.zeros((self.H, self.W, 3), np.float32)
         cnt = np.zeros((self.H, self.W), np.float32)

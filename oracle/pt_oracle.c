@@ -851,7 +851,9 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
 /* ------------------------------------------------------------------ getColor (Raytracer.cpp:196-664), in-scope branches */
 /* Fog, subsurface, ghost and background-photo branches are OUT OF SCOPE; with
  * them removed the Contrib queue never holds more than one entry, so it is a plain loop. */
-static v3 get_color(const o_ctx* c, o_ray r, int sampleID, int screenI, int screenJ, pcg32_t* rng, uint64_t* nrays2) {
+/* normalValue / albedoValue: the denoiser inputs of Raytracer.cpp:255-258 (shading normal and Kd of the FIRST hit;
+   left untouched without one, so they keep the zeros `Vector normal, albedo;` starts from, :1628).  May be NULL. */
+static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int screenJ, pcg32_t* rng, uint64_t* nrays2, v3* normalValue, v3* albedoValue) {
 	v3 color = V(0, 0, 0);
 	v3 pathWeight = V(1.f, 1.f, 1.f);
 	o_ray currentRay = r;
@@ -867,6 +869,10 @@ static v3 get_color(const o_ctx* c, o_ray r, int sampleID, int screenI, int scre
 		int has_inter = scene_intersection(c, &currentRay, &P, &sphere_id, &t, &mat, &tri_id);   /* :251 */
 		if (nrays2) nrays2[0]++;
 		v3 N = mat.shadingN;
+		if (has_inter && nbrebonds == c->nb_bounces) {              /* :255-258 */
+			if (normalValue) *normalValue = N;
+			if (albedoValue) *albedoValue = mat.Kd;
+		}
 		v3 rayDirection = currentRay.direction;
 		if (!has_inter) break;                                      /* :654-657 */
 		if (sphere_id == 1) {                                       /* :275-301 (show_envmap always true in scope) */
@@ -1457,6 +1463,10 @@ void o_phong_eval(int n, const float* mat9, const float* wi3, const float* wo3, 
 	}
 }
 
+static v3 get_color(const o_ctx* c, o_ray r, int sampleID, int screenI, int screenJ, pcg32_t* rng, uint64_t* nrays2) {
+	return get_color_aov(c, r, sampleID, screenI, screenJ, rng, nrays2, NULL, NULL);
+}
+
 /* ------------------------------------------------------------------ radiance API */
 /* one (pixel, sample): seeding rule + the 4 camera draws of Raytracer.cpp:1462-1466 */
 static v3 sample_radiance(const o_ctx* c, int i, int j, int k, float* dx_out, float* dy_out, uint64_t* nrays2) {
@@ -1470,6 +1480,55 @@ static v3 sample_radiance(const o_ctx* c, int i, int j, int k, float* dx_out, fl
 	o_ray r = generate_direction(c, c->double_frustum_start_t, i, j, dx, dy, dx_aperture, dy_aperture, c->W, c->H);
 	*dx_out = dx; *dy_out = dy;
 	return get_color(c, r, k, i, j, &rng, nrays2);
+}
+
+/* per-sample denoiser inputs: getColor's normalValue / albedoValue beside the colour */
+static v3 sample_radiance_aov(const o_ctx* c, int i, int j, int k, v3* normal, v3* albedo) {
+	pcg32_t rng;
+	uint64_t p = (uint64_t)i * (uint64_t)c->W + (uint64_t)j;
+	pcg_seed(&rng, p * 65536ull + (uint64_t)k);
+	float dx = pcg_uniform(&rng) - 0.5f;
+	float dy = pcg_uniform(&rng) - 0.5f;
+	float dx_aperture = (pcg_uniform(&rng) - 0.5f) * c->aperture;
+	float dy_aperture = (pcg_uniform(&rng) - 0.5f) * c->aperture;
+	o_ray r = generate_direction(c, c->double_frustum_start_t, i, j, dx, dy, dx_aperture, dy_aperture, c->W, c->H);
+	*normal = V(0, 0, 0); *albedo = V(0, 0, 0);                   /* Vector normal, albedo; (:1628) */
+	return get_color_aov(c, r, k, i, j, &rng, NULL, normal, albedo);
+}
+void o_getcolor_samples_aov(o_ctx* c, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_normal, float* out_albedo) {
+	#pragma omp parallel for schedule(dynamic, 256) if(npix >= 4096)
+	for (int q = 0; q < npix; q++) for (int k = k0; k < k1; k++) {
+		v3 n, a;
+		v3 col = sample_radiance_aov(c, ij[2 * q], ij[2 * q + 1], k, &n, &a);
+		size_t o = (size_t)q * (size_t)(k1 - k0) + (size_t)(k - k0);
+		out_rgb[3 * o] = col.x; out_rgb[3 * o + 1] = col.y; out_rgb[3 * o + 2] = col.z;
+		out_normal[3 * o] = n.x; out_normal[3 * o + 1] = n.y; out_normal[3 * o + 2] = n.z;
+		out_albedo[3 * o] = a.x; out_albedo[3 * o + 1] = a.y; out_albedo[3 * o + 2] = a.z;
+	}
+	#pragma omp parallel
+	cnt_flush();
+}
+/* has_denoiser accumulation of render_image_nopreviz (Raytracer.cpp:1631-1645): no splat, every sample adds its colour,
+   normal and albedo to its own pixel and 1 to the sample count.  Sums only (the caller divides, :1689-1696); `normal`
+   receives the sum of the shading normals — the reference's normalImage adds imagedoublethreads instead (:1680). */
+void o_render_denoiser_inputs(o_ctx* c, float* imagedouble, float* sample_count, float* albedo, float* normal) {
+	const int W = c->W, H = c->H;
+	memset(imagedouble, 0, sizeof(float) * (size_t)W * H * 3);
+	memset(albedo, 0, sizeof(float) * (size_t)W * H * 3);
+	memset(normal, 0, sizeof(float) * (size_t)W * H * 3);
+	memset(sample_count, 0, sizeof(float) * (size_t)W * H);
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) for (int k = 0; k < c->nrays; k++) {
+		v3 n, a;
+		v3 color = sample_radiance_aov(c, i, j, k, &n, &a);
+		const int idx = ((H - i - 1) * W + j) * 3;
+		imagedouble[idx + 0] += color.x; imagedouble[idx + 1] += color.y; imagedouble[idx + 2] += color.z;
+		sample_count[(H - i - 1) * W + j] += 1;
+		normal[idx + 0] += n.x; normal[idx + 1] += n.y; normal[idx + 2] += n.z;
+		albedo[idx + 0] += a.x; albedo[idx + 1] += a.y; albedo[idx + 2] += a.z;
+	}
+	#pragma omp parallel
+	cnt_flush();
 }
 
 void o_getcolor_samples(o_ctx* c, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy) {

@@ -413,6 +413,60 @@ void ref_getcolor_samples(RefCtx* c, int npix, const int* ij, int k0, int k1, fl
 	}
 }
 
+// The denoiser inputs getColor hands back (normalValue / albedoValue of the first hit, Raytracer.cpp:255-258), per sample
+// and accumulated as render_image_nopreviz does with has_denoiser (:1631-1645: no splat, count += 1).
+void ref_getcolor_samples_aov(RefCtx* c, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_normal, float* out_albedo) {
+	Raytracer* rt = c->rt;
+	omp_set_num_threads(1);
+	const float invmax = rt->invmax;
+	for (int q = 0; q < npix; q++) {
+		int i = ij[2 * q], j = ij[2 * q + 1];
+		uint64_t p = (uint64_t)i * (uint64_t)rt->W + (uint64_t)j;
+		for (int k = k0; k < k1; k++) {
+			engine[0] = pcg32(p * 65536ull + (uint64_t)k);
+			float dx = engine[0]()*invmax - 0.5f;
+			float dy = engine[0]()*invmax - 0.5f;
+			float dx_aperture = (engine[0]()*invmax - 0.5f) * rt->cam.aperture;
+			float dy_aperture = (engine[0]()*invmax - 0.5f) * rt->cam.aperture;
+			float time = rt->s.current_frame;
+			Ray r = rt->cam.generateDirection(rt->s.double_frustum_start_t, i, j, time, dx, dy, dx_aperture, dy_aperture, rt->W, rt->H);
+			Vector normal, albedo;
+			Vector color = rt->getColor(r, k, rt->nb_bounces, i, j, normal, albedo, false, false);
+			size_t o = (size_t)q * (size_t)(k1 - k0) + (size_t)(k - k0);
+			for (int a = 0; a < 3; a++) { out_rgb[3 * o + a] = color[a]; out_normal[3 * o + a] = normal[a]; out_albedo[3 * o + a] = albedo[a]; }
+		}
+	}
+}
+void ref_render_denoiser_inputs(RefCtx* c, float* imagedouble, float* sample_count, float* albedoImage, float* normalImage) {
+	Raytracer* rt = c->rt;
+	omp_set_num_threads(1);
+	const int W = rt->W, H = rt->H;
+	const float invmax = rt->invmax;
+	memset(imagedouble, 0, sizeof(float)*(size_t)W*H * 3);
+	memset(albedoImage, 0, sizeof(float)*(size_t)W*H * 3);
+	memset(normalImage, 0, sizeof(float)*(size_t)W*H * 3);
+	memset(sample_count, 0, sizeof(float)*(size_t)W*H);
+	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+		uint64_t p = (uint64_t)i * (uint64_t)W + (uint64_t)j;
+		for (int k = 0; k < rt->nrays; k++) {
+			engine[0] = pcg32(p * 65536ull + (uint64_t)k);
+			float dx = engine[0]()*invmax - 0.5f;
+			float dy = engine[0]()*invmax - 0.5f;
+			float dx_aperture = (engine[0]()*invmax - 0.5f) * rt->cam.aperture;
+			float dy_aperture = (engine[0]()*invmax - 0.5f) * rt->cam.aperture;
+			float time = rt->s.current_frame;
+			Ray r = rt->cam.generateDirection(rt->s.double_frustum_start_t, i, j, time, dx, dy, dx_aperture, dy_aperture, W, H);
+			Vector normal, albedo;
+			Vector color = rt->getColor(r, k, rt->nb_bounces, i, j, normal, albedo, false, false);
+			int idx = ((H - i - 1)*W + j) * 3;                       // Raytracer.cpp:1632-1645
+			imagedouble[idx + 0] += color[0]; imagedouble[idx + 1] += color[1]; imagedouble[idx + 2] += color[2];
+			sample_count[(H - i - 1)*W + j] += 1;
+			normalImage[idx + 0] += normal[0]; normalImage[idx + 1] += normal[1]; normalImage[idx + 2] += normal[2];
+			albedoImage[idx + 0] += albedo[0]; albedoImage[idx + 1] += albedo[1]; albedoImage[idx + 2] += albedo[2];
+		}
+	}
+}
+
 // Full image with the seeding rule above and the reference's own splat arithmetic
 // (Raytracer.cpp:1477-1497), visiting pixels row-major and k innermost (single thread).
 // imagedouble[W*H*3] (row-flipped as the reference), sample_count[W*H].

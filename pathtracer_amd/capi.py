@@ -28,7 +28,7 @@ MIPT_ERR_UNSUPPORTED = 4
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
                 "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
-                "mipt_build_bvh", "mipt_build_bvh_error"]
+                "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs"]
 
 _f = C.c_float
 _i = C.c_int
@@ -412,6 +412,32 @@ class HostRaytracer:
         return rgb, dxdy
 
     getcolor_samples = sample_radiance
+
+    def getcolor_samples_aov(self, ij, k0, k1):
+        """(rgb, normal, albedo) per sample: getColor's colour and its normalValue / albedoValue outputs (mipt_sample_denoiser_inputs)."""
+        self._need_device()
+        ij = np.ascontiguousarray(ij, np.int32)
+        n = ij.shape[0]
+        out = [np.zeros((n, k1 - k0, 3), np.float32) for _ in range(3)]
+        self._check(self.mipt.mipt_sample_denoiser_inputs(self.ctx, self.render_params, _p(ij, C.c_int32), n, k0, k1, *[_p(a, _f) for a in out]), "mipt_sample_denoiser_inputs")
+        return tuple(out)
+
+    def render_denoiser_inputs(self):
+        """mipt_render_denoiser_inputs into zeroed accumulators: (imagedouble, sample_count, albedo sums, normal sums)."""
+        self._need_device()
+        img, alb, nrm = (np.zeros((self.H, self.W, 3), np.float32) for _ in range(3))
+        cnt = np.zeros((self.H, self.W), np.float32)
+        self._check(self.mipt.mipt_render_denoiser_inputs(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), _p(alb, _f), _p(nrm, _f)), "mipt_render_denoiser_inputs")
+        return img, cnt, alb, nrm
+
+    def set_has_denoiser(self, on=True):
+        self.host.mh_set_has_denoiser(self.h, 1 if on else 0)
+
+    def denoiser_images(self):
+        """(albedoImage, normalImage as the reference computes it, shadingNormalImage) after render_image_nopreviz with has_denoiser."""
+        self.host.mh_denoiser_image.restype = C.c_void_p
+        n = self.W * self.H
+        return tuple(np.ctypeslib.as_array(C.cast(self.host.mh_denoiser_image(self.h, k), C.POINTER(_f)), shape=(n * 3,)).reshape(self.H, self.W, 3).copy() for k in range(3))
 
     def render(self):
         """mipt_render into zeroed host accumulators: (imagedouble[H,W,3], sample_count[H,W])."""

@@ -188,6 +188,54 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 #include "mipt_persistent.h"
 #include "mipt_build.h"
 
+// ---- denoiser inputs (has_denoiser branch of render_image_nopreviz, Raytracer.cpp:1631-1645) ---------------------------
+// getColor hands back the shading normal and Kd of the first hit (Raytracer.cpp:255-258).  They are read off the hit
+// records of depth 0 by a stage of their own, launched only when the caller asked for them: the tuned shade kernels
+// stay as they are.  No hit: (0,0,0), the value `Vector normal, albedo;` starts from (:1628).
+__global__ void __launch_bounds__(256) k_wf_aov(const DScene* __restrict__ sc, DWave wf, unsigned n, float4* __restrict__ aov_n, float4* __restrict__ aov_kd) {
+	const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n) return;
+	float4 on = make_float4(0.f, 0.f, 0.f, 0.f), okd = on;
+	const float4 w = wf.wgt[id];
+	if (__float_as_uint(w.w) & MIPT_WF_VALID) {
+		const float4 o = wf.ray_o[id], d = wf.ray_d[id], hr = wf.hit[id];
+		const unsigned packed = __float_as_uint(hr.w);
+		if (packed != MIPT_HIT_MISS) {
+			Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
+			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
+			h.obj = (int)(packed >> 27);
+			h.tri = ((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI);
+			f3 P = mk3(0, 0, 0); Mat m;
+			m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
+			hit_material(sc, ray, h, P, m);
+			on = make_float4(m.shadingN.x, m.shadingN.y, m.shadingN.z, 0.f);
+			okd = make_float4(m.Kd.x, m.Kd.y, m.Kd.z, 0.f);
+		}
+	}
+	aov_n[id] = on; aov_kd[id] = okd;
+}
+// every sample adds its colour, normal and albedo to its own pixel and 1 to the sample count (no splat); the sums of a
+// pass are formed from zero in sample order, like the per-thread buffers of the reference, and then added to the image
+__global__ void __launch_bounds__(256) k_resolve_aov(DRender R, DPass ps, DSamples in, const float4* __restrict__ aov_n, const float4* __restrict__ aov_kd,
+                                                     float* __restrict__ accum, float* __restrict__ aov) {
+	const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pid >= R.W * R.H) return;
+	const int slot = ps.pix2slot[pid];
+	if (slot < 0) return;
+	const int W = R.W, H = R.H, i = pid / W, j = pid % W;
+	const size_t d = (size_t)(H - i - 1) * W + j, npx = (size_t)W * H;
+	float c[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f}, a[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+	for (int kk = 0; kk < ps.k1 - ps.k0; kk++) {
+		const size_t s = (size_t)kk * ps.npix_slots + slot;
+		const float4 col = in.col[s], nn = aov_n[s], kd = aov_kd[s];
+		c[0] += col.x; c[1] += col.y; c[2] += col.z; cnt += 1.f;
+		n[0] += nn.x; n[1] += nn.y; n[2] += nn.z;
+		a[0] += kd.x; a[1] += kd.y; a[2] += kd.z;
+	}
+	for (int k = 0; k < 3; k++) { accum[3 * d + k] += c[k]; aov[3 * d + k] += a[k]; aov[3 * npx + 3 * d + k] += n[k]; }
+	accum[3 * npx + d] += cnt;
+}
+
 // =====================================================================================
 // host side: context, upload, C-ABI
 // =====================================================================================
@@ -602,9 +650,9 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 }
 
 // Parity hook plumbing: instead of splatting, hand the per-sample results of ONE pass back to the host.
-struct SampleDump { const int32_t* ij; int npix; float* out_rgb; float* out_dxdy; };
+struct SampleDump { const int32_t* ij; int npix; float* out_rgb; float* out_dxdy; float* out_normal; float* out_albedo; };
 static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<int>& blocks, std::vector<int>& pix2slot);
-static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump);
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov = nullptr);
 
 extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1, float* out_rgb, float* out_dxdy) {
 	if (!c || !pixels_ij || !out_rgb || npix < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
@@ -620,7 +668,7 @@ extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, co
 	if (c->opt_pipeline == 1) {      // same stage kernels as mipt_render, results handed back instead of splatted
 		mipt_render_params q = *p;
 		q.sample_begin = k0; q.sample_end = k1; q.tile_nranks = 1; q.tile_rank = 0;
-		SampleDump dump{pixels_ij, npix, out_rgb, out_dxdy};
+		SampleDump dump{pixels_ij, npix, out_rgb, out_dxdy, nullptr, nullptr};
 		rc = render_impl(c, &q, nullptr, 0, nullptr, nullptr, nullptr, &dump);
 		hipDeviceSynchronize();
 		return rc;
@@ -670,7 +718,7 @@ static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<in
 	return MIPT_OK;
 }
 
-static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump) {
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov) {
 	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
 	DRender R; float denom2;
 	int rc = make_render_consts(c, p, R, denom2, st);
@@ -719,11 +767,13 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	spp_pass = std::min(spp_pass, ke - kb);
 	if (dump && spp_pass < ke - kb) return fail(c, MIPT_ERR_INVALID, "mipt_sample_radiance with the wavefront pipeline needs paths_per_pass >= pixels x samples");
 	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
-	const int pipeline = (int)c->opt_pipeline;
+	const bool want_aov = d_aov || (dump && dump->out_normal);
+	const int pipeline = want_aov ? 1 : (int)c->opt_pipeline;   // the denoiser inputs are a stage of the wavefront pipeline
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
 	// carve the pass buffer
 	size_t bytes = N * (sizeof(float4) + sizeof(float2));
 	if (pipeline == 1) bytes += N * (7 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned)) + MIPT_WF_COUNTERS * sizeof(unsigned) + 256;
+	if (want_aov) bytes += N * 2 * sizeof(float4) + 64;
 	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, bytes))) return rc;
 	char* base = (char*)c->pass_buf;
 	auto carve = [&](size_t b) { char* r = base; base += (b + 15) & ~(size_t)15; return r; };
@@ -741,6 +791,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
 	}
+	float4 *aov_n = nullptr, *aov_kd = nullptr;
+	if (want_aov) { aov_n = (float4*)carve(N * sizeof(float4)); aov_kd = (float4*)carve(N * sizeof(float4)); }
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;
@@ -791,6 +843,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 					else hipLaunchKernelGGL(k_wf_extend, G(6), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
 				}
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_fast_shade) {
@@ -807,13 +860,20 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			}
 			c->stats.traverse_merged = merge ? 1u : 0u;
 		}
-		if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+		if (!dump && d_aov) hipLaunchKernelGGL(k_resolve_aov, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, aov_n, aov_kd, d_accum, d_aov);
+		else if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
 		HIPCHK(c, hipGetLastError());
 		if (dump) {
 			HIPCHK(c, hipStreamSynchronize(st));
 			std::vector<float4> hc(N); std::vector<float2> hj(N);
 			HIPCHK(c, hipMemcpy(hc.data(), S.col, N * sizeof(float4), hipMemcpyDeviceToHost));
 			HIPCHK(c, hipMemcpy(hj.data(), S.dxdy, N * sizeof(float2), hipMemcpyDeviceToHost));
+			std::vector<float4> hn, hk;
+			if (dump->out_normal) {
+				hn.resize(N); hk.resize(N);
+				HIPCHK(c, hipMemcpy(hn.data(), aov_n, N * sizeof(float4), hipMemcpyDeviceToHost));
+				HIPCHK(c, hipMemcpy(hk.data(), aov_kd, N * sizeof(float4), hipMemcpyDeviceToHost));
+			}
 			std::vector<int> blocks, pix2slot;
 			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
 			const int nk = ke - kb;
@@ -824,6 +884,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					size_t s = (size_t)k * npix_slots + slot, o = (size_t)q * nk + k;
 					dump->out_rgb[3 * o] = hc[s].x; dump->out_rgb[3 * o + 1] = hc[s].y; dump->out_rgb[3 * o + 2] = hc[s].z;
 					if (dump->out_dxdy) { dump->out_dxdy[2 * o] = hj[s].x; dump->out_dxdy[2 * o + 1] = hj[s].y; }
+					if (dump->out_normal) {
+						dump->out_normal[3 * o] = hn[s].x; dump->out_normal[3 * o + 1] = hn[s].y; dump->out_normal[3 * o + 2] = hn[s].z;
+						dump->out_albedo[3 * o] = hk[s].x; dump->out_albedo[3 * o + 1] = hk[s].y; dump->out_albedo[3 * o + 2] = hk[s].z;
+					}
 				}
 			}
 		}
@@ -895,6 +959,45 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 		if (pub.failed) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed");
 	}
 	hipFree(d_acc);
+	return rc;
+}
+
+extern "C" int mipt_sample_denoiser_inputs(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1,
+                                           float* out_rgb, float* out_normal, float* out_albedo) {
+	if (!c || !p || !pixels_ij || !out_rgb || !out_normal || !out_albedo || npix < 0 || k0 < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	if ((size_t)npix * (size_t)(k1 - k0) == 0) return MIPT_OK;
+	mipt_render_params q = *p;
+	q.sample_begin = k0; q.sample_end = k1; q.tile_nranks = 1; q.tile_rank = 0;
+	SampleDump dump{pixels_ij, npix, out_rgb, nullptr, out_normal, out_albedo};
+	int rc = render_impl(c, &q, nullptr, 0, nullptr, nullptr, nullptr, &dump);
+	hipDeviceSynchronize();
+	return rc;
+}
+
+extern "C" int mipt_render_denoiser_inputs(mipt_ctx* c, const mipt_render_params* p, float* accum_rgb, float* accum_w, float* albedo_rgb, float* normal_xyz) {
+	if (!c || !p || !accum_rgb || !accum_w || !albedo_rgb || !normal_xyz) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (p->W <= 0 || p->H <= 0) return fail(c, MIPT_ERR_INVALID, "bad image size");
+	const size_t npx = (size_t)p->W * p->H;
+	float* d = nullptr;                               // [rgb 3][w 1][albedo 3][normal 3] x npx, starting from the caller's running sums
+	HIPCHK(c, hipMalloc((void**)&d, npx * 10 * sizeof(float)));
+	hipError_t e = hipMemcpy(d, accum_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + npx * 3, accum_w, npx * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + npx * 4, albedo_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + npx * 7, normal_xyz, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { hipFree(d); return fail(c, MIPT_ERR_HIP, "upload of accumulators failed: %s", hipGetErrorString(e)); }
+	int rc = render_impl(c, p, d, 0, nullptr, nullptr, nullptr, nullptr, d + npx * 4);
+	hipError_t es = hipDeviceSynchronize();
+	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
+	if (rc == MIPT_OK) {
+		e = hipMemcpy(accum_rgb, d, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(accum_w, d + npx * 3, npx * sizeof(float), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(albedo_rgb, d + npx * 4, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(normal_xyz, d + npx * 7, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed");
+	}
+	hipFree(d);
 	return rc;
 }
 

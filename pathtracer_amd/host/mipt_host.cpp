@@ -1025,7 +1025,7 @@ bool Raytracer::load_scene(const char* filename) {
 	} else if (R.starts("bounces:")) nb_bounces = (int)strtoul(R.after("bounces:"), nullptr, 10);
 	else return bail("expected bounces");
 	if (!R.next()) return bail("truncated header");
-	if (R.starts("has_denoiser:")) { if (!R.getf("intensite_lum:", s.intensite_lumiere)) return bail(""); }
+	if (R.starts("has_denoiser:")) { has_denoiser = strtoul(R.after("has_denoiser:"), nullptr, 10) != 0; if (!R.getf("intensite_lum:", s.intensite_lumiere)) return bail(""); }
 	else if (R.starts("intensite_lum:")) s.intensite_lumiere = strtof(R.after("intensite_lum:"), nullptr);
 	else return bail("expected intensite_lum");
 	if (!R.getf("intensite_envmap:", s.envmap_intensity)) return bail("");
@@ -1106,7 +1106,7 @@ bool Raytracer::save_scene(const char* filename) const {
 	fprintf(f, "Cam: (%f, %f, %f), (%f, %f, %f), (%f, %f, %f)\n", cam.position[0], cam.position[1], cam.position[2], cam.direction[0], cam.direction[1], cam.direction[2], cam.up[0], cam.up[1], cam.up[2]);
 	fprintf(f, "fov: %f\nfocus: %f\naperture: %f\nsigma_filter: %f\ngamma: %f\n", cam.fov, cam.focus_distance, cam.aperture, sigma_filter, gamma);
 	fprintf(f, "is_lenticular: 0\nlenticular_nb_images: 10\nlenticular_max_angle: %f\nlenticular_pixel_width: 1\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n", (float)(35 * M_PI / 180. * 0.25), 0.f, 0.f);   // Camera defaults (Vector.h:720-730)
-	fprintf(f, "bounces: %u\nhas_denoiser: 0\n", nb_bounces);
+	fprintf(f, "bounces: %u\nhas_denoiser: %u\n", nb_bounces, has_denoiser ? 1u : 0u);
 	fprintf(f, "intensite_lum: %f\nintensite_envmap: %f\n", s.intensite_lumiere, s.envmap_intensity);
 	fprintf(f, "nbobjects: %u\n", (unsigned)s.objects.size());
 	auto list3 = [&](const char* key, const std::vector<Texture>& l) {
@@ -1298,6 +1298,24 @@ void Raytracer::render_image_nopreviz() {
 	err_.clear();
 	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
 	stopped = 0;
+	if (has_denoiser) {   // :1631-1645, 1676-1696; the denoiser itself (OpenImageDenoise, :1721-1737) is not part of the path
+		const size_t npx = (size_t)W * H;
+		albedoImage.assign(npx * 3, 0.f); normalImage.assign(npx * 3, 0.f); shadingNormalImage.assign(npx * 3, 0.f);
+		if ((last_status = mipt_render_denoiser_inputs(ctx, &render_params, imagedouble.data(), sample_count.data(), albedoImage.data(), shadingNormalImage.data())) != MIPT_OK) return;
+		for (size_t i = 0; i < npx * 3; i++) normalImage[i] += imagedouble[i];   // normalImage += imagedoublethreads (:1680)
+		for (size_t i = 0; i < npx; i++) {
+			const float nn = std::sqrt(normalImage[i * 3] * normalImage[i * 3] + normalImage[i * 3 + 1] * normalImage[i * 3 + 1] + normalImage[i * 3 + 2] * normalImage[i * 3 + 2]);
+			const float ns = std::sqrt(shadingNormalImage[i * 3] * shadingNormalImage[i * 3] + shadingNormalImage[i * 3 + 1] * shadingNormalImage[i * 3 + 1] + shadingNormalImage[i * 3 + 2] * shadingNormalImage[i * 3 + 2]);
+			for (int j = 0; j < 3; j++) {
+				imagedouble[i * 3 + j] /= sample_count[i];
+				albedoImage[i * 3 + j] /= sample_count[i];
+				normalImage[i * 3 + j] /= nn;
+				shadingNormalImage[i * 3 + j] /= ns;
+			}
+		}
+		tone_map(true);
+		return;
+	}
 	if ((last_status = mipt_render(ctx, &render_params, imagedouble.data(), sample_count.data(), nullptr, nullptr, &stopped)) != MIPT_OK) return;
 	for (size_t i = 0; i < (size_t)W * H; i++) for (int j = 0; j < 3; j++) imagedouble[i * 3 + j] /= sample_count[i];
 	tone_map(true);
@@ -1326,6 +1344,8 @@ void mh_set_camera(mh_raytracer* h, const float* pos, const float* dir, const fl
 void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite) {
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
 }
+void mh_set_has_denoiser(mh_raytracer* h, int on) { h->rt.has_denoiser = on != 0; }
+float* mh_denoiser_image(mh_raytracer* h, int which) { std::vector<float>& v = which == 0 ? h->rt.albedoImage : (which == 1 ? h->rt.normalImage : h->rt.shadingNormalImage); return v.empty() ? nullptr : v.data(); }
 void mh_set_envmap_intensity(mh_raytracer* h, float v) { h->rt.s.envmap_intensity = v; }
 // decode an image file the way Texture::loadColors' load_image does (stb_image, 3 channels, rows as in the file): for tests
 int mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W, int* H, char* err, int errlen) {

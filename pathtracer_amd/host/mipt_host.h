@@ -184,6 +184,12 @@ public:
 	std::vector<unsigned char> image;
 	std::vector<float> imagedouble;
 	std::vector<float> sample_count;
+	// has_denoiser (Raytracer.h:88): render_image_nopreviz accumulates without the splat and fills the denoiser's
+	// auxiliary images (Raytracer.cpp:1631-1645, 1676-1696).  albedoImage = mean Kd of the first hits;
+	// normalImage = what the reference computes (the colour sums, normalised: it adds imagedoublethreads at :1680),
+	// shadingNormalImage = the normalised sum of the first hits' shading normals (what :1680 presumably meant).
+	bool has_denoiser = false;
+	std::vector<float> albedoImage, normalImage, shadingNormalImage;
 	std::vector<float> filter_value, filter_integral;
 	std::vector<Vector> samples2d, randomPerPixel;
 	Vector centerLight;
@@ -251,6 +257,8 @@ void* mh_ctx(mh_raytracer*);                              // mipt_ctx*
 const void* mh_scene_desc(mh_raytracer*);                 // const mipt_scene_desc*
 const void* mh_render_params(mh_raytracer*);              // const mipt_render_params*
 float* mh_imagedouble(mh_raytracer*);
+void mh_set_has_denoiser(mh_raytracer*, int on);
+float* mh_denoiser_image(mh_raytracer*, int which);          // 0 albedoImage, 1 normalImage (as the reference), 2 shadingNormalImage
 float* mh_sample_count(mh_raytracer*);
 unsigned char* mh_image(mh_raytracer*);
 // dumps with the layouts of oracle/ref_harness.cpp (so one test body serves all three)

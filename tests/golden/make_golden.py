@@ -199,5 +199,24 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv:
     main()
+
+
+def main_denoiser_inputs():
+    """tests/golden/denoiser_inputs.npz: getColor's normalValue / albedoValue per sample and the has_denoiser sums
+    (Raytracer.cpp:255-258, 1631-1645) of three golden scenes, from the compiled reference."""
+    g = {}
+    for name in ("textured", "cutout", "glass"):
+        R = Ref()
+        mesh, cfg, oid = setup(R, name)
+        rgb, nrm, alb = R.getcolor_samples_aov(all_pixels(cfg), 0, 2)
+        g[name + "_rgb"], g[name + "_normal"], g[name + "_albedo"] = rgb, nrm, alb
+        if name == "textured":
+            img, cnt, a, n = R.render_denoiser_inputs()
+            g[name + "_img"], g[name + "_cnt"], g[name + "_albedo_sum"], g[name + "_normal_sum"] = img, cnt, a, n
+    np.savez_compressed(os.path.join(OUT, "denoiser_inputs.npz"), **g)
+
+
+if __name__ == "__main__" and "--denoiser-inputs" in sys.argv:
+    main_denoiser_inputs()
