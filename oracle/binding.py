@@ -99,6 +99,17 @@ class _Base:
     def set_object_flags(self, obj, miroir=False, flip_normals=False):
         self.lib.ref_set_object_flags(self.ctx, obj, int(miroir), int(flip_normals))
 
+    def set_object_ghost(self, obj, ghost=True):
+        self.lib.ref_set_object_ghost(self.ctx, obj, int(ghost))
+
+    def set_background(self, rgb):
+        """Scene::background: float [H, W, 3], rows as in the file, in the renderer's x196964.699 units (None clears it)."""
+        if rgb is None:
+            self.lib.ref_set_background(self.ctx, None, 0, 0)
+            return
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        self.lib.ref_set_background(self.ctx, _p(rgb, _f), rgb.shape[1], rgb.shape[0])
+
     def set_group_material(self, obj, grp, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
         a = lambda v: (_f * 3)(*v)
         self.lib.ref_set_group_material(self.ctx, obj, grp, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))

@@ -119,6 +119,7 @@ enum { OT_SPHERE = 1, OT_PLANE = 2, OT_TRIMESH = 0 };
 typedef struct {
 	int type;
 	int miroir, flip_normals;
+	int ghost;                       /* Object::ghost (Geometry.h:721): invisible, but receives shadows / reflects (compositing over a photo) */
 	float scale; v3 max_translation; float mat_rotation[9]; v3 rotation_center;
 	float trans[12], inv[12], rot[9];                /* Geometry.h:322-360 */
 	int ntex[T_NSLOTS]; o_tex* tex[T_NSLOTS];
@@ -137,6 +138,7 @@ struct o_ctx {
 	v3 cam_pos, cam_dir, cam_up; float fov, focus, aperture;
 	o_obj* objs; int nobj, cap_obj;
 	float intensite_lumiere, envmap_intensity;
+	float* background; int backgroundW, backgroundH;   /* Scene::background (Geometry.h:1355-1366), top row first, x196964.699 */
 	float* randomPerPixel; float* samples2d;
 	v3 centerLight; float radiusLight, lightPower, lum_scale;
 	int current_frame; float double_frustum_start_t;
@@ -665,10 +667,11 @@ static int scene_intersection(const o_ctx* c, const o_ray* d, v3* P, int* sphere
 }
 
 /* ------------------------------------------------------------------ Scene::intersection_shadow (Geometry.cpp:691-744) */
-static int scene_intersection_shadow(const o_ctx* c, const o_ray* d, float dist_light) {
+static int scene_intersection_shadow_g(const o_ctx* c, const o_ray* d, float dist_light, int avoid_ghosts) {
 	float min_t = INFINITY;
 	for (int i = 0; i < c->nobj; i++) {
 		const o_obj* o = &c->objs[i];
+		if (avoid_ghosts && o->ghost) continue;                     /* Geometry.cpp:722 */
 		o_ray tr;
 		tr.direction = apply_inverse_rotation_scaling(o, d->direction);
 		tr.origin = apply_inverse_transformation(o, d->origin);
@@ -683,6 +686,8 @@ static int scene_intersection_shadow(const o_ctx* c, const o_ray* d, float dist_
 	}
 	return 0;
 }
+
+static int scene_intersection_shadow(const o_ctx* c, const o_ray* d, float dist_light) { return scene_intersection_shadow_g(c, d, dist_light, 0); }
 
 /* ------------------------------------------------------------------ samplers */
 /* Vector.h:567-579 getTangent */
@@ -853,19 +858,37 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
  * them removed the Contrib queue never holds more than one entry, so it is a plain loop. */
 /* normalValue / albedoValue: the denoiser inputs of Raytracer.cpp:255-258 (shading normal and Kd of the FIRST hit;
    left untouched without one, so they keep the zeros `Vector normal, albedo;` starts from, :1628).  May be NULL. */
+typedef struct { v3 weight; o_ray r; int depth; int show_lights, showenvmap; } o_contrib;   /* Raytracer.h:15-23 (no subsurface here) */
+#define O_SIZE_CIRC_ARRAY 200                                                                /* Raytracer.h:114 */
+static v3 background_pixel(const o_ctx* c, int screenI, int screenJ) {                       /* :261-265 */
+	int bi = (int)(screenI / (float)c->H * c->backgroundH); if (bi < 0) bi = 0; if (bi > c->backgroundH - 1) bi = c->backgroundH - 1;
+	int bj = (int)(screenJ / (float)c->W * c->backgroundW); if (bj < 0) bj = 0; if (bj > c->backgroundW - 1) bj = c->backgroundW - 1;
+	const float* px = c->background + ((size_t)bi * c->backgroundW + bj) * 3;
+	return V(px[0], px[1], px[2]);
+}
 static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int screenJ, pcg32_t* rng, uint64_t* nrays2, v3* normalValue, v3* albedoValue) {
 	v3 color = V(0, 0, 0);
-	v3 pathWeight = V(1.f, 1.f, 1.f);
-	o_ray currentRay = r;
-	int nbrebonds = c->nb_bounces;
-	int show_lights = 1;
 	o_mat mat; mat_default(&mat);
 	v3 P = V(0, 0, 0);
 	int sphere_id = -1, tri_id = -1;
 	float t;
-	for (;;) {
-		if (nbrebonds == 0) break;                                  /* :240 */
-		if (vnorm2(pathWeight) < sqrf(0.01f)) break;                /* :241 */
+	/* the contributions of a sample wait in a circular FIFO (:213-238); without ghosts (and fog) a vertex queues at most one */
+	o_contrib contribs[O_SIZE_CIRC_ARRAY];
+	int contribIndexStart = 0, contribIndexEnd = 1;
+	contribs[0].weight = V(1.f, 1.f, 1.f); contribs[0].r = r; contribs[0].depth = c->nb_bounces; contribs[0].show_lights = 1; contribs[0].showenvmap = 1;
+#define PUSH(w_, ray_, depth_, lights_, env_) do { o_contrib* q_ = &contribs[contribIndexEnd]; q_->weight = (w_); q_->r = (ray_); q_->depth = (depth_); q_->show_lights = (lights_); q_->showenvmap = (env_); \
+		contribIndexEnd++; if (contribIndexEnd >= O_SIZE_CIRC_ARRAY) contribIndexEnd = 0; } while (0)
+	const int has_dome = 1;                                         /* sphereEnv: object 1 is the environment sphere (loadScene) */
+	const int has_backgroundimage = c->backgroundW > 0 && c->background != NULL;   /* :220 */
+	while (contribIndexStart != contribIndexEnd) {
+		const o_contrib cur = contribs[contribIndexStart];
+		o_ray currentRay = cur.r;
+		int nbrebonds = cur.depth;
+		v3 pathWeight = cur.weight;
+		int show_lights = cur.show_lights, show_envmap = cur.showenvmap;
+		contribIndexStart++; if (contribIndexStart >= O_SIZE_CIRC_ARRAY) contribIndexStart = 0;
+		if (nbrebonds == 0) continue;                               /* :240 */
+		if (vnorm2(pathWeight) < sqrf(0.01f)) continue;             /* :241 */
 		int has_inter = scene_intersection(c, &currentRay, &P, &sphere_id, &t, &mat, &tri_id);   /* :251 */
 		if (nrays2) nrays2[0]++;
 		v3 N = mat.shadingN;
@@ -873,25 +896,30 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			if (normalValue) *normalValue = N;
 			if (albedoValue) *albedoValue = mat.Kd;
 		}
+		if (nbrebonds == c->nb_bounces && has_backgroundimage && (!has_inter || (has_inter && sphere_id == 1 && has_dome))) {   /* :260-268 */
+			color = vadd(color, vmul(pathWeight, background_pixel(c, screenI, screenJ)));
+			continue;
+		}
 		v3 rayDirection = currentRay.direction;
-		if (!has_inter) break;                                      /* :654-657 */
-		if (sphere_id == 1) {                                       /* :275-301 (show_envmap always true in scope) */
+		if (!has_inter) continue;                                   /* :654-655 (fog_density == 0) */
+		if (sphere_id == 1) {                                       /* :275-301 (no_envmap = false) */
+			if (!show_envmap) continue;
 			color = vadd(color, vmul(vscale(c->envmap_intensity, pathWeight), mat.Ke));
-			break;
+			continue;
 		}
 		if (sphere_id == 0) {                                       /* :303-316 */
 			v3 currentContrib = show_lights ? V(c->lightPower, c->lightPower, c->lightPower) : V(0.f, 0.f, 0.f);
 			color = vadd(color, vmul(pathWeight, currentContrib));
-			break;
+			continue;
 		}
 		const o_obj* obj = &c->objs[sphere_id];
 		v3 subsW = V(1.f / (1.f - 0.f), 1.f / (1.f - 0.f), 1.f / (1.f - 0.f));   /* :318-321, subsProba = 0 */
 		color = vadd(color, vscale(c->envmap_intensity, vmul(pathWeight, mat.Ke)));   /* :411 */
 		if (obj->miroir) {                                          /* :413-436 */
-			v3 direction_miroir = vreflect(rayDirection, N);
-			currentRay.origin = vadd(P, vscale(0.001f, N));
-			currentRay.direction = direction_miroir;
-			nbrebonds--;
+			o_ray rayon_miroir;
+			rayon_miroir.origin = vadd(P, vscale(0.001f, N));
+			rayon_miroir.direction = vreflect(rayDirection, N);
+			PUSH(pathWeight, rayon_miroir, nbrebonds - 1, show_lights, 1);
 			continue;
 		}
 		if (mat.transp) {                                           /* :438-489 */
@@ -916,8 +944,7 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			} else {
 				new_ray.origin = vadd(P, vscale(0.001f, normale)); new_ray.direction = vreflect(rayDirection, N);
 			}
-			currentRay = new_ray;
-			nbrebonds--;
+			PUSH(pathWeight, new_ray, nbrebonds - 1, show_lights, 1);   /* :483-486: showenvmap takes its default, true */
 			continue;
 		}
 		/* diffuse / glossy (:490-632) */
@@ -930,13 +957,20 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		o_ray ray_light; ray_light.origin = vadd(P, vscale(0.01f, wi)); ray_light.direction = wi;
 		int isShadowed;
 		if (vdot(mat.shadingN, wi) < 0) isShadowed = 1;
-		else { isShadowed = scene_intersection_shadow(c, &ray_light, sqrtf(d_light2) - 0.01f); if (nrays2) nrays2[1]++; }
+		else { isShadowed = scene_intersection_shadow_g(c, &ray_light, sqrtf(d_light2) - 0.01f, 1); if (nrays2) nrays2[1]++; }   /* :513: ghosts cast no shadow */
 		v3 currentContrib = V(0, 0, 0);
 		if (!isShadowed) {
+			if (obj->ghost) {                                       /* :522-536: the path goes straight on through the ghost, at the same depth */
+				v3 offset = vdot(N, rayDirection) > 0 ? N : vneg(N);
+				o_ray through;
+				through.origin = vadd(vadd(P, vscale(0.001f, rayDirection)), vscale(0.001f, offset));
+				through.direction = rayDirection;
+				PUSH(pathWeight, through, nbrebonds, show_lights, show_envmap);
+			}
 			v3 BRDF = obj->merl ? merl_eval(obj->merl, wi, vneg(rayDirection), N) : phong_eval(&mat, wi, vneg(rayDirection), N);
 			float J = vdot(Np, vneg(wi)) / d_light2;
 			float proba = vdot(axeOP, dir_aleatoire) / (M_PI * c->radiusLight * c->radiusLight);   /* double, narrowed */
-			if (proba > 0.f) {
+			if (!obj->ghost && proba > 0.f) {                       /* :547-553: no direct light on a ghost */
 				currentContrib = vadd(currentContrib, vmul(vscale((c->lightPower * fmaxf(0.f, vdot(N, wi)) * J / proba), subsW), BRDF));
 			}
 		}
@@ -953,15 +987,19 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			proba_globale = vdot(N, direction_aleatoire) / (M_PI);
 			has_sampled_diffuse = 0;
 		} else direction_aleatoire = phong_sample(&mat, vneg(rayDirection), N, &proba_globale, r1, r2, &has_sampled_diffuse, rng);
-		if (vdot(direction_aleatoire, N) < 0 || vdot(direction_aleatoire, vreflect(rayDirection, N)) < 0 || proba_globale <= 0) break;   /* :593 */
+		if (vdot(direction_aleatoire, N) < 0 || vdot(direction_aleatoire, vreflect(rayDirection, N)) < 0 || proba_globale <= 0) continue;   /* :593 */
 		v3 BRDFindirect = obj->merl ? merl_eval(obj->merl, direction_aleatoire, vneg(rayDirection), N) : phong_eval(&mat, direction_aleatoire, vneg(rayDirection), N);
 		v3 newpathWeight = vscale((vdot(N, direction_aleatoire) / proba_globale), vmul(vmul(pathWeight, subsW), BRDFindirect));   /* :611 */
-		currentRay.origin = vadd(P, vscale(0.01f, direction_aleatoire));
-		currentRay.direction = direction_aleatoire;
-		pathWeight = newpathWeight;
-		show_lights = 0;
-		nbrebonds--;
+		if (obj->ghost && has_backgroundimage) {                    /* :614-621: the photo shows through, tinted by what the ghost receives */
+			v3 bg = background_pixel(c, screenI, screenJ);
+			newpathWeight = vmul(newpathWeight, V(bg.x / 196964.699f, bg.y / 196964.699f, bg.z / 196964.699f));
+		}
+		o_ray rayon_aleatoire;
+		rayon_aleatoire.origin = vadd(P, vscale(0.01f, direction_aleatoire));
+		rayon_aleatoire.direction = direction_aleatoire;
+		PUSH(newpathWeight, rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :629 */
 	}
+#undef PUSH
 	return color;
 }
 
@@ -1246,6 +1284,17 @@ int o_add_mesh(o_ctx* c, int nv, const float* verts, int nn, const float* normal
 	return c->nobj - 1;
 }
 
+void o_set_object_ghost(o_ctx* c, int obj, int ghost) { c->objs[obj].ghost = ghost != 0; }
+/* Scene::background as load_background leaves it (Geometry.h:1355-1363): W*H*3 floats, rows as in the file, already
+   pow(v/255, gamma) * 196964.699 */
+void o_set_background(o_ctx* c, const float* rgb, int W, int H) {
+	free(c->background); c->background = NULL; c->backgroundW = c->backgroundH = 0;
+	if (rgb && W > 0 && H > 0) {
+		c->background = (float*)malloc(sizeof(float) * (size_t)W * H * 3);
+		memcpy(c->background, rgb, sizeof(float) * (size_t)W * H * 3);
+		c->backgroundW = W; c->backgroundH = H;
+	}
+}
 void o_set_object_flags(o_ctx* c, int obj, int miroir, int flip_normals) { c->objs[obj].miroir = miroir != 0; c->objs[obj].flip_normals = flip_normals != 0; }
 void o_set_group_material(o_ctx* c, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
 	o_obj* o = &c->objs[obj];

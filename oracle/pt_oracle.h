@@ -70,6 +70,8 @@ void   o_phong_eval(int n, const float* mat9, const float* wi3, const float* wo3
 /* radiance: per-(pixel,sample) stream pcg32(p*65536+k), p = i*W+j */
 void   o_getcolor_samples(o_ctx*, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy);
 void   o_render_seeded(o_ctx*, float* imagedouble, float* sample_count);
+void   o_set_object_ghost(o_ctx*, int obj, int ghost);
+void   o_set_background(o_ctx*, const float* rgb, int W, int H);
 void   o_getcolor_samples_aov(o_ctx*, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_normal, float* out_albedo);
 void   o_render_denoiser_inputs(o_ctx*, float* imagedouble, float* sample_count, float* albedo, float* normal);
 /* nopreviz-style schedule (4x4 pixel batches, dynamic,1, per-thread framebuffers then serial

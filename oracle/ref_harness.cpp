@@ -175,6 +175,13 @@ void ref_set_object_flags(RefCtx* c, int obj, int miroir, int flip_normals) {
 	c->rt->s.objects[obj]->miroir = miroir != 0;
 	c->rt->s.objects[obj]->flip_normals = flip_normals != 0;
 }
+void ref_set_object_ghost(RefCtx* c, int obj, int ghost) { c->rt->s.objects[obj]->ghost = ghost != 0; }
+// Scene::background as Scene::load_background leaves it (Geometry.h:1355-1363), set directly (the loader reads BMP files)
+void ref_set_background(RefCtx* c, const float* rgb, int W, int H) {
+	Scene& s = c->rt->s;
+	s.clear_background();
+	if (rgb && W > 0 && H > 0) { s.background.assign(rgb, rgb + (size_t)W * H * 3); s.backgroundW = W; s.backgroundH = H; }
+}
 void ref_set_group_material(RefCtx* c, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
 	Object* o = c->rt->s.objects[obj];
 	if (grp < (int)o->textures.size()) o->textures[grp].multiplier = Vector(Kd[0], Kd[1], Kd[2]);
