@@ -114,6 +114,11 @@ typedef struct mipt_object {
 typedef struct mipt_scene_desc {
 	int32_t n_objects;
 	const mipt_object* objects;
+	/* Scene::background (Geometry.h:1355-1366): the photo camera rays see when they leave the scene and that ghost
+	 * objects let through (Raytracer.cpp:260-268, 614-621); backgroundW x backgroundH x 3 floats, rows as in the file,
+	 * values as load_background leaves them (pow(v/255, gamma) * 196964.699), or NULL / 0 / 0. */
+	const float* background;
+	int32_t backgroundW, backgroundH;
 } mipt_scene_desc;
 
 /* Per-render inputs: the Raytracer members getColor / render_image read after

@@ -110,6 +110,15 @@ class _Base:
         rgb = np.ascontiguousarray(rgb, np.float32)
         self.lib.ref_set_background(self.ctx, _p(rgb, _f), rgb.shape[1], rgb.shape[0])
 
+    def load_background(self, path):
+        self.lib.ref_load_background(self.ctx, os.fsencode(path))
+
+    def get_background(self):
+        W, H = _i(0), _i(0)
+        buf = np.zeros(1 << 22, np.float32)
+        n = self.lib.ref_get_background(self.ctx, _p(buf, _f), buf.size, C.byref(W), C.byref(H))
+        return buf[:max(n, 0)].reshape(H.value, W.value, 3).copy() if n > 0 else None
+
     def set_group_material(self, obj, grp, Kd, Ks, Ne, transp_col=1.0, refr=1.3):
         a = lambda v: (_f * 3)(*v)
         self.lib.ref_set_group_material(self.ctx, obj, grp, a(Kd), a(Ks), a(Ne), _f(transp_col), _f(refr))

@@ -182,6 +182,14 @@ void ref_set_background(RefCtx* c, const float* rgb, int W, int H) {
 	s.clear_background();
 	if (rgb && W > 0 && H > 0) { s.background.assign(rgb, rgb + (size_t)W * H * 3); s.backgroundW = W; s.backgroundH = H; }
 }
+void ref_load_background(RefCtx* c, const char* file) { c->rt->s.load_background(file, c->rt->gamma); }
+int ref_get_background(RefCtx* c, float* out, int capacity, int* W, int* H) {
+	const Scene& s = c->rt->s;
+	*W = s.backgroundW; *H = s.backgroundH;
+	if ((int)s.background.size() > capacity) return -1;
+	if (out && !s.background.empty()) memcpy(out, s.background.data(), s.background.size() * sizeof(float));
+	return (int)s.background.size();
+}
 void ref_set_group_material(RefCtx* c, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
 	Object* o = c->rt->s.objects[obj];
 	if (grp < (int)o->textures.size()) o->textures[grp].multiplier = Vector(Kd[0], Kd[1], Kd[2]);

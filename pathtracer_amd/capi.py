@@ -67,7 +67,7 @@ class MiptObject(C.Structure):
 
 
 class MiptSceneDesc(C.Structure):
-    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(MiptObject))]
+    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(MiptObject)), ("background", C.POINTER(_f)), ("backgroundW", C.c_int32), ("backgroundH", C.c_int32)]
 
 
 class MiptHit(C.Structure):
@@ -429,6 +429,27 @@ class HostRaytracer:
         cnt = np.zeros((self.H, self.W), np.float32)
         self._check(self.mipt.mipt_render_denoiser_inputs(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), _p(alb, _f), _p(nrm, _f)), "mipt_render_denoiser_inputs")
         return img, cnt, alb, nrm
+
+    def set_object_ghost(self, obj, ghost=True):
+        self.host.mh_set_object_ghost(self.h, obj, int(ghost))
+
+    def set_background(self, rgb):
+        """Scene::background: float [H, W, 3], rows as in memory after load_background, x196964.699 units (None clears it)."""
+        if rgb is None:
+            self.host.mh_set_background(self.h, None, 0, 0)
+            return
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        self.host.mh_set_background(self.h, _p(rgb, _f), rgb.shape[1], rgb.shape[0])
+
+    def load_background(self, path):
+        if self.host.mh_load_background(self.h, os.fsencode(path)) != 0:
+            raise MiptError(self.host.mh_last_error(self.h).decode())
+
+    def get_background(self):
+        W, H = _i(0), _i(0)
+        buf = np.zeros(1 << 22, np.float32)
+        n = self.host.mh_get_background(self.h, _p(buf, _f), buf.size, C.byref(W), C.byref(H))
+        return buf[:max(n, 0)].reshape(H.value, W.value, 3).copy() if n > 0 else None
 
     def set_has_denoiser(self, on=True):
         self.host.mh_set_has_denoiser(self.h, 1 if on else 0)

@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 #include "mipt_wavefront.h"
 #include "mipt_persistent.h"
 #include "mipt_build.h"
+#include "mipt_compositing.h"
 
 // ---- denoiser inputs (has_denoiser branch of render_image_nopreviz, Raytracer.cpp:1631-1645) ---------------------------
 // getColor hands back the shading normal and Kd of the first hit (Raytracer.cpp:255-258).  They are read off the hit
@@ -247,6 +248,9 @@ struct mipt_ctx {
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
+	bool scene_has_ghost = false;     // some object is a ghost, or the scene has a background photo: rendered by the queue kernel (mipt_compositing.h)
+	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
+	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
 	unsigned grid_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of: traverse<0,1,2>, shade<0,1,2>, extend, shadow
@@ -321,6 +325,7 @@ static void free_scene(mipt_ctx* c) {
 
 extern "C" void mipt_destroy(mipt_ctx* c) {
 	if (!c) return;
+	if (c->queue_buf) hipFree(c->queue_buf);
 	hipSetDevice(c->device);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
@@ -489,16 +494,18 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false;
+	bool scene_merl = false, scene_ghost = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
 		DObject& d = H.obj[i];
-		if (o.ghost) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d is a ghost object (compositing branch is outside the hot path)", i);
+		if (o.ghost && i < 2) return fail(c, MIPT_ERR_UNSUPPORTED, "the light / environment sphere cannot be a ghost object");
 		if (o.brdf_kind != MIPT_BRDF_PHONG && o.brdf_kind != MIPT_BRDF_MERL) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: unknown BRDF kind %d", i, o.brdf_kind);
 		if (o.brdf_kind == MIPT_BRDF_MERL && !o.merl_data) return fail(c, MIPT_ERR_INVALID, "object %d: MERL BRDF without a table", i);
 		if (i < 2 && o.type != MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_INVALID, "objects 0 and 1 must be the light and environment spheres");
 		d.type = o.type; d.miroir = o.miroir; d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
+		d.ghost = o.ghost ? 1 : 0;
+		if (o.ghost) scene_ghost = true;
 		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
 		d.brdf_kind = o.brdf_kind; d.merl = nullptr;
 		if (o.brdf_kind == MIPT_BRDF_MERL) { int rc = upload(c, o.merl_data, (size_t)3 * 90 * 90 * 180, &d.merl); if (rc) return rc; scene_merl = true; }
@@ -563,6 +570,13 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
+	c->d_background = nullptr; c->backgroundW = c->backgroundH = 0;
+	if (s->background && s->backgroundW > 0 && s->backgroundH > 0) {
+		int rc = upload(c, s->background, (size_t)s->backgroundW * s->backgroundH * 3, &c->d_background);
+		if (rc) return rc;
+		c->backgroundW = s->backgroundW; c->backgroundH = s->backgroundH;
+	}
+	c->scene_has_ghost = scene_ghost || c->d_background != nullptr;
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	return MIPT_OK;
 }
@@ -626,6 +640,7 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	memcpy(R.centerLight, p->centerLight, 12); R.radiusLight = p->radiusLight; R.lightPower = p->lightPower; R.envmap_intensity = p->envmap_intensity;
 	R.sigma_filter = p->sigma_filter; R.filter_size = p->filter_size;
 	R.seed_stride = p->seed_stride ? p->seed_stride : 65536ull;
+	R.background = c->d_background; R.backgroundW = c->backgroundW; R.backgroundH = c->backgroundH;
 	denom2 = (float)(1.f / (2. * (double)p->sigma_filter * (double)p->sigma_filter));   // Raytracer.cpp:1430
 	// tables: compact the reference's Vector[] (stride 3) arrays to stride 2
 	const int ftw = 2 * p->filter_size + 1;
@@ -665,7 +680,7 @@ extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, co
 	for (int q = 0; q < npix; q++) if (pixels_ij[2 * q] < 0 || pixels_ij[2 * q] >= p->H || pixels_ij[2 * q + 1] < 0 || pixels_ij[2 * q + 1] >= p->W) return fail(c, MIPT_ERR_INVALID, "pixel outside the image");
 	size_t n = (size_t)npix * (size_t)(k1 - k0);
 	if (n == 0) return MIPT_OK;
-	if (c->opt_pipeline == 1) {      // same stage kernels as mipt_render, results handed back instead of splatted
+	if (c->opt_pipeline == 1 || c->scene_has_ghost) {      // same kernels as mipt_render, results handed back instead of splatted
 		mipt_render_params q = *p;
 		q.sample_begin = k0; q.sample_end = k1; q.tile_nranks = 1; q.tile_rank = 0;
 		SampleDump dump{pixels_ij, npix, out_rgb, out_dxdy, nullptr, nullptr};
@@ -764,11 +779,13 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
+	if (c->scene_has_ghost) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
 	spp_pass = std::min(spp_pass, ke - kb);
-	if (dump && spp_pass < ke - kb) return fail(c, MIPT_ERR_INVALID, "mipt_sample_radiance with the wavefront pipeline needs paths_per_pass >= pixels x samples");
 	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
 	const bool want_aov = d_aov || (dump && dump->out_normal);
-	const int pipeline = want_aov ? 1 : (int)c->opt_pipeline;   // the denoiser inputs are a stage of the wavefront pipeline
+	if (want_aov && c->scene_has_ghost) return fail(c, MIPT_ERR_UNSUPPORTED, "denoiser inputs of a scene with ghost objects / a background photo");
+	// 2 = the queue kernel (ghost objects, background photo); the denoiser inputs are a stage of the wavefront pipeline
+	const int pipeline = c->scene_has_ghost ? 2 : (want_aov ? 1 : (int)c->opt_pipeline);
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
 	// carve the pass buffer
 	size_t bytes = N * (sizeof(float4) + sizeof(float2));
@@ -793,6 +810,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	float4 *aov_n = nullptr, *aov_kd = nullptr;
 	if (want_aov) { aov_n = (float4*)carve(N * sizeof(float4)); aov_kd = (float4*)carve(N * sizeof(float4)); }
+	QContrib* queues = nullptr;
+	if (pipeline == 2) {
+		if ((rc = ensure(c, &c->queue_buf, &c->queue_buf_bytes, N * MIPT_SIZE_CIRC_ARRAY * sizeof(QContrib)))) return rc;
+		queues = (QContrib*)c->queue_buf;
+	}
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;
@@ -827,6 +849,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		if (pipeline == 0) {
 			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_render_paths, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt);
+			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+		} else if (pipeline == 2) {
+			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+			hipLaunchKernelGGL(k_render_paths_queue, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt, queues);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 		} else {
 			HIPCHK(c, hipMemsetAsync(wf.counters, 0, MIPT_WF_COUNTERS * sizeof(unsigned), st));
@@ -880,8 +906,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			for (int q = 0; q < dump->npix; q++) {
 				int slot = pix2slot[(size_t)dump->ij[2 * q] * p->W + dump->ij[2 * q + 1]];
 				if (slot < 0) return fail(c, MIPT_ERR_INVALID, "pixel not owned by this rank");
-				for (int k = 0; k < nk; k++) {
-					size_t s = (size_t)k * npix_slots + slot, o = (size_t)q * nk + k;
+				for (int k = P.k0 - kb; k < P.k1 - kb; k++) {          // the samples of this pass
+					size_t s = (size_t)(k - (P.k0 - kb)) * npix_slots + slot, o = (size_t)q * nk + k;
 					dump->out_rgb[3 * o] = hc[s].x; dump->out_rgb[3 * o + 1] = hc[s].y; dump->out_rgb[3 * o + 2] = hc[s].z;
 					if (dump->out_dxdy) { dump->out_dxdy[2 * o] = hj[s].x; dump->out_dxdy[2 * o + 1] = hj[s].y; }
 					if (dump->out_normal) {

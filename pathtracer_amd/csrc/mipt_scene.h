@@ -64,6 +64,7 @@ struct DObject {
 	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
 	int ntri, nuvs;
 	int alpha_test;            // an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
+	int ghost;                 // Object::ghost (Geometry.h:721): only the queue kernel (mipt_compositing.h) renders such scenes
 	const float* uvs;          // Vector[nuvs]
 	const int* uvidx;          // 3 ints per triangle (uvi,uvj,uvk), only when alpha_test
 	const float* tangent_soup; // Vector[3*ntri] or null
@@ -91,6 +92,8 @@ struct DRender {
 	const float* samples2d;      // nrays * 2
 	const float* randomPerPixel; // W*H * 2
 	uint64_t seed_stride;
+	const float* background;     // Scene::background (Geometry.h:1355-1366): backgroundW x backgroundH x 3 floats or null
+	int backgroundW, backgroundH;
 };
 
 // One render pass: samples [k0,k1) of every owned 8x8 pixel block.

@@ -469,7 +469,7 @@ MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& 
 }
 
 // ---------------------------------------------------------------- Scene::intersection_shadow (Geometry.cpp:691-744)
-template <class STK>
+template <class STK, bool AVOID_GHOSTS = false>   // AVOID_GHOSTS: getColor's shadow rays skip ghost objects (Geometry.cpp:722, Raytracer.cpp:513)
 MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_light, STK& stk) {
 	const int nobj = sc->nobj;
 	const float inf = __int_as_float(0x7f800000);
@@ -477,6 +477,7 @@ MIPT_DEV bool scene_occluded(const DScene* __restrict__ sc, Ray r, float dist_li
 	for (int i = 0; i < nobj; i++) {
 		if (occluded) break;
 		const DObject& o = sc->obj[i];
+		if (AVOID_GHOSTS && o.ghost) continue;
 		f3 d = xf_dir(o.inv, r.d);
 		f3 org = xf_point(o.inv, r.o);
 		float t; int tri; float b, g;

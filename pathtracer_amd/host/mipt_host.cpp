@@ -882,7 +882,7 @@ void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
 // 132-162).  Values are written with "%f" (six decimals) and read back from those decimals, exactly like the reference,
 // so a scene loaded here and there is the same scene.  The optional / backward-compatible records of load_scene are
 // accepted.  What the hot path does not cover is refused loudly rather than dropped: lenticular / array cameras, a
-// background image, fog, key-framed transforms, PointSet objects, per-face colour files.
+// fog, key-framed transforms, PointSet objects, per-face colour files.
 namespace {
 struct ScnReader {
 	FILE* f;
@@ -1030,7 +1030,12 @@ bool Raytracer::load_scene(const char* filename) {
 	else return bail("expected intensite_lum");
 	if (!R.getf("intensite_envmap:", s.envmap_intensity)) return bail("");
 	if (!R.next()) return bail("truncated header");
-	if (R.starts("background:")) return bail("background images are outside the hot path");
+	s.clear_background();                                                         // Raytracer.cpp:1205-1211
+	if (R.starts("background:")) {
+		std::string why;
+		if (!s.load_background(R.after("background:"), gamma, why)) return bail("background " + std::string(R.after("background:")) + ": " + why);
+		if (!R.next()) return bail("truncated header");
+	}
 	if (!R.starts("nbobjects:")) return bail("expected nbobjects");
 	const int nbo = (int)strtoul(R.after("nbobjects:"), nullptr, 10);
 	for (int i = 0; i < nbo; i++) {
@@ -1108,6 +1113,7 @@ bool Raytracer::save_scene(const char* filename) const {
 	fprintf(f, "is_lenticular: 0\nlenticular_nb_images: 10\nlenticular_max_angle: %f\nlenticular_pixel_width: 1\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n", (float)(35 * M_PI / 180. * 0.25), 0.f, 0.f);   // Camera defaults (Vector.h:720-730)
 	fprintf(f, "bounces: %u\nhas_denoiser: %u\n", nb_bounces, has_denoiser ? 1u : 0u);
 	fprintf(f, "intensite_lum: %f\nintensite_envmap: %f\n", s.intensite_lumiere, s.envmap_intensity);
+	if (s.backgroundfilename.size() > 0) fprintf(f, "background: %s\n", s.backgroundfilename.c_str());   // :1125-1126
 	fprintf(f, "nbobjects: %u\n", (unsigned)s.objects.size());
 	auto list3 = [&](const char* key, const std::vector<Texture>& l) {
 		fprintf(f, "%s: %u\n", key, (unsigned)l.size());
@@ -1140,6 +1146,17 @@ bool Raytracer::save_scene(const char* filename) const {
 	fprintf(f, "fog_density: %f\nfog_absorption: %f\nfog_density_decay: %f\nfog_absorption_decay: %f\nfog_type: 0\nfog_phase_type: 0\n", 0.f, 0.f, 0.f, 0.f);
 	fprintf(f, "double_frustum_start_t: %f\n", s.double_frustum_start_t);
 	fclose(f);
+	return true;
+}
+
+bool Scene::load_background(const char* filename, float gamma, std::string& why) {   // Geometry.h:1355-1363
+	std::vector<unsigned char> bg; int w = 0, h = 0;
+	if (!read_image_rgb8(filename, bg, w, h, why)) return false;
+	backgroundfilename = filename;
+	backgroundW = w; backgroundH = h;
+	background.resize(bg.size());
+	for (int i = 0; i < h; i++) for (int j = 0; j < w * 3; j++)                // load_image flips the rows (utils.cpp:112-118)
+		background[(size_t)i * w * 3 + j] = (float)(std::pow(bg[(size_t)(h - 1 - i) * w * 3 + j] / 255., gamma) * 196964.699);
 	return true;
 }
 
@@ -1250,6 +1267,9 @@ void Raytracer::build_descs() {
 		}
 	}
 	scene_desc.n_objects = (int)n; scene_desc.objects = desc_objects_.data();
+	const bool has_bg = s.backgroundW > 0 && s.background.size() == (size_t)s.backgroundW * s.backgroundH * 3;   // Raytracer.cpp:220
+	scene_desc.background = has_bg ? s.background.data() : nullptr;
+	scene_desc.backgroundW = has_bg ? s.backgroundW : 0; scene_desc.backgroundH = has_bg ? s.backgroundH : 0;
 	mipt_render_params& p = render_params;
 	memset(&p, 0, sizeof p);
 	p.W = W; p.H = H; p.nrays = nrays; p.nb_bounces = nb_bounces;
@@ -1343,6 +1363,24 @@ void mh_set_camera(mh_raytracer* h, const float* pos, const float* dir, const fl
 }
 void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite) {
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
+}
+void mh_set_object_ghost(mh_raytracer* h, int obj, int ghost) { h->rt.s.objects[obj]->ghost = ghost != 0; }
+int mh_load_background(mh_raytracer* h, const char* file) {
+	std::string why;
+	if (!h->rt.s.load_background(file, h->rt.gamma, why)) { h->rt.set_error(std::string("background ") + file + ": " + why); return -1; }
+	return 0;
+}
+void mh_set_background(mh_raytracer* h, const float* rgb, int W, int H) {
+	Scene& s = h->rt.s;
+	s.clear_background();
+	if (rgb && W > 0 && H > 0) { s.background.assign(rgb, rgb + (size_t)W * H * 3); s.backgroundW = W; s.backgroundH = H; }
+}
+int mh_get_background(mh_raytracer* h, float* out, int capacity, int* W, int* H) {
+	const Scene& s = h->rt.s;
+	*W = s.backgroundW; *H = s.backgroundH;
+	if ((int)s.background.size() > capacity) return -1;
+	if (out && !s.background.empty()) memcpy(out, s.background.data(), s.background.size() * sizeof(float));
+	return (int)s.background.size();
 }
 void mh_set_has_denoiser(mh_raytracer* h, int on) { h->rt.has_denoiser = on != 0; }
 float* mh_denoiser_image(mh_raytracer* h, int which) { std::vector<float>& v = which == 0 ? h->rt.albedoImage : (which == 1 ? h->rt.normalImage : h->rt.shadingNormalImage); return v.empty() ? nullptr : v.data(); }

@@ -145,6 +145,13 @@ public:
 	// Scene::intersection / intersection_shadow (Geometry.h:1340-1344) through mipt_trace*.
 	bool intersection(const mipt_ray& d, Vector& P, int& sphere_id, float& min_t, mipt_hit& mat, int& triangle_id) const;
 	bool intersection_shadow(const mipt_ray& d, float& min_t, float dist_light) const;
+	// Scene::background (Geometry.h:1348-1367): the photo behind ghost objects.  load_background decodes the file
+	// (load_image: rows flipped) and stores pow(v/255., gamma) * 196964.699; false + reason when the file cannot be read.
+	void clear_background() { background.clear(); backgroundW = backgroundH = 0; backgroundfilename.clear(); }
+	bool load_background(const char* filename, float gamma, std::string& why);
+	std::vector<float> background;
+	int backgroundW = 0, backgroundH = 0;
+	std::string backgroundfilename;
 	std::vector<Object*> objects;
 	Sphere* lumiere = nullptr;
 	float intensite_lumiere = 0, envmap_intensity = 1;
@@ -257,7 +264,11 @@ void* mh_ctx(mh_raytracer*);                              // mipt_ctx*
 const void* mh_scene_desc(mh_raytracer*);                 // const mipt_scene_desc*
 const void* mh_render_params(mh_raytracer*);              // const mipt_render_params*
 float* mh_imagedouble(mh_raytracer*);
+int  mh_get_background(mh_raytracer*, float* out, int capacity, int* W, int* H);
 void mh_set_has_denoiser(mh_raytracer*, int on);
+void mh_set_object_ghost(mh_raytracer*, int obj, int ghost);                 // Object::ghost
+int  mh_load_background(mh_raytracer*, const char* file);                     // Scene::load_background(file, gamma); -1 + mh_last_error on failure
+void mh_set_background(mh_raytracer*, const float* rgb, int W, int H);        // Scene::background set directly (NULL clears it)
 float* mh_denoiser_image(mh_raytracer*, int which);          // 0 albedoImage, 1 normalImage (as the reference), 2 shadingNormalImage
 float* mh_sample_count(mh_raytracer*);
 unsigned char* mh_image(mh_raytracer*);

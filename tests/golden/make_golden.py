@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv:
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv:
     main()
 
 
@@ -220,3 +220,57 @@ def main_denoiser_inputs():
 
 if __name__ == "__main__" and "--denoiser-inputs" in sys.argv:
     main_denoiser_inputs()
+
+
+# ---------------------------------------------------------------- ghost objects / background photo
+COMPOSITING_KINDS = ("bgonly", "plane", "mesh", "both", "planenobg", "glossyghost", "mirrorghost")
+
+
+def background_photo(W=48, H=32):
+    """Scene::background as load_background leaves it: pow(v/255., 2.2) * 196964.699 of an 8-bit test pattern."""
+    y, x = np.mgrid[0:H, 0:W]
+    img = np.stack([(x * 5) % 256, (y * 7) % 256, ((x + y) * 3) % 256], -1).astype(np.float64)
+    return (np.power(img / 255., 2.2) * 196964.699).astype(np.float32)
+
+
+def compositing_scene(X, kind):
+    """A blob over the floor plane with ghost objects and / or a background photo; X: Ref, Oracle or HostRaytracer."""
+    cfg = scenes.config_c1(64, 36, 4)
+    cfg.nb_bounces = 4
+    X.apply_config(cfg)
+    oid = X.add_mesh(scenes.blob_mesh(16))
+    if kind in ("plane", "both", "planenobg"):
+        X.set_object_ghost(2, True)                      # the floor catches the blob's shadow on the photo
+    if kind in ("mesh", "both"):
+        o2 = X.add_mesh(scenes.blob_mesh(8), scale=45.0)  # a closed ghost mesh around the blob: paths pass through it at the same depth
+        X.set_object_ghost(o2, True)
+    if kind == "glossyghost":
+        X.set_group_material(oid, 0, (0.4, 0.3, 0.2), (0.5, 0.5, 0.4), (40., 60., 80.))
+        X.set_object_ghost(oid, True)
+    if kind == "mirrorghost":
+        X.set_object_flags(oid, True, False)             # a ghost that is a mirror: the mirror branch comes first (:413)
+        X.set_object_ghost(oid, True)
+        X.set_object_ghost(2, True)
+    if kind != "planenobg":
+        X.set_background(background_photo())
+    X.prepare()
+    return cfg
+
+
+def main_compositing():
+    """tests/golden/compositing.npz: per-sample radiance of the ghost / background scenes from the compiled reference."""
+    g = {}
+    for kind in COMPOSITING_KINDS:
+        R = Ref()
+        cfg = compositing_scene(R, kind)
+        rgb, dxdy = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+        g[kind + "_rgb"] = rgb
+        if kind == "both":
+            img, cnt = R.render_seeded()
+            g["both_img"], g["both_cnt"] = img, cnt
+        print(kind, "mean radiance / white", float(rgb.mean() / 196964.7))
+    np.savez_compressed(os.path.join(OUT, "compositing.npz"), **g)
+
+
+if __name__ == "__main__" and "--compositing" in sys.argv:
+    main_compositing()

@@ -1,0 +1,118 @@
+"""ghost objects and the background photo — getColor's contribution queue (Raytracer.cpp:213-238),
+the pass-through of ghosts (:522-536), their missing direct term (:547-553), the photo behind camera rays and behind
+ghosts (:260-268, :614-621), the showenvmap flag (:629) and shadow rays that ignore ghosts (Geometry.cpp:722).
+tests/golden/compositing.npz comes from the compiled reference (tests/golden/make_golden.py --compositing)."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import assert_bits
+from pathtracer_amd import capi, scenes
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden import COMPOSITING_KINDS, all_pixels, background_photo, compositing_scene  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compositing.npz")
+
+
+@pytest.mark.parametrize("kind", COMPOSITING_KINDS)
+def test_oracle_compositing_matches_reference_golden(kind):
+    from oracle.binding import Oracle
+    g = np.load(GOLD)
+    O = Oracle()
+    cfg = compositing_scene(O, kind)
+    rgb, _ = O.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+    assert_bits(rgb, g[kind + "_rgb"], "per-sample radiance")
+    if kind == "both":
+        img, cnt = O.render_seeded()
+        assert_bits(img, g["both_img"], "splatted image")
+
+
+def test_ghosts_change_the_picture():
+    """The fixtures are not vacuous: the photo, the ghost floor and the ghost mesh each change many samples."""
+    g = np.load(GOLD)
+    assert (g["plane_rgb"] != g["bgonly_rgb"]).any(-1).mean() > 0.2
+    assert (g["both_rgb"] != g["plane_rgb"]).any(-1).mean() > 0.1
+    assert (g["mesh_rgb"] != g["bgonly_rgb"]).any(-1).mean() > 0.2
+    assert (g["planenobg_rgb"] != g["plane_rgb"]).any(-1).mean() > 0.1
+
+
+def write_bmp(path, rgb8):
+    """24-bit uncompressed BMP, rows bottom-up, BGR, padded to 4 bytes."""
+    h, w, _ = rgb8.shape
+    row = (w * 3 + 3) & ~3
+    data = bytearray()
+    for i in range(h - 1, -1, -1):
+        line = rgb8[i, :, ::-1].tobytes()
+        data += line + b"\0" * (row - len(line))
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + len(data), 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(data), 2835, 2835, 0, 0))
+        f.write(data)
+
+
+def test_load_background_like_the_reference(tmp_path):
+    """Scene::load_background (Geometry.h:1355-1363): load_image's row order, pow(v/255., gamma) * 196964.699."""
+    from oracle import binding
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (13, 21, 3), dtype=np.uint8)
+    p = str(tmp_path / "photo.bmp")
+    write_bmp(p, img)
+    H = capi.HostRaytracer()
+    H.load_background(p)
+    mine = H.get_background()
+    assert mine.shape == (13, 21, 3)
+    want = (np.power(img[::-1].astype(np.float64) / 255., np.float64(np.float32(2.2))) * 196964.699).astype(np.float32)
+    assert np.allclose(mine, want, rtol=1e-6)
+    if binding.ref_available():
+        R = binding.Ref()
+        R.load_background(p)
+        assert_bits(mine, R.get_background(), "Scene::background")
+    with pytest.raises(capi.MiptError):
+        H.load_background(str(tmp_path / "missing.bmp"))
+
+
+def test_compositing_against_live_reference():
+    from oracle import binding
+    if not binding.ref_available():
+        pytest.skip("compiled reference not present")
+    outs = []
+    for X in (binding.Ref(), binding.Oracle()):
+        cfg = compositing_scene(X, "both")
+        outs.append(X.getcolor_samples(all_pixels(cfg)[::5], 0, 3)[0])
+    assert_bits(outs[1], outs[0], "ghost mesh + ghost floor + photo")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", COMPOSITING_KINDS)
+def test_gpu_compositing_per_sample(kind):
+    g = np.load(GOLD)
+    H = capi.HostRaytracer(device=0)
+    cfg = compositing_scene(H, kind)
+    rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+    assert_bits(rgb, g[kind + "_rgb"], "per-sample radiance")
+
+
+@pytest.mark.gpu
+def test_gpu_compositing_image_and_passes():
+    g = np.load(GOLD)
+    H = capi.HostRaytracer(device=0)
+    cfg = compositing_scene(H, "both")
+    img, cnt = H.render()
+    assert_bits(img, g["both_img"], "splatted image")
+    assert_bits(cnt, g["both_cnt"], "sample_count")
+    st = H.stats()
+    assert st["rays_closest"] > cfg.W * cfg.H * cfg.spp and st["rays_shadow"] > 0
+    # denoiser inputs of a ghost scene are refused, loudly
+    with pytest.raises(capi.MiptError):
+        H.render_denoiser_inputs()
+    # a scene without ghosts on the same context goes back to the wavefront pipeline
+    H2 = capi.HostRaytracer(device=0)
+    cfg2 = compositing_scene(H2, "planenobg")
+    H2.set_object_ghost(2, False)
+    H2.prepare()
+    H2.render()
+    assert H2.stats()["pipeline"] == 1
