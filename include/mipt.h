@@ -32,7 +32,7 @@ enum {
 	MIPT_ERR_INVALID = 1,      /* bad argument / inconsistent description */
 	MIPT_ERR_NO_DEVICE = 2,    /* no HIP device, or device id out of range */
 	MIPT_ERR_HIP = 3,          /* a HIP runtime call failed (text in mipt_last_error) */
-	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature outside the hot path (ghost, fog, SSS, extra spheres ...) */
+	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature outside the hot path (fog, SSS, extra spheres ...) */
 	MIPT_ERR_NO_SCENE = 5,     /* render/trace before mipt_upload_scene */
 	MIPT_ERR_CANCELLED = 6     /* *cancel became non-zero between passes (Raytracer::stopRender) */
 };
@@ -92,7 +92,7 @@ enum { MIPT_BRDF_PHONG = 0, MIPT_BRDF_MERL = 1 };
 /* Object (Geometry.h:240-735) + Sphere (:849-1103) / Plane (:1127-1217) / TriMesh fields. */
 typedef struct mipt_object {
 	int32_t type;
-	int32_t miroir, ghost, flip_normals, interp_normals;
+	int32_t miroir, ghost, flip_normals, interp_normals;   /* ghost (Geometry.h:721): the scene is rendered by the contribution-queue kernel */
 	float trans_matrix[12], inv_trans_matrix[12], rot_matrix[9];   /* after Object::build_matrix */
 	int32_t brdf_kind;
 	const double* merl_data;                 /* IsoMERLBRDF::data (3*90*90*180 doubles) or NULL */
