@@ -99,6 +99,10 @@ class _Base:
     def set_object_flags(self, obj, miroir=False, flip_normals=False):
         self.lib.ref_set_object_flags(self.ctx, obj, int(miroir), int(flip_normals))
 
+    def set_fog(self, density, absorption, density_decay=0.0, absorption_decay=0.0, fog_type=0, phase_type=0, phase_aniso=0.0):
+        """Scene::fog_* (Geometry.h:1371-1377): fog_type 0 uniform / 1 exponential in height, phase 0 isotropic / 1 Schlick / 2 Rayleigh."""
+        self.lib.ref_set_fog(self.ctx, _f(density), _f(absorption), _f(density_decay), _f(absorption_decay), int(fog_type), int(phase_type), _f(phase_aniso))
+
     def set_object_ghost(self, obj, ghost=True):
         self.lib.ref_set_object_ghost(self.ctx, obj, int(ghost))
 

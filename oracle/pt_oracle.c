@@ -138,7 +138,9 @@ struct o_ctx {
 	v3 cam_pos, cam_dir, cam_up; float fov, focus, aperture;
 	o_obj* objs; int nobj, cap_obj;
 	float intensite_lumiere, envmap_intensity;
-	float* background; int backgroundW, backgroundH;   /* Scene::background (Geometry.h:1355-1366), top row first, x196964.699 */
+	float* background; int backgroundW, backgroundH;
+	float fog_density, fog_absorption, fog_density_decay, fog_absorption_decay, phase_aniso;   /* Geometry.h:1371-1377 */
+	int fog_type, fog_phase_type;   /* Scene::background (Geometry.h:1355-1366), top row first, x196964.699 */
 	float* randomPerPixel; float* samples2d;
 	v3 centerLight; float radiusLight, lightPower, lum_scale;
 	int current_frame; float double_frustum_start_t;
@@ -858,7 +860,119 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
  * them removed the Contrib queue never holds more than one entry, so it is a plain loop. */
 /* normalValue / albedoValue: the denoiser inputs of Raytracer.cpp:255-258 (shading normal and Kd of the FIRST hit;
    left untouched without one, so they keep the zeros `Vector normal, albedo;` starts from, :1628).  May be NULL. */
+/* ------------------------------------------------------------------ fog: single scattering (Raytracer.cpp:20-192) */
+static float int_exponential(float y0, float ysol, float beta, float s, float uy) {          /* :20-40 */
+	float result;
+	if (fabsf(uy * beta) < 0.0001) {
+		result = expf(-beta * (y0 - ysol)) * (s);
+	} else {
+		result = (expf(-beta * (y0 - ysol)) - expf(-beta * (y0 + s * uy - ysol))) / (uy * beta);
+	}
+	return result;
+}
+static v3 random_uniform_sphere(pcg32_t* rng) {                                                /* Vector.h:604-615, T = float */
+	float r1 = pcg_uniform(rng);
+	float r2 = pcg_uniform(rng);
+	v3 result;
+	result.x = 2.f * cosf((float)(2. * M_PI) * r1) * sqrtf(r2 * (1 - r2));
+	result.y = 2.f * sinf((float)(2. * M_PI) * r1) * sqrtf(r2 * (1 - r2));
+	result.z = 1.f - 2.f * r2;
+	return result;
+}
 typedef struct { v3 weight; o_ray r; int depth; int show_lights, showenvmap; } o_contrib;   /* Raytracer.h:15-23 (no subsurface here) */
+/* One in-scattering event on the segment [0, t] of ray r: equi-angular (towards the sampled light point) or exponential
+   distance sampling, direction uniform or towards the light (p = 1/2 each), one closest-hit query for the visibility of
+   the light sample.  *attenuationFactor (the transmittance of the segment) is only written once the event is above
+   the ground (:114): the caller keeps the previous value otherwise, as the reference's local does. */
+static int fog_contribution(const o_ctx* c, const o_ray* r, v3 sampleLightPos, float t, v3 curWeight, int nbrebonds, int showLight,
+                            o_contrib* newContrib, float* attenuationFactor, pcg32_t* rng, uint64_t* nrays2) {
+	if (vnorm2(curWeight) < 1E-12) return 0;
+	v3 rayDirection = r->direction;
+	float p_uniform = 0.5f;
+	int is_uniform_fog = (c->fog_type == 0);
+	float alpha = c->fog_absorption;
+	float sigmaT = c->fog_absorption_decay;
+	int phase = c->fog_phase_type;
+	float groundLevel = c->objs[2].max_translation.y;            /* objects[2]->get_translation()[1], no key frames */
+	float int_ext;
+	if (is_uniform_fog) int_ext = alpha * t * 0.05;
+	else int_ext = alpha * int_exponential(r->origin.y, groundLevel, sigmaT, t, rayDirection.y);
+	float T = expf(-int_ext);
+	float proba_t, random_t;
+	float clamped_t = 1000.f < t ? 1000.f : t;                   /* std::min(1000.f, t) */
+	float a = vdot(vsub(sampleLightPos, r->origin), r->direction);
+	if (a > 0) {                                                  /* equi-angular sampling (:71-84) */
+		v3 projP = vadd(r->origin, vscale(a, r->direction));
+		float D = sqrtf(vnorm2(vsub(sampleLightPos, projP)));
+		float thetaA = -atan2f(a, D);
+		float b = t - a;
+		float thetaB = atan2f(b, D);
+		float x = pcg_uniform(rng);
+		random_t = D * tanf((1 - x) * thetaA + x * thetaB);
+		proba_t = D / ((thetaB - thetaA) * (D * D + random_t * random_t));
+		random_t += a;
+	} else {                                                      /* :85-99 */
+		float alpha2 = 5.f / clamped_t;
+		do {
+			random_t = -logf(pcg_uniform(rng)) / alpha2;
+		} while (random_t > clamped_t);
+		float normalization = 1.f / alpha2 * (1.f - expf(-alpha2 * clamped_t));
+		proba_t = expf(-alpha2 * random_t) / normalization;
+	}
+	float int_ext_partielle;
+	if (is_uniform_fog) int_ext_partielle = alpha * random_t * 0.05;
+	else int_ext_partielle = alpha * int_exponential(r->origin.y, groundLevel, sigmaT, random_t, rayDirection.y);
+	v3 random_P = vadd(r->origin, vscale(random_t, rayDirection));
+	if (random_P.y < groundLevel) return 0;                       /* :114 */
+	v3 random_dir;
+	float proba_dir;
+	v3 point_aleatoire = V(0, 0, 0);
+	v3 axeOP = vnormalize(vsub(random_P, c->centerLight));
+	int is_uniform;
+	if (pcg_uniform(rng) < p_uniform) {
+		random_dir = random_uniform_sphere(rng);
+		is_uniform = 1;
+	} else {
+		v3 dir_aleatoire = random_cos_rng(axeOP, rng);
+		point_aleatoire = vadd(vscale(c->radiusLight, dir_aleatoire), c->centerLight);
+		random_dir = vnormalize(vsub(point_aleatoire, random_P));
+		is_uniform = 0;
+	}
+	float phase_func = 0;
+	float k = c->phase_aniso;
+	switch (phase) {
+	case 0: phase_func = 1. / (4. * M_PI); break;
+	case 1: phase_func = (1 - k * k) / (4. * M_PI * (1 + k * vdot(random_dir, vneg(rayDirection)))); break;
+	case 2: phase_func = 3 / (16 * M_PI) * (1 + sqrf(vdot(random_dir, rayDirection))); break;
+	}
+	o_ray L_ray; L_ray.origin = random_P; L_ray.direction = random_dir;
+	o_mat interMat; mat_default(&interMat);
+	v3 interP = V(0, 0, 0);
+	int interid = -1, intertri = -1;
+	float intert = 0;
+	int interinter = scene_intersection(c, &L_ray, &interP, &interid, &intert, &interMat, &intertri);
+	if (nrays2) nrays2[0]++;
+	v3 interN = interMat.shadingN;
+	float Vis;
+	if (is_uniform) Vis = 1;
+	else {
+		float d_light2 = vnorm2(vsub(point_aleatoire, random_P));
+		if (interinter && intert * intert < d_light2 * 0.99) Vis = 0; else Vis = 1;
+	}
+	*attenuationFactor = T;
+	if (Vis == 0) return 0;
+	float pdf_uniform = 1. / (4. * M_PI);
+	float J = vdot(interN, vneg(random_dir)) / vnorm2(vsub(interP, random_P));
+	float pdf_light = (interinter && interid == 0) ? (vdot(vnormalize(vsub(interP, c->centerLight)), axeOP) / (M_PI * sqrf(c->radiusLight)) / J) : 0.;
+	proba_dir = p_uniform * pdf_uniform + (1 - p_uniform) * pdf_light;
+	float ext;
+	if (is_uniform_fog) ext = c->fog_density * 0.05;
+	else ext = c->fog_density * expf(-c->fog_density_decay * (random_P.y - groundLevel));
+	v3 newweight = vscale((phase_func * ext * expf(-int_ext_partielle) / (proba_t * proba_dir)), curWeight);
+	newContrib->weight = newweight; newContrib->r = L_ray; newContrib->depth = nbrebonds - 1; newContrib->show_lights = showLight; newContrib->showenvmap = 1;
+	return 1;
+}
+
 #define O_SIZE_CIRC_ARRAY 200                                                                /* Raytracer.h:114 */
 static v3 background_pixel(const o_ctx* c, int screenI, int screenJ) {                       /* :261-265 */
 	int bi = (int)(screenI / (float)c->H * c->backgroundH); if (bi < 0) bi = 0; if (bi > c->backgroundH - 1) bi = c->backgroundH - 1;
@@ -878,6 +992,11 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 	contribs[0].weight = V(1.f, 1.f, 1.f); contribs[0].r = r; contribs[0].depth = c->nb_bounces; contribs[0].show_lights = 1; contribs[0].showenvmap = 1;
 #define PUSH(w_, ray_, depth_, lights_, env_) do { o_contrib* q_ = &contribs[contribIndexEnd]; q_->weight = (w_); q_->r = (ray_); q_->depth = (depth_); q_->show_lights = (lights_); q_->showenvmap = (env_); \
 		contribIndexEnd++; if (contribIndexEnd >= O_SIZE_CIRC_ARRAY) contribIndexEnd = 0; } while (0)
+	const int has_fog = c->fog_density > 1E-8;                      /* :207 */
+	float attenuationFactor = 0;                                    /* :206 (uninitialised there) */
+	o_contrib newContrib;
+#define FOG(ray_, lightpos_) do { if (fog_contribution(c, &(ray_), (lightpos_), t, pathWeight, nbrebonds, show_lights, &newContrib, &attenuationFactor, rng, nrays2)) { \
+		contribs[contribIndexEnd] = newContrib; contribIndexEnd++; if (contribIndexEnd >= O_SIZE_CIRC_ARRAY) contribIndexEnd = 0; } } while (0)
 	const int has_dome = 1;                                         /* sphereEnv: object 1 is the environment sphere (loadScene) */
 	const int has_backgroundimage = c->backgroundW > 0 && c->background != NULL;   /* :220 */
 	while (contribIndexStart != contribIndexEnd) {
@@ -901,15 +1020,21 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			continue;
 		}
 		v3 rayDirection = currentRay.direction;
-		if (!has_inter) continue;                                   /* :654-655 (fog_density == 0) */
+		if (!has_inter) { if (c->fog_density == 0) continue; else break; }   /* :654-657 */
 		if (sphere_id == 1) {                                       /* :275-301 (no_envmap = false) */
-			if (!show_envmap) continue;
-			color = vadd(color, vmul(vscale(c->envmap_intensity, pathWeight), mat.Ke));
+			if (!show_envmap) { if (has_fog) FOG(currentRay, c->centerLight); continue; }
+			if (has_fog) {
+				FOG(currentRay, c->centerLight);
+				color = vadd(color, vmul(vscale(c->envmap_intensity, vscale(attenuationFactor, pathWeight)), mat.Ke));
+			} else color = vadd(color, vmul(vscale(c->envmap_intensity, pathWeight), mat.Ke));
 			continue;
 		}
 		if (sphere_id == 0) {                                       /* :303-316 */
 			v3 currentContrib = show_lights ? V(c->lightPower, c->lightPower, c->lightPower) : V(0.f, 0.f, 0.f);
-			color = vadd(color, vmul(pathWeight, currentContrib));
+			if (has_fog) {
+				FOG(currentRay, c->centerLight);
+				color = vadd(color, vmul(vscale(attenuationFactor, pathWeight), currentContrib));
+			} else color = vadd(color, vmul(pathWeight, currentContrib));
 			continue;
 		}
 		const o_obj* obj = &c->objs[sphere_id];
@@ -919,7 +1044,8 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			o_ray rayon_miroir;
 			rayon_miroir.origin = vadd(P, vscale(0.001f, N));
 			rayon_miroir.direction = vreflect(rayDirection, N);
-			PUSH(pathWeight, rayon_miroir, nbrebonds - 1, show_lights, 1);
+			if (has_fog) { FOG(currentRay, c->centerLight); PUSH(vscale(attenuationFactor, pathWeight), rayon_miroir, nbrebonds - 1, show_lights, 1); }
+			else PUSH(pathWeight, rayon_miroir, nbrebonds - 1, show_lights, 1);
 			continue;
 		}
 		if (mat.transp) {                                           /* :438-489 */
@@ -944,7 +1070,8 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			} else {
 				new_ray.origin = vadd(P, vscale(0.001f, normale)); new_ray.direction = vreflect(rayDirection, N);
 			}
-			PUSH(pathWeight, new_ray, nbrebonds - 1, show_lights, 1);   /* :483-486: showenvmap takes its default, true */
+			if (has_fog) { FOG(currentRay, c->centerLight); PUSH(vscale(attenuationFactor, pathWeight), new_ray, nbrebonds - 1, show_lights, 1); }   /* :473-481 */
+			else PUSH(pathWeight, new_ray, nbrebonds - 1, show_lights, 1);   /* :483-486: showenvmap takes its default, true */
 			continue;
 		}
 		/* diffuse / glossy (:490-632) */
@@ -962,10 +1089,9 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		if (!isShadowed) {
 			if (obj->ghost) {                                       /* :522-536: the path goes straight on through the ghost, at the same depth */
 				v3 offset = vdot(N, rayDirection) > 0 ? N : vneg(N);
-				o_ray through;
-				through.origin = vadd(vadd(P, vscale(0.001f, rayDirection)), vscale(0.001f, offset));
-				through.direction = rayDirection;
-				PUSH(pathWeight, through, nbrebonds, show_lights, show_envmap);
+				currentRay.origin = vadd(vadd(P, vscale(0.001f, rayDirection)), vscale(0.001f, offset));   /* :531: currentRay itself is replaced, */
+				currentRay.direction = rayDirection;                                                         /* the fog event below (:557) runs along it */
+				PUSH(pathWeight, currentRay, nbrebonds, show_lights, show_envmap);
 			}
 			v3 BRDF = obj->merl ? merl_eval(obj->merl, wi, vneg(rayDirection), N) : phong_eval(&mat, wi, vneg(rayDirection), N);
 			float J = vdot(Np, vneg(wi)) / d_light2;
@@ -974,7 +1100,10 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 				currentContrib = vadd(currentContrib, vmul(vscale((c->lightPower * fmaxf(0.f, vdot(N, wi)) * J / proba), subsW), BRDF));
 			}
 		}
-		color = vadd(color, vmul(pathWeight, currentContrib));      /* :566 */
+		if (has_fog) {                                              /* :557-565 */
+			FOG(currentRay, point_aleatoire);
+			color = vadd(color, vmul(vscale(attenuationFactor, pathWeight), currentContrib));
+		} else color = vadd(color, vmul(pathWeight, currentContrib));      /* :566 */
 		/* indirect (:570-632) */
 		float proba_globale;
 		int has_sampled_diffuse;
@@ -997,9 +1126,11 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		o_ray rayon_aleatoire;
 		rayon_aleatoire.origin = vadd(P, vscale(0.01f, direction_aleatoire));
 		rayon_aleatoire.direction = direction_aleatoire;
-		PUSH(newpathWeight, rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :629 */
+		if (has_fog) PUSH(vscale(attenuationFactor, newpathWeight), rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :626 */
+		else PUSH(newpathWeight, rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :629 */
 	}
 #undef PUSH
+#undef FOG
 	return color;
 }
 
@@ -1284,6 +1415,11 @@ int o_add_mesh(o_ctx* c, int nv, const float* verts, int nn, const float* normal
 	return c->nobj - 1;
 }
 
+/* Scene::fog_* (Geometry.h:1371-1377) */
+void o_set_fog(o_ctx* c, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso) {
+	c->fog_density = density; c->fog_absorption = absorption; c->fog_density_decay = density_decay; c->fog_absorption_decay = absorption_decay;
+	c->fog_type = type; c->fog_phase_type = phase_type; c->phase_aniso = phase_aniso;
+}
 void o_set_object_ghost(o_ctx* c, int obj, int ghost) { c->objs[obj].ghost = ghost != 0; }
 /* Scene::background as load_background leaves it (Geometry.h:1355-1363): W*H*3 floats, rows as in the file, already
    pow(v/255, gamma) * 196964.699 */

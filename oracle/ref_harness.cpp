@@ -175,6 +175,11 @@ void ref_set_object_flags(RefCtx* c, int obj, int miroir, int flip_normals) {
 	c->rt->s.objects[obj]->miroir = miroir != 0;
 	c->rt->s.objects[obj]->flip_normals = flip_normals != 0;
 }
+void ref_set_fog(RefCtx* c, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso) {
+	Scene& s = c->rt->s;
+	s.fog_density = density; s.fog_absorption = absorption; s.fog_density_decay = density_decay; s.fog_absorption_decay = absorption_decay;
+	s.fog_type = type; s.fog_phase_type = phase_type; s.phase_aniso = phase_aniso;
+}
 void ref_set_object_ghost(RefCtx* c, int obj, int ghost) { c->rt->s.objects[obj]->ghost = ghost != 0; }
 // Scene::background as Scene::load_background leaves it (Geometry.h:1355-1363), set directly (the loader reads BMP files)
 void ref_set_background(RefCtx* c, const float* rgb, int W, int H) {
