@@ -119,6 +119,12 @@ typedef struct mipt_scene_desc {
 	 * values as load_background leaves them (pow(v/255, gamma) * 196964.699), or NULL / 0 / 0. */
 	const float* background;
 	int32_t backgroundW, backgroundH;
+	/* Fog (Geometry.h:1371-1377): single scattering in a uniform (fog_type 0) or height-exponential (1) medium with an
+	 * isotropic (fog_phase_type 0), Schlick (1, phase_aniso) or Rayleigh (2) phase function — fogContribution,
+	 * Raytracer.cpp:45-192.  fog_density <= 1e-8: no fog.  fog_ground_level = objects[2]->get_translation(time)[1], the
+	 * height of the floor the exponential medium starts at (Raytracer.cpp:55). */
+	float fog_density, fog_absorption, fog_density_decay, fog_absorption_decay, phase_aniso, fog_ground_level;
+	int32_t fog_type, fog_phase_type;
 } mipt_scene_desc;
 
 /* Per-render inputs: the Raytracer members getColor / render_image read after

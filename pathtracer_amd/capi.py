@@ -67,7 +67,9 @@ class MiptObject(C.Structure):
 
 
 class MiptSceneDesc(C.Structure):
-    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(MiptObject)), ("background", C.POINTER(_f)), ("backgroundW", C.c_int32), ("backgroundH", C.c_int32)]
+    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(MiptObject)), ("background", C.POINTER(_f)), ("backgroundW", C.c_int32), ("backgroundH", C.c_int32),
+                ("fog_density", _f), ("fog_absorption", _f), ("fog_density_decay", _f), ("fog_absorption_decay", _f), ("phase_aniso", _f), ("fog_ground_level", _f),
+                ("fog_type", C.c_int32), ("fog_phase_type", C.c_int32)]
 
 
 class MiptHit(C.Structure):
@@ -429,6 +431,10 @@ class HostRaytracer:
         cnt = np.zeros((self.H, self.W), np.float32)
         self._check(self.mipt.mipt_render_denoiser_inputs(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), _p(alb, _f), _p(nrm, _f)), "mipt_render_denoiser_inputs")
         return img, cnt, alb, nrm
+
+    def set_fog(self, density, absorption, density_decay=0.0, absorption_decay=0.0, fog_type=0, phase_type=0, phase_aniso=0.0):
+        """Scene::fog_* (Geometry.h:1371-1377)."""
+        self.host.mh_set_fog(self.h, _f(density), _f(absorption), _f(density_decay), _f(absorption_decay), int(fog_type), int(phase_type), _f(phase_aniso))
 
     def set_object_ghost(self, obj, ghost=True):
         self.host.mh_set_object_ghost(self.h, obj, int(ghost))

@@ -248,8 +248,9 @@ struct mipt_ctx {
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
-	bool scene_has_ghost = false;     // some object is a ghost, or the scene has a background photo: rendered by the queue kernel (mipt_compositing.h)
+	bool scene_has_ghost = false;     // a ghost object, a background photo or fog: rendered by the queue kernel (mipt_compositing.h)
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
+	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
 	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
@@ -576,7 +577,10 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (rc) return rc;
 		c->backgroundW = s->backgroundW; c->backgroundH = s->backgroundH;
 	}
-	c->scene_has_ghost = scene_ghost || c->d_background != nullptr;
+	c->fog.density = s->fog_density; c->fog.absorption = s->fog_absorption; c->fog.density_decay = s->fog_density_decay; c->fog.absorption_decay = s->fog_absorption_decay;
+	c->fog.phase_aniso = s->phase_aniso; c->fog.ground_level = s->fog_ground_level; c->fog.type = s->fog_type; c->fog.phase_type = s->fog_phase_type;
+	if (s->fog_density > 1E-8f && (s->n_objects < 3 || s->fog_type < 0 || s->fog_type > 1 || s->fog_phase_type < 0 || s->fog_phase_type > 2)) return fail(c, MIPT_ERR_INVALID, "bad fog description");
+	c->scene_has_ghost = scene_ghost || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	return MIPT_OK;
 }
@@ -641,6 +645,8 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	R.sigma_filter = p->sigma_filter; R.filter_size = p->filter_size;
 	R.seed_stride = p->seed_stride ? p->seed_stride : 65536ull;
 	R.background = c->d_background; R.backgroundW = c->backgroundW; R.backgroundH = c->backgroundH;
+	R.fog_density = c->fog.density; R.fog_absorption = c->fog.absorption; R.fog_density_decay = c->fog.density_decay; R.fog_absorption_decay = c->fog.absorption_decay;
+	R.phase_aniso = c->fog.phase_aniso; R.ground_level = c->fog.ground_level; R.fog_type = c->fog.type; R.fog_phase_type = c->fog.phase_type;
 	denom2 = (float)(1.f / (2. * (double)p->sigma_filter * (double)p->sigma_filter));   // Raytracer.cpp:1430
 	// tables: compact the reference's Vector[] (stride 3) arrays to stride 2
 	const int ftw = 2 * p->filter_size + 1;

@@ -9,6 +9,7 @@
 // one sample in one thread (like k_render_paths), with the FIFO in HBM; scenes with ghosts or a background image are
 // routed here (a few of a production's shots, not the throughput path).
 #pragma once
+#include "mipt_explog.h"
 
 #define MIPT_SIZE_CIRC_ARRAY 200          // Raytracer.h:114
 
@@ -21,6 +22,105 @@ MIPT_DEV f3 background_pixel(const DRender& R, int screenI, int screenJ) {   // 
 	return mk3(px[0], px[1], px[2]);
 }
 
+// ---- fog: single scattering (Raytracer.cpp:20-192) --------------------------------------------------------------
+MIPT_DEV float fog_tanf(float x) { float r; if (mipt_tanf_main(x, r)) return r; return tanf(x); }   // |x| <= pi/2 here: always the exact branch
+MIPT_DEV float int_exponential(float y0, float ysol, float beta, float s, float uy) {             // :20-40
+	float result;
+	if ((double)fabsf(uy * beta) < 0.0001) result = mipt_expf(-beta * (y0 - ysol)) * (s);
+	else result = (mipt_expf(-beta * (y0 - ysol)) - mipt_expf(-beta * (y0 + s * uy - ysol))) / (uy * beta);
+	return result;
+}
+MIPT_DEV f3 random_uniform_sphere(uint64_t& rng) {                                                // Vector.h:604-615, T = float
+	const float r1 = pcg_uniform(rng);
+	const float r2 = pcg_uniform(rng);
+	return mk3(2.f * pt_cosf((float)(2. * MIPT_PI) * r1) * sqrtf(r2 * (1 - r2)), 2.f * pt_sinf((float)(2. * MIPT_PI) * r1) * sqrtf(r2 * (1 - r2)), 1.f - 2.f * r2);
+}
+struct FogEvent { f3 weight; Ray ray; };
+// One in-scattering event on [0, t] of ray r (fogContribution).  `attenuation` (the transmittance of the segment) is
+// written only once the event is known to lie above the ground (:114) — the caller's variable keeps its previous
+// value otherwise, like the reference's local.
+template <class STK>
+__device__ __noinline__ bool fog_contribution(const DScene* __restrict__ sc, const DRender& R, const Ray& r, f3 sampleLightPos, float t, f3 curWeight,
+                                              FogEvent& ev, float& attenuation, uint64_t& rng, unsigned& n_closest, STK& stk) {
+	if (norm2(curWeight) < 1E-12) return false;
+	const f3 rayDirection = r.d;
+	const float p_uniform = 0.5f;
+	const bool is_uniform_fog = R.fog_type == 0;
+	const float alpha = R.fog_absorption, sigmaT = R.fog_absorption_decay, groundLevel = R.ground_level;
+	float int_ext;
+	if (is_uniform_fog) int_ext = (float)((double)(alpha * t) * 0.05);
+	else int_ext = alpha * int_exponential(r.o.y, groundLevel, sigmaT, t, rayDirection.y);
+	const float T = mipt_expf(-int_ext);
+	float proba_t, random_t;
+	const float clamped_t = 1000.f < t ? 1000.f : t;
+	const f3 cl = ld3(R.centerLight);
+	const float a = dot(sampleLightPos - r.o, r.d);
+	if (a > 0) {                                                            // equi-angular sampling (:71-84)
+		const f3 projP = r.o + a * r.d;
+		const float D = sqrtf(norm2(sampleLightPos - projP));
+		const float thetaA = -mipt_atan2f(a, D);
+		const float b = t - a;
+		const float thetaB = mipt_atan2f(b, D);
+		const float x = pcg_uniform(rng);
+		random_t = D * fog_tanf((1 - x) * thetaA + x * thetaB);
+		proba_t = D / ((thetaB - thetaA) * (D * D + random_t * random_t));
+		random_t += a;
+	} else {                                                                // :85-99
+		const float alpha2 = 5.f / clamped_t;
+		do { random_t = -mipt_logf(pcg_uniform(rng)) / alpha2; } while (random_t > clamped_t);
+		const float normalization = 1.f / alpha2 * (1.f - mipt_expf(-alpha2 * clamped_t));
+		proba_t = mipt_expf(-alpha2 * random_t) / normalization;
+	}
+	float int_ext_partielle;
+	if (is_uniform_fog) int_ext_partielle = (float)((double)(alpha * random_t) * 0.05);
+	else int_ext_partielle = alpha * int_exponential(r.o.y, groundLevel, sigmaT, random_t, rayDirection.y);
+	const f3 random_P = r.o + random_t * rayDirection;
+	if (random_P.y < groundLevel) return false;                             // :114
+	f3 random_dir, point_aleatoire = mk3(0, 0, 0);
+	const f3 axeOP = normalize(random_P - cl);
+	bool is_uniform;
+	if (pcg_uniform(rng) < p_uniform) { random_dir = random_uniform_sphere(rng); is_uniform = true; }
+	else {
+		const float l1 = pcg_uniform(rng), l2 = pcg_uniform(rng);
+		const f3 dir_l = random_cos(axeOP, l1, l2);
+		point_aleatoire = dir_l * R.radiusLight + cl;
+		random_dir = normalize(point_aleatoire - random_P);
+		is_uniform = false;
+	}
+	float phase_func = 0.f;
+	const float k = R.phase_aniso;
+	if (R.fog_phase_type == 0) phase_func = (float)(1. / (4. * MIPT_PI));
+	else if (R.fog_phase_type == 1) phase_func = (float)((double)(1 - k * k) / (4. * MIPT_PI * (double)(1 + k * dot(random_dir, -rayDirection))));
+	else if (R.fog_phase_type == 2) phase_func = (float)(3 / (16 * MIPT_PI) * (double)(1 + sqr(dot(random_dir, rayDirection))));
+	Ray L; L.o = random_P; L.d = random_dir;
+	Hit ih; f3 interP = mk3(0, 0, 0); Mat im;
+	im.shadingN = mk3(0, 1, 0); im.Kd = mk3(0.5f, 0.5f, 0.5f); im.Ks = mk3(0, 0, 0); im.Ne = mk3(100, 100, 100); im.Ke = mk3(0, 0, 0); im.transp = false; im.refr_index = 0;
+	const bool interinter = scene_intersect(sc, L, ih, interP, im, stk);
+	n_closest++;
+	bool visible = true;
+	if (!is_uniform) {
+		const float d_light2 = norm2(point_aleatoire - random_P);
+		if (interinter && (double)(ih.t * ih.t) < (double)d_light2 * 0.99) visible = false;
+	}
+	attenuation = T;
+	if (!visible) return false;
+	const float pdf_uniform = (float)(1. / (4. * MIPT_PI));
+	float pdf_light = 0.f;
+	if (interinter && ih.obj == 0) {
+		const float J = dot(im.shadingN, -random_dir) / norm2(interP - random_P);
+		pdf_light = (float)((double)dot(normalize(interP - cl), axeOP) / (MIPT_PI * (double)sqr(R.radiusLight)) / (double)J);
+	}
+	const float proba_dir = p_uniform * pdf_uniform + (1 - p_uniform) * pdf_light;
+	float ext;
+	if (is_uniform_fog) ext = (float)((double)R.fog_density * 0.05);
+	else ext = R.fog_density * mipt_expf(-R.fog_density_decay * (random_P.y - groundLevel));
+	ev.weight = curWeight * (phase_func * ext * mipt_expf(-int_ext_partielle) / (proba_t * proba_dir));
+	ev.ray = L;
+	return true;
+}
+
+// getColor, literally: pop a contribution, trace it, add what it sees, queue its successors (Raytracer.cpp:196-664 with
+// subsProba = 0, no_envmap = false, has_precomputed_rays = false).
 template <class STK>
 __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const DRender& R, int i, int j, int k, float& dx, float& dy,
                                             unsigned& n_closest, unsigned& n_shadow, STK& stk, QContrib* __restrict__ q) {
@@ -28,6 +128,9 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 	path_begin(R, i, j, k, ps, dx, dy);
 	const int pix = i * R.W + j;
 	const bool has_bg = R.backgroundW > 0 && R.background != nullptr;       // :220
+	const bool has_fog = R.fog_density > 1E-8;                              // :207
+	float attenuationFactor = 0.f;                                          // :206 (uninitialised in the reference)
+	f3 color = mk3(0, 0, 0);
 	int start = 0, end = 1;
 	auto push = [&](f3 w, const Ray& r, int depth, bool lights, bool env) {
 		QContrib c;
@@ -38,43 +141,74 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 	};
 	q[0].w = make_float4(1.f, 1.f, 1.f, __uint_as_float((unsigned)(R.nb_bounces & 0xffff) | 0x10000u | 0x20000u));
 	q[0].o = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.f); q[0].d = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.f);
+	const f3 cl = ld3(R.centerLight);
 	while (start != end) {
 		const QContrib cur = q[start];
 		start++; if (start >= MIPT_SIZE_CIRC_ARRAY) start = 0;
 		const unsigned bits = __float_as_uint(cur.w.w);
-		ps.ray.o = mk3(cur.o.x, cur.o.y, cur.o.z); ps.ray.d = mk3(cur.d.x, cur.d.y, cur.d.z);
-		ps.weight = mk3(cur.w.x, cur.w.y, cur.w.z);
-		ps.depth = (int)(bits & 0xffffu); ps.show_lights = (bits & 0x10000u) != 0;
-		const bool show_envmap = (bits & 0x20000u) != 0;
-		if (!path_alive(ps)) continue;                                      // :240-241
-		const int nbrebonds = ps.depth;
+		Ray currentRay; currentRay.o = mk3(cur.o.x, cur.o.y, cur.o.z); currentRay.d = mk3(cur.d.x, cur.d.y, cur.d.z);
+		const f3 pathWeight = mk3(cur.w.x, cur.w.y, cur.w.z);
+		const int nbrebonds = (int)(bits & 0xffffu);
+		const bool show_lights = (bits & 0x10000u) != 0, show_envmap = (bits & 0x20000u) != 0;
+		if (nbrebonds == 0) continue;                                       // :240
+		if (norm2(pathWeight) < sqr(0.01f)) continue;                       // :241
 		Hit h; f3 P = mk3(0, 0, 0); Mat m;
-		const bool hit = scene_intersect(sc, ps.ray, h, P, m, stk);
+		const bool hit = scene_intersect(sc, currentRay, h, P, m, stk);
 		n_closest++;
+		const float t = h.t;
+		// fog event along the ray just traced, towards `lightpos`; queues the in-scattered path (showenvmap = true)
+		auto fog = [&](const Ray& ray, f3 lightpos) {
+			FogEvent ev;
+			if (fog_contribution(sc, R, ray, lightpos, t, pathWeight, ev, attenuationFactor, ps.rng, n_closest, stk)) push(ev.weight, ev.ray, nbrebonds - 1, show_lights, true);
+		};
 		if (nbrebonds == R.nb_bounces && has_bg && (!hit || h.obj == 1)) {  // :260-268: a camera ray that leaves the scene shows the photo
-			ps.color = ps.color + ps.weight * background_pixel(R, i, j);
+			color = color + pathWeight * background_pixel(R, i, j);
 			continue;
 		}
-		if (!hit) continue;
-		if (h.obj == 1 && !show_envmap) continue;                           // :276-287
+		if (!hit) { if (R.fog_density == 0) continue; else break; }         // :654-657
+		const f3 N = m.shadingN, rayDirection = currentRay.d;
+		if (h.obj == 1) {                                                   // :275-301
+			if (!show_envmap) { if (has_fog) fog(currentRay, cl); continue; }
+			if (has_fog) { fog(currentRay, cl); color = color + ((attenuationFactor * pathWeight) * R.envmap_intensity) * m.Ke; }
+			else color = color + (pathWeight * R.envmap_intensity) * m.Ke;
+			continue;
+		}
+		if (h.obj == 0) {                                                   // :303-316
+			const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f);
+			if (has_fog) { fog(currentRay, cl); color = color + (attenuationFactor * pathWeight) * cc; }
+			else color = color + pathWeight * cc;
+			continue;
+		}
 		const DObject& obj = sc->obj[h.obj];
-		if (h.obj < 2 || !obj.ghost || obj.miroir || m.transp) {            // everything but the diffuse / glossy vertex of a ghost: as in the linear loop
-			ShadowRequest sh; f3 wv;
-			const bool cont = path_vertex(sc, R, ps, hit, h, P, m, pix, k, sh, wv);
-			if (sh.diffuse) {
-				f3 contrib = sh.contrib;
-				if (sh.cast) { n_shadow++; if (scene_occluded<STK, true>(sc, sh.ray, sh.dist, stk)) contrib = mk3(0, 0, 0); }   // :513: ghosts cast no shadow
-				else contrib = mk3(0, 0, 0);
-				ps.color = ps.color + wv * contrib;                          // :566
-			}
-			if (cont) push(ps.weight, ps.ray, ps.depth, ps.show_lights, true);   // showenvmap: default argument (:425, :485) or `... || !ghost` (:629)
+		const double* const merl = obj.merl;
+		color = color + (pathWeight * m.Ke) * R.envmap_intensity;           // :411
+		if (obj.miroir) {                                                   // :413-436
+			Ray rm; rm.o = P + 0.001f * N; rm.d = reflect(rayDirection, N);
+			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, rm, nbrebonds - 1, show_lights, true); }
+			else push(pathWeight, rm, nbrebonds - 1, show_lights, true);
 			continue;
 		}
-		// ---- diffuse / glossy vertex on a ghost object (:490-632)
-		const f3 N = m.shadingN, rayDirection = ps.ray.d, pathWeight = ps.weight;
-		const double* const merl = obj.merl;
-		ps.color = ps.color + (pathWeight * m.Ke) * R.envmap_intensity;      // :411
-		const f3 cl = ld3(R.centerLight);
+		if (m.transp) {                                                     // :438-489
+			float n1 = 1.f, n2 = m.refr_index;
+			f3 nt = N;
+			bool entering = true;
+			if (dot(rayDirection, N) > 0) { n1 = m.refr_index; n2 = 1; nt = -N; entering = false; }
+			const float radical = 1.f - sqr(n1 / n2) * (1.f - sqr(dot(nt, rayDirection)));
+			Ray nr;
+			if (radical > 0) {
+				const f3 refr = (n1 / n2) * (rayDirection - dot(rayDirection, nt) * nt) - nt * sqrtf(radical);
+				const float R0 = sqr((n1 - n2) / (n1 + n2));
+				float Rf;
+				if (entering) Rf = R0 + (1 - R0) * pt_powf(1.f + dot(rayDirection, N), 5.f);
+				else Rf = R0 + (1 - R0) * pt_powf(1.f - dot(refr, N), 5.f);
+				if (pcg_uniform(ps.rng) < Rf) { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
+				else { nr.o = P - 0.001f * nt; nr.d = refr; }
+			} else { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
+			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, nr, nbrebonds - 1, show_lights, true); }
+			else push(pathWeight, nr, nbrebonds - 1, show_lights, true);
+			continue;
+		}
+		// ---- diffuse / glossy vertex (:490-632)
 		const f3 axeOP = fast_normalize(P - cl);
 		const float l1 = pcg_uniform(ps.rng);
 		const float l2 = pcg_uniform(ps.rng);
@@ -87,14 +221,24 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		else {
 			Ray rl; rl.o = P + 0.01f * wi; rl.d = wi;
 			n_shadow++;
-			isShadowed = scene_occluded<STK, true>(sc, rl, sqrtf(d_light2) - 0.01f, stk);
+			isShadowed = scene_occluded<STK, true>(sc, rl, sqrtf(d_light2) - 0.01f, stk);   // :513: ghosts cast no shadow
 		}
-		if (!isShadowed) {                                                  // :522-536: straight on through the ghost, same depth
-			const f3 offset = dot(N, rayDirection) > 0 ? N : -N;
-			Ray through; through.o = (P + rayDirection * 0.001f) + offset * 0.001f; through.d = rayDirection;
-			push(pathWeight, through, nbrebonds, ps.show_lights, show_envmap);
+		f3 currentContrib = mk3(0, 0, 0);
+		if (!isShadowed) {
+			if (obj.ghost) {                                                // :522-536: straight on through the ghost, same depth; currentRay itself is replaced
+				const f3 offset = dot(N, rayDirection) > 0 ? N : -N;
+				currentRay.o = (P + rayDirection * 0.001f) + offset * 0.001f;
+				currentRay.d = rayDirection;
+				push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap);
+			} else {                                                        // :538-553 (no direct light on a ghost)
+				const f3 brdf = merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(m, wi, -rayDirection, N);
+				const float J = dot(dir_l, -wi) / d_light2;
+				const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+				if (proba > 0.f) currentContrib = currentContrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+			}
 		}
-		ps.color = ps.color + pathWeight * mk3(0.f, 0.f, 0.f);              // :547-566: no direct light on a ghost
+		if (has_fog) { fog(currentRay, pt_l); color = color + (attenuationFactor * pathWeight) * currentContrib; }   // :557-565
+		else color = color + pathWeight * currentContrib;                   // :566
 		float ip;
 		const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * k], &ip);
 		const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * k + 1], &ip);
@@ -108,14 +252,16 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) continue;   // :593
 		const f3 brdf_i = merl ? merl_eval(merl, dir, -rayDirection, N) : phong_eval(m, dir, -rayDirection, N);
 		f3 nw = ((pathWeight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);             // :611
-		if (has_bg) {                                                       // :614-621
+		if (obj.ghost && has_bg) {                                          // :614-621
 			const f3 bg = background_pixel(R, i, j);
 			nw = nw * mk3(bg.x / 196964.699f, bg.y / 196964.699f, bg.z / 196964.699f);
 		}
 		Ray next; next.o = P + 0.01f * dir; next.d = dir;
-		push(nw, next, nbrebonds - 1, false, show_envmap && isShadowed && has_sampled_diffuse);   // :629
+		const bool env = (show_envmap && isShadowed && has_sampled_diffuse) || !obj.ghost;      // :626-629
+		if (has_fog) push(attenuationFactor * nw, next, nbrebonds - 1, false, env);
+		else push(nw, next, nbrebonds - 1, false, env);
 	}
-	return ps.color;
+	return color;
 }
 
 // one thread per (pixel, sample), as k_render_paths; `queues` holds MIPT_SIZE_CIRC_ARRAY entries per thread

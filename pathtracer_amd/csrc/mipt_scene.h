@@ -94,6 +94,9 @@ struct DRender {
 	uint64_t seed_stride;
 	const float* background;     // Scene::background (Geometry.h:1355-1366): backgroundW x backgroundH x 3 floats or null
 	int backgroundW, backgroundH;
+	// Scene::fog_* (Geometry.h:1371-1377) and the height of the floor, objects[2]->get_translation()[1] (Raytracer.cpp:55)
+	float fog_density, fog_absorption, fog_density_decay, fog_absorption_decay, phase_aniso, ground_level;
+	int fog_type, fog_phase_type;
 };
 
 // One render pass: samples [k0,k1) of every owned 8x8 pixel block.

@@ -882,7 +882,7 @@ void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
 // 132-162).  Values are written with "%f" (six decimals) and read back from those decimals, exactly like the reference,
 // so a scene loaded here and there is the same scene.  The optional / backward-compatible records of load_scene are
 // accepted.  What the hot path does not cover is refused loudly rather than dropped: lenticular / array cameras, a
-// fog, key-framed transforms, PointSet objects, per-face colour files.
+// key-framed transforms, PointSet objects, per-face colour files.
 namespace {
 struct ScnReader {
 	FILE* f;
@@ -1091,9 +1091,16 @@ bool Raytracer::load_scene(const char* filename) {
 			s.addObject(g);
 		} else return bail("object kind outside the hot path");
 	}
-	float fog = 0;
-	if (R.next() && R.starts("fog_density:")) { fog = strtof(R.after("fog_density:"), nullptr); if (fog != 0.f) return bail("fog is outside the hot path"); }
-	while (R.next()) if (R.starts("double_frustum_start_t:")) s.double_frustum_start_t = strtof(R.after("double_frustum_start_t:"), nullptr);
+	// fog block (:1217-1232; older files stop after fog_type or fog_phase_type)
+	if (R.next() && R.starts("fog_density:")) s.fog_density = strtof(R.after("fog_density:"), nullptr);
+	while (R.next()) {
+		if (R.starts("fog_absorption:")) s.fog_absorption = strtof(R.after("fog_absorption:"), nullptr);
+		else if (R.starts("fog_density_decay:")) s.fog_density_decay = strtof(R.after("fog_density_decay:"), nullptr);
+		else if (R.starts("fog_absorption_decay:")) s.fog_absorption_decay = strtof(R.after("fog_absorption_decay:"), nullptr);
+		else if (R.starts("fog_type:")) s.fog_type = (int)strtoul(R.after("fog_type:"), nullptr, 10);
+		else if (R.starts("fog_phase_type:")) s.fog_phase_type = (int)strtoul(R.after("fog_phase_type:"), nullptr, 10);
+		else if (R.starts("double_frustum_start_t:")) s.double_frustum_start_t = strtof(R.after("double_frustum_start_t:"), nullptr);
+	}
 	fclose(R.f); R.f = nullptr;
 	if (s.objects.empty() || s.objects[0]->type != OT_SPHERE) { err_ = std::string(filename) + ": object 0 must be the light sphere"; return false; }
 	s.lumiere = static_cast<Sphere*>(s.objects[0]);
@@ -1143,7 +1150,8 @@ bool Raytracer::save_scene(const char* filename) const {
 			fprintf(f, "is_centered: %u\nhas_csv: 0\ncsv_file: \n", static_cast<const TriMesh*>(o)->is_centered ? 1 : 0);
 		}
 	}
-	fprintf(f, "fog_density: %f\nfog_absorption: %f\nfog_density_decay: %f\nfog_absorption_decay: %f\nfog_type: 0\nfog_phase_type: 0\n", 0.f, 0.f, 0.f, 0.f);
+	fprintf(f, "fog_density: %f\nfog_absorption: %f\nfog_density_decay: %f\nfog_absorption_decay: %f\nfog_type: %u\nfog_phase_type: %u\n",
+	        s.fog_density, s.fog_absorption, s.fog_density_decay, s.fog_absorption_decay, (unsigned)s.fog_type, (unsigned)s.fog_phase_type);
 	fprintf(f, "double_frustum_start_t: %f\n", s.double_frustum_start_t);
 	fclose(f);
 	return true;
@@ -1270,6 +1278,9 @@ void Raytracer::build_descs() {
 	const bool has_bg = s.backgroundW > 0 && s.background.size() == (size_t)s.backgroundW * s.backgroundH * 3;   // Raytracer.cpp:220
 	scene_desc.background = has_bg ? s.background.data() : nullptr;
 	scene_desc.backgroundW = has_bg ? s.backgroundW : 0; scene_desc.backgroundH = has_bg ? s.backgroundH : 0;
+	scene_desc.fog_density = s.fog_density; scene_desc.fog_absorption = s.fog_absorption; scene_desc.fog_density_decay = s.fog_density_decay;
+	scene_desc.fog_absorption_decay = s.fog_absorption_decay; scene_desc.phase_aniso = s.phase_aniso; scene_desc.fog_type = s.fog_type; scene_desc.fog_phase_type = s.fog_phase_type;
+	scene_desc.fog_ground_level = n > 2 ? s.objects[2]->max_translation[1] : 0.f;   // objects[2]->get_translation(time, is_recording)[1], no key frames (Raytracer.cpp:55)
 	mipt_render_params& p = render_params;
 	memset(&p, 0, sizeof p);
 	p.W = W; p.H = H; p.nrays = nrays; p.nb_bounces = nb_bounces;
@@ -1363,6 +1374,11 @@ void mh_set_camera(mh_raytracer* h, const float* pos, const float* dir, const fl
 }
 void mh_set_light(mh_raytracer* h, const float* center, float R, float intensite) {
 	Sphere* l = h->rt.s.lumiere; l->O = Vector(center[0], center[1], center[2]); l->R = R; l->rotation_center = l->O; h->rt.s.intensite_lumiere = intensite;
+}
+void mh_set_fog(mh_raytracer* h, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso) {
+	Scene& s = h->rt.s;
+	s.fog_density = density; s.fog_absorption = absorption; s.fog_density_decay = density_decay; s.fog_absorption_decay = absorption_decay;
+	s.fog_type = type; s.fog_phase_type = phase_type; s.phase_aniso = phase_aniso;
 }
 void mh_set_object_ghost(mh_raytracer* h, int obj, int ghost) { h->rt.s.objects[obj]->ghost = ghost != 0; }
 int mh_load_background(mh_raytracer* h, const char* file) {

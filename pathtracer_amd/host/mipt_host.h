@@ -149,6 +149,9 @@ public:
 	// (load_image: rows flipped) and stores pow(v/255., gamma) * 196964.699; false + reason when the file cannot be read.
 	void clear_background() { background.clear(); backgroundW = backgroundH = 0; backgroundfilename.clear(); }
 	bool load_background(const char* filename, float gamma, std::string& why);
+	// fog (Geometry.h:1371-1377)
+	float fog_density = 0, fog_absorption = 0, fog_density_decay = 0, fog_absorption_decay = 0, phase_aniso = 0;
+	int fog_type = 0, fog_phase_type = 0;
 	std::vector<float> background;
 	int backgroundW = 0, backgroundH = 0;
 	std::string backgroundfilename;
@@ -266,6 +269,7 @@ const void* mh_render_params(mh_raytracer*);              // const mipt_render_p
 float* mh_imagedouble(mh_raytracer*);
 int  mh_get_background(mh_raytracer*, float* out, int capacity, int* W, int* H);
 void mh_set_has_denoiser(mh_raytracer*, int on);
+void mh_set_fog(mh_raytracer*, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso);   // Scene::fog_*
 void mh_set_object_ghost(mh_raytracer*, int obj, int ghost);                 // Object::ghost
 int  mh_load_background(mh_raytracer*, const char* file);                     // Scene::load_background(file, gamma); -1 + mh_last_error on failure
 void mh_set_background(mh_raytracer*, const float* rgb, int W, int H);        // Scene::background set directly (NULL clears it)

@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv:
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv:
     main()
 
 
@@ -257,6 +257,45 @@ def compositing_scene(X, kind):
     return cfg
 
 
+FOG_KINDS = ("uniform", "dense", "exp", "schlick", "rayleigh", "glossyfog", "mirrorfog", "glassfog", "ghostfog")
+
+
+def fog_scene(X, kind):
+    """Blob over the floor in a participating medium (fogContribution, Raytracer.cpp:45-192)."""
+    cfg = scenes.config_c1(64, 36, 4)
+    cfg.nb_bounces = 4
+    X.apply_config(cfg)
+    oid = X.add_mesh(scenes.blob_mesh(16))
+    fog = dict(uniform=(0.5, 0.4), dense=(3.0, 2.0), exp=(0.8, 0.6, 0.05, 0.04, 1, 0, 0.0), schlick=(0.5, 0.4, 0, 0, 0, 1, 0.6),
+               rayleigh=(0.5, 0.4, 0.02, 0.03, 1, 2, 0.0)).get(kind, (0.5, 0.4))
+    if kind == "glossyfog":
+        X.set_group_material(oid, 0, (0.4, 0.3, 0.2), (0.5, 0.5, 0.4), (40., 60., 80.))
+    if kind == "mirrorfog":
+        X.set_object_flags(oid, True, False)
+    if kind == "glassfog":
+        X.set_group_material(oid, 0, (0.5, 0.5, 0.5), (0, 0, 0), (0, 0, 0), 0.0, 1.3)
+    if kind == "ghostfog":
+        X.set_object_ghost(2, True)
+        X.set_background(background_photo())
+        o2 = X.add_mesh(scenes.blob_mesh(8), scale=45.0)
+        X.set_object_ghost(o2, True)
+    X.set_fog(*fog)
+    X.prepare()
+    return cfg
+
+
+def main_fog():
+    """tests/golden/fog.npz: per-sample radiance of the fog scenes from the compiled reference."""
+    g = {}
+    for kind in FOG_KINDS:
+        R = Ref()
+        cfg = fog_scene(R, kind)
+        rgb, dxdy = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+        g[kind + "_rgb"] = rgb
+        print(kind, "mean radiance / white", float(rgb.mean() / 196964.7))
+    np.savez_compressed(os.path.join(OUT, "fog.npz"), **g)
+
+
 def main_compositing():
     """tests/golden/compositing.npz: per-sample radiance of the ghost / background scenes from the compiled reference."""
     g = {}
@@ -274,3 +313,5 @@ def main_compositing():
 
 if __name__ == "__main__" and "--compositing" in sys.argv:
     main_compositing()
+if __name__ == "__main__" and "--fog" in sys.argv:
+    main_fog()
