@@ -41,6 +41,7 @@ static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x 
 static inline float vget(v3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 static inline void vset(v3* a, int k, float v) { if (k == 0) a->x = v; else if (k == 1) a->y = v; else a->z = v; }
 static inline float sqrf(float x) { return x * x; }
+static inline double sqr_d(double x) { return x * x; }
 
 /* Vector.h:294-309 invSqRoot.  The reference reads the float through a `long*`; the intended
  * (and, as compiled, observed) semantics are the classic 32-bit ones. */
@@ -860,6 +861,108 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
  * them removed the Contrib queue never holds more than one entry, so it is a plain loop. */
 /* normalValue / albedoValue: the denoiser inputs of Raytracer.cpp:255-258 (shading normal and Kd of the FIRST hit;
    left untouched without one, so they keep the zeros `Vector normal, albedo;` starts from, :1628).  May be NULL. */
+/* ------------------------------------------------------------------ subsurface probe: a uniformly random one of the intersections in [min_t, max_t)
+   TriMesh::reservoir_sampling_intersection (TriangleMesh.cpp:1321-1426): the closest-hit traversal order with a fixed far
+   bound; every accepted triangle draws one number, so the visiting order decides the draws. */
+static int mesh_reservoir_intersection(const o_obj* o, const o_ray* d, v3* P, float* t, o_mat* mat, int* triangle_id, int* current_nb_intersections,
+                                       float min_t, float max_t, pcg32_t* rng) {
+	const o_mesh* g = o->mesh;
+	int has_inter = 0;
+	float t_box_left, t_box_right;
+	int best_index = -1;
+	int goleft, goright;
+	v3 localP = V(0, 0, 0);
+	float localt, alpha = 0, beta = 0, gamma = 0;
+	o_ray invd; invd.origin = d->origin;
+	invd.direction = V(1.f / d->direction.x, 1.f / d->direction.y, 1.f / d->direction.z);
+	char signs[3];
+	signs[0] = (invd.direction.x >= 0) ? 1 : 0;
+	signs[1] = (invd.direction.y >= 0) ? 1 : 0;
+	signs[2] = (invd.direction.z >= 0) ? 1 : 0;
+	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &t_box_left)) return 0;
+	if (t_box_left > max_t) return 0;
+	int l[50];
+	float tnear[50];
+	int idx_back = -1;
+	l[++idx_back] = 0;
+	tnear[idx_back] = t_box_left;
+	while (idx_back >= 0) {
+		if (tnear[idx_back] > max_t) { idx_back--; continue; }
+		const int current = l[idx_back--];
+		const int fg = g->nodes[current].fg;
+		const int fd = g->nodes[current].fd;
+		if (!g->nodes[current].isleaf) {
+			if (signs[0] == 1) {
+				goleft = (box_invd_posx(g->nodes[fg].bmin, g->nodes[fg].bmax, invd.origin, invd.direction, signs, &t_box_left) && t_box_left < max_t);
+				goright = (box_invd_posx(g->nodes[fd].bmin, g->nodes[fd].bmax, invd.origin, invd.direction, signs, &t_box_right) && t_box_right < max_t);
+			} else {
+				goleft = (box_invd_negx(g->nodes[fg].bmin, g->nodes[fg].bmax, invd.origin, invd.direction, signs, &t_box_left) && t_box_left < max_t);
+				goright = (box_invd_negx(g->nodes[fd].bmin, g->nodes[fd].bmax, invd.origin, invd.direction, signs, &t_box_right) && t_box_right < max_t);
+			}
+			if (goleft && goright) {
+				if (t_box_left < t_box_right) {
+					l[++idx_back] = fd; tnear[idx_back] = t_box_right;
+					l[++idx_back] = fg; tnear[idx_back] = t_box_left;
+				} else {
+					l[++idx_back] = fg; tnear[idx_back] = t_box_left;
+					l[++idx_back] = fd; tnear[idx_back] = t_box_right;
+				}
+			} else {
+				if (goleft) { l[++idx_back] = fg; tnear[idx_back] = t_box_left; }
+				if (goright) { l[++idx_back] = fd; tnear[idx_back] = t_box_right; }
+			}
+		} else {
+			for (int i = fg; i < fd; i++) {
+				if (tri_intersection(&g->soup[i], d, &localP, &localt, &alpha, &beta, &gamma)) {
+					if (localt < max_t && localt >= min_t) {
+						if (mesh_alpha_rejects(o, i, alpha, beta, gamma)) continue;
+						(*current_nb_intersections)++;
+						float r1 = pcg_uniform(rng);
+						if (r1 < 1. / *current_nb_intersections) {
+							has_inter = 1;
+							best_index = i;
+							*t = localt;
+						}
+					}
+				}
+			}
+		}
+	}
+	if (has_inter) {
+		int i = best_index;
+		*triangle_id = best_index;
+		tri_intersection(&g->soup[i], d, &localP, &localt, &alpha, &beta, &gamma);
+		if (isnan(alpha) && isnan(beta) && isnan(gamma)) { alpha = 1; beta = 0; gamma = 0; }
+		if (isnan(alpha)) alpha = 0;
+		if (isnan(beta)) beta = 0;
+		if (isnan(gamma)) gamma = 0;
+		if (isinf(alpha)) alpha = 1;
+		if (isinf(beta)) beta = 1;
+		if (isinf(gamma)) gamma = 1;
+		*P = localP;
+		mesh_get_material(o, i, alpha, beta, gamma, mat);
+	}
+	return has_inter;
+}
+/* Scene::get_random_intersection (Geometry.cpp:339-470) restricted to one object (sphere_id != -1), which is how the
+   subsurface branch calls it; only meshes carry a subsurface colour here (spheres / planes: not restated). */
+static int scene_get_random_intersection(const o_ctx* c, const o_ray* d, v3* P, int sphere_id, float* min_t, o_mat* mat, int* triangle_id, float tmin, float tmax, pcg32_t* rng) {
+	int has_inter = 0;
+	*min_t = INFINITY;
+	int nb_intersections = 0;
+	const o_obj* o = &c->objs[sphere_id];
+	o_ray tr;
+	tr.direction = apply_inverse_rotation_scaling(o, d->direction);
+	tr.origin = apply_inverse_transformation(o, d->origin);
+	if (o->type == OT_TRIMESH) has_inter = mesh_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
+	if (has_inter) {
+		*P = apply_transformation(o, *P);
+		mat->shadingN = apply_rotation(o, mat->shadingN);
+	}
+	mat->shadingN = vfast_normalize(mat->shadingN);
+	return has_inter;
+}
+
 /* ------------------------------------------------------------------ fog: single scattering (Raytracer.cpp:20-192) */
 static float int_exponential(float y0, float ysol, float beta, float s, float uy) {          /* :20-40 */
 	float result;
@@ -879,12 +982,12 @@ static v3 random_uniform_sphere(pcg32_t* rng) {                                 
 	result.z = 1.f - 2.f * r2;
 	return result;
 }
-typedef struct { v3 weight; o_ray r; int depth; int show_lights, showenvmap; } o_contrib;   /* Raytracer.h:15-23 (no subsurface here) */
+typedef struct { v3 weight; o_ray r; int depth; int show_lights, showenvmap, hadSS; } o_contrib;   /* Raytracer.h:15-23 */
 /* One in-scattering event on the segment [0, t] of ray r: equi-angular (towards the sampled light point) or exponential
    distance sampling, direction uniform or towards the light (p = 1/2 each), one closest-hit query for the visibility of
    the light sample.  *attenuationFactor (the transmittance of the segment) is only written once the event is above
    the ground (:114): the caller keeps the previous value otherwise, as the reference's local does. */
-static int fog_contribution(const o_ctx* c, const o_ray* r, v3 sampleLightPos, float t, v3 curWeight, int nbrebonds, int showLight,
+static int fog_contribution(const o_ctx* c, const o_ray* r, v3 sampleLightPos, float t, v3 curWeight, int nbrebonds, int showLight, int hadSS,
                             o_contrib* newContrib, float* attenuationFactor, pcg32_t* rng, uint64_t* nrays2) {
 	if (vnorm2(curWeight) < 1E-12) return 0;
 	v3 rayDirection = r->direction;
@@ -969,7 +1072,7 @@ static int fog_contribution(const o_ctx* c, const o_ray* r, v3 sampleLightPos, f
 	if (is_uniform_fog) ext = c->fog_density * 0.05;
 	else ext = c->fog_density * expf(-c->fog_density_decay * (random_P.y - groundLevel));
 	v3 newweight = vscale((phase_func * ext * expf(-int_ext_partielle) / (proba_t * proba_dir)), curWeight);
-	newContrib->weight = newweight; newContrib->r = L_ray; newContrib->depth = nbrebonds - 1; newContrib->show_lights = showLight; newContrib->showenvmap = 1;
+	newContrib->weight = newweight; newContrib->r = L_ray; newContrib->depth = nbrebonds - 1; newContrib->show_lights = showLight; newContrib->showenvmap = 1; newContrib->hadSS = hadSS;
 	return 1;
 }
 
@@ -989,13 +1092,14 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 	/* the contributions of a sample wait in a circular FIFO (:213-238); without ghosts (and fog) a vertex queues at most one */
 	o_contrib contribs[O_SIZE_CIRC_ARRAY];
 	int contribIndexStart = 0, contribIndexEnd = 1;
-	contribs[0].weight = V(1.f, 1.f, 1.f); contribs[0].r = r; contribs[0].depth = c->nb_bounces; contribs[0].show_lights = 1; contribs[0].showenvmap = 1;
-#define PUSH(w_, ray_, depth_, lights_, env_) do { o_contrib* q_ = &contribs[contribIndexEnd]; q_->weight = (w_); q_->r = (ray_); q_->depth = (depth_); q_->show_lights = (lights_); q_->showenvmap = (env_); \
+	contribs[0].weight = V(1.f, 1.f, 1.f); contribs[0].r = r; contribs[0].depth = c->nb_bounces; contribs[0].show_lights = 1; contribs[0].showenvmap = 1; contribs[0].hadSS = 0;
+#define PUSH(w_, ray_, depth_, lights_, env_) PUSHS(w_, ray_, depth_, lights_, env_, has_had_subsurface_interaction)
+#define PUSHS(w_, ray_, depth_, lights_, env_, ss_) do { o_contrib* q_ = &contribs[contribIndexEnd]; q_->weight = (w_); q_->r = (ray_); q_->depth = (depth_); q_->show_lights = (lights_); q_->showenvmap = (env_); q_->hadSS = (ss_); \
 		contribIndexEnd++; if (contribIndexEnd >= O_SIZE_CIRC_ARRAY) contribIndexEnd = 0; } while (0)
 	const int has_fog = c->fog_density > 1E-8;                      /* :207 */
 	float attenuationFactor = 0;                                    /* :206 (uninitialised there) */
 	o_contrib newContrib;
-#define FOG(ray_, lightpos_) do { if (fog_contribution(c, &(ray_), (lightpos_), t, pathWeight, nbrebonds, show_lights, &newContrib, &attenuationFactor, rng, nrays2)) { \
+#define FOG(ray_, lightpos_) do { if (fog_contribution(c, &(ray_), (lightpos_), t, pathWeight, nbrebonds, show_lights, has_had_subsurface_interaction, &newContrib, &attenuationFactor, rng, nrays2)) { \
 		contribs[contribIndexEnd] = newContrib; contribIndexEnd++; if (contribIndexEnd >= O_SIZE_CIRC_ARRAY) contribIndexEnd = 0; } } while (0)
 	const int has_dome = 1;                                         /* sphereEnv: object 1 is the environment sphere (loadScene) */
 	const int has_backgroundimage = c->backgroundW > 0 && c->background != NULL;   /* :220 */
@@ -1005,6 +1109,7 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		int nbrebonds = cur.depth;
 		v3 pathWeight = cur.weight;
 		int show_lights = cur.show_lights, show_envmap = cur.showenvmap;
+		const int has_had_subsurface_interaction = cur.hadSS;
 		contribIndexStart++; if (contribIndexStart >= O_SIZE_CIRC_ARRAY) contribIndexStart = 0;
 		if (nbrebonds == 0) continue;                               /* :240 */
 		if (vnorm2(pathWeight) < sqrf(0.01f)) continue;             /* :241 */
@@ -1038,7 +1143,61 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 			continue;
 		}
 		const o_obj* obj = &c->objs[sphere_id];
-		v3 subsW = V(1.f / (1.f - 0.f), 1.f / (1.f - 0.f), 1.f / (1.f - 0.f));   /* :318-321, subsProba = 0 */
+		const int is_subsurface = vnorm2(mat.Ksub) > 1E-8;           /* :271 */
+		const float subsProba = (has_had_subsurface_interaction || !is_subsurface) ? 0.f : 0.6f;   /* :318 */
+		const float inv1MSubsProba = 1.f / (1.f - subsProba);
+		v3 subsW = V(inv1MSubsProba, inv1MSubsProba, inv1MSubsProba);
+		int sub_interaction = 0;
+		if (is_subsurface && (pcg_uniform(rng) < subsProba)) {      /* :324-404: leave through a random point of the same object nearby */
+			sub_interaction = 1;
+			const float invSubsProba = 1.f / subsProba;
+			subsW = V(invSubsProba, invSubsProba, invSubsProba);
+			const float sigmasub = 1.5f;
+			const float diskR = sqrtf(12.46f) * sigmasub;
+			float integ = 1.f - expf(-diskR * diskR / (2.f * sigmasub * sigmasub));
+			float randR = sigmasub * sqrtf(-2.f * logf(1.f - pcg_uniform(rng) * integ));
+			float randangle = pcg_uniform(rng) * 2.f * (float)M_PI;
+			float gauss0 = randR * sinf(randangle), gauss1 = randR * cosf(randangle), gauss2 = randR;
+			float gaussval = (1. / (sigmasub * sigmasub * 2.f * (float)M_PI)) * expf(-(gauss2 * gauss2) / (2.f * sigmasub * sigmasub));
+			float pdfgauss = gaussval / integ;
+			v3 Tg = get_tangent(N);
+			v3 Tg2 = vcross(N, Tg);
+			v3 PtaboveP = vadd(vadd(vadd(P, vscale(gauss0, Tg)), vscale(gauss1, Tg2)), vscale(diskR, N));
+			float r1s = pcg_uniform(rng);
+			v3 axis = vneg(N);
+			float tmax;
+			float hh = sqrtf(diskR * diskR - gauss2 * gauss2);
+			v3 subsOrigin = vadd(PtaboveP, vscale((diskR - hh), vneg(N)));
+			float wAxis;
+			if (r1s < 0.5f) { wAxis = 0.5f; tmax = 2.f * hh; }
+			else {
+				wAxis = 0.25f;
+				tmax = 2.f * gauss2;
+				if (r1s < 0.75f) axis = Tg; else axis = Tg2;
+				float r2s = pcg_uniform(rng);
+				if (r2s < 0.5f) subsOrigin = vsub(subsOrigin, vscale(hh, N));
+			}
+			o_mat subsmat; mat_default(&subsmat);
+			int substriid = -1;
+			float subst;
+			v3 localP2 = V(0, 0, 0);
+			o_ray probe; probe.origin = subsOrigin; probe.direction = axis;
+			int subsinter = scene_get_random_intersection(c, &probe, &localP2, sphere_id, &subst, &subsmat, &substriid, 0, tmax, rng);
+			if (subsinter) {
+				float chris = exp(-vnorm2(vsub(P, localP2)) / (2. * sigmasub * sigmasub));
+				float sumpdfs = sqr_d(0.5 * vdot(subsmat.shadingN, N)) + sqr_d(0.25 * vdot(subsmat.shadingN, Tg)) + sqr_d(0.25 * vdot(subsmat.shadingN, Tg2));
+				float pdfdisk = wAxis * fabsf(vdot(axis, subsmat.shadingN)) / sumpdfs;
+				subsW = vscale(pdfdisk / fmaxf(pdfgauss, 0.05f) * chris, subsW);
+				rayDirection = vnormalize(vsub(localP2, P));
+				P = vadd(localP2, vscale(0.005f, subsmat.shadingN));
+				if (r1s < 0.5f) subsW = vscale(2.f, subsW); else subsW = vscale(4.f, subsW);
+				subsW = vmul(subsW, vdivs(mat.Ksub, (float)M_PI));
+				mat = subsmat;
+				N = mat.shadingN;
+				tri_id = substriid;
+			}
+		}
+		const int next_hadSS = sub_interaction ? 1 : has_had_subsurface_interaction;
 		color = vadd(color, vscale(c->envmap_intensity, vmul(pathWeight, mat.Ke)));   /* :411 */
 		if (obj->miroir) {                                          /* :413-436 */
 			o_ray rayon_miroir;
@@ -1093,7 +1252,9 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 				currentRay.direction = rayDirection;                                                         /* the fog event below (:557) runs along it */
 				PUSH(pathWeight, currentRay, nbrebonds, show_lights, show_envmap);
 			}
-			v3 BRDF = obj->merl ? merl_eval(obj->merl, wi, vneg(rayDirection), N) : phong_eval(&mat, wi, vneg(rayDirection), N);
+			v3 BRDF;
+			if (sub_interaction) BRDF = vdivs(mat.Ksub, (float)M_PI);   /* :540-541 */
+			else BRDF = obj->merl ? merl_eval(obj->merl, wi, vneg(rayDirection), N) : phong_eval(&mat, wi, vneg(rayDirection), N);
 			float J = vdot(Np, vneg(wi)) / d_light2;
 			float proba = vdot(axeOP, dir_aleatoire) / (M_PI * c->radiusLight * c->radiusLight);   /* double, narrowed */
 			if (!obj->ghost && proba > 0.f) {                       /* :547-553: no direct light on a ghost */
@@ -1111,13 +1272,19 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		float r1 = modff(c->randomPerPixel[(screenI * c->W + screenJ) * 2 + 0] + c->samples2d[sampleID * 2 + 0], &tmp);
 		float r2 = modff(c->randomPerPixel[(screenI * c->W + screenJ) * 2 + 1] + c->samples2d[sampleID * 2 + 1], &tmp);
 		v3 direction_aleatoire;
-		if (obj->merl) {   /* IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw */
+		if (sub_interaction) {                                      /* :584-587 */
+			direction_aleatoire = random_cos12(mat.shadingN, r1, r2);
+			proba_globale = vdot(N, direction_aleatoire) / (float)M_PI;
+			has_sampled_diffuse = 1;
+		} else if (obj->merl) {   /* IsoMERLBRDF::sample (BRDF.h:198-203): cosine lobe, no engine draw */
 			direction_aleatoire = random_cos12(N, r1, r2);
 			proba_globale = vdot(N, direction_aleatoire) / (M_PI);
 			has_sampled_diffuse = 0;
 		} else direction_aleatoire = phong_sample(&mat, vneg(rayDirection), N, &proba_globale, r1, r2, &has_sampled_diffuse, rng);
 		if (vdot(direction_aleatoire, N) < 0 || vdot(direction_aleatoire, vreflect(rayDirection, N)) < 0 || proba_globale <= 0) continue;   /* :593 */
-		v3 BRDFindirect = obj->merl ? merl_eval(obj->merl, direction_aleatoire, vneg(rayDirection), N) : phong_eval(&mat, direction_aleatoire, vneg(rayDirection), N);
+		v3 BRDFindirect;
+		if (sub_interaction) BRDFindirect = vdivs(mat.Ksub, (float)M_PI);   /* :603-604 */
+		else BRDFindirect = obj->merl ? merl_eval(obj->merl, direction_aleatoire, vneg(rayDirection), N) : phong_eval(&mat, direction_aleatoire, vneg(rayDirection), N);
 		v3 newpathWeight = vscale((vdot(N, direction_aleatoire) / proba_globale), vmul(vmul(pathWeight, subsW), BRDFindirect));   /* :611 */
 		if (obj->ghost && has_backgroundimage) {                    /* :614-621: the photo shows through, tinted by what the ghost receives */
 			v3 bg = background_pixel(c, screenI, screenJ);
@@ -1126,10 +1293,11 @@ static v3 get_color_aov(const o_ctx* c, o_ray r, int sampleID, int screenI, int 
 		o_ray rayon_aleatoire;
 		rayon_aleatoire.origin = vadd(P, vscale(0.01f, direction_aleatoire));
 		rayon_aleatoire.direction = direction_aleatoire;
-		if (has_fog) PUSH(vscale(attenuationFactor, newpathWeight), rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :626 */
-		else PUSH(newpathWeight, rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost);   /* :629 */
+		if (has_fog) PUSHS(vscale(attenuationFactor, newpathWeight), rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost, next_hadSS);   /* :626 */
+		else PUSHS(newpathWeight, rayon_aleatoire, nbrebonds - 1, 0, (show_envmap && isShadowed && has_sampled_diffuse) || !obj->ghost, next_hadSS);   /* :629 */
 	}
 #undef PUSH
+#undef PUSHS
 #undef FOG
 	return color;
 }
@@ -1415,6 +1583,11 @@ int o_add_mesh(o_ctx* c, int nv, const float* verts, int nn, const float* normal
 	return c->nobj - 1;
 }
 
+/* Object::subsurface[grp] as a constant colour (add_col_subsurface, Geometry.h) */
+void o_set_group_subsurface(o_ctx* c, int obj, int grp, const float* rgb) {
+	o_obj* o = &c->objs[obj];
+	if (grp >= 0 && grp < o->ntex[T_KSUB]) o->tex[T_KSUB][grp].multiplier = V(rgb[0], rgb[1], rgb[2]);
+}
 /* Scene::fog_* (Geometry.h:1371-1377) */
 void o_set_fog(o_ctx* c, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso) {
 	c->fog_density = density; c->fog_absorption = absorption; c->fog_density_decay = density_decay; c->fog_absorption_decay = absorption_decay;

@@ -180,6 +180,10 @@ void ref_set_fog(RefCtx* c, float density, float absorption, float density_decay
 	s.fog_density = density; s.fog_absorption = absorption; s.fog_density_decay = density_decay; s.fog_absorption_decay = absorption_decay;
 	s.fog_type = type; s.fog_phase_type = phase_type; s.phase_aniso = phase_aniso;
 }
+void ref_set_group_subsurface(RefCtx* c, int obj, int grp, const float* rgb) {
+	Object* o = c->rt->s.objects[obj];
+	if (grp >= 0 && grp < (int)o->subsurface.size()) o->subsurface[grp].multiplier = Vector(rgb[0], rgb[1], rgb[2]);
+}
 void ref_set_object_ghost(RefCtx* c, int obj, int ghost) { c->rt->s.objects[obj]->ghost = ghost != 0; }
 // Scene::background as Scene::load_background leaves it (Geometry.h:1355-1363), set directly (the loader reads BMP files)
 void ref_set_background(RefCtx* c, const float* rgb, int W, int H) {
