@@ -13,13 +13,84 @@
 
 #define MIPT_SIZE_CIRC_ARRAY 200          // Raytracer.h:114
 
-struct QContrib { float4 w; float4 o; float4 d; };   // w.xyz weight, w.w bits: depth | show_lights << 16 | showenvmap << 17
+struct QContrib { float4 w; float4 o; float4 d; };   // w.xyz weight, w.w bits: depth | show_lights << 16 | showenvmap << 17 | has_had_subsurface_interaction << 18
 
 MIPT_DEV f3 background_pixel(const DRender& R, int screenI, int screenJ) {   // Raytracer.cpp:261-265
 	int bi = (int)((float)screenI / (float)R.H * (float)R.backgroundH); bi = min(R.backgroundH - 1, max(0, bi));
 	int bj = (int)((float)screenJ / (float)R.W * (float)R.backgroundW); bj = min(R.backgroundW - 1, max(0, bj));
 	const float* px = R.background + ((size_t)bi * R.backgroundW + bj) * 3;
 	return mk3(px[0], px[1], px[2]);
+}
+
+// ---- subsurface probe (Raytracer.cpp:318-406) --------------------------------------------------------------------
+// TriMesh::reservoir_sampling_intersection (TriangleMesh.cpp:1321-1426): a uniformly random one of the intersections in
+// [min_t, max_t).  Same visiting order as the closest-hit traversal with a fixed far bound; every accepted triangle draws
+// one number from the sample's engine, so the order of the visits decides the draws.
+template <class STK>
+MIPT_DEV bool mesh_reservoir(const DObject& o, f3 org, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out, int& tri_out, float& beta_out, float& gamma_out, STK& stk) {
+	bool has_inter = false;
+	int count = 0;
+	f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+	bool sx = invd.x >= 0, sy = invd.y >= 0, sz = invd.z >= 0;
+	float t_root;
+	if (!box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, sx, sy, sz, t_root)) return false;
+	if (t_root > max_t) return false;
+	int sp = 0;
+	const uint32_t NONE = 0x7fffffffu;
+	uint32_t cur = o.root_ref;
+	const float4* __restrict__ nodes = reinterpret_cast<const float4*>(o.nodes);
+	auto pop_next = [&]() -> uint32_t {
+		while (sp > 0) {
+			--sp;
+			uint32_t r; float tn;
+			stk.pop(sp, r, tn);
+			if (!(tn > max_t)) return r;
+		}
+		return NONE;
+	};
+	for (;;) {
+		while (cur != NONE && !(cur & MIPT_LEAF_BIT)) {
+			const float4* q = nodes + 4 * (size_t)cur;
+			float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+			f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
+			f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
+			uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+			float tl, tr;
+			const bool goleft = box_test<true>(lmin, lmax, org, invd, sx, sy, sz, tl) && (tl < max_t);
+			const bool goright = box_test<true>(rmin, rmax, org, invd, sx, sy, sz, tr) && (tr < max_t);
+			if (goleft && goright) {
+				if (tl < tr) { stk.push(sp, rref, tr); sp++; cur = lref; }
+				else { stk.push(sp, lref, tl); sp++; cur = rref; }
+			} else if (goleft) cur = lref;
+			else if (goright) cur = rref;
+			else cur = pop_next();
+		}
+		if (cur == NONE) break;
+		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
+		int cnt = (int)((cur >> 26) & 31u) + 1;
+		for (int i = first; i < first + cnt; i++) {
+			float lt, lb, lg;
+			if (tri_test(o.tris + i, org, d, lt, lb, lg)) {
+				bool accept = lt < max_t && lt >= min_t;
+				if (accept && o.alpha_test) accept = !alpha_rejects(o, i - (int)o.tri_base, 1 - lb - lg, lb, lg);
+				if (accept) {
+					count++;
+					const float r1 = pcg_uniform(rng);
+					if ((double)r1 < 1. / (double)count) { has_inter = true; t_out = lt; tri_out = i - (int)o.tri_base; beta_out = lb; gamma_out = lg; }
+				}
+			}
+		}
+		cur = pop_next();
+	}
+	return has_inter;
+}
+// MaterialValues::Ksub of a mesh hit: Object::subsurface[group] (Geometry.h:418-424); constant colours only (upload refuses images)
+MIPT_DEV f3 mesh_ksub(const DObject& o, int tri) {
+	if (o.type != 0 || tri < 0) return mk3(0, 0, 0);
+	const int graw = o.shade[tri].group;
+	const int group = graw >= 0 ? (graw & MIPT_GROUP_MASK) : graw;
+	if ((unsigned)group >= (unsigned)o.ntex[MT_KSUB]) return mk3(0, 0, 0);
+	return ld3(o.tex[MT_KSUB][group].mult);
 }
 
 // ---- fog: single scattering (Raytracer.cpp:20-192) --------------------------------------------------------------
@@ -132,9 +203,9 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 	float attenuationFactor = 0.f;                                          // :206 (uninitialised in the reference)
 	f3 color = mk3(0, 0, 0);
 	int start = 0, end = 1;
-	auto push = [&](f3 w, const Ray& r, int depth, bool lights, bool env) {
+	auto push = [&](f3 w, const Ray& r, int depth, bool lights, bool env, bool hadSS) {
 		QContrib c;
-		c.w = make_float4(w.x, w.y, w.z, __uint_as_float((unsigned)(depth & 0xffff) | (lights ? 0x10000u : 0u) | (env ? 0x20000u : 0u)));
+		c.w = make_float4(w.x, w.y, w.z, __uint_as_float((unsigned)(depth & 0xffff) | (lights ? 0x10000u : 0u) | (env ? 0x20000u : 0u) | (hadSS ? 0x40000u : 0u)));
 		c.o = make_float4(r.o.x, r.o.y, r.o.z, 0.f); c.d = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
 		q[end] = c;
 		end++; if (end >= MIPT_SIZE_CIRC_ARRAY) end = 0;
@@ -149,7 +220,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		Ray currentRay; currentRay.o = mk3(cur.o.x, cur.o.y, cur.o.z); currentRay.d = mk3(cur.d.x, cur.d.y, cur.d.z);
 		const f3 pathWeight = mk3(cur.w.x, cur.w.y, cur.w.z);
 		const int nbrebonds = (int)(bits & 0xffffu);
-		const bool show_lights = (bits & 0x10000u) != 0, show_envmap = (bits & 0x20000u) != 0;
+		const bool show_lights = (bits & 0x10000u) != 0, show_envmap = (bits & 0x20000u) != 0, hadSS = (bits & 0x40000u) != 0;
 		if (nbrebonds == 0) continue;                                       // :240
 		if (norm2(pathWeight) < sqr(0.01f)) continue;                       // :241
 		Hit h; f3 P = mk3(0, 0, 0); Mat m;
@@ -159,14 +230,14 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		// fog event along the ray just traced, towards `lightpos`; queues the in-scattered path (showenvmap = true)
 		auto fog = [&](const Ray& ray, f3 lightpos) {
 			FogEvent ev;
-			if (fog_contribution(sc, R, ray, lightpos, t, pathWeight, ev, attenuationFactor, ps.rng, n_closest, stk)) push(ev.weight, ev.ray, nbrebonds - 1, show_lights, true);
+			if (fog_contribution(sc, R, ray, lightpos, t, pathWeight, ev, attenuationFactor, ps.rng, n_closest, stk)) push(ev.weight, ev.ray, nbrebonds - 1, show_lights, true, hadSS);
 		};
 		if (nbrebonds == R.nb_bounces && has_bg && (!hit || h.obj == 1)) {  // :260-268: a camera ray that leaves the scene shows the photo
 			color = color + pathWeight * background_pixel(R, i, j);
 			continue;
 		}
 		if (!hit) { if (R.fog_density == 0) continue; else break; }         // :654-657
-		const f3 N = m.shadingN, rayDirection = currentRay.d;
+		f3 N = m.shadingN, rayDirection = currentRay.d;
 		if (h.obj == 1) {                                                   // :275-301
 			if (!show_envmap) { if (has_fog) fog(currentRay, cl); continue; }
 			if (has_fog) { fog(currentRay, cl); color = color + ((attenuationFactor * pathWeight) * R.envmap_intensity) * m.Ke; }
@@ -181,11 +252,68 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		}
 		const DObject& obj = sc->obj[h.obj];
 		const double* const merl = obj.merl;
+		f3 Ksub = mesh_ksub(obj, h.tri);
+		const bool is_subsurface = norm2(Ksub) > 1E-8;                      // :271
+		const float subsProba = (hadSS || !is_subsurface) ? 0.f : 0.6f;     // :318
+		const float inv1MSubsProba = 1.f / (1.f - subsProba);
+		f3 subsW = mk3(inv1MSubsProba, inv1MSubsProba, inv1MSubsProba);
+		bool sub_interaction = false;
+		if (is_subsurface && (pcg_uniform(ps.rng) < subsProba)) {           // :324-404: leave through a random point of the same object nearby
+			sub_interaction = true;
+			const float invSubsProba = 1.f / subsProba;
+			subsW = mk3(invSubsProba, invSubsProba, invSubsProba);
+			const float sigmasub = 1.5f;
+			const float diskR = sqrtf(12.46f) * sigmasub;
+			const float integ = 1.f - mipt_expf(-diskR * diskR / (2.f * sigmasub * sigmasub));
+			const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(ps.rng) * integ));
+			const float randangle = pcg_uniform(ps.rng) * 2.f * (float)MIPT_PI;
+			const float gauss0 = randR * pt_sinf(randangle), gauss1 = randR * pt_cosf(randangle), gauss2 = randR;
+			const float gaussval = (float)((1. / (double)(sigmasub * sigmasub * 2.f * (float)MIPT_PI)) * (double)mipt_expf(-(gauss2 * gauss2) / (2.f * sigmasub * sigmasub)));
+			const float pdfgauss = gaussval / integ;
+			const f3 Tg = tangent_of(N);
+			const f3 Tg2 = cross(N, Tg);
+			const f3 PtaboveP = ((P + gauss0 * Tg) + gauss1 * Tg2) + N * diskR;
+			const float r1s = pcg_uniform(ps.rng);
+			f3 axis = -N;
+			float tmax;
+			const float hh = sqrtf(diskR * diskR - gauss2 * gauss2);
+			f3 subsOrigin = PtaboveP + (diskR - hh) * (-N);
+			float wAxis;
+			if (r1s < 0.5f) { wAxis = 0.5f; tmax = 2.f * hh; }
+			else {
+				wAxis = 0.25f;
+				tmax = 2.f * gauss2;
+				if (r1s < 0.75f) axis = Tg; else axis = Tg2;
+				const float r2s = pcg_uniform(ps.rng);
+				if (r2s < 0.5f) subsOrigin = subsOrigin - hh * N;
+			}
+			// Scene::get_random_intersection on this object only (Geometry.cpp:339-470)
+			Ray probe; probe.o = subsOrigin; probe.d = axis;
+			Hit sh; sh.obj = h.obj; sh.tri = -1; sh.t = 0; sh.beta = sh.gamma = 0;
+			const bool subsinter = mesh_reservoir(obj, xf_point(obj.inv, probe.o), xf_dir(obj.inv, probe.d), 0.f, tmax, ps.rng, sh.t, sh.tri, sh.beta, sh.gamma, stk);
+			if (subsinter) {
+				f3 localP2; Mat subsmat;
+				subsmat.shadingN = mk3(0, 1, 0); subsmat.Kd = mk3(0.5f, 0.5f, 0.5f); subsmat.Ks = mk3(0, 0, 0); subsmat.Ne = mk3(100, 100, 100); subsmat.Ke = mk3(0, 0, 0); subsmat.transp = false; subsmat.refr_index = 0;
+				hit_material_obj(obj, probe, sh, localP2, subsmat);
+				const float chris = (float)exp((double)(-norm2(P - localP2)) / (2. * (double)sigmasub * (double)sigmasub));
+				const double d0 = 0.5 * (double)dot(subsmat.shadingN, N), d1 = 0.25 * (double)dot(subsmat.shadingN, Tg), d2 = 0.25 * (double)dot(subsmat.shadingN, Tg2);
+				const float sumpdfs = (float)((d0 * d0 + d1 * d1) + d2 * d2);
+				const float pdfdisk = wAxis * fabsf(dot(axis, subsmat.shadingN)) / sumpdfs;
+				subsW = subsW * (pdfdisk / fmaxf(pdfgauss, 0.05f) * chris);
+				rayDirection = normalize(localP2 - P);
+				P = localP2 + 0.005f * subsmat.shadingN;
+				if (r1s < 0.5f) subsW = subsW * 2.f; else subsW = subsW * 4.f;
+				subsW = subsW * (Ksub / (float)MIPT_PI);
+				m = subsmat;
+				Ksub = mesh_ksub(obj, sh.tri);
+				N = m.shadingN;
+			}
+		}
 		color = color + (pathWeight * m.Ke) * R.envmap_intensity;           // :411
 		if (obj.miroir) {                                                   // :413-436
 			Ray rm; rm.o = P + 0.001f * N; rm.d = reflect(rayDirection, N);
-			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, rm, nbrebonds - 1, show_lights, true); }
-			else push(pathWeight, rm, nbrebonds - 1, show_lights, true);
+			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, rm, nbrebonds - 1, show_lights, true, hadSS); }
+			else push(pathWeight, rm, nbrebonds - 1, show_lights, true, hadSS);
 			continue;
 		}
 		if (m.transp) {                                                     // :438-489
@@ -204,8 +332,8 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 				if (pcg_uniform(ps.rng) < Rf) { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
 				else { nr.o = P - 0.001f * nt; nr.d = refr; }
 			} else { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, N); }
-			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, nr, nbrebonds - 1, show_lights, true); }
-			else push(pathWeight, nr, nbrebonds - 1, show_lights, true);
+			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, nr, nbrebonds - 1, show_lights, true, hadSS); }
+			else push(pathWeight, nr, nbrebonds - 1, show_lights, true, hadSS);
 			continue;
 		}
 		// ---- diffuse / glossy vertex (:490-632)
@@ -229,12 +357,12 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 				const f3 offset = dot(N, rayDirection) > 0 ? N : -N;
 				currentRay.o = (P + rayDirection * 0.001f) + offset * 0.001f;
 				currentRay.d = rayDirection;
-				push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap);
+				push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap, hadSS);
 			} else {                                                        // :538-553 (no direct light on a ghost)
-				const f3 brdf = merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(m, wi, -rayDirection, N);
+				const f3 brdf = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(m, wi, -rayDirection, N));   // :540-544
 				const float J = dot(dir_l, -wi) / d_light2;
 				const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
-				if (proba > 0.f) currentContrib = currentContrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+				if (proba > 0.f) currentContrib = currentContrib + (subsW * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
 			}
 		}
 		if (has_fog) { fog(currentRay, pt_l); color = color + (attenuationFactor * pathWeight) * currentContrib; }   // :557-565
@@ -243,23 +371,24 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * k], &ip);
 		const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * k + 1], &ip);
 		float pdf; f3 dir; bool has_sampled_diffuse;
-		if (merl) { dir = random_cos(N, r1, r2); pdf = (float)((double)dot(N, dir) / (MIPT_PI)); has_sampled_diffuse = false; }
+		if (sub_interaction) { dir = random_cos(m.shadingN, r1, r2); pdf = dot(N, dir) / (float)MIPT_PI; has_sampled_diffuse = true; }   // :584-587
+		else if (merl) { dir = random_cos(N, r1, r2); pdf = (float)((double)dot(N, dir) / (MIPT_PI)); has_sampled_diffuse = false; }
 		else {
 			uint64_t peek = ps.rng;                                          // the lobe pick of PhongBRDF::sample (BRDF.h:73-78)
 			has_sampled_diffuse = (float)pcg_next(peek) / 4294967296.f < 1 - (m.Ks.x + m.Ks.y + m.Ks.z) / 3.f;
 			dir = phong_sample(m, -rayDirection, N, pdf, r1, r2, ps.rng);
 		}
 		if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) continue;   // :593
-		const f3 brdf_i = merl ? merl_eval(merl, dir, -rayDirection, N) : phong_eval(m, dir, -rayDirection, N);
-		f3 nw = ((pathWeight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);             // :611
+		const f3 brdf_i = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, dir, -rayDirection, N) : phong_eval(m, dir, -rayDirection, N));   // :603-607
+		f3 nw = ((pathWeight * subsW) * brdf_i) * (dot(N, dir) / pdf);                          // :611
 		if (obj.ghost && has_bg) {                                          // :614-621
 			const f3 bg = background_pixel(R, i, j);
 			nw = nw * mk3(bg.x / 196964.699f, bg.y / 196964.699f, bg.z / 196964.699f);
 		}
 		Ray next; next.o = P + 0.01f * dir; next.d = dir;
 		const bool env = (show_envmap && isShadowed && has_sampled_diffuse) || !obj.ghost;      // :626-629
-		if (has_fog) push(attenuationFactor * nw, next, nbrebonds - 1, false, env);
-		else push(nw, next, nbrebonds - 1, false, env);
+		if (has_fog) push(attenuationFactor * nw, next, nbrebonds - 1, false, env, sub_interaction ? true : hadSS);
+		else push(nw, next, nbrebonds - 1, false, env, sub_interaction ? true : hadSS);
 	}
 	return color;
 }

@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv:
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv:
     main()
 
 
@@ -296,6 +296,49 @@ def main_fog():
     np.savez_compressed(os.path.join(OUT, "fog.npz"), **g)
 
 
+SSS_KINDS = ("ss", "ssglossy", "ssfog", "ssghost", "sstex", "ssdeep")
+
+
+def subsurface_scene(X, kind):
+    """A blob with a subsurface colour (Raytracer.cpp:318-406: with probability 0.6 the path leaves through a random nearby
+    point of the same object found by Scene::get_random_intersection)."""
+    cfg = scenes.config_c1(64, 36, 4)
+    cfg.nb_bounces = 8 if kind == "ssdeep" else 4
+    X.apply_config(cfg)
+    oid = X.add_mesh(scenes.blob_mesh(16, with_uv=(kind == "sstex"), fine_detail=(kind == "ssdeep")))
+    X.set_group_subsurface(oid, 0, (0.8, 0.5, 0.3))
+    if kind == "ssglossy":
+        X.set_group_material(oid, 0, (0.4, 0.3, 0.2), (0.5, 0.5, 0.4), (40., 60., 80.))
+    if kind == "ssfog":
+        X.set_fog(0.5, 0.4)
+    if kind == "ssghost":
+        X.set_object_ghost(2, True)
+        X.set_background(background_photo())
+    if kind == "sstex":
+        X.set_group_texture(oid, 0, 0, scenes.checker_texture())
+        X.set_envmap(scenes.sky_envmap())
+    X.prepare()
+    return cfg
+
+
+def main_subsurface():
+    """tests/golden/subsurface.npz: per-sample radiance of the subsurface scenes from the compiled reference."""
+    g = {}
+    for kind in SSS_KINDS:
+        R = Ref()
+        cfg = subsurface_scene(R, kind)
+        rgb, dxdy = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)
+        g[kind + "_rgb"] = rgb
+        print(kind, "mean radiance / white", float(rgb.mean() / 196964.7))
+    R = Ref()
+    cfg = subsurface_scene(R, "ss")
+    R2 = Ref()                       # the same scene without the subsurface colour, to show the branch is taken
+    cfg2 = scenes.config_c1(64, 36, 4); cfg2.nb_bounces = 4
+    R2.apply_config(cfg2); R2.add_mesh(scenes.blob_mesh(16)); R2.prepare()
+    g["plain_rgb"] = R2.getcolor_samples(all_pixels(cfg2), 0, cfg2.spp)[0]
+    np.savez_compressed(os.path.join(OUT, "subsurface.npz"), **g)
+
+
 def main_compositing():
     """tests/golden/compositing.npz: per-sample radiance of the ghost / background scenes from the compiled reference."""
     g = {}
@@ -315,3 +358,5 @@ if __name__ == "__main__" and "--compositing" in sys.argv:
     main_compositing()
 if __name__ == "__main__" and "--fog" in sys.argv:
     main_fog()
+if __name__ == "__main__" and "--subsurface" in sys.argv:
+    main_subsurface()
