@@ -857,8 +857,8 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
 }
 
 /* ------------------------------------------------------------------ getColor (Raytracer.cpp:196-664), in-scope branches */
-/* Fog, subsurface, ghost and background-photo branches are OUT OF SCOPE; with
- * them removed the Contrib queue never holds more than one entry, so it is a plain loop. */
+/* The whole loop incl. the fog, subsurface, ghost and background-photo branches; subsurface colours are
+ * restated for meshes only (Sphere / Plane::reservoir_sampling_intersection are not). */
 /* normalValue / albedoValue: the denoiser inputs of Raytracer.cpp:255-258 (shading normal and Kd of the FIRST hit;
    left untouched without one, so they keep the zeros `Vector normal, albedo;` starts from, :1628).  May be NULL. */
 /* ------------------------------------------------------------------ subsurface probe: a uniformly random one of the intersections in [min_t, max_t)
