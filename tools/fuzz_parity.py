@@ -1,6 +1,8 @@
 """Differential fuzzing of the HIP path against the oracle: random scenes (tessellation, one or two meshes, scales,
 camera, light, aperture, depth, materials incl. glossy / mirror / dielectric / textures / MERL), per-sample radiance
-compared bit for bit on both pipelines.  usage: python tools/fuzz_parity.py [n_scenes] [seed]"""
+compared bit for bit on both pipelines.  usage: python tools/fuzz_parity.py [n_scenes] [seed] [--queue]
+--queue: every scene also draws from the features of the contribution-queue kernel (ghost objects, background photo, fog in
+both media with the three phase functions, subsurface colours), alone and combined."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -8,8 +10,10 @@ from helpers import bits_equal, WHITE
 from pathtracer_amd import capi, scenes
 from oracle.binding import Oracle
 
-n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+QUEUE = "--queue" in sys.argv
+argv = [a for a in sys.argv if not a.startswith("--")]
+n_scenes = int(argv[1]) if len(argv) > 1 else 20
+rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
 bad = 0
 for it in range(n_scenes):
     W, H, spp = int(rng.integers(8, 97)), int(rng.integers(8, 65)), int(rng.integers(1, 5))
@@ -52,12 +56,28 @@ for it in range(n_scenes):
             X.set_brdf_merl(oid, scenes.synthetic_merl_table())
         elif kind == "two":
             X.add_mesh(scenes.blob_mesh(12), scale=scale * 0.4)
+    feats = []
+    if QUEUE:
+        photo = (rng.uniform(0, 1, (int(rng.integers(2, 40)), int(rng.integers(2, 40)), 3)) ** 2.2 * 196964.699).astype(np.float32)
+        fog = (float(rng.uniform(0.05, 3.0)), float(rng.uniform(0.05, 2.0)), float(rng.uniform(0, 0.08)), float(rng.uniform(0, 0.08)),
+               int(rng.integers(0, 2)), int(rng.integers(0, 3)), float(rng.uniform(-0.8, 0.8)))
+        ksub = tuple(float(v) for v in rng.uniform(0.05, 0.9, 3))
+        pick = rng.random(5)
+        for X, oid in out:
+            if pick[0] < 0.45: X.set_object_ghost(2, True)
+            if pick[1] < 0.25: X.set_object_ghost(oid, True)
+            if pick[2] < 0.6: X.set_background(photo)
+            if pick[3] < 0.5: X.set_fog(*fog)
+            if pick[4] < 0.4 and kind not in ("two",): X.set_group_subsurface(oid, 0, ksub)
+        feats = [n for n, on in (("ghostfloor", pick[0] < 0.45), ("ghostmesh", pick[1] < 0.25), ("photo", pick[2] < 0.6), ("fog%d/%d" % (fog[4], fog[5]), pick[3] < 0.5), ("sss", pick[4] < 0.4 and kind != "two")) if on]
+    for X, oid in out:
         X.prepare()
     O, G = out[0][0], out[1][0]
     pix = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
     want = O.getcolor_samples(pix, 0, spp)[0]
     line = "%2d %-8s n=%-3d scale %-5g %3dx%-3d spp %d depth %d aperture %-4g" % (it, kind, n, scale, W, H, spp, cfg.nb_bounces, cfg.aperture)
-    for pipeline in (1, 0):
+    line += " " + "+".join(feats)
+    for pipeline in ((1,) if feats else (1, 0)):
         G.set_option("pipeline", pipeline)
         got = G.getcolor_samples(pix, 0, spp)[0]
         same = bits_equal(got, want).all(-1).mean()
