@@ -9,9 +9,10 @@ Workload (config.workload): the configuration BASELINE.json's metric is quoted o
 4096x2048 environment map, Phong BRDF, 1920x1080, depth 4, default loadScene() light and camera; it
 fits one GPU.  --workload c1 / c3 / c4 select the other configs (c1 = 133 128-triangle diffuse blob).
 One STEP = one pass of the hot path (camera rays -> getColor -> splat) over the whole frame at
---spp-per-step samples per pixel (default 64: 133 M paths, ~21 GB of path state in flight — sized for
-288 GB of HBM; the per-launch ramp and drain of the persistent kernels is amortised over a large batch);
-the default K = 16 steps x 64 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
+--spp-per-step samples per pixel (default 256: 531 M paths, ~85 GB of path state in flight — sized for
+288 GB of HBM; the per-launch ramp and drain of the persistent kernels is amortised over a large batch: 3.72 Grays/s
+at 64 spp per step, 3.82 at 128, 3.94 at 256, 3.98 at 512);
+the default K = 4 steps x 256 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
 32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated), a step
 renders N x --spp-per-step samples per pixel so that every rank keeps the same number of paths in
 flight per pass as the single-GPU run ("scaling": "weak": per-GPU work per step is fixed), and the
@@ -39,16 +40,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_STEP = 64
+SPP_PER_STEP = 256          # at 1080p; scaled down with the pixel count so that a pass keeps <= 2^29 paths (~86 GB of path state)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c1", "c1g", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
-    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
+    ap.add_argument("--spp-per-step", type=int, default=0, help="samples per pixel per step (default: 256 at 1080p, 64 at 4K)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--grid", type=int, default=None, help="override the blob tessellation n (2 n^2 triangles)")
@@ -152,6 +153,12 @@ def main():
         dist.barrier()
     from pathtracer_amd import capi, scenes
 
+    if args.spp_per_step <= 0:
+        dims = {"c4": (3840, 2160)}.get(args.workload, (1920, 1080))
+        npx = (args.width or dims[0]) * (args.height or dims[1])
+        args.spp_per_step = SPP_PER_STEP
+        while args.spp_per_step > 1 and npx * args.spp_per_step > (1 << 29) + (1 << 24):
+            args.spp_per_step //= 2
     SPS = args.spp_per_step * world     # weak scaling: a rank owns 1/world of the pixels and renders world x the samples per step
     total_spp = SPS * (args.steps + args.warmup)
     mesh, cfg, mat, wl_text = scenes.workload(args.workload, args.width, args.height, total_spp, args.grid)

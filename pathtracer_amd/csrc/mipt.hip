@@ -284,7 +284,7 @@ struct mipt_ctx {
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
-	int64_t opt_paths_per_pass = 1 << 27;   // 134 M paths (64 spp at 1080p), ~21 GB of path state
+	int64_t opt_paths_per_pass = 1 << 29;   // 537 M paths (259 spp at 1080p), ~86 GB of path state: sized for 288 GB of HBM
 };
 
 static int fail(mipt_ctx* c, int code, const char* fmt, ...) {

@@ -75,7 +75,7 @@ def test_gpu_denoiser_accumulation_and_host_mirror():
     # several passes: the same sums up to the order of the additions
     H.set_option("paths_per_pass", cfg.W * cfg.H * 3)
     img2, cnt2, alb2, nrm2 = H.render_denoiser_inputs()
-    H.set_option("paths_per_pass", 1 << 27)
+    H.set_option("paths_per_pass", 1 << 29)
     assert np.array_equal(cnt2, cnt)
     for a, b in ((img2, img), (alb2, alb), (nrm2, nrm)):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-4 * max(1.0, float(np.abs(b).max())))

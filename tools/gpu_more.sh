@@ -1,5 +1,5 @@
-python bench.py --workload c3 --no-cpu-baseline --steps 4 --warmup 1 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; tail -2 gpurun_out/bench_c3.err
-python bench.py --workload c4 --no-cpu-baseline --steps 2 --warmup 1 --spp-per-step 16 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; tail -2 gpurun_out/bench_c4.err
+python bench.py --workload c3 --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; tail -2 gpurun_out/bench_c3.err
+python bench.py --workload c4 --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; tail -2 gpurun_out/bench_c4.err
 bash tools/pmc.sh c1 --workload c1 > /dev/null 2>&1
 python - <<'PY'
 import json

@@ -1,0 +1,35 @@
+"""Throughput of the contribution-queue kernel (ghost / photo / fog / subsurface scenes): configs[1]'s scene at 1080p with
+the feature switched on, N spp through mipt_render_device-equivalent host call; prints Mrays/s from the ABI's counters.
+usage: python tools/queue_kernel_rate.py [spp]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd import capi, scenes   # noqa: E402
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
+    mesh, cfg, mat, text = scenes.workload("c1", 1920, 1080, spp, None)
+    H = capi.HostRaytracer(device=0)
+    H.apply_config(cfg)
+    oid = scenes.install(H, mesh, mat)
+    if feature == "photo+ghostfloor":
+        H.set_object_ghost(2, True)
+        H.set_background((np.random.default_rng(1).uniform(0, 1, (270, 480, 3)) ** 2.2 * 196964.699).astype(np.float32))
+    if feature == "fog":
+        H.set_fog(0.5, 0.4, 0.02, 0.03, 1, 1, 0.4)
+    if feature == "subsurface":
+        H.set_group_subsurface(oid, 0, (0.8, 0.5, 0.3))
+    H.prepare()
+    H.render()                                    # warm-up (code object load, buffers)
+    t0 = time.time()
+    img, cnt = H.render()
+    dt = time.time() - t0
+    st = H.stats()
+    rays = st["rays_closest"] + st["rays_shadow"]
+    print(json.dumps({"feature": feature, "pipeline": st["pipeline"], "spp": spp, "Mrays_per_s": round(rays / dt / 1e6, 1), "seconds": round(dt, 3),
+                      "rays_per_path": round(rays / max(1, st["paths"]), 2), "finite": bool(np.isfinite(img).all())}), flush=True)
