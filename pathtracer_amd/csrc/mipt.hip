@@ -457,6 +457,12 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 				const mipt_triangle& T = m->triangleSoup[i];
 				memcpy(ti[i].A, T.A, 12); memcpy(ti[i].u, T.u, 12); memcpy(ti[i].v, T.v, 12); memcpy(ti[i].N, T.N, 12);
 				ti[i].m11 = T.m11; ti[i].m12 = T.m12; ti[i].m22 = T.m22; ti[i].invdetm = T.invdetm;
+				{   // the traversal derives N and m22 from u and v: they must be the ones of the caller's records, bit for bit
+					const float chk[4] = {T.u[1] * T.v[2] - T.u[2] * T.v[1], T.u[2] * T.v[0] - T.u[0] * T.v[2], T.u[0] * T.v[1] - T.u[1] * T.v[0],
+					                      T.v[0] * T.v[0] + T.v[1] * T.v[1] + T.v[2] * T.v[2]};
+					const float have[4] = {T.N[0], T.N[1], T.N[2], T.m22};
+					for (int k = 0; k < 4; k++) if (memcmp(&chk[k], &have[k], 4) != 0 && !(chk[k] != chk[k] && have[k] != have[k])) bad[t] = 2;
+				}
 				memcpy(ts[i].normals, T.normals, 36);
 				if (has_uv) memcpy(ts[i].uvs, T.uvs, 24); else memset(ts[i].uvs, 0, 24);
 				ts[i].group = m->indices[i].group;
@@ -467,6 +473,7 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		};
 		if (nthreads == 1) work(0);
 		else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+		for (int b : bad) if (b == 2) return fail(c, MIPT_ERR_INVALID, "triangleSoup record whose N / m22 are not those Triangle's constructor derives from u and v (TriangleMesh.h:70-78)");
 		for (int b : bad) if (b) return fail(c, MIPT_ERR_UNSUPPORTED, "material group index above 2^30");
 	}
 	d.node_base = node_base; d.tri_base = tri_base;

@@ -14,6 +14,12 @@
 #pragma once
 
 #define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
+#ifndef MIPT_DERIVE_SHADOW
+#define MIPT_DERIVE_SHADOW 1           // the any-hit traversal loads 48 of the 64 bytes of a triangle record and derives N, m22 (-7 % stage time)
+#endif
+#ifndef MIPT_DERIVE_EXTEND
+#define MIPT_DERIVE_EXTEND 0           // the closest-hit traversal keeps the fourth load (deriving costs it registers: +15 %)
+#endif
 #ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 1024u           // ids reserved per global atomic (sub-allocated wave-locally)
 #endif
@@ -273,7 +279,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						if (j < total) {
 							MIPT_PROF_COUNT(4)
 							float a, bb, gg;
-							if (tri_test(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
+							if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
 						}
 						int wj = 0;
 						bool upd = false;
@@ -311,7 +317,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				for (int i = first; i < first + count; i++) {
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
-					if (tri_test(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
+					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
 						bool accept = lt < st.t;
 						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 						if (accept) {

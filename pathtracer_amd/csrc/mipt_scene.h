@@ -37,7 +37,9 @@ struct DFatNode {          // 64 B, 64-B aligned.  Slabs are stored per axis as 
 	uint32_t _pad[2];
 };
 
-struct DTriIsect { float A[3], u[3], v[3], N[3]; float m11, m12, m22, invdetm; };   // 64 B
+// Intersection record, 64 B.  A test that loads only the first 48 bytes derives N = cross(u, v) and m22 = |v|^2 with the
+// operations Triangle's constructor used (TriangleMesh.h:70-78: same bits) and saves one vector-memory instruction.
+struct DTriIsect { float A[3], u[3], v[3]; float invdetm, m11, m12, m22; float N[3]; };
 #define MIPT_GROUP_UV_OK 0x40000000      // DTriShade::group bit: indices[tri].uvi is a valid UV index
 #define MIPT_GROUP_MASK 0x3fffffff
 struct DTriShade { float normals[9]; float uvs[6]; int group; };                    // 64 B (group: material group | MIPT_GROUP_UV_OK)

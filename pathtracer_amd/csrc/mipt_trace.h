@@ -109,11 +109,15 @@ MIPT_DEV bool box_test_pairs(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mipt
 }
 
 // ---------------------------------------------------------------- Triangle::intersection (TriangleMesh.h:82-104)
+template <bool DERIVE = false>
 MIPT_DEV bool tri_test(const DTriIsect* __restrict__ T, f3 o, f3 d, float& t, float& beta, float& gamma) {
 	const float4* q = reinterpret_cast<const float4*>(T);
-	float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-	f3 A = mk3(q0.x, q0.y, q0.z), u = mk3(q0.w, q1.x, q1.y), v = mk3(q1.z, q1.w, q2.x), N = mk3(q2.y, q2.z, q2.w);
-	float m11 = q3.x, m12 = q3.y, m22 = q3.z, invdetm = q3.w;
+	const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+	const f3 A = mk3(q0.x, q0.y, q0.z), u = mk3(q0.w, q1.x, q1.y), v = mk3(q1.z, q1.w, q2.x);
+	const float invdetm = q2.y, m11 = q2.z, m12 = q2.w;
+	f3 N; float m22;
+	if (DERIVE) { N = cross(u, v); m22 = norm2(v); }
+	else { const float4 q3 = q[3]; m22 = q3.x; N = mk3(q3.y, q3.z, q3.w); }
 	t = dot(A - o, N) / dot(d, N);
 	if (t < 0 || t != t) return false;
 	f3 P = o + t * d;
