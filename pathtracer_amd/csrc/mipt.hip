@@ -799,7 +799,6 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	spp_pass = std::min(spp_pass, ke - kb);
 	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
 	const bool want_aov = d_aov || (dump && dump->out_normal);
-	if (want_aov && c->scene_has_ghost) return fail(c, MIPT_ERR_UNSUPPORTED, "denoiser inputs of a scene with ghost objects / a background photo");
 	// 2 = the queue kernel (ghost objects, background photo); the denoiser inputs are a stage of the wavefront pipeline
 	const int pipeline = c->scene_has_ghost ? 2 : (want_aov ? 1 : (int)c->opt_pipeline);
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
@@ -868,7 +867,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 		} else if (pipeline == 2) {
 			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-			hipLaunchKernelGGL(k_render_paths_queue, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt, queues);
+			hipLaunchKernelGGL(k_render_paths_queue, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt, queues, aov_n, aov_kd);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 		} else {
 			HIPCHK(c, hipMemsetAsync(wf.counters, 0, MIPT_WF_COUNTERS * sizeof(unsigned), st));

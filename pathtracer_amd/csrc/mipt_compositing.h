@@ -194,7 +194,8 @@ __device__ __noinline__ bool fog_contribution(const DScene* __restrict__ sc, con
 // subsProba = 0, no_envmap = false, has_precomputed_rays = false).
 template <class STK>
 __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const DRender& R, int i, int j, int k, float& dx, float& dy,
-                                            unsigned& n_closest, unsigned& n_shadow, STK& stk, QContrib* __restrict__ q) {
+                                            unsigned& n_closest, unsigned& n_shadow, STK& stk, QContrib* __restrict__ q, f3& normalValue, f3& albedoValue) {
+	normalValue = mk3(0, 0, 0); albedoValue = mk3(0, 0, 0);            // Vector normal, albedo; (:1628)
 	PathState ps;
 	path_begin(R, i, j, k, ps, dx, dy);
 	const int pix = i * R.W + j;
@@ -232,6 +233,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 			FogEvent ev;
 			if (fog_contribution(sc, R, ray, lightpos, t, pathWeight, ev, attenuationFactor, ps.rng, n_closest, stk)) push(ev.weight, ev.ray, nbrebonds - 1, show_lights, true, hadSS);
 		};
+		if (hit && nbrebonds == R.nb_bounces) { normalValue = m.shadingN; albedoValue = m.Kd; }   // :255-258 (every contribution still at the first depth)
 		if (nbrebonds == R.nb_bounces && has_bg && (!hit || h.obj == 1)) {  // :260-268: a camera ray that leaves the scene shows the photo
 			color = color + pathWeight * background_pixel(R, i, j);
 			continue;
@@ -394,7 +396,8 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 }
 
 // one thread per (pixel, sample), as k_render_paths; `queues` holds MIPT_SIZE_CIRC_ARRAY entries per thread
-__global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths_queue(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt, QContrib* __restrict__ queues) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths_queue(const DScene* __restrict__ sc, DRender R, DPass ps, DSamples out, DCounters* __restrict__ cnt, QContrib* __restrict__ queues,
+                                                                   float4* __restrict__ aov_n, float4* __restrict__ aov_kd) {
 	MIPT_DECLARE_STACK(stk);
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
@@ -404,10 +407,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_render_paths_queue(const DScene*
 		int slot = (int)(tid % ps.npix_slots);
 		int blk = slot >> 6, in = slot & 63;
 		int i = ps.blocks[2 * blk] + (in >> 3), j = ps.blocks[2 * blk + 1] + (in & 7);
+		if (aov_n) { aov_n[tid] = make_float4(0.f, 0.f, 0.f, 0.f); aov_kd[tid] = make_float4(0.f, 0.f, 0.f, 0.f); }
 		if (i < R.H && j < R.W) {
 			float dx, dy;
-			f3 c = trace_path_queue(sc, R, i, j, ps.k0 + kk, dx, dy, n_closest, n_shadow, stk, queues + (size_t)tid * MIPT_SIZE_CIRC_ARRAY);
+			f3 nv, av;
+			f3 c = trace_path_queue(sc, R, i, j, ps.k0 + kk, dx, dy, n_closest, n_shadow, stk, queues + (size_t)tid * MIPT_SIZE_CIRC_ARRAY, nv, av);
 			out.col[tid] = make_float4(c.x, c.y, c.z, 0.f); out.dxdy[tid] = make_float2(dx, dy);
+			if (aov_n) { aov_n[tid] = make_float4(nv.x, nv.y, nv.z, 0.f); aov_kd[tid] = make_float4(av.x, av.y, av.z, 0.f); }
 			n_paths = 1;
 		}
 	}

@@ -106,9 +106,18 @@ def test_gpu_compositing_image_and_passes():
     assert_bits(cnt, g["both_cnt"], "sample_count")
     st = H.stats()
     assert st["rays_closest"] > cfg.W * cfg.H * cfg.spp and st["rays_shadow"] > 0
-    # denoiser inputs of a ghost scene are refused, loudly
-    with pytest.raises(capi.MiptError):
-        H.render_denoiser_inputs()
+    # denoiser inputs of a ghost scene: the last first-depth hit of the sample's contributions (Raytracer.cpp:255-258)
+    from oracle.binding import Oracle
+    O = Oracle()
+    compositing_scene(O, "both")
+    want = O.getcolor_samples_aov(all_pixels(cfg), 0, 2)
+    got = H.getcolor_samples_aov(all_pixels(cfg), 0, 2)
+    for a, b, what in zip(got, want, ("colour", "normalValue", "albedoValue")):
+        assert_bits(a, b, what)
+    oimg = O.render_denoiser_inputs()
+    gimg = H.render_denoiser_inputs()
+    for a, b, what in zip(gimg, oimg, ("imagedouble", "sample_count", "albedo sums", "normal sums")):
+        assert_bits(a, b, what)
     # a scene without ghosts on the same context goes back to the wavefront pipeline
     H2 = capi.HostRaytracer(device=0)
     cfg2 = compositing_scene(H2, "planenobg")
