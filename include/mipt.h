@@ -286,7 +286,10 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
  *                     every ray (normally only for rays with a zero direction component)
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
- *   "paths_per_pass"  upper bound on paths in flight per pass */
+ *   "paths_per_pass"  upper bound on paths in flight per pass
+ *   "samples_per_pass" > 0: a pass renders at most this many samples per pixel; with 1 and a progress callback
+ *                     mipt_render behaves like the sample loop of Raytracer::render_image (the caller's buffers hold the
+ *                     running sums after every sample) without paying an upload and an allocation per sample; 0 = off */
 int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -284,6 +284,7 @@ struct mipt_ctx {
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
+	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
 	int64_t opt_paths_per_pass = 1 << 29;   // 537 M paths (259 spp at 1080p), ~86 GB of path state: sized for 288 GB of HBM
 };
 
@@ -344,6 +345,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!c || !name) return MIPT_ERR_INVALID;
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
@@ -796,6 +798,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
 	if (c->scene_has_ghost) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
+	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass);
 	spp_pass = std::min(spp_pass, ke - kb);
 	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
 	const bool want_aov = d_aov || (dump && dump->out_normal);
@@ -992,6 +995,11 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 		if (e2 != hipSuccess) q->failed = true;
 	};
 	static auto trampoline = +[](void* u, int done, int total) { Publish* q = (Publish*)u; hipError_t e2 = hipMemcpy(q->rgb, q->d_acc, q->npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e2 == hipSuccess) e2 = hipMemcpy(q->w, q->d_acc + q->npx * 3, q->npx * sizeof(float), hipMemcpyDeviceToHost); if (e2 != hipSuccess) q->failed = true; q->cb(q->user, done, total); };
+	// the running sums go back to the caller after every pass: pin its buffers for the duration of the call (a pageable
+	// 33 MB download costs more than a one-sample pass at 1080p)
+	const bool pin_rgb = cb && hipHostRegister(accum_rgb, npx * 3 * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+	const bool pin_w = cb && hipHostRegister(accum_w, npx * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+	if (cb) (void)hipGetLastError();
 	int rc = render_impl(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel, nullptr);
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
@@ -999,6 +1007,8 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 		publish(&pub);
 		if (pub.failed) rc = fail(c, MIPT_ERR_HIP, "download of accumulators failed");
 	}
+	if (pin_rgb) hipHostUnregister(accum_rgb);
+	if (pin_w) hipHostUnregister(accum_w);
 	hipFree(d_acc);
 	return rc;
 }

@@ -1295,11 +1295,19 @@ void Raytracer::build_descs() {
 }
 
 void Raytracer::tone_map(bool divided) {   // Raytracer.cpp:1540-1547 / 1701-1708
-	for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) for (int c = 0; c < 3; c++) {
-		size_t idx = ((size_t)(H - i - 1) * W + j) * 3 + c;
-		double v = divided ? imagedouble[idx] / 196964.7 : imagedouble[idx] / 196964.7 / std::max(sample_count[(size_t)(H - i - 1) * W + j], 1.f);
-		image[idx] = (unsigned char)std::min(255., std::max(0., 255. * std::pow(v, (double)(1 / gamma))));
-	}
+	const int W_ = W, H_ = H;
+	const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), H_ / 16));   // #pragma omp parallel for over the rows in the reference
+	auto rows = [&](int i0, int i1) {
+		for (int i = i0; i < i1; i++) for (int j = 0; j < W_; j++) for (int c = 0; c < 3; c++) {
+			size_t idx = ((size_t)(H_ - i - 1) * W_ + j) * 3 + c;
+			double v = divided ? imagedouble[idx] / 196964.7 : imagedouble[idx] / 196964.7 / std::max(sample_count[(size_t)(H_ - i - 1) * W_ + j], 1.f);
+			image[idx] = (unsigned char)std::min(255., std::max(0., 255. * std::pow(v, (double)(1 / gamma))));
+		}
+	};
+	if (nt == 1) { rows(0, H_); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) th.emplace_back(rows, (int)((long long)H_ * t / nt), (int)((long long)H_ * (t + 1) / nt));
+	for (auto& x : th) x.join();
 }
 
 // Progressive render: one pass per sample index, buffers valid after every pass, `stopped`
@@ -1310,13 +1318,15 @@ void Raytracer::render_image() {
 	err_.clear();
 	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
 	stopped = 0;
-	for (int k = 0; k < nrays; k++) {
-		current_nb_rays = k;
-		if (stopped) return;
-		mipt_render_params p = render_params;
-		p.sample_begin = k; p.sample_end = k + 1;
-		if ((last_status = mipt_render(ctx, &p, imagedouble.data(), sample_count.data(), nullptr, nullptr, &stopped)) != MIPT_OK) return;
-	}
+	// the sample loop of :1444-1531 as ONE call: one pass per sample, imagedouble / sample_count hold the running sums
+	// after every pass (the GUI thread reads them while this runs), stopRender() ends it between two passes
+	mipt_set_option(ctx, "samples_per_pass", 1);
+	current_nb_rays = 0;
+	last_status = mipt_render(ctx, &render_params, imagedouble.data(), sample_count.data(),
+	                          [](void* self, int done, int) { static_cast<Raytracer*>(self)->current_nb_rays = done; }, this, &stopped);
+	mipt_set_option(ctx, "samples_per_pass", 0);
+	if (last_status == MIPT_ERR_CANCELLED) { last_status = MIPT_OK; return; }   // if (stopped) return; (:1452)
+	if (last_status != MIPT_OK) return;
 	tone_map(false);
 	stopped = 1;
 }

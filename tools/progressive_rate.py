@@ -1,0 +1,23 @@
+"""Cost of Raytracer::render_image (one pass per sample, buffers published after every pass) on configs[1]'s scene at
+1080p: per-pass cost from the difference of a 16-sample and a 64-sample call (the rest is prepare_render + scene upload)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd import capi, scenes   # noqa: E402
+
+wall = {}
+for spp in (16, 64):
+    mesh, cfg, mat, text = scenes.workload("c1", 1920, 1080, spp, None)
+    H = capi.HostRaytracer(device=0)
+    H.apply_config(cfg)
+    scenes.install(H, mesh, mat)
+    H.prepare()
+    H.render_image()            # warm-up
+    t0 = time.time(); H.render_image(); wall[spp] = time.time() - t0
+    st = H.stats()
+    rays = st["rays_closest"] + st["rays_shadow"]
+    print("render_image %d spp: %.1f ms wall, GPU span %.1f ms, %.1f M rays" % (spp, wall[spp] * 1e3, st["render_ms"], rays / 1e6))
+per_pass = (wall[64] - wall[16]) / 48
+print("per one-sample pass: %.2f ms (%.0f Mrays/s); fixed per call: %.0f ms" % (per_pass * 1e3, rays / 64 / per_pass / 1e6, (wall[16] - 16 * per_pass) * 1e3))
