@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -291,7 +293,7 @@ struct mipt_ctx {
 static int fail(mipt_ctx* c, int code, const char* fmt, ...) {
 	char buf[512];
 	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-	if (c) c->err = buf;
+	if (c) { static std::mutex mu; std::lock_guard<std::mutex> g(mu); c->err = buf; }   // conversion loops report from worker threads
 	return code;
 }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), MIPT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -384,7 +386,9 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 }
 
 // staging of all meshes' traversal records (one device buffer each)
-struct MeshStaging { std::vector<DFatNode> fat; std::vector<DTriIsect> ti; std::vector<DTriShade> ts; };
+// (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
+struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; };
+struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; };
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
@@ -392,10 +396,10 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	if (!m || m->n_triangles <= 0 || m->n_nodes <= 0 || !m->nodes || !m->triangleSoup || !m->indices) return fail(c, MIPT_ERR_INVALID, "incomplete mesh description");
 	const int nn = m->n_nodes, nt = m->n_triangles;
 	if ((unsigned)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
-	if (stg.ti.size() + (size_t)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
+	if (stg.nt_total + (size_t)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
 	// child references are scene-wide: inner = index into the scene's node buffer, leaf = first triangle in the
 	// scene's triangle buffer (the traversal then needs no per-mesh base registers)
-	const uint32_t node_base = (uint32_t)stg.fat.size(), tri_base = (uint32_t)stg.ti.size();
+	const uint32_t node_base = (uint32_t)stg.nfat_total, tri_base = (uint32_t)stg.nt_total;
 	std::vector<int> fat_index(nn, -1);
 	int nfat = 0;
 	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) fat_index[i] = nfat++;
@@ -427,25 +431,36 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		}
 		if (deepest > MIPT_STACK_DEPTH) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH with %d levels of inner nodes: the traversal stack holds %d", deepest, MIPT_STACK_DEPTH);
 	}
-	std::vector<DFatNode> fat(nfat > 0 ? nfat : 1);
-	memset(fat.data(), 0, fat.size() * sizeof(DFatNode));
-	for (int i = 0; i < nn; i++) {
-		if (m->nodes[i].isleaf) continue;
-		DFatNode& f = fat[fat_index[i]];
-		int l = m->nodes[i].fg, r = m->nodes[i].fd;
-		int rc;
-		if ((rc = child_ref(l, f.lref))) return rc;
-		if ((rc = child_ref(r, f.rref))) return rc;
-		for (int k = 0; k < 3; k++) {
-			f.l[k][0] = m->nodes[l].bbox_min[k]; f.l[k][1] = m->nodes[l].bbox_max[k];
-			f.r[k][0] = m->nodes[r].bbox_min[k]; f.r[k][1] = m->nodes[r].bbox_max[k];
-		}
+	MeshChunk chunk;
+	chunk.nfat = (size_t)(nfat > 0 ? nfat : 1); chunk.nt = (size_t)nt;
+	chunk.fat.reset(new DFatNode[chunk.nfat]); chunk.ti.reset(new DTriIsect[nt]); chunk.ts.reset(new DTriShade[nt]);
+	DFatNode* fat = chunk.fat.get(); DTriIsect* ti = chunk.ti.get(); DTriShade* ts = chunk.ts.get();
+	memset(&fat[0], 0, sizeof(DFatNode));
+	{   // one fat node per inner node, independent of each other: on the host's hardware threads for large trees
+		const int nthreads = std::max(1, std::min((int)std::thread::hardware_concurrency(), nn / 65536));
+		std::vector<int> err(nthreads, MIPT_OK);
+		auto work = [&](int t) {
+			const int i0 = (int)((long long)nn * t / nthreads), i1 = (int)((long long)nn * (t + 1) / nthreads);
+			for (int i = i0; i < i1; i++) {
+				if (m->nodes[i].isleaf) continue;
+				DFatNode& f = fat[fat_index[i]];
+				const int l = m->nodes[i].fg, r = m->nodes[i].fd;
+				f._pad[0] = f._pad[1] = 0;
+				int rc;
+				if ((rc = child_ref(l, f.lref)) || (rc = child_ref(r, f.rref))) { err[t] = rc; return; }
+				for (int k = 0; k < 3; k++) {
+					f.l[k][0] = m->nodes[l].bbox_min[k]; f.l[k][1] = m->nodes[l].bbox_max[k];
+					f.r[k][0] = m->nodes[r].bbox_min[k]; f.r[k][1] = m->nodes[r].bbox_max[k];
+				}
+			}
+		};
+		if (nthreads == 1) work(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+		for (int e : err) if (e) return e;
 	}
 	int rc;
 	if ((rc = child_ref(0, d.root_ref))) return rc;
 	memcpy(d.root_min, m->bvh_bbox_min, 12); memcpy(d.root_max, m->bvh_bbox_max, 12);
-	std::vector<DTriIsect> ti(nt);
-	std::vector<DTriShade> ts(nt);
 	std::vector<int> uvidx;
 	const bool has_uv = m->n_uvs > 0 && m->uvs;
 	if (has_uv) uvidx.resize((size_t)nt * 3);
@@ -479,9 +494,8 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		for (int b : bad) if (b) return fail(c, MIPT_ERR_UNSUPPORTED, "material group index above 2^30");
 	}
 	d.node_base = node_base; d.tri_base = tri_base;
-	stg.fat.insert(stg.fat.end(), fat.begin(), fat.end());
-	stg.ti.insert(stg.ti.end(), ti.begin(), ti.end());
-	stg.ts.insert(stg.ts.end(), ts.begin(), ts.end());
+	stg.nfat_total += chunk.nfat; stg.nt_total += chunk.nt;
+	stg.chunks.push_back(std::move(chunk));
 	d.ntri = nt;
 	d.nuvs = has_uv ? m->n_uvs : 0;
 	d.uvs = nullptr; d.uvidx = nullptr; d.tangent_soup = nullptr;
@@ -568,9 +582,20 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 	}
 	const DTriShade* all_shade = nullptr;
 	int rc;
-	if ((rc = upload(c, stg.fat.data(), stg.fat.size(), &H.all_nodes))) return rc;
-	if ((rc = upload(c, stg.ti.data(), stg.ti.size(), &H.all_tris))) return rc;
-	if ((rc = upload(c, stg.ts.data(), stg.ts.size(), &all_shade))) return rc;
+	if (stg.nt_total > 0) {   // one device buffer per record kind, the meshes' chunks copied to their offsets
+		void *dn = nullptr, *dt = nullptr, *dsh = nullptr;
+		HIPCHK(c, hipMalloc(&dn, stg.nfat_total * sizeof(DFatNode))); c->scene_allocs.push_back(dn);
+		HIPCHK(c, hipMalloc(&dt, stg.nt_total * sizeof(DTriIsect))); c->scene_allocs.push_back(dt);
+		HIPCHK(c, hipMalloc(&dsh, stg.nt_total * sizeof(DTriShade))); c->scene_allocs.push_back(dsh);
+		size_t on = 0, ot = 0;
+		for (const MeshChunk& ch : stg.chunks) {
+			HIPCHK(c, hipMemcpy((DFatNode*)dn + on, ch.fat.get(), ch.nfat * sizeof(DFatNode), hipMemcpyHostToDevice));
+			HIPCHK(c, hipMemcpy((DTriIsect*)dt + ot, ch.ti.get(), ch.nt * sizeof(DTriIsect), hipMemcpyHostToDevice));
+			HIPCHK(c, hipMemcpy((DTriShade*)dsh + ot, ch.ts.get(), ch.nt * sizeof(DTriShade), hipMemcpyHostToDevice));
+			on += ch.nfat; ot += ch.nt;
+		}
+		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
+	}
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
 		if (d.type != MIPT_OBJ_TRIMESH) continue;
