@@ -1,6 +1,6 @@
 """Differential fuzzing of the HIP path against the oracle: random scenes (tessellation, one or two meshes, scales,
 camera, light, aperture, depth, materials incl. glossy / mirror / dielectric / textures / MERL), per-sample radiance
-compared bit for bit on both pipelines.  usage: python tools/fuzz_parity.py [n_scenes] [seed] [--queue]
+compared bit for bit on both pipelines.  usage: python tests/tools/fuzz_parity.py [n_scenes] [seed] [--queue]   (test infrastructure: the oracle is the checker)
 --queue: every scene also draws from the features of the contribution-queue kernel (ghost objects, background photo, fog in
 both media with the three phase functions, subsurface colours), alone and combined."""
 import os, sys

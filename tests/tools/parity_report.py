@@ -1,5 +1,5 @@
 """Fraction of per-sample radiance values that are bit-identical to the reference's (golden fixtures) and the max
-normalised error, per golden scene.  usage: python tools/parity_report.py"""
+normalised error, per golden scene.  usage: python tests/tools/parity_report.py"""
 import os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))

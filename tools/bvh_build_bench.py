@@ -1,6 +1,6 @@
 """Times TriMesh::init's BVH build with the host recursion and with mipt_build_bvh on the GPU, on the meshes of the
 bench workloads, and checks that both give the same tree.  `python tools/bvh_build_bench.py [grid ...]`
-(grid 1120 = 2.5 M triangles (configs[2]), 3444 = 23.7 M (configs[4])); `--ref` also times the compiled reference."""
+(grid 1120 = 2.5 M triangles (configs[2]), 3444 = 23.7 M (configs[4])); the compiled reference's own build is timed by tests/tools/ref_build_time.py."""
 import json
 import os
 import sys
@@ -32,14 +32,6 @@ def main():
             d = H.mesh_dump(obj)
             dumps[mode] = (d["perm"], d["nodes_i"], d["nodes_bb"])
             del H
-        if "--ref" in sys.argv:                      # the compiled reference's own TriMesh::init on the same arrays (serial recursion)
-            from oracle import binding
-            if binding.ref_available():
-                R = binding.Ref()
-                R.apply_config(cfg)
-                t0 = time.time()
-                R.add_mesh(mesh)
-                row["reference_add_mesh_s"] = round(time.time() - t0, 2)
         same = all(np.array_equal(a, b) for a, b in zip(dumps["gpu"], dumps["host"]))
         row["same_tree"] = bool(same)
         row["nodes"] = int(dumps["gpu"][1].shape[0])
