@@ -32,7 +32,7 @@ enum {
 	MIPT_ERR_INVALID = 1,      /* bad argument / inconsistent description */
 	MIPT_ERR_NO_DEVICE = 2,    /* no HIP device, or device id out of range */
 	MIPT_ERR_HIP = 3,          /* a HIP runtime call failed (text in mipt_last_error) */
-	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature that is not built (subsurface on a sphere / plane or from an image, extra spheres ...) */
+	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature that is not built (textured or extra spheres ...) */
 	MIPT_ERR_NO_SCENE = 5,     /* render/trace before mipt_upload_scene */
 	MIPT_ERR_CANCELLED = 6     /* *cancel became non-zero between passes (Raytracer::stopRender) */
 };

@@ -103,6 +103,10 @@ class _Base:
         """Scene::fog_* (Geometry.h:1371-1377): fog_type 0 uniform / 1 exponential in height, phase 0 isotropic / 1 Schlick / 2 Rayleigh."""
         self.lib.ref_set_fog(self.ctx, _f(density), _f(absorption), _f(density_decay), _f(absorption_decay), int(fog_type), int(phase_type), _f(phase_aniso))
 
+    def add_col_subsurface(self, obj, rgb):
+        """Object::add_col_subsurface: appends a constant subsurface colour (planes have no material lists by default)."""
+        self.lib.ref_add_col_subsurface(self.ctx, obj, (_f * 3)(*rgb))
+
     def set_group_subsurface(self, obj, grp, rgb):
         """Object::subsurface[grp]: a constant subsurface colour Ksub (non-zero switches the subsurface branch on)."""
         self.lib.ref_set_group_subsurface(self.ctx, obj, grp, (_f * 3)(*rgb))

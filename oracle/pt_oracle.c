@@ -944,8 +944,27 @@ static int mesh_reservoir_intersection(const o_obj* o, const o_ray* d, v3* P, fl
 	}
 	return has_inter;
 }
+/* Plane::reservoir_sampling_intersection (Geometry.h:1159-1183) */
+static int plane_reservoir_intersection(const o_obj* p, const o_ray* d, v3* P, float* t, o_mat* mat, int* triangle_id, int* current_nb_intersections,
+                                        float min_t, float max_t, pcg32_t* rng) {
+	mat->shadingN = p->vecN;
+	float ddot = vdot(d->direction, p->vecN);
+	if (fabsf(ddot) < 1E-9) return 0;
+	float curt = vdot(vsub(p->A, d->origin), p->vecN) / ddot;
+	if (curt < min_t || curt >= max_t) return 0;
+	(*current_nb_intersections)++;
+	float r1 = pcg_uniform(rng);
+	if (r1 >= 1. / *current_nb_intersections) return 0;
+	*t = curt;
+	*P = vadd(d->origin, vscale(*t, d->direction));
+	*triangle_id = -1;
+	float u = P->x * 0.1f;
+	float v = P->z * 0.1f;
+	query_material(p, 0, u, v, mat);
+	return 1;
+}
 /* Scene::get_random_intersection (Geometry.cpp:339-470) restricted to one object (sphere_id != -1), which is how the
-   subsurface branch calls it; only meshes carry a subsurface colour here (spheres / planes: not restated). */
+   subsurface branch calls it; meshes and planes (a sphere has no subsurface colour in scope: textured spheres are not). */
 static int scene_get_random_intersection(const o_ctx* c, const o_ray* d, v3* P, int sphere_id, float* min_t, o_mat* mat, int* triangle_id, float tmin, float tmax, pcg32_t* rng) {
 	int has_inter = 0;
 	*min_t = INFINITY;
@@ -955,6 +974,7 @@ static int scene_get_random_intersection(const o_ctx* c, const o_ray* d, v3* P, 
 	tr.direction = apply_inverse_rotation_scaling(o, d->direction);
 	tr.origin = apply_inverse_transformation(o, d->origin);
 	if (o->type == OT_TRIMESH) has_inter = mesh_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
+	else if (o->type == OT_PLANE) has_inter = plane_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
 	if (has_inter) {
 		*P = apply_transformation(o, *P);
 		mat->shadingN = apply_rotation(o, mat->shadingN);
@@ -1583,6 +1603,8 @@ int o_add_mesh(o_ctx* c, int nv, const float* verts, int nn, const float* normal
 	return c->nobj - 1;
 }
 
+/* Object::add_col_subsurface (a plane has no material lists until the GUI adds one) */
+void o_add_col_subsurface(o_ctx* c, int obj, const float* rgb) { obj_push_tex(&c->objs[obj], T_KSUB, V(rgb[0], rgb[1], rgb[2])); }
 /* Object::subsurface[grp] as a constant colour (add_col_subsurface, Geometry.h) */
 void o_set_group_subsurface(o_ctx* c, int obj, int grp, const float* rgb) {
 	o_obj* o = &c->objs[obj];

@@ -72,6 +72,7 @@ void   o_getcolor_samples(o_ctx*, int npix, const int* ij, int k0, int k1, float
 void   o_render_seeded(o_ctx*, float* imagedouble, float* sample_count);
 void   o_set_object_ghost(o_ctx*, int obj, int ghost);
 void   o_set_group_subsurface(o_ctx*, int obj, int grp, const float* rgb);
+void   o_add_col_subsurface(o_ctx*, int obj, const float* rgb);
 void   o_set_fog(o_ctx*, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso);
 void   o_set_background(o_ctx*, const float* rgb, int W, int H);
 void   o_getcolor_samples_aov(o_ctx*, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_normal, float* out_albedo);

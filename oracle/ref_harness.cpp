@@ -180,6 +180,7 @@ void ref_set_fog(RefCtx* c, float density, float absorption, float density_decay
 	s.fog_density = density; s.fog_absorption = absorption; s.fog_density_decay = density_decay; s.fog_absorption_decay = absorption_decay;
 	s.fog_type = type; s.fog_phase_type = phase_type; s.phase_aniso = phase_aniso;
 }
+void ref_add_col_subsurface(RefCtx* c, int obj, const float* rgb) { c->rt->s.objects[obj]->add_col_subsurface(Vector(rgb[0], rgb[1], rgb[2])); }
 void ref_set_group_subsurface(RefCtx* c, int obj, int grp, const float* rgb) {
 	Object* o = c->rt->s.objects[obj];
 	if (grp >= 0 && grp < (int)o->subsurface.size()) o->subsurface[grp].multiplier = Vector(rgb[0], rgb[1], rgb[2]);
@@ -228,6 +229,7 @@ void ref_set_group_texture_file(RefCtx* c, int obj, int grp, int slot, const cha
 	case 2: o->set_normalmap(file, grp); break;
 	case 3: o->set_alphamap(file, grp); break;
 	case 4: o->set_roughnessmap(file, grp); break;
+	case 7: o->set_subsurface(file, grp); break;
 	}
 }
 // mainApp.cpp:2593: ((Sphere*)objects[1])->load_envmap(file)

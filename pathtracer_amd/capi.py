@@ -436,6 +436,9 @@ class HostRaytracer:
         """Scene::fog_* (Geometry.h:1371-1377)."""
         self.host.mh_set_fog(self.h, _f(density), _f(absorption), _f(density_decay), _f(absorption_decay), int(fog_type), int(phase_type), _f(phase_aniso))
 
+    def add_col_subsurface(self, obj, rgb):
+        self.host.mh_add_col_subsurface(self.h, obj, (_f * 3)(*rgb))
+
     def set_group_subsurface(self, obj, grp, rgb):
         self.host.mh_set_group_subsurface(self.h, obj, grp, (_f * 3)(*rgb))
 

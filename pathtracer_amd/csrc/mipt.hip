@@ -542,12 +542,11 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 		lists[MT_TRANSP] = o.transparent_map; counts[MT_TRANSP] = o.n_transparent_map;
 		lists[MT_REFR] = o.refr_index_map; counts[MT_REFR] = o.n_refr_index_map;
 		lists[MT_KSUB] = o.subsurface; counts[MT_KSUB] = o.n_subsurface;
-		for (int k = 0; k < o.n_subsurface; k++) {   // subsurface: constant colours on meshes (mipt_compositing.h); anything else is refused
+		for (int k = 0; k < o.n_subsurface; k++) {   // a subsurface colour (constant or image): the scene is rendered by the queue kernel
 			const mipt_texture& t = o.subsurface[k];
-			if (t.W > 0) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d has an image-textured subsurface colour", i);
-			if (t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0) {
-				if (o.type != MIPT_OBJ_TRIMESH) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: subsurface scattering on a sphere / plane", i);
-				scene_ghost = true;                  // rendered by the queue kernel
+			if (t.W > 0 || t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0) {
+				if (o.type == MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: subsurface scattering on a sphere", i);
+				scene_ghost = true;
 			}
 		}
 		for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) {

@@ -1478,6 +1478,7 @@ int mh_add_mesh(mh_raytracer* h, int nv, const float* verts, int nn, const float
 	return (int)r.s.objects.size() - 1;
 }
 void mh_set_object_flags(mh_raytracer* h, int obj, int miroir, int flip) { h->rt.s.objects[obj]->miroir = miroir != 0; h->rt.s.objects[obj]->flip_normals = flip != 0; }
+void mh_add_col_subsurface(mh_raytracer* h, int obj, const float* rgb) { h->rt.s.objects[obj]->add_col_subsurface(Vector(rgb[0], rgb[1], rgb[2])); }
 void mh_set_group_subsurface(mh_raytracer* h, int obj, int grp, const float* rgb) {   // Object::subsurface[grp] as a constant colour
 	Object* o = h->rt.s.objects[obj];
 	if (grp >= 0 && grp < (int)o->subsurface.size()) o->subsurface[grp].multiplier = Vector(rgb[0], rgb[1], rgb[2]);

@@ -270,6 +270,7 @@ float* mh_imagedouble(mh_raytracer*);
 int  mh_get_background(mh_raytracer*, float* out, int capacity, int* W, int* H);
 void mh_set_has_denoiser(mh_raytracer*, int on);
 void mh_set_fog(mh_raytracer*, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso);   // Scene::fog_*
+void mh_add_col_subsurface(mh_raytracer*, int obj, const float* rgb);             // Object::add_col_subsurface
 void mh_set_group_subsurface(mh_raytracer*, int obj, int grp, const float* rgb);   // Object::subsurface[grp].multiplier
 void mh_set_object_ghost(mh_raytracer*, int obj, int ghost);                 // Object::ghost
 int  mh_load_background(mh_raytracer*, const char* file);                     // Scene::load_background(file, gamma); -1 + mh_last_error on failure

@@ -296,7 +296,7 @@ def main_fog():
     np.savez_compressed(os.path.join(OUT, "fog.npz"), **g)
 
 
-SSS_KINDS = ("ss", "ssglossy", "ssfog", "ssghost", "sstex", "ssdeep")
+SSS_KINDS = ("ss", "ssglossy", "ssfog", "ssghost", "sstex", "ssdeep", "ssplane", "ssimage")
 
 
 def subsurface_scene(X, kind):
@@ -305,8 +305,13 @@ def subsurface_scene(X, kind):
     cfg = scenes.config_c1(64, 36, 4)
     cfg.nb_bounces = 8 if kind == "ssdeep" else 4
     X.apply_config(cfg)
-    oid = X.add_mesh(scenes.blob_mesh(16, with_uv=(kind == "sstex"), fine_detail=(kind == "ssdeep")))
+    oid = X.add_mesh(scenes.blob_mesh(16, with_uv=(kind in ("sstex", "ssimage")), fine_detail=(kind == "ssdeep")))
     X.set_group_subsurface(oid, 0, (0.8, 0.5, 0.3))
+    if kind == "ssplane":                                # the floor scatters as well (Plane::reservoir_sampling_intersection)
+        X.add_col_subsurface(2, (0.7, 0.6, 0.2))
+    if kind == "ssimage":                                # the subsurface colour comes from an image (Object::set_subsurface)
+        X.set_group_subsurface(oid, 0, (1.0, 1.0, 1.0))
+        X.set_group_texture(oid, 0, 7, scenes.checker_texture(32, 16, 9, 4))
     if kind == "ssglossy":
         X.set_group_material(oid, 0, (0.4, 0.3, 0.2), (0.5, 0.5, 0.4), (40., 60., 80.))
     if kind == "ssfog":
