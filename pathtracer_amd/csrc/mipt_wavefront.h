@@ -157,6 +157,26 @@ MIPT_DEV bool analytic_occluded(const DScene* __restrict__ sc, f3 ro, f3 rd, flo
 	return occ;
 }
 
+// true when the shadow ray fails the root-box test of every mesh (the two early returns of TriMesh::intersection_shadow,
+// TriangleMesh.cpp:1262-1263, with cur_best_t = inf): no mesh can occlude it
+#ifndef MIPT_SHADE_ROOT_TEST
+#define MIPT_SHADE_ROOT_TEST 1
+#endif
+MIPT_DEV bool meshes_missed(const DScene* __restrict__ sc, f3 ro, f3 rd, float dist) {
+	const int n = sc->nobj;
+	bool missed = true;
+	for (int i = sc->first_mesh; i < n; i++) {
+		const DObject& o = sc->obj[i];
+		if (o.type != 0) continue;
+		const f3 d = xf_dir(o.inv, rd);
+		const f3 org = xf_point(o.inv, ro);
+		const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+		float t_root;
+		if (box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root) && !(t_root > dist)) missed = false;
+	}
+	return missed;
+}
+
 // the same for two destination queues whose sizes share one 64-bit word (low: list_a, high: list_b): one atomic
 __device__ __forceinline__ void queue_push2(unsigned* __restrict__ list_a, unsigned* __restrict__ list_b, unsigned long long* __restrict__ count2,
                                             unsigned bits_a, unsigned bits_b, const unsigned* __restrict__ src, unsigned src_base) {
@@ -321,6 +341,18 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				c = r == VERTEX_CONTINUE;
 			} else c = path_vertex<TIER != 2>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
+			// The shadow request of this vertex: an analytic occluder settles it here (never queued); so does a ray that
+			// misses the root box of every mesh — TriMesh::intersection_shadow returns before it visits a node
+			// (TriangleMesh.cpp:1262-1263), the light sample is visible and its term is added now, in the reference's order
+			// (emission :411, then direct light :566).  Everything else goes to the shadow stage.
+			bool sh_queue = false;
+			if (sh.diffuse && sh.cast) {
+				n_shadow++;                                               // counted like the reference counts intersection_shadow calls
+				if (!analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
+					if (MIPT_SHADE_ROOT_TEST && meshes_missed(sc, sh.ray.o, sh.ray.d, sh.dist)) p.color = p.color + wv * sh.contrib;
+					else sh_queue = true;
+				}
+			}
 			if (TIER == 1) {
 				// the vertex ran with colour 0, so p.color is exactly the term it adds (0 + x = x); on a non-emissive surface
 				// that term is 0 and colour + 0 = colour: the path's colour is neither read nor written (it is never -0)
@@ -329,8 +361,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 					wf_st(&wf.out.col[id], make_float4(c0.x + p.color.x, c0.y + p.color.y, c0.z + p.color.z, 0.f));
 				}
 			} else wf_st(&wf.out.col[id], make_float4(p.color.x, p.color.y, p.color.z, 0.f));
-			if (sh.diffuse && sh.cast) n_shadow++;                         // counted like the reference counts intersection_shadow calls
-			if (sh.diffuse && sh.cast && !analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
+			if (sh_queue) {
 				cast_bits |= 1u << u;
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
 				wf_st(&wf.sh_o[id], make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist));
