@@ -14,11 +14,14 @@
 #pragma once
 
 #define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
+#ifndef MIPT_EXTEND_WAVES
+#define MIPT_EXTEND_WAVES 6             // closest-hit kernel: 6 waves/SIMD with the derived triangle terms beats 7 waves with the fourth load (-1.7 % / -4 % stage time on C2 / C1)
+#endif
 #ifndef MIPT_DERIVE_SHADOW
 #define MIPT_DERIVE_SHADOW 1           // the any-hit traversal loads 48 of the 64 bytes of a triangle record and derives N, m22 (-7 % stage time)
 #endif
 #ifndef MIPT_DERIVE_EXTEND
-#define MIPT_DERIVE_EXTEND 0           // the closest-hit traversal keeps the fourth load (deriving costs it registers: +15 %)
+#define MIPT_DERIVE_EXTEND 1           // the closest-hit traversal too, at 6 waves per SIMD (84 registers; at 7 waves / 72 registers deriving spills: +15 %)
 #endif
 #ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 1024u           // ids reserved per global atomic (sub-allocated wave-locally)
@@ -355,7 +358,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
 template <int MODE>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
 	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min_flags, stk, leafmap);
