@@ -1153,7 +1153,6 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return build_fail(MIPT_ERR_NO_DEVICE, "no usable HIP device");
 	BHIP(hipSetDevice(device_id));
 	const int n = ntri;
-	phase("pack indices");
 	hipEvent_t e0, e1;
 	BHIP(hipEventCreate(&e0)); BHIP(hipEventCreate(&e1));
 	struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
