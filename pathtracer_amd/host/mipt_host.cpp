@@ -187,7 +187,7 @@ void TriMesh::finish_init(bool center) {
 	const auto t_build = std::chrono::steady_clock::now();
 	bvh_builder = 0;
 	if (g_bvh_builder_mode != 0 && !build_bvh_gpu()) {
-		if (g_bvh_builder_mode == 1 || !bvh_gpu_unavailable) { loaded = false; return; }   // forced, or a real failure: say so
+		if (g_bvh_builder_mode == 1 || !bvh_gpu_unavailable) { loaded = false; return; }   // forced, or bad input: say so
 	}
 	if (!bvh_builder) {
 		bvh.nodes.clear();
@@ -672,7 +672,7 @@ bool TriMesh::build_bvh_gpu() {
 	                              reinterpret_cast<mipt_bvh_node*>(bvh.nodes.data()), nf * 2, &nn, perm.data(), &dev_s);
 	phase("mipt_build_bvh");
 	if (rc != MIPT_OK) {
-		bvh_gpu_unavailable = (rc == MIPT_ERR_NO_DEVICE);
+		bvh_gpu_unavailable = (rc != MIPT_ERR_INVALID);   // no device, out of memory, a degenerate mesh: the host recursion builds the same tree
 		load_error = std::string("mipt_build_bvh: ") + mipt_build_bvh_error();
 		bvh.nodes.clear();
 		return false;
