@@ -3,6 +3,7 @@
 // -ffp-contract=off: several results (BVH splits, matrices, tables) must match the reference's
 // float arithmetic exactly because the device path consumes them.
 #include "mipt_host.h"
+#include "mipt_jpeg.h"
 
 #include <algorithm>
 #include <cmath>
@@ -398,7 +399,15 @@ bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, i
 	if (got >= 2 && magic[0] == 'P' && magic[1] == '6') { if (read_ppm(file, rgb, W, H)) return true; why = "malformed binary PPM (P6, maxval 255 expected)"; return false; }
 	if (got == 4 && magic[0] == 0x89 && magic[1] == 'P' && magic[2] == 'N' && magic[3] == 'G') return read_png(file, rgb, W, H, why);
 	if (got >= 2 && magic[0] == 'B' && magic[1] == 'M') return read_bmp(file, rgb, W, H, why);
-	why = "only binary PPM, PNG and uncompressed BMP images are decoded here (JPEG / TGA / HDR need the reference's codecs)";
+	if (got >= 2 && magic[0] == 0xff && magic[1] == 0xd8) {   // JPEG (baseline / progressive Huffman): mipt_jpeg.h
+		std::vector<unsigned char> buf;
+		FILE* g = fopen(file.c_str(), "rb");
+		if (!g) { why = "cannot open"; return false; }
+		{ unsigned char tmp[65536]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, g)) > 0) buf.insert(buf.end(), tmp, tmp + n); }
+		fclose(g);
+		return mipt_jpeg::decode(buf.data(), buf.size(), rgb, W, H, why);
+	}
+	why = "only JPEG, PNG, binary PPM and uncompressed BMP images are decoded here (TGA / HDR / GIF need the reference's codecs)";
 	return false;
 }
 }  // namespace

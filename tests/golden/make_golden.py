@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv:
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv:
     main()
 
 
@@ -365,3 +365,48 @@ if __name__ == "__main__" and "--fog" in sys.argv:
     main_fog()
 if __name__ == "__main__" and "--subsurface" in sys.argv:
     main_subsurface()
+
+
+def main_jpeg():
+    """tests/golden/jpeg_cases.npz: small JPEG files (written by Pillow from a synthetic pattern: baseline / progressive, 4:4:4 /
+    4:2:2 / 4:2:0, grey, restart markers, optimised tables, odd sizes) and the pixels the reference's load_image (stb_image)
+    makes of them, rows as in the file."""
+    import ctypes as C
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(11)
+
+    def pattern(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 7.) * np.cos(y / 5.), 127 + 100 * np.cos(x / 3. + y / 11.), (x * 3 + y * 5) % 256], -1)
+        return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+    R = Ref()
+    g = {}
+    cases = [(37, 53, 0, 90, False, False, 0), (37, 53, 1, 35, False, False, 0), (37, 53, 2, 75, False, False, 0), (37, 53, 2, 75, True, False, 0),
+             (16, 16, 1, 90, True, False, 0), (1, 1, 2, 80, False, False, 0), (8, 9, 2, 35, True, False, 0), (40, 56, 0, 80, False, True, 0),
+             (40, 56, 0, 80, True, True, 0), (33, 47, 2, 75, False, False, 2), (33, 47, 1, 75, True, False, 1), (3, 120, 2, 60, False, False, 0)]
+    tmp = os.path.join(OUT, "_tmp.jpg")
+    for n, (h, w, sub, q, prog, grey, rst) in enumerate(cases):
+        img = pattern(h, w)
+        im = Image.fromarray(img[..., 0] if grey else img, "L" if grey else "RGB")
+        kw = dict(quality=q, progressive=prog, optimize=(q == 35))
+        if not grey:
+            kw["subsampling"] = sub
+        if rst:
+            kw["restart_marker_rows"] = rst
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **kw)
+        open(tmp, "wb").write(buf.getvalue())
+        W, H = C.c_int(0), C.c_int(0)
+        out = (C.c_ubyte * (1 << 20))()
+        assert R.lib.ref_load_image(tmp.encode(), out, len(out), C.byref(W), C.byref(H)) == 0
+        g[f"file{n}"] = np.frombuffer(buf.getvalue(), np.uint8)
+        g[f"rgb{n}"] = np.frombuffer(out, np.uint8, W.value * H.value * 3).reshape(H.value, W.value, 3)[::-1].copy()   # load_image flips the rows
+    os.remove(tmp)
+    g["count"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(OUT, "jpeg_cases.npz"), **g)
+    print("jpeg cases", len(cases))
+
+
+if __name__ == "__main__" and "--jpeg" in sys.argv:
+    main_jpeg()

@@ -109,9 +109,12 @@ def test_undecodable_images_are_refused(tmp_path):
     (tmp_path / "cut.png").write_bytes(data[: len(data) // 2])
     with pytest.raises(capi.MiptError):
         host_read(tmp_path / "cut.png")
-    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))
-    with pytest.raises(capi.MiptError, match="PPM, PNG"):
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))          # a JPEG header with nothing behind it
+    with pytest.raises(capi.MiptError):
         host_read(tmp_path / "x.jpg")
+    (tmp_path / "x.tga").write_bytes(bytes(18) + bytes(64))
+    with pytest.raises(capi.MiptError, match="JPEG, PNG"):
+        host_read(tmp_path / "x.tga")
     ihdr16 = data.replace(struct.pack(">IIBB", 37, 23, 8, 2), struct.pack(">IIBB", 37, 23, 16, 2), 1)
     (tmp_path / "deep.png").write_bytes(ihdr16)
     with pytest.raises(capi.MiptError, match="16-bit"):
@@ -148,3 +151,46 @@ def test_bmp_decoding(tmp_path, bpp, topdown):
         assert R.lib.ref_load_image(str(p).encode(), buf, len(buf), C.byref(Wc), C.byref(Hc)) == 0
         ref = np.frombuffer(buf, np.uint8, Wc.value * Hc.value * 3).reshape(Hc.value, Wc.value, 3)[::-1]
         assert np.array_equal(ref, want)
+
+
+def test_jpeg_decoding_matches_the_reference_fixture(tmp_path):
+    """Baseline and progressive JPEG (4:4:4 / 4:2:2 / 4:2:0, grey, restart markers, optimised tables, sizes that are not
+    multiples of the MCU) against the pixels the reference's stb_image made of the same files
+    (tests/golden/jpeg_cases.npz, tests/golden/make_golden.py --jpeg): bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_cases.npz"))
+    for n in range(int(g["count"])):
+        p = tmp_path / f"case{n}.jpg"
+        p.write_bytes(g[f"file{n}"].tobytes())
+        got = host_read(p)
+        assert got.shape == g[f"rgb{n}"].shape and np.array_equal(got, g[f"rgb{n}"]), f"JPEG case {n}"
+
+
+def test_jpeg_against_live_reference(tmp_path):
+    from oracle import binding
+    PIL = pytest.importorskip("PIL.Image")
+    if not binding.ref_available():
+        pytest.skip("compiled reference not present")
+    rng = np.random.default_rng(4)
+    R = binding.Ref()
+    for h, w, sub, q, prog in ((50, 70, 2, 85, False), (50, 70, 1, 50, True), (23, 31, 0, 95, True), (64, 64, 2, 20, False)):
+        img = rng.integers(0, 256, (h // 4 + 1, w // 4 + 1, 3), dtype=np.uint8).repeat(4, 0).repeat(4, 1)[:h, :w]
+        p = tmp_path / "t.jpg"
+        PIL.fromarray(img, "RGB").save(str(p), quality=q, subsampling=sub, progressive=prog)
+        W, H = C.c_int(0), C.c_int(0)
+        buf = (C.c_ubyte * (1 << 22))()
+        assert R.lib.ref_load_image(str(p).encode(), buf, len(buf), C.byref(W), C.byref(H)) == 0
+        ref = np.frombuffer(buf, np.uint8, W.value * H.value * 3).reshape(H.value, W.value, 3)[::-1]
+        assert np.array_equal(host_read(p), ref)
+
+
+def test_jpeg_kinds_outside_the_decoder_are_refused(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    p = tmp_path / "cmyk.jpg"
+    PIL.fromarray(np.zeros((8, 8, 4), np.uint8), "CMYK").save(str(p))
+    with pytest.raises(capi.MiptError, match="CMYK"):
+        host_read(p)
+    q = tmp_path / "cut.jpg"
+    q.write_bytes(b"\xff\xd8\xff\xdb\x00")
+    with pytest.raises(capi.MiptError):
+        host_read(q)
