@@ -22,12 +22,17 @@ MIPT_DEV f3 background_pixel(const DRender& R, int screenI, int screenJ) {   // 
 	return mk3(px[0], px[1], px[2]);
 }
 
+// The traversals are kept out of line here: inlined four times into the getColor loop they push it to 272 registers and one
+// wave per SIMD; as calls the loop needs about half of that.
+template <class STK> __device__ __attribute__((noinline)) bool q_intersect(const DScene* __restrict__ sc, const Ray& r, Hit& h, f3& P, Mat& m, STK& stk) { return scene_intersect(sc, r, h, P, m, stk); }
+template <class STK> __device__ __attribute__((noinline)) bool q_occluded(const DScene* __restrict__ sc, const Ray& r, float dist, STK& stk) { return scene_occluded<STK, true>(sc, r, dist, stk); }
+
 // ---- subsurface probe (Raytracer.cpp:318-406) --------------------------------------------------------------------
 // TriMesh::reservoir_sampling_intersection (TriangleMesh.cpp:1321-1426): a uniformly random one of the intersections in
 // [min_t, max_t).  Same visiting order as the closest-hit traversal with a fixed far bound; every accepted triangle draws
 // one number from the sample's engine, so the order of the visits decides the draws.
 template <class STK>
-MIPT_DEV bool mesh_reservoir(const DObject& o, f3 org, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out, int& tri_out, float& beta_out, float& gamma_out, STK& stk) {
+__device__ __attribute__((noinline)) bool mesh_reservoir(const DObject& o, f3 org, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out, int& tri_out, float& beta_out, float& gamma_out, STK& stk) {
 	bool has_inter = false;
 	int count = 0;
 	f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
@@ -199,7 +204,7 @@ __device__ __noinline__ bool fog_contribution(const DScene* __restrict__ sc, con
 	Ray L; L.o = random_P; L.d = random_dir;
 	Hit ih; f3 interP = mk3(0, 0, 0); Mat im;
 	im.shadingN = mk3(0, 1, 0); im.Kd = mk3(0.5f, 0.5f, 0.5f); im.Ks = mk3(0, 0, 0); im.Ne = mk3(100, 100, 100); im.Ke = mk3(0, 0, 0); im.transp = false; im.refr_index = 0;
-	const bool interinter = scene_intersect(sc, L, ih, interP, im, stk);
+	const bool interinter = q_intersect(sc, L, ih, interP, im, stk);
 	n_closest++;
 	bool visible = true;
 	if (!is_uniform) {
@@ -258,7 +263,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		if (nbrebonds == 0) continue;                                       // :240
 		if (norm2(pathWeight) < sqr(0.01f)) continue;                       // :241
 		Hit h; f3 P = mk3(0, 0, 0); Mat m;
-		const bool hit = scene_intersect(sc, currentRay, h, P, m, stk);
+		const bool hit = q_intersect(sc, currentRay, h, P, m, stk);
 		n_closest++;
 		const float t = h.t;
 		// fog event along the ray just traced, towards `lightpos`; queues the in-scattered path (showenvmap = true)
@@ -386,7 +391,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		else {
 			Ray rl; rl.o = P + 0.01f * wi; rl.d = wi;
 			n_shadow++;
-			isShadowed = scene_occluded<STK, true>(sc, rl, sqrtf(d_light2) - 0.01f, stk);   // :513: ghosts cast no shadow
+			isShadowed = q_occluded(sc, rl, sqrtf(d_light2) - 0.01f, stk);   // :513: ghosts cast no shadow
 		}
 		f3 currentContrib = mk3(0, 0, 0);
 		if (!isShadowed) {
