@@ -184,7 +184,8 @@ typedef struct mipt_stats {
 	uint32_t traverse_launches;
 	uint32_t shadow_launches;
 	uint32_t passes;
-	uint32_t pipeline;            /* pipeline that produced these numbers */
+	uint32_t pipeline;            /* pipeline that produced these numbers: 0 per-path kernel, 1 wavefront stages, 2 the contribution-queue
+	                                 kernel (scenes with ghost objects, a background photo, fog or subsurface colours) */
 	uint32_t traverse_merged;     /* 1 = option "merge_traverse" was in effect (see traverse_ms) */
 	uint32_t reserved;
 } mipt_stats;
@@ -276,7 +277,8 @@ const char* mipt_build_bvh_error(void);
 int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
 
 /* Tunables (name/value); unknown names return MIPT_ERR_INVALID.
- *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default)
+ *   "pipeline"        0 = per-path kernel, 1 = wavefront queues (default); scenes with ghost objects, a background photo, fog or
+ *                     subsurface colours always run on the contribution-queue kernel (reported as pipeline 2)
  *   "refill"          pipeline 1: 1 = traversal stages refill idle lanes from the queue (default), 0 = one ray per lane
  *   "merge_traverse"  pipeline 1: 1 = the shadow rays of depth b and the closest-hit rays of depth b+1 share one
  *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
