@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >
 // ---- step A: box of the vertices and box of the centroids of every segment ----------------------------------------
 // One wave per block; a wave walks `gpw` groups of 64 consecutive positions.  While all 64 positions of a group belong
 // to the segment of the current run the lanes accumulate privately; the run is flushed (wave reduction + 12 atomics)
-// when the segment changes.  Groups that straddle segments fall back to per-lane atomics.
+// when the segment changes.  Groups that straddle segments are reduced by a segmented shuffle scan (one set of atomics per run).
 __global__ __launch_bounds__(64) void k_lvl_bounds(const float4* __restrict__ rec, const uint32_t* __restrict__ order, const int* __restrict__ segof,
                                                    int n, int gpw, uint32_t* __restrict__ acc) {
 	const int lane = threadIdx.x;
