@@ -163,3 +163,33 @@ def test_every_pixel_of_the_full_size_frame(wl):
     assert np.abs(got.astype(np.float64) - want).max() / WHITE < 1e-4
     assert_bits(got, want, "per-sample radiance of all 2 073 600 pixels")
     assert 0.01 < want.mean() / WHITE < 1.0
+
+
+@pytest.mark.parametrize("feature", ["fog+ghost+photo", "subsurface"])
+def test_every_pixel_full_size_queue_kernel(feature):
+    """configs[1]'s scene at 1920x1080 with the features of the contribution-queue kernel: one sample of every pixel through
+    the oracle against the HIP path (2.07 M samples each; exponential fog with the Schlick phase function + a ghost floor
+    over a background photo, and a subsurface colour on the mesh)."""
+    from oracle.binding import Oracle
+    mesh, cfg, mat, _ = scenes.workload("c1", spp=1)
+    photo = (np.random.default_rng(5).uniform(0, 1, (90, 160, 3)) ** 2.2 * 196964.699).astype(np.float32)
+    out = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        X.apply_config(cfg)
+        oid = scenes.install(X, mesh, mat)
+        if feature == "subsurface":
+            X.set_group_subsurface(oid, 0, (0.8, 0.5, 0.3))
+        else:
+            X.set_object_ghost(2, True)
+            X.set_background(photo)
+            X.set_fog(0.4, 0.3, 0.02, 0.03, 1, 1, 0.5)
+        X.prepare()
+        out.append(X)
+    pix = np.stack(np.meshgrid(np.arange(cfg.H), np.arange(cfg.W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+    want, _ = out[0].getcolor_samples(pix, 0, 1)
+    got, _ = out[1].sample_radiance(pix, 0, 1)
+    same = bits_equal(got, want).all(-1).mean()
+    err = np.abs(got.astype(np.float64) - want).max() / WHITE
+    assert err < 1e-4 and same > 0.99999, (feature, same, err)      # the fp64 exp of the subsurface weight is the device library's
+    assert out[1].stats()["pipeline"] == 2
+    assert 0.01 < want.mean() / WHITE < 2.0
