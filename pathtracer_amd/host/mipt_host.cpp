@@ -36,7 +36,10 @@ static inline Vector cross(const Vector& a, const Vector& b) { return Vector(a[1
 static inline Vector normalized(const Vector& a) { float n = std::sqrt(norm2(a)); return Vector(a[0] / n, a[1] / n, a[2] / n); }
 
 // ---------------------------------------------------------------- Texture
+uint64_t g_content_epoch = 1;
+
 void Texture::loadColorsRGB8(const unsigned char* rgb, int w, int h) {
+	g_content_epoch++;
 	W = (size_t)w; H = (size_t)h;
 	values.resize(W * H * 3);
 	for (int i = 0; i < h; i++)
@@ -50,6 +53,7 @@ void Texture::loadColorsRGB8(const unsigned char* rgb, int w, int h) {
 }
 
 void Texture::loadNormalsRGB8(const unsigned char* rgb, int w, int h) {
+	g_content_epoch++;
 	W = (size_t)w; H = (size_t)h;
 	values.resize(W * H * 3);
 	for (int i = 0; i < h; i++)
@@ -101,6 +105,7 @@ Sphere::Sphere(const Vector& origin, float rayon) {   // Sphere::init (Geometry.
 	type = OT_SPHERE; O = origin; R = rayon; rotation_center = origin; name = "Sphere";
 }
 void Sphere::load_envmap_rgb8(const unsigned char* rgb, int w, int h) {
+	g_content_epoch++;
 	envtex.resize((size_t)w * h * 3);
 	for (int i = 0; i < h; i++) memcpy(&envtex[(size_t)i * w * 3], rgb + (size_t)(h - 1 - i) * w * 3, (size_t)w * 3);
 	envW = w; envH = h; has_envmap = true; flip_normals = true;
@@ -159,6 +164,7 @@ void TriMesh::add_default_group_materials(int ngroups) {
 
 // TriMesh::init after the file has been read (TriangleMesh.cpp:742-841), scaling = 1, offset = 0, preserve_input = false
 void TriMesh::finish_init(bool center) {
+	g_content_epoch++;
 	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
 	const int nvtx = (int)vertices.size();
@@ -1167,6 +1173,7 @@ bool Raytracer::save_scene(const char* filename) const {
 }
 
 bool Scene::load_background(const char* filename, float gamma, std::string& why) {   // Geometry.h:1355-1363
+	g_content_epoch++;
 	std::vector<unsigned char> bg; int w = 0, h = 0;
 	if (!read_image_rgb8(filename, bg, w, h, why)) return false;
 	backgroundfilename = filename;
@@ -1185,6 +1192,7 @@ void Raytracer::clear_image() {
 
 int Raytracer::open_device(int device_id) {
 	if (ctx) { mipt_destroy(ctx); ctx = nullptr; }
+	uploaded_ = false;
 	last_status = mipt_create(&device_id, 1, &ctx);
 	if (last_status != MIPT_OK) err_ = "mipt_create failed (no usable HIP device: this library has no CPU path)";
 	else g_bvh_builder_device = device_id;   // meshes loaded by this process build their BVH on the GPU it renders on
@@ -1319,13 +1327,40 @@ void Raytracer::tone_map(bool divided) {   // Raytracer.cpp:1540-1547 / 1701-170
 	for (auto& x : th) x.join();
 }
 
+// FNV-1a over everything mipt_upload_scene receives by value, the addresses / sizes of what it receives by pointer, and
+// the epoch of in-place rewrites of bulk data (the staging vectors of the material lists are hashed by content: they are
+// rebuilt by every prepare_render)
+uint64_t Raytracer::scene_fingerprint() const {
+	uint64_t hsh = 1469598103934665603ull;
+	auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
+	mix(&g_content_epoch, sizeof g_content_epoch);
+	mipt_scene_desc sd = scene_desc; sd.objects = nullptr;
+	mix(&sd, sizeof sd);
+	for (size_t i = 0; i < desc_objects_.size(); i++) {
+		mipt_object o = desc_objects_[i];
+		o.textures = o.specularmap = o.alphamap = o.roughnessmap = o.normal_map = o.subsurface = o.transparent_map = o.refr_index_map = nullptr;
+		const mipt_mesh* m = o.mesh; o.mesh = nullptr;
+		mix(&o, sizeof o);
+		for (int l = 0; l < 8; l++) { const auto& v = desc_tex_[i * 8 + l]; if (!v.empty()) mix(v.data(), v.size() * sizeof(mipt_texture)); }
+		if (m) mix(m, sizeof *m);
+	}
+	return hsh;
+}
+int Raytracer::upload_scene_if_changed() {
+	const uint64_t fp = scene_fingerprint();
+	if (uploaded_ && fp == uploaded_fingerprint_) return MIPT_OK;
+	const int rc = mipt_upload_scene(ctx, &scene_desc);
+	uploaded_ = (rc == MIPT_OK); uploaded_fingerprint_ = fp;
+	return rc;
+}
+
 // Progressive render: one pass per sample index, buffers valid after every pass, `stopped`
 // polled between passes (Raytracer.cpp:1444-1453).
 void Raytracer::render_image() {
 	prepare_render((float)s.current_frame);
 	if (!ctx) { last_status = MIPT_ERR_NO_DEVICE; err_ = "no device opened"; return; }
 	err_.clear();
-	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
+	if ((last_status = upload_scene_if_changed()) != MIPT_OK) return;
 	stopped = 0;
 	// the sample loop of :1444-1531 as ONE call: one pass per sample, imagedouble / sample_count hold the running sums
 	// after every pass (the GUI thread reads them while this runs), stopRender() ends it between two passes
@@ -1346,7 +1381,7 @@ void Raytracer::render_image_nopreviz() {
 	prepare_render((float)s.current_frame);
 	if (!ctx) { last_status = MIPT_ERR_NO_DEVICE; err_ = "no device opened"; return; }
 	err_.clear();
-	if ((last_status = mipt_upload_scene(ctx, &scene_desc)) != MIPT_OK) return;
+	if ((last_status = upload_scene_if_changed()) != MIPT_OK) return;
 	stopped = 0;
 	if (has_denoiser) {   // :1631-1645, 1676-1696; the denoiser itself (OpenImageDenoise, :1721-1737) is not part of the path
 		const size_t npx = (size_t)W * H;
@@ -1407,6 +1442,7 @@ int mh_load_background(mh_raytracer* h, const char* file) {
 }
 void mh_set_background(mh_raytracer* h, const float* rgb, int W, int H) {
 	Scene& s = h->rt.s;
+	g_content_epoch++;
 	s.clear_background();
 	if (rgb && W > 0 && H > 0) { s.background.assign(rgb, rgb + (size_t)W * H * 3); s.backgroundW = W; s.backgroundH = H; }
 }
@@ -1515,7 +1551,7 @@ void mh_set_group_texture(mh_raytracer* h, int obj, int grp, int slot, int W, in
 	if (slot == 2) t.loadNormalsRGB8(rgb, W, H); else t.loadColorsRGB8(rgb, W, H);
 }
 void mh_set_envmap(mh_raytracer* h, int W, int H, const unsigned char* rgb) { static_cast<Sphere*>(h->rt.s.objects[1])->load_envmap_rgb8(rgb, W, H); }
-void mh_set_brdf_merl(mh_raytracer* h, int obj, const double* table) { h->rt.s.objects[obj]->merl_data.assign(table, table + (size_t)3 * 90 * 90 * 180); }
+void mh_set_brdf_merl(mh_raytracer* h, int obj, const double* table) { g_content_epoch++; h->rt.s.objects[obj]->merl_data.assign(table, table + (size_t)3 * 90 * 90 * 180); }
 // objects[obj]->brdf = new IsoMERLBRDF(file): the MERL ".binary" layout read like read_brdf (MERLBRDFRead.cpp:212-236):
 // three int32 dimensions whose product must be 90*90*180 (= BRDF_SAMPLING_RES_THETA_H * _THETA_D * _PHI_D / 2), then
 // 3 planes of that many doubles.  Returns 0, or -1 with mh_last_error set (the reference prints and carries on with no BRDF).
@@ -1538,7 +1574,8 @@ int mh_prepare(mh_raytracer* h, int upload) {
 	r.prepare_render((float)r.s.current_frame);
 	if (!upload) return MIPT_OK;
 	if (!r.ctx) return MIPT_ERR_NO_DEVICE;
-	r.last_status = mipt_upload_scene(r.ctx, &r.scene_desc);
+	r.scene_changed();                                  // an explicit prepare always uploads
+	r.last_status = r.upload_scene_if_changed();
 	return r.last_status;
 }
 int mh_render_image(mh_raytracer* h) { h->rt.render_image(); return h->rt.last_status; }

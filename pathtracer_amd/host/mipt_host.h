@@ -19,6 +19,9 @@
 
 namespace mipt_host {
 
+// bumped by everything that rewrites bulk scene data in place (meshes, texture / environment / background images, MERL tables)
+extern uint64_t g_content_epoch;
+
 struct Vector {
 	float c[3];
 	Vector(float x = 0, float y = 0, float z = 0) { c[0] = x; c[1] = y; c[2] = z; }
@@ -175,8 +178,14 @@ public:
 	void render_image_nopreviz();     // Raytracer.cpp:1565-1718: offline, image divided by sample_count
 	void clear_image();
 	void stopRender() { stopped = 1; }
+	// render_image / render_image_nopreviz upload the scene only when it changed since the last upload: a fingerprint of
+	// every description the ABI receives (object parameters, matrices, material lists, array addresses and sizes) plus a
+	// counter that the mutators of bulk data bump (meshes, texture / environment / background images, MERL tables).
+	// Code that edits such arrays in place through the public members calls scene_changed().
+	void scene_changed() { uploaded_ = false; }
 	// the GPU this Raytracer renders on, and its share of the image (multi-GPU: one process per GPU)
 	int open_device(int device_id);
+	int upload_scene_if_changed();    // mipt_upload_scene unless the resident copy is current; returns the mipt status
 	void set_partition(int tile_size, int rank, int nranks) { tile_size_ = tile_size; tile_rank_ = rank; tile_nranks_ = nranks; }
 	const char* last_error() const;
 	void set_error(const std::string& e) { err_ = e; }
@@ -218,6 +227,9 @@ private:
 	std::vector<mipt_mesh> desc_meshes_;
 	std::vector<std::vector<mipt_texture>> desc_tex_;
 	int tile_size_ = 32, tile_rank_ = 0, tile_nranks_ = 1;
+	bool uploaded_ = false;           // the device holds a scene uploaded from this object
+	uint64_t uploaded_fingerprint_ = 0;
+	uint64_t scene_fingerprint() const;
 	std::string err_;
 };
 

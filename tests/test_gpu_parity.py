@@ -277,3 +277,23 @@ def test_degenerate_deep_bvh_is_refused_not_overrun():
         assert b"traversal stack" in rt.mipt.mipt_last_error(rt.ctx)
     finally:
         mesh.nodes, mesh.n_nodes = old_nodes, old_n
+
+
+def test_scene_is_uploaded_again_only_when_it_changed():
+    """The host mirror's render calls skip mipt_upload_scene while the scene's fingerprint (every description the ABI gets +
+    the epoch of in-place rewrites of bulk data) is unchanged, and upload again after a material edit or a new texture image."""
+    rt, (mesh, cfg, oid) = gpu("textured")
+    a, _, _ = rt.render_image_nopreviz()
+    b, _, _ = rt.render_image_nopreviz()
+    assert np.array_equal(a, b)
+    rt.set_group_material(oid, 0, (0.2, 0.9, 0.3), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))      # a multiplier: the descriptions change
+    c, _, _ = rt.render_image_nopreviz()
+    assert not np.array_equal(a, c)
+    rt.set_group_texture(oid, 0, 0, scenes.checker_texture(64, 32, 99, 4))               # same size, new pixels: only the epoch changes
+    d, _, _ = rt.render_image_nopreviz()
+    assert not np.array_equal(c, d)
+    fresh, _ = gpu("textured")                                                          # the same edits on a new context
+    fresh.set_group_material(oid, 0, (0.2, 0.9, 0.3), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+    fresh.set_group_texture(oid, 0, 0, scenes.checker_texture(64, 32, 99, 4))
+    e, _, _ = fresh.render_image_nopreviz()
+    assert_bits(d, e, "image after the edits")
