@@ -151,7 +151,10 @@ typedef struct mipt_render_params {
 	/* Work partition across GPUs (one context per GPU): pixel tiles of tile_size x tile_size,
 	 * tile t belongs to rank t % tile_nranks.  tile_nranks = 1 renders everything. */
 	int32_t tile_size, tile_rank, tile_nranks;
-	int32_t reserved[4];
+	/* Lenticular camera (Camera::generateDirection, Vector.h:799-812): pixel column j is seen from one of
+	 * lenticular_nb_images cameras shifted along camera_right.  is_lenticular = 0: the pinhole of the other branch. */
+	int32_t is_lenticular, lenticular_nb_images, lenticular_pixel_width;
+	float lenticular_max_angle;
 } mipt_render_params;
 
 typedef struct mipt_ray { float origin[3]; float direction[3]; } mipt_ray;

@@ -111,6 +111,10 @@ class _Base:
         """Object::subsurface[grp]: a constant subsurface colour Ksub (non-zero switches the subsurface branch on)."""
         self.lib.ref_set_group_subsurface(self.ctx, obj, grp, (_f * 3)(*rgb))
 
+    def set_lenticular(self, on, nb_images=10, max_angle=35 * np.pi / 180. * 0.25, pixel_width=1):
+        """Camera::is_lenticular & co (Vector.h:720-723, 799-812)."""
+        self.lib.ref_set_lenticular(self.ctx, int(on), int(nb_images), _f(max_angle), int(pixel_width))
+
     def set_object_ghost(self, obj, ghost=True):
         self.lib.ref_set_object_ghost(self.ctx, obj, int(ghost))
 

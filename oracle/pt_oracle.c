@@ -139,6 +139,7 @@ struct o_ctx {
 	v3 cam_pos, cam_dir, cam_up; float fov, focus, aperture;
 	o_obj* objs; int nobj, cap_obj;
 	float intensite_lumiere, envmap_intensity;
+	int is_lenticular, lenticular_nb_images, lenticular_pixel_width; float lenticular_max_angle;   /* Camera, Vector.h:831-834 */
 	float* background; int backgroundW, backgroundH;
 	float fog_density, fog_absorption, fog_density_decay, fog_absorption_decay, phase_aniso;   /* Geometry.h:1371-1377 */
 	int fog_type, fog_phase_type;   /* Scene::background (Geometry.h:1355-1366), top row first, x196964.699 */
@@ -844,7 +845,18 @@ static o_ray generate_direction(const o_ctx* c, float init_t, int i, int j, floa
 	float k = W / (2 * tanf(c->fov / 2));
 	v3 camera_right = vcross(c->cam_dir, c->cam_up);
 	v3 C1 = c->cam_pos;
-	v3 dv = V((float)(j - W / 2 + 0.5 + dx_sensor), (float)(i - H / 2 + 0.5 + dy_sensor), k);  /* int, then double sum, narrowed */
+	v3 dv;
+	if (c->is_lenticular) {                                        /* Vector.h:799-812 */
+		float L = c->focus * tanf(c->lenticular_max_angle / 2) / (c->lenticular_nb_images / 2.0);
+		int offset = -((j / c->lenticular_pixel_width) % c->lenticular_nb_images - c->lenticular_nb_images / 2);
+		v3 P = vadd(c->cam_pos, vscale(c->focus, V(0, 0, 1)));
+		C1 = vadd(c->cam_pos, vscale(offset * L, camera_right));
+		v3 v1 = vnormalize(vsub(P, C1));
+		v3 PprojCam1 = vadd(vscale(k / vdot(v1, c->cam_dir), v1), C1);
+		float pixProjCam1_j = PprojCam1.x + W / 2 - 0.5;
+		float pixProjCam1_i = PprojCam1.y + H / 2 - 0.5;
+		dv = V((j - pixProjCam1_j) + dx_sensor, (i - pixProjCam1_i) + dy_sensor, k);
+	} else dv = V((float)(j - W / 2 + 0.5 + dx_sensor), (float)(i - H / 2 + 0.5 + dy_sensor), k);  /* int, then double sum, narrowed */
 	dv = vnormalize(dv);
 	dv = vadd(vadd(vscale(dv.x, camera_right), vscale(dv.y, c->cam_up)), vscale(dv.z, c->cam_dir));
 	v3 destination = vadd(C1, vscale(c->focus / fabsf(vdot(dv, c->cam_dir)), dv));
@@ -1609,6 +1621,9 @@ void o_add_col_subsurface(o_ctx* c, int obj, const float* rgb) { obj_push_tex(&c
 void o_set_group_subsurface(o_ctx* c, int obj, int grp, const float* rgb) {
 	o_obj* o = &c->objs[obj];
 	if (grp >= 0 && grp < o->ntex[T_KSUB]) o->tex[T_KSUB][grp].multiplier = V(rgb[0], rgb[1], rgb[2]);
+}
+void o_set_lenticular(o_ctx* c, int on, int nb_images, float max_angle, int pixel_width) {
+	c->is_lenticular = on != 0; c->lenticular_nb_images = nb_images; c->lenticular_max_angle = max_angle; c->lenticular_pixel_width = pixel_width;
 }
 /* Scene::fog_* (Geometry.h:1371-1377) */
 void o_set_fog(o_ctx* c, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso) {

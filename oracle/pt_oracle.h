@@ -71,6 +71,7 @@ void   o_phong_eval(int n, const float* mat9, const float* wi3, const float* wo3
 void   o_getcolor_samples(o_ctx*, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy);
 void   o_render_seeded(o_ctx*, float* imagedouble, float* sample_count);
 void   o_set_object_ghost(o_ctx*, int obj, int ghost);
+void   o_set_lenticular(o_ctx*, int on, int nb_images, float max_angle, int pixel_width);
 void   o_set_group_subsurface(o_ctx*, int obj, int grp, const float* rgb);
 void   o_add_col_subsurface(o_ctx*, int obj, const float* rgb);
 void   o_set_fog(o_ctx*, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso);

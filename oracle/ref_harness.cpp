@@ -185,6 +185,10 @@ void ref_set_group_subsurface(RefCtx* c, int obj, int grp, const float* rgb) {
 	Object* o = c->rt->s.objects[obj];
 	if (grp >= 0 && grp < (int)o->subsurface.size()) o->subsurface[grp].multiplier = Vector(rgb[0], rgb[1], rgb[2]);
 }
+void ref_set_lenticular(RefCtx* c, int on, int nb_images, float max_angle, int pixel_width) {
+	Camera& cam = c->rt->cam;
+	cam.is_lenticular = on != 0; cam.lenticular_nb_images = nb_images; cam.lenticular_max_angle = max_angle; cam.lenticular_pixel_width = pixel_width;
+}
 void ref_set_object_ghost(RefCtx* c, int obj, int ghost) { c->rt->s.objects[obj]->ghost = ghost != 0; }
 // Scene::background as Scene::load_background leaves it (Geometry.h:1355-1363), set directly (the loader reads BMP files)
 void ref_set_background(RefCtx* c, const float* rgb, int W, int H) {

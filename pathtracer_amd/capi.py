@@ -86,7 +86,8 @@ class MiptRenderParams(C.Structure):
                 ("filter_integral", C.c_void_p), ("samples2d", C.c_void_p), ("randomPerPixel", C.c_void_p),
                 ("centerLight", _f * 3), ("radiusLight", _f), ("lightPower", _f), ("envmap_intensity", _f),
                 ("seed_stride", C.c_uint64), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
-                ("tile_size", C.c_int32), ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("tile_size", C.c_int32), ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32),
+                ("is_lenticular", C.c_int32), ("lenticular_nb_images", C.c_int32), ("lenticular_pixel_width", C.c_int32), ("lenticular_max_angle", _f)]
 
 
 HIT_DTYPE = np.dtype([("has_inter", np.int32), ("object_id", np.int32), ("triangle_id", np.int32), ("t", np.float32), ("P", np.float32, 3),
@@ -462,6 +463,10 @@ class HostRaytracer:
         buf = np.zeros(1 << 22, np.float32)
         n = self.host.mh_get_background(self.h, _p(buf, _f), buf.size, C.byref(W), C.byref(H))
         return buf[:max(n, 0)].reshape(H.value, W.value, 3).copy() if n > 0 else None
+
+    def set_lenticular(self, on, nb_images=10, max_angle=35 * np.pi / 180. * 0.25, pixel_width=1):
+        """Camera::is_lenticular & co (Vector.h:720-723, 799-812)."""
+        self.host.mh_set_lenticular(self.h, int(on), int(nb_images), _f(max_angle), int(pixel_width))
 
     def set_has_denoiser(self, on=True):
         self.host.mh_set_has_denoiser(self.h, 1 if on else 0)

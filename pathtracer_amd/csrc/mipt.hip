@@ -676,6 +676,11 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	const float* a = p->cam_direction; const float* b = p->cam_up;
 	R.cam_right[0] = a[1] * b[2] - a[2] * b[1]; R.cam_right[1] = a[2] * b[0] - a[0] * b[2]; R.cam_right[2] = a[0] * b[1] - a[1] * b[0];
 	R.cam_k = (float)p->W / (2 * tanf(p->cam_fov / 2));     // Vector.h:793, host libm like the reference
+	R.lent_on = p->is_lenticular != 0; R.lent_nb = p->lenticular_nb_images; R.lent_pw = p->lenticular_pixel_width; R.lent_L = 0.f;
+	if (R.lent_on) {
+		if (R.lent_nb <= 0 || R.lent_pw <= 0) return fail(c, MIPT_ERR_INVALID, "lenticular camera: nb_images and pixel_width must be positive");
+		R.lent_L = (float)((double)(p->cam_focus_distance * tanf(p->lenticular_max_angle / 2)) / ((double)R.lent_nb / 2.0));   // Vector.h:800
+	}
 	R.focus = p->cam_focus_distance; R.aperture = p->cam_aperture; R.init_t = p->double_frustum_start_t;
 	memcpy(R.centerLight, p->centerLight, 12); R.radiusLight = p->radiusLight; R.lightPower = p->lightPower; R.envmap_intensity = p->envmap_intensity;
 	R.sigma_filter = p->sigma_filter; R.filter_size = p->filter_size;

@@ -87,6 +87,7 @@ struct DRender {
 	int W, H, nrays, nb_bounces;
 	float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
 	float cam_k;               // W / (2*tan(fov/2)) (Vector.h:793), evaluated on the host
+	int lent_on, lent_nb, lent_pw; float lent_L;   // lenticular camera (Vector.h:799-812); L = focus*tan(max_angle/2)/(nb/2.0), on the host
 	float focus, aperture, init_t;
 	float centerLight[3], radiusLight, lightPower, envmap_intensity;
 	float sigma_filter; int filter_size;

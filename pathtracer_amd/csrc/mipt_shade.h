@@ -7,12 +7,23 @@
 // ---------------------------------------------------------------- Camera::generateDirection (Vector.h:792-825)
 MIPT_DEV Ray camera_ray(const DRender& R, int i, int j, float dx_sensor, float dy_sensor, float dx_aperture, float dy_aperture) {
 	f3 pos = ld3(R.cam_pos), dir = ld3(R.cam_dir), up = ld3(R.cam_up), right = ld3(R.cam_right);
-	// Vector(j - W/2 + 0.5 + dx, i - H/2 + 0.5 + dy, k): integer W/2, double sum, narrowed
-	f3 dv = mk3((float)((double)(j - R.W / 2) + 0.5 + (double)dx_sensor), (float)((double)(i - R.H / 2) + 0.5 + (double)dy_sensor), R.cam_k);
+	f3 dv, C1 = pos;
+	if (R.lent_on) {                                                      // Vector.h:799-812: one of lent_nb cameras per pixel column
+		const int offset = -((j / R.lent_pw) % R.lent_nb - R.lent_nb / 2);
+		const f3 Pf = pos + R.focus * mk3(0, 0, 1);
+		C1 = pos + ((float)offset * R.lent_L) * right;
+		const f3 v1 = normalize(Pf - C1);
+		const f3 proj = (R.cam_k / dot(v1, dir)) * v1 + C1;
+		const float pj = (float)((double)(proj.x + (float)(R.W / 2)) - 0.5), pi = (float)((double)(proj.y + (float)(R.H / 2)) - 0.5);
+		dv = mk3(((float)j - pj) + dx_sensor, ((float)i - pi) + dy_sensor, R.cam_k);
+	} else {
+		// Vector(j - W/2 + 0.5 + dx, i - H/2 + 0.5 + dy, k): integer W/2, double sum, narrowed
+		dv = mk3((float)((double)(j - R.W / 2) + 0.5 + (double)dx_sensor), (float)((double)(i - R.H / 2) + 0.5 + (double)dy_sensor), R.cam_k);
+	}
 	dv = normalize(dv);
 	dv = right * dv.x + up * dv.y + dir * dv.z;
-	f3 destination = pos + (R.focus / fabsf(dot(dv, dir))) * dv;
-	f3 new_origin = pos + dx_aperture * right + dy_aperture * up;
+	f3 destination = C1 + (R.focus / fabsf(dot(dv, dir))) * dv;
+	f3 new_origin = C1 + dx_aperture * right + dy_aperture * up;
 	f3 new_direction = normalize(destination - new_origin);
 	Ray r;
 	r.o = new_origin + (R.init_t * new_direction) / dot(new_direction, dir);

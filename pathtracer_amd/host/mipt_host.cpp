@@ -896,7 +896,7 @@ void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
 // load_from_file, Geometry.h:455-662; Sphere / Plane / TriMesh tails, Geometry.h:875-908, 1193-1213, TriangleMesh.h:
 // 132-162).  Values are written with "%f" (six decimals) and read back from those decimals, exactly like the reference,
 // so a scene loaded here and there is the same scene.  The optional / backward-compatible records of load_scene are
-// accepted.  What the hot path does not cover is refused loudly rather than dropped: lenticular / array cameras, a
+// accepted.  What the hot path does not cover is refused loudly rather than dropped: array cameras, a
 // key-framed transforms, PointSet objects, per-face colour files.
 namespace {
 struct ScnReader {
@@ -1030,9 +1030,9 @@ bool Raytracer::load_scene(const char* filename) {
 	if (!R.getf("fov:", cam.fov) || !R.getf("focus:", cam.focus_distance) || !R.getf("aperture:", cam.aperture) || !R.getf("sigma_filter:", sigma_filter) || !R.getf("gamma:", gamma)) return bail("");
 	if (!R.next()) return bail("truncated header");
 	if (R.starts("is_lenticular:")) {
-		if (strtoul(R.after("is_lenticular:"), nullptr, 10) != 0) return bail("lenticular cameras are outside the hot path");
+		cam.is_lenticular = strtoul(R.after("is_lenticular:"), nullptr, 10) != 0;
 		int u = 0; float fl = 0;
-		if (!R.getu("lenticular_nb_images:", u) || !R.getf("lenticular_max_angle:", fl) || !R.getu("lenticular_pixel_width:", u)) return bail("");
+		if (!R.getu("lenticular_nb_images:", cam.lenticular_nb_images) || !R.getf("lenticular_max_angle:", cam.lenticular_max_angle) || !R.getu("lenticular_pixel_width:", cam.lenticular_pixel_width)) return bail("");
 		if (!R.getu("isArray:", u)) return bail("");
 		if (u != 0) return bail("camera arrays are outside the hot path");
 		if (!R.getu("nbviewX:", u) || !R.getu("nbviewY:", u) || !R.getf("maxSpacingX:", fl) || !R.getf("maxSpacingY:", fl)) return bail("");
@@ -1132,7 +1132,8 @@ bool Raytracer::save_scene(const char* filename) const {
 	fprintf(f, "nbframes: %u\n", 1u);
 	fprintf(f, "Cam: (%f, %f, %f), (%f, %f, %f), (%f, %f, %f)\n", cam.position[0], cam.position[1], cam.position[2], cam.direction[0], cam.direction[1], cam.direction[2], cam.up[0], cam.up[1], cam.up[2]);
 	fprintf(f, "fov: %f\nfocus: %f\naperture: %f\nsigma_filter: %f\ngamma: %f\n", cam.fov, cam.focus_distance, cam.aperture, sigma_filter, gamma);
-	fprintf(f, "is_lenticular: 0\nlenticular_nb_images: 10\nlenticular_max_angle: %f\nlenticular_pixel_width: 1\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n", (float)(35 * M_PI / 180. * 0.25), 0.f, 0.f);   // Camera defaults (Vector.h:720-730)
+	fprintf(f, "is_lenticular: %u\nlenticular_nb_images: %u\nlenticular_max_angle: %f\nlenticular_pixel_width: %u\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n",
+	        cam.is_lenticular ? 1u : 0u, (unsigned)cam.lenticular_nb_images, cam.lenticular_max_angle, (unsigned)cam.lenticular_pixel_width, 0.f, 0.f);
 	fprintf(f, "bounces: %u\nhas_denoiser: %u\n", nb_bounces, has_denoiser ? 1u : 0u);
 	fprintf(f, "intensite_lum: %f\nintensite_envmap: %f\n", s.intensite_lumiere, s.envmap_intensity);
 	if (s.backgroundfilename.size() > 0) fprintf(f, "background: %s\n", s.backgroundfilename.c_str());   // :1125-1126
@@ -1309,6 +1310,8 @@ void Raytracer::build_descs() {
 	p.radiusLight = radiusLight; p.lightPower = lightPower; p.envmap_intensity = s.envmap_intensity;
 	p.seed_stride = seed_stride; p.sample_begin = 0; p.sample_end = nrays;
 	p.tile_size = tile_size_; p.tile_rank = tile_rank_; p.tile_nranks = tile_nranks_;
+	p.is_lenticular = cam.is_lenticular ? 1 : 0; p.lenticular_nb_images = cam.lenticular_nb_images;
+	p.lenticular_pixel_width = cam.lenticular_pixel_width; p.lenticular_max_angle = cam.lenticular_max_angle;
 }
 
 void Raytracer::tone_map(bool divided) {   // Raytracer.cpp:1540-1547 / 1701-1708
@@ -1452,6 +1455,10 @@ int mh_get_background(mh_raytracer* h, float* out, int capacity, int* W, int* H)
 	if ((int)s.background.size() > capacity) return -1;
 	if (out && !s.background.empty()) memcpy(out, s.background.data(), s.background.size() * sizeof(float));
 	return (int)s.background.size();
+}
+void mh_set_lenticular(mh_raytracer* h, int on, int nb_images, float max_angle, int pixel_width) {
+	Camera& c = h->rt.cam;
+	c.is_lenticular = on != 0; c.lenticular_nb_images = nb_images; c.lenticular_max_angle = max_angle; c.lenticular_pixel_width = pixel_width;
 }
 void mh_set_has_denoiser(mh_raytracer* h, int on) { h->rt.has_denoiser = on != 0; }
 float* mh_denoiser_image(mh_raytracer* h, int which) { std::vector<float>& v = which == 0 ? h->rt.albedoImage : (which == 1 ? h->rt.normalImage : h->rt.shadingNormalImage); return v.empty() ? nullptr : v.data(); }

@@ -136,6 +136,10 @@ private:
 struct Camera {                       // Vector.h:700-842 (fields the path reads)
 	Vector position{0, 0, 50}, direction{0, 0, -1}, up{0, 1, 0};
 	float fov = 0, focus_distance = 50, aperture = 0.1f;
+	// lenticular prints: pixel column j is seen from one of lenticular_nb_images shifted cameras (Vector.h:720-723, 799-812)
+	bool is_lenticular = false;
+	int lenticular_nb_images = 10, lenticular_pixel_width = 1;
+	float lenticular_max_angle = (float)(35 * 3.14159265358979323846 / 180. * 0.25);
 };
 
 class Raytracer;
@@ -280,6 +284,7 @@ const void* mh_scene_desc(mh_raytracer*);                 // const mipt_scene_de
 const void* mh_render_params(mh_raytracer*);              // const mipt_render_params*
 float* mh_imagedouble(mh_raytracer*);
 int  mh_get_background(mh_raytracer*, float* out, int capacity, int* W, int* H);
+void mh_set_lenticular(mh_raytracer*, int on, int nb_images, float max_angle, int pixel_width);   // Camera::is_lenticular & co
 void mh_set_has_denoiser(mh_raytracer*, int on);
 void mh_set_fog(mh_raytracer*, float density, float absorption, float density_decay, float absorption_decay, int type, int phase_type, float phase_aniso);   // Scene::fog_*
 void mh_add_col_subsurface(mh_raytracer*, int obj, const float* rgb);             // Object::add_col_subsurface

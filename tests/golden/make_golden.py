@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv:
+if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
     main()
 
 
@@ -410,3 +410,37 @@ def main_jpeg():
 
 if __name__ == "__main__" and "--jpeg" in sys.argv:
     main_jpeg()
+
+
+LENTICULAR_KINDS = ("default", "wide", "dof")
+
+
+def lenticular_scene(X, kind):
+    """Camera::generateDirection with is_lenticular (Vector.h:799-812): pixel column j is seen from one of nb_images cameras."""
+    cfg = scenes.config_c1(64, 36, 3)
+    cfg.nb_bounces = 3
+    if kind == "dof":
+        cfg.aperture = 0.5
+    X.apply_config(cfg)
+    X.add_mesh(scenes.blob_mesh(16))
+    X.set_lenticular(True, *((10, 35 * np.pi / 180. * 0.25, 1) if kind != "wide" else (6, 0.4, 3)))
+    X.prepare()
+    return cfg
+
+
+def main_lenticular():
+    g = {}
+    for kind in LENTICULAR_KINDS:
+        R = Ref()
+        cfg = lenticular_scene(R, kind)
+        g[kind + "_rgb"] = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0]
+    R = Ref()
+    cfg = scenes.config_c1(64, 36, 3); cfg.nb_bounces = 3
+    R.apply_config(cfg); R.add_mesh(scenes.blob_mesh(16)); R.prepare()
+    g["pinhole_rgb"] = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0]
+    np.savez_compressed(os.path.join(OUT, "lenticular.npz"), **g)
+    print("lenticular goldens written")
+
+
+if __name__ == "__main__" and "--lenticular" in sys.argv:
+    main_lenticular()
