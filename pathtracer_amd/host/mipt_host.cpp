@@ -896,7 +896,7 @@ void Raytracer::loadScene() {   // Raytracer.cpp:1238-1274
 // load_from_file, Geometry.h:455-662; Sphere / Plane / TriMesh tails, Geometry.h:875-908, 1193-1213, TriangleMesh.h:
 // 132-162).  Values are written with "%f" (six decimals) and read back from those decimals, exactly like the reference,
 // so a scene loaded here and there is the same scene.  The optional / backward-compatible records of load_scene are
-// accepted.  What the hot path does not cover is refused loudly rather than dropped: array cameras, a
+// accepted.  What the hot path does not cover is refused loudly rather than dropped: a
 // key-framed transforms, PointSet objects, per-face colour files.
 namespace {
 struct ScnReader {
@@ -1033,9 +1033,12 @@ bool Raytracer::load_scene(const char* filename) {
 		cam.is_lenticular = strtoul(R.after("is_lenticular:"), nullptr, 10) != 0;
 		int u = 0; float fl = 0;
 		if (!R.getu("lenticular_nb_images:", cam.lenticular_nb_images) || !R.getf("lenticular_max_angle:", cam.lenticular_max_angle) || !R.getu("lenticular_pixel_width:", cam.lenticular_pixel_width)) return bail("");
+		// camera arrays: the GUI moves the camera from view to view and calls the renderer once per view (mainApp.cpp:886-905);
+		// inside Raytracer the fields only name the exported files, so they are kept and written back
 		if (!R.getu("isArray:", u)) return bail("");
-		if (u != 0) return bail("camera arrays are outside the hot path");
-		if (!R.getu("nbviewX:", u) || !R.getu("nbviewY:", u) || !R.getf("maxSpacingX:", fl) || !R.getf("maxSpacingY:", fl)) return bail("");
+		cam.isArray = u != 0;
+		if (!R.getu("nbviewX:", cam.nbviewX) || !R.getu("nbviewY:", cam.nbviewY) || !R.getf("maxSpacingX:", cam.maxSpacingX) || !R.getf("maxSpacingY:", cam.maxSpacingY)) return bail("");
+		(void)fl;
 		if (!R.getu("bounces:", nb_bounces)) return bail("");
 	} else if (R.starts("bounces:")) nb_bounces = (int)strtoul(R.after("bounces:"), nullptr, 10);
 	else return bail("expected bounces");
@@ -1132,8 +1135,9 @@ bool Raytracer::save_scene(const char* filename) const {
 	fprintf(f, "nbframes: %u\n", 1u);
 	fprintf(f, "Cam: (%f, %f, %f), (%f, %f, %f), (%f, %f, %f)\n", cam.position[0], cam.position[1], cam.position[2], cam.direction[0], cam.direction[1], cam.direction[2], cam.up[0], cam.up[1], cam.up[2]);
 	fprintf(f, "fov: %f\nfocus: %f\naperture: %f\nsigma_filter: %f\ngamma: %f\n", cam.fov, cam.focus_distance, cam.aperture, sigma_filter, gamma);
-	fprintf(f, "is_lenticular: %u\nlenticular_nb_images: %u\nlenticular_max_angle: %f\nlenticular_pixel_width: %u\nisArray: 0\nnbviewX: 1\nnbviewY: 1\nmaxSpacingX: %f\nmaxSpacingY: %f\n",
-	        cam.is_lenticular ? 1u : 0u, (unsigned)cam.lenticular_nb_images, cam.lenticular_max_angle, (unsigned)cam.lenticular_pixel_width, 0.f, 0.f);
+	fprintf(f, "is_lenticular: %u\nlenticular_nb_images: %u\nlenticular_max_angle: %f\nlenticular_pixel_width: %u\nisArray: %u\nnbviewX: %u\nnbviewY: %u\nmaxSpacingX: %f\nmaxSpacingY: %f\n",
+	        cam.is_lenticular ? 1u : 0u, (unsigned)cam.lenticular_nb_images, cam.lenticular_max_angle, (unsigned)cam.lenticular_pixel_width,
+	        cam.isArray ? 1u : 0u, (unsigned)cam.nbviewX, (unsigned)cam.nbviewY, cam.maxSpacingX, cam.maxSpacingY);
 	fprintf(f, "bounces: %u\nhas_denoiser: %u\n", nb_bounces, has_denoiser ? 1u : 0u);
 	fprintf(f, "intensite_lum: %f\nintensite_envmap: %f\n", s.intensite_lumiere, s.envmap_intensity);
 	if (s.backgroundfilename.size() > 0) fprintf(f, "background: %s\n", s.backgroundfilename.c_str());   // :1125-1126

@@ -140,6 +140,8 @@ struct Camera {                       // Vector.h:700-842 (fields the path reads
 	bool is_lenticular = false;
 	int lenticular_nb_images = 10, lenticular_pixel_width = 1;
 	float lenticular_max_angle = (float)(35 * 3.14159265358979323846 / 180. * 0.25);
+	// camera array (light-field renders): driven by the caller, one render per view; kept for the scene files
+	bool isArray = false; int nbviewX = 1, nbviewY = 1; float maxSpacingX = 0, maxSpacingY = 0;
 };
 
 class Raytracer;

@@ -75,8 +75,7 @@ def test_unsupported_scene_features_are_refused(tmp_path):
     scn = stage(tmp_path)
     text = open(scn).read()
     H = capi.HostRaytracer()
-    for old, new, what in (("isArray: 0", "isArray: 1", "camera arrays"),
-                           ("nb_transforms: 0", "nb_transforms: 2", "key-framed")):
+    for old, new, what in (("nb_transforms: 0", "nb_transforms: 2", "key-framed"),):
         bad = os.path.join(str(tmp_path), "bad.scn")
         open(bad, "w").write(text.replace(old, new, 1))
         with pytest.raises(capi.MiptError, match=what):
