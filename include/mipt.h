@@ -291,7 +291,10 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
  *                     every ray (normally only for rays with a zero direction component)
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
- *   "paths_per_pass"  upper bound on paths in flight per pass
+ *   "paths_per_pass"  upper bound on paths in flight per pass (default 2^29, ~86 GB of path state).  Whatever its value, a pass
+ *                     is sized so that its state fits in ~80 % of the device memory that is free when the render starts
+ *                     (hipMemGetInfo) and holds at most 2^31 paths; if the allocation still fails the pass is halved and retried
+ *   "pass_memory_limit" test hook: > 0 = size the pass as if only this many bytes were free (0 = ask the device)
  *   "samples_per_pass" > 0: a pass renders at most this many samples per pixel; with 1 and a progress callback
  *                     mipt_render behaves like the sample loop of Raytracer::render_image (the caller's buffers hold the
  *                     running sums after every sample) without paying an upload and an allocation per sample; 0 = off */

@@ -222,9 +222,10 @@ class HostRaytracer:
             raise MiptError(self.host.mh_last_error(self.h).decode())
 
     # ---- .scn scene files (Raytracer::load_scene / save_scene of the host mirror)
-    def load_scene(self, path):
-        self.host.mh_load_scene.restype = C.c_int
-        if self.host.mh_load_scene(self.h, str(path).encode()) != 0:
+    def load_scene(self, path, replaced_names=None):
+        """Raytracer::load_scene(filename, replacedNames) (Raytracer.cpp:1149): replaced_names takes the place of the '#' in mesh names."""
+        self.host.mh_load_scene_subst.restype = C.c_int
+        if self.host.mh_load_scene_subst(self.h, str(path).encode(), None if replaced_names is None else str(replaced_names).encode()) != 0:
             raise MiptError("load_scene(%s): %s" % (path, self.host.mh_last_error(self.h).decode()))
         hdr = self.scene_header()
         self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])

@@ -273,7 +273,7 @@ struct mipt_ctx {
 	mipt_stats stats{};
 	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
 	// size changes, or after mipt_set_option("invalidate_tables", 1))
-	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; } tab_key;
+	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; float sigma = 0.f; uint64_t fi_hash = 0; } tab_key;
 	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0, fs = -1; } blk_key;
 	int blk_ndest = 0;
 	int blk_nblocks = 0;
@@ -287,6 +287,7 @@ struct mipt_ctx {
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
+	int64_t opt_pass_memory_limit = 0;      // test hook: > 0 = size the pass as if only this many bytes were free on the device
 	int64_t opt_paths_per_pass = 1 << 29;   // 537 M paths (259 spp at 1080p), ~86 GB of path state: sized for 288 GB of HBM
 };
 
@@ -347,6 +348,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!c || !name) return MIPT_ERR_INVALID;
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
@@ -692,8 +694,13 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 	// tables: compact the reference's Vector[] (stride 3) arrays to stride 2
 	const int ftw = 2 * p->filter_size + 1;
 	size_t n_fi = (size_t)ftw * ftw, n_s2 = (size_t)p->nrays * 2, n_rpp = (size_t)p->W * p->H * 2;
+	// The key also holds sigma and a hash of the summed-area table itself (at most 17 x 17 floats): prepare_render refills
+	// filter_integral in place when sigma changes but ceil(2 sigma) does not (Raytracer.cpp:1354-1369), same address and size.
+	uint64_t fi_hash = 1469598103934665603ull;
+	for (size_t k = 0; k < n_fi; k++) { uint32_t w; memcpy(&w, p->filter_integral + k, 4); fi_hash = (fi_hash ^ w) * 1099511628211ull; }
 	const bool cached = c->tab_buf && c->tab_key.fi == p->filter_integral && c->tab_key.s2 == p->samples2d && c->tab_key.rpp == p->randomPerPixel &&
-	                    c->tab_key.W == p->W && c->tab_key.H == p->H && c->tab_key.nrays == p->nrays && c->tab_key.fs == p->filter_size;
+	                    c->tab_key.W == p->W && c->tab_key.H == p->H && c->tab_key.nrays == p->nrays && c->tab_key.fs == p->filter_size &&
+	                    memcmp(&c->tab_key.sigma, &p->sigma_filter, 4) == 0 && c->tab_key.fi_hash == fi_hash;
 	if (!cached) {
 		std::vector<float> h(n_fi + n_s2 + n_rpp);
 		memcpy(h.data(), p->filter_integral, n_fi * 4);
@@ -705,6 +712,7 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 		HIPCHK(c, hipStreamSynchronize(st));   // h goes out of scope
 		c->tab_key.fi = p->filter_integral; c->tab_key.s2 = p->samples2d; c->tab_key.rpp = p->randomPerPixel;
 		c->tab_key.W = p->W; c->tab_key.H = p->H; c->tab_key.nrays = p->nrays; c->tab_key.fs = p->filter_size;
+		c->tab_key.sigma = p->sigma_filter; c->tab_key.fi_hash = fi_hash;
 	}
 	float* t = (float*)c->tab_buf;
 	R.filter_integral = t; R.samples2d = t + n_fi; R.randomPerPixel = t + n_fi + n_s2;
@@ -829,16 +837,40 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (c->scene_has_ghost) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
 	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass);
 	spp_pass = std::min(spp_pass, ke - kb);
-	const size_t N = (size_t)npix_slots * spp_pass;          // path ids per pass
 	const bool want_aov = d_aov || (dump && dump->out_normal);
 	// 2 = the queue kernel (ghost objects, background photo); the denoiser inputs are a stage of the wavefront pipeline
 	const int pipeline = c->scene_has_ghost ? 2 : (want_aov ? 1 : (int)c->opt_pipeline);
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
-	// carve the pass buffer
-	size_t bytes = N * (sizeof(float4) + sizeof(float2));
-	if (pipeline == 1) bytes += N * (7 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned)) + MIPT_WF_COUNTERS * sizeof(unsigned) + 256;
-	if (want_aov) bytes += N * 2 * sizeof(float4) + 64;
-	if ((rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, bytes))) return rc;
+	// Bytes of pass state per path id, and the part that does not depend on the pass size
+	size_t per_path = sizeof(float4) + sizeof(float2), fixed_bytes = 4096;
+	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES; fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned); }
+	if (want_aov) per_path += 2 * sizeof(float4);
+	const size_t per_path_queue = pipeline == 2 ? MIPT_SIZE_CIRC_ARRAY * sizeof(QContrib) : 0;
+	// The pass is sized for the memory that is actually free (the default of 2^29 paths is ~86 GB of state, sized for an
+	// otherwise empty 288 GB device): at most ~80 % of free + what this context already holds for passes, path ids < 2^31.
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = ~(size_t)0 >> 2; }
+		size_t have = c->pass_buf_bytes + (pipeline == 2 ? c->queue_buf_bytes : 0);
+		if (c->opt_pass_memory_limit > 0) { free_b = (size_t)c->opt_pass_memory_limit; have = 0; }
+		const double budget = 0.8 * ((double)free_b + (double)have) - (double)fixed_bytes;
+		int64_t max_paths = (int64_t)std::max(0.0, budget / (double)(per_path + per_path_queue));
+		max_paths = std::min<int64_t>(max_paths, (int64_t)1 << 31);
+		const int fit = (int)std::min<int64_t>(std::max<int64_t>(1, max_paths / npix_slots), 1 << 30);
+		spp_pass = std::min(spp_pass, fit);
+		if ((int64_t)npix_slots * spp_pass > ((int64_t)1 << 31)) return fail(c, MIPT_ERR_INVALID, "image with more than 2^31 owned pixel slots");
+	}
+	// carve the pass buffer; when the allocation fails all the same (fragmentation, another process), halve the pass and retry
+	size_t N = 0;
+	for (;;) {
+		N = (size_t)npix_slots * spp_pass;          // path ids per pass
+		rc = ensure(c, &c->pass_buf, &c->pass_buf_bytes, N * per_path + fixed_bytes);
+		if (rc == MIPT_OK && pipeline == 2) rc = ensure(c, &c->queue_buf, &c->queue_buf_bytes, N * per_path_queue);
+		if (rc == MIPT_OK) break;
+		(void)hipGetLastError();
+		if (spp_pass == 1) return rc;
+		spp_pass = (spp_pass + 1) / 2;
+	}
 	char* base = (char*)c->pass_buf;
 	auto carve = [&](size_t b) { char* r = base; base += (b + 15) & ~(size_t)15; return r; };
 	DSamples S;
@@ -857,11 +889,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	float4 *aov_n = nullptr, *aov_kd = nullptr;
 	if (want_aov) { aov_n = (float4*)carve(N * sizeof(float4)); aov_kd = (float4*)carve(N * sizeof(float4)); }
-	QContrib* queues = nullptr;
-	if (pipeline == 2) {
-		if ((rc = ensure(c, &c->queue_buf, &c->queue_buf_bytes, N * MIPT_SIZE_CIRC_ARRAY * sizeof(QContrib)))) return rc;
-		queues = (QContrib*)c->queue_buf;
-	}
+	QContrib* queues = pipeline == 2 ? (QContrib*)c->queue_buf : nullptr;
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;

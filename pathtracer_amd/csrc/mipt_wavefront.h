@@ -30,6 +30,8 @@ struct DWave {
 	unsigned* counters;         // queue sizes and heads, one per 128-byte line (MIPT_CNT_* below)
 	DSamples out;
 };
+// bytes of DWave state per path id: 7 float4 + rng + 4 id lists (the pass is sized with it, mipt.hip render_impl)
+#define MIPT_WF_STATE_BYTES (7 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned))
 // Path state is written once and read once per depth, 10 GB per pass: it is accessed with the non-temporal
 // (streaming) cache policy so that it does not displace the BVH from L2 / Infinity Cache.
 #ifndef MIPT_STREAM_STATE

@@ -1,10 +1,14 @@
 // mipt_render — a GUI-free front end on top of the host mirror, in the spirit of the reference's command line
 // (`pathtracer scene.scn out.png`, mainApp.cpp:38-49): the default loadScene() scene (light, environment sphere, ground
 // plane, camera) plus one OBJ/MTL mesh placed like a file dropped on the GUI (scale 30, bottom on the plane,
-// mainApp.cpp:2402-2410), rendered with Raytracer::render_image_nopreviz() on the GPU and written as a binary PPM.
+// mainApp.cpp:2402-2410), rendered with Raytracer::render_image_nopreviz() on the GPU and written by save_image's rule:
+// the container follows the extension of the output name (utils.cpp:178-234; .png / .bmp / .tga / .ppm are written, any
+// other extension is an error, never another format under that name).
 //
-//   mipt_render mesh.obj out.ppm [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]
-//   mipt_render scene.scn out.ppm [-s WxH] [-n spp] [-b bounces] [-d device]     (the reference's scene files; options override the file)
+//   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device]
+//        the reference's command line (mainApp.cpp:38-49): loadScene(), load_scene(argv[1][, argv[3]]), render_image_nopreviz(),
+//        save_image(argv[2]); nameSubst replaces the '#' in the mesh file names of the scene (Geometry.h:524-526); options override the file
+//   mipt_render mesh.obj out.png [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,11 +19,20 @@
 using namespace mipt_host;
 
 int main(int argc, char** argv) {
-	if (argc < 3) { fprintf(stderr, "usage: %s mesh.obj out.ppm [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
+	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.ppm [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
 	int W = 1000, H = 800, spp = 100, bounces = 3, device = 0;
 	const char* merl = nullptr;
 	bool mirror = false;
-	for (int i = 3; i < argc; i++) {
+	const char* name_subst = nullptr;                    // argv[3] of the reference's command line, when it is not an option
+	int first_opt = 3;
+	if (argc > 3 && argv[3][0] != '-') { name_subst = argv[3]; first_opt = 4; }
+	{   // an output name no writer exists for is refused before anything is rendered
+		char why[256];
+		const unsigned char px[3] = {0, 0, 0};
+		if (mh_save_image(argv[2], px, 1, 1, why, sizeof why) != 0) { fprintf(stderr, "%s: %s\n", argv[2], why); return 2; }
+		remove(argv[2]);
+	}
+	for (int i = first_opt; i < argc; i++) {
 		if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { fprintf(stderr, "bad size\n"); return 2; } }
 		else if (!strcmp(argv[i], "-n") && i + 1 < argc) spp = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-b") && i + 1 < argc) bounces = atoi(argv[++i]);
@@ -34,10 +47,10 @@ int main(int argc, char** argv) {
 	auto t0 = std::chrono::steady_clock::now();
 	const size_t len = strlen(argv[1]);
 	if (len > 4 && !strcmp(argv[1] + len - 4, ".scn")) {                   // Raytracer::load_scene; explicit options override the file
-		if (mh_load_scene(h, argv[1]) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
+		if (mh_load_scene_subst(h, argv[1], name_subst) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
 		float hdr[32]; mh_get_scene_header(h, hdr);
 		bool sized = false, sampled = false, bounced = false;
-		for (int i = 3; i < argc; i++) { sized |= !strcmp(argv[i], "-s"); sampled |= !strcmp(argv[i], "-n"); bounced |= !strcmp(argv[i], "-b"); }
+		for (int i = first_opt; i < argc; i++) { sized |= !strcmp(argv[i], "-s"); sampled |= !strcmp(argv[i], "-n"); bounced |= !strcmp(argv[i], "-b"); }
 		if (!sized) { W = (int)hdr[0]; H = (int)hdr[1]; }
 		if (!sampled) spp = (int)hdr[2];
 		if (!bounced) bounces = (int)hdr[3];
@@ -53,11 +66,10 @@ int main(int argc, char** argv) {
 	rc = mh_render_image_nopreviz(h);
 	auto t2 = std::chrono::steady_clock::now();
 	if (rc != MIPT_OK) { fprintf(stderr, "render failed (status %d): %s\n", rc, mh_last_error(h)); return 1; }
-	FILE* f = fopen(argv[2], "wb");
-	if (!f) { fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
-	fprintf(f, "P6\n%d %d\n255\n", W, H);
-	fwrite(mh_image(h), 1, (size_t)W * H * 3, f);
-	fclose(f);
+	{
+		char why[256];
+		if (mh_save_image(argv[2], mh_image(h), W, H, why, sizeof why) != 0) { fprintf(stderr, "%s: %s\n", argv[2], why); return 1; }   // save_image(argv[2], &raytracer.image[0], W, H)
+	}
 	auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
 	fprintf(stderr, "%s: load + BVH %.2f s, render %dx%d x %d spp %.2f s -> %s\n", argv[1], secs(t0, t1), W, H, spp, secs(t1, t2), argv[2]);
 	mh_destroy(h);

@@ -416,6 +416,94 @@ bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, i
 	why = "only JPEG, PNG, binary PPM and uncompressed BMP images are decoded here (TGA / HDR / GIF need the reference's codecs)";
 	return false;
 }
+
+// save_image for 8-bit RGB (utils.cpp:178-234): the container is chosen by the file name's extension, found anywhere in
+// the lower-cased name like the reference's `ls.find(".png")`, in its order of tests (.hdr, .bmp, .tga, .jpg, .png).
+// PNG (8-bit RGB, zlib deflate, per-row choice among the five scanline filters), 24-bit BMP, uncompressed TGA and binary
+// PPM are written here; what the reference writes through a lossy or float codec (.jpg, .hdr) or through CImg (anything
+// else) is refused loudly instead of being written in another format under that name.
+bool write_image_rgb8(const std::string& file, const unsigned char* rgb, int W, int H, std::string& why) {
+	if (W <= 0 || H <= 0 || !rgb) { why = "empty image"; return false; }
+	std::string ls(file);
+	for (char& ch : ls) ch = (char)tolower((unsigned char)ch);
+	auto has = [&](const char* ext) { return ls.find(ext) != std::string::npos; };
+	enum { F_PNG, F_BMP, F_TGA, F_PPM } fmt;
+	if (has(".hdr")) { why = "Radiance .hdr output is not written here (float codec of the reference)"; return false; }
+	else if (has(".bmp")) fmt = F_BMP;
+	else if (has(".tga")) fmt = F_TGA;
+	else if (has(".jpg")) { why = "JPEG output is not written here (lossy codec of the reference)"; return false; }
+	else if (has(".png")) fmt = F_PNG;
+	else if (has(".ppm")) fmt = F_PPM;
+	else { why = "unknown image extension (written here: .png, .bmp, .tga, .ppm)"; return false; }
+	std::vector<unsigned char> out;
+	auto put = [&](const void* p, size_t n) { out.insert(out.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+	auto le16 = [&](unsigned v) { unsigned char b[2] = {(unsigned char)v, (unsigned char)(v >> 8)}; put(b, 2); };
+	auto le32 = [&](unsigned v) { unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; put(b, 4); };
+	const size_t row = (size_t)W * 3;
+	if (fmt == F_PPM) {
+		char hdr[64]; const int n = snprintf(hdr, sizeof hdr, "P6\n%d %d\n255\n", W, H);
+		put(hdr, (size_t)n); put(rgb, row * H);
+	} else if (fmt == F_BMP) {                           // BITMAPINFOHEADER, 24 bits, rows bottom-up, BGR, padded to 4 bytes
+		const size_t pad = (4 - row % 4) % 4, img = (row + pad) * H;
+		put("BM", 2); le32((unsigned)(54 + img)); le32(0); le32(54);
+		le32(40); le32((unsigned)W); le32((unsigned)H); le16(1); le16(24); le32(0); le32((unsigned)img); le32(0); le32(0); le32(0); le32(0);
+		const unsigned char zero[3] = {0, 0, 0};
+		for (int i = H - 1; i >= 0; i--) {
+			for (int j = 0; j < W; j++) { const unsigned char* q = rgb + (size_t)i * row + 3 * j; const unsigned char bgr[3] = {q[2], q[1], q[0]}; put(bgr, 3); }
+			put(zero, pad);
+		}
+	} else if (fmt == F_TGA) {                           // type 2 (uncompressed true colour), top-left origin, BGR
+		const unsigned char hdr[18] = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, (unsigned char)W, (unsigned char)(W >> 8), (unsigned char)H, (unsigned char)(H >> 8), 24, 0x20};
+		put(hdr, 18);
+		for (size_t k = 0; k < (size_t)W * H; k++) { const unsigned char bgr[3] = {rgb[3 * k + 2], rgb[3 * k + 1], rgb[3 * k]}; put(bgr, 3); }
+	} else {
+		// scanlines with the filter (None / Sub / Up / Average / Paeth) whose output has the smallest sum of |signed byte|
+		std::vector<unsigned char> raw((row + 1) * H), cand(row);
+		std::vector<unsigned char> zero_row(row, 0);
+		for (int i = 0; i < H; i++) {
+			const unsigned char* cur = rgb + (size_t)i * row;
+			const unsigned char* up = i ? cur - row : zero_row.data();
+			int best_f = 0; unsigned long best_sum = ~0ul;
+			for (int f = 0; f < 5; f++) {
+				unsigned long sum = 0;
+				for (size_t x = 0; x < row; x++) {
+					const int a = x >= 3 ? cur[x - 3] : 0, b = up[x], c = x >= 3 ? up[x - 3] : 0;
+					int pred = 0;
+					if (f == 1) pred = a; else if (f == 2) pred = b; else if (f == 3) pred = (a + b) >> 1;
+					else if (f == 4) { const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+					const unsigned char v = (unsigned char)(cur[x] - pred);
+					cand[x] = v; sum += (unsigned long)abs((int)(signed char)v);
+				}
+				if (sum < best_sum) { best_sum = sum; best_f = f; raw[(size_t)i * (row + 1)] = (unsigned char)f; memcpy(&raw[(size_t)i * (row + 1) + 1], cand.data(), row); }
+			}
+			(void)best_f;
+		}
+		uLongf zlen = compressBound((uLong)raw.size());
+		std::vector<unsigned char> z(zlen);
+		if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { why = "zlib compress failed"; return false; }
+		auto chunk = [&](const char* tag, const unsigned char* data, size_t n) {
+			const unsigned char len[4] = {(unsigned char)(n >> 24), (unsigned char)(n >> 16), (unsigned char)(n >> 8), (unsigned char)n};
+			put(len, 4);
+			const size_t at = out.size();
+			put(tag, 4); if (n) put(data, n);
+			const unsigned long crc = crc32(0L, out.data() + at, (uInt)(n + 4));
+			const unsigned char cb[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+			put(cb, 4);
+		};
+		const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+		put(sig, 8);
+		const unsigned char ihdr[13] = {(unsigned char)(W >> 24), (unsigned char)(W >> 16), (unsigned char)(W >> 8), (unsigned char)W,
+		                                (unsigned char)(H >> 24), (unsigned char)(H >> 16), (unsigned char)(H >> 8), (unsigned char)H, 8, 2, 0, 0, 0};
+		chunk("IHDR", ihdr, 13);
+		chunk("IDAT", z.data(), (size_t)zlen);
+		chunk("IEND", nullptr, 0);
+	}
+	FILE* f = fopen(file.c_str(), "wb");
+	if (!f) { why = "cannot write " + file; return false; }
+	const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+	if (fclose(f) != 0 || !ok) { why = "short write to " + file; return false; }
+	return true;
+}
 }  // namespace
 
 namespace {
@@ -967,9 +1055,14 @@ void scn_texture_list(ScnReader& R, const char* count_key, bool count_already_re
 	}
 }
 
-bool scn_object_common(ScnReader& R, Object* o, const std::string& dir) {      // Object::load_from_file
+bool scn_object_common(ScnReader& R, Object* o, const std::string& dir, const char* replacedNames = nullptr) {      // Object::load_from_file
 	if (!R.expect("name:")) return false;
 	o->name = R.after("name:");
+	if (replacedNames) {                                // Geometry.h:524-526: the first '#' of the name becomes replacedNames
+		const size_t at = o->name.find("#");            // (no '#': std::string::replace throws there and the program ends)
+		if (at == std::string::npos) return R.fail("object name without a '#' to substitute \"" + std::string(replacedNames) + "\" for");
+		o->name.replace(at, 1, std::string(replacedNames));
+	}
 	int b = 0;
 	if (!R.getu("miroir:", b)) return false;
 	o->miroir = b != 0;
@@ -1011,7 +1104,7 @@ bool scn_object_common(ScnReader& R, Object* o, const std::string& dir) {      /
 }
 }  // namespace
 
-bool Raytracer::load_scene(const char* filename) {
+bool Raytracer::load_scene(const char* filename, const char* replacedNames) {
 	ScnReader R; R.f = fopen(filename, "r");
 	if (!R.f) { err_ = std::string("cannot open ") + filename; return false; }
 	const std::string dir = dir_of(filename);
@@ -1087,7 +1180,7 @@ bool Raytracer::load_scene(const char* filename) {
 			pl->name = "Plane";
 		} else if (R.starts("NEW MESH")) {
 			Object tmp;                                                   // Object::load_from_file runs before TriMesh::init
-			if (!scn_object_common(R, &tmp, dir)) return bail("");
+			if (!scn_object_common(R, &tmp, dir, replacedNames)) return bail("");      // only meshes (and PointSets) substitute: Geometry.cpp:11-25
 			if (!R.next()) return bail("truncated mesh");
 			bool centered = true;
 			int hascsv = 0;
@@ -1476,6 +1569,13 @@ int mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W
 	return 0;
 }
 int mh_load_scene(mh_raytracer* h, const char* scn) { return h->rt.load_scene(scn) ? 0 : -1; }
+int mh_load_scene_subst(mh_raytracer* h, const char* scn, const char* replacedNames) { return h->rt.load_scene(scn, replacedNames) ? 0 : -1; }
+int mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char* err, int errlen) {
+	std::string why;
+	if (write_image_rgb8(file, rgb, W, H, why)) return 0;
+	if (err && errlen > 0) { strncpy(err, why.c_str(), errlen - 1); err[errlen - 1] = 0; }
+	return -1;
+}
 int mh_save_scene(mh_raytracer* h, const char* scn) { return h->rt.save_scene(scn) ? 0 : -1; }
 int mh_num_objects(mh_raytracer* h) { return (int)h->rt.s.objects.size(); }
 void mh_get_scene_header(mh_raytracer* h, float* o) {

@@ -177,7 +177,7 @@ public:
 	Raytracer();
 	~Raytracer();
 	void loadScene();                 // Raytracer.cpp:1238-1274
-	bool load_scene(const char* filename);         // Raytracer.cpp:1148-1236 (.scn text format); false + last_error() on refusal
+	bool load_scene(const char* filename, const char* replacedNames = nullptr);   // Raytracer.cpp:1148-1236 (.scn text format; replacedNames: Geometry.h:524-526); false + last_error() on refusal
 	bool save_scene(const char* filename) const;   // Raytracer.cpp:1096-1145
 	void prepare_render(float time);  // Raytracer.cpp:1321-1391 + scene upload
 	void render_image();              // Raytracer.cpp:1424-1563: progressive, one pass per sample
@@ -254,6 +254,8 @@ void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_l
 void mh_set_envmap_intensity(mh_raytracer*, float v);
 int  mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W, int* H, char* err, int errlen);   // PPM / PNG as stb_image delivers them (3 channels)
 int  mh_load_scene(mh_raytracer*, const char* scn_file);   // Raytracer::load_scene; 0 or -1 (mh_last_error)
+int  mh_load_scene_subst(mh_raytracer*, const char* scn_file, const char* replacedNames);   // Raytracer::load_scene(filename, replacedNames): the '#' of mesh names
+int  mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char* err, int errlen);   // save_image (utils.cpp:178-234) for 8-bit RGB: .png / .bmp / .tga / .ppm by extension; -1 + text otherwise
 int  mh_save_scene(mh_raytracer*, const char* scn_file);   // Raytracer::save_scene
 int  mh_num_objects(mh_raytracer*);
 void mh_get_scene_header(mh_raytracer*, float* out32);     // W,H,nrays,bounces, cam pos/dir/up, fov, focus, aperture, sigma, gamma, intensite_lum, intensite_envmap, frustum t

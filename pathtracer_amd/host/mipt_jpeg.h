@@ -22,9 +22,10 @@ namespace mipt_jpeg {
 
 struct Huff {
 	uint8_t bits[17] = {0};
-	uint8_t vals[256];
-	int mincode[18], maxcode[18], valptr[17];
-	bool present = false;
+	uint8_t vals[256] = {0};
+	int mincode[18] = {0}, maxcode[18], valptr[17] = {0};
+	bool present = false;                   // set by build(); a scan that names a table no DHT defined is refused (scan_header)
+	Huff() { for (int& m : maxcode) m = -1; }   // no code length matches until build() ran
 	void build() {
 		int code = 0, k = 0;
 		for (int l = 1; l <= 16; l++) {
@@ -155,7 +156,7 @@ struct Decoder {
 	bool block_baseline(int16_t* data, Comp& cp) {
 		const uint16_t* dq = dequant[cp.tq];
 		int t = decode(hdc[cp.hd]);
-		if (t < 0) return fail("bad huffman code");
+		if (t < 0 || t > 15) return fail("bad huffman code");     // a DC category above 15 (crafted DHT) would shift by more than the bit buffer holds
 		memset(data, 0, 64 * sizeof(int16_t));
 		int dc = cp.dc_pred + (t ? extend(t) : 0);
 		cp.dc_pred = dc;
@@ -175,7 +176,7 @@ struct Decoder {
 		if (succ_high == 0) {
 			memset(data, 0, 64 * sizeof(int16_t));
 			int t = decode(hdc[cp.hd]);
-			if (t < 0) return fail("bad huffman code");
+			if (t < 0 || t > 15) return fail("bad huffman code");
 			int dc = cp.dc_pred + (t ? extend(t) : 0);
 			cp.dc_pred = dc;
 			data[0] = (int16_t)(dc << succ_low);
@@ -311,6 +312,9 @@ struct Decoder {
 		}
 		hmax = vmax = 1;
 		for (int i = 0; i < ncomp; i++) { if (c[i].h > hmax) hmax = c[i].h; if (c[i].v > vmax) vmax = c[i].v; }
+		// the upsampling walks whole multiples (hs = hmax / h): factors that do not divide the maximum (h = 3 under hmax = 4)
+		// would read W samples from rows that hold fewer
+		for (int i = 0; i < ncomp; i++) if (hmax % c[i].h != 0 || vmax % c[i].v != 0) return fail("sampling factors that do not divide the largest one");
 		mcux = (W + hmax * 8 - 1) / (hmax * 8); mcuy = (H + vmax * 8 - 1) / (vmax * 8);
 		for (int i = 0; i < ncomp; i++) {
 			c[i].x = (W * c[i].h + hmax - 1) / hmax; c[i].y = (H * c[i].v + vmax - 1) / vmax;
@@ -337,6 +341,11 @@ struct Decoder {
 		int a = get8(); succ_high = a >> 4; succ_low = a & 15;
 		if (progressive) { if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) return fail("bad SOS"); }
 		else { if (spec_start != 0 || succ_high != 0 || succ_low != 0) return fail("bad SOS"); spec_end = 63; }
+		for (int i = 0; i < scan_n; i++) {                    // every table the scan will decode with must have come in a DHT
+			const Comp& cp = c[order[i]];
+			const bool need_dc = !progressive || (spec_start == 0 && succ_high == 0), need_ac = !progressive || spec_start > 0;
+			if ((need_dc && !hdc[cp.hd].present) || (need_ac && !hac[cp.ha].present)) return fail("scan uses a huffman table that was never defined");
+		}
 		return true;
 	}
 	bool other_marker(int m) {

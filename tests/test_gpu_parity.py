@@ -297,3 +297,46 @@ def test_scene_is_uploaded_again_only_when_it_changed():
     fresh.set_group_texture(oid, 0, 0, scenes.checker_texture(64, 32, 99, 4))
     e, _, _ = fresh.render_image_nopreviz()
     assert_bits(d, e, "image after the edits")
+
+
+def test_filter_sigma_change_on_one_context():
+    """prepare_render refills filter_integral IN PLACE when sigma changes but ceil(2 sigma) does not (Raytracer.cpp:1354-1369:
+    same address, same size), so the device copy of the tables is keyed on sigma and on the table's content too: a
+    second render on the same context with another sigma must match a fresh oracle at that sigma, bit for bit."""
+    from oracle.binding import Oracle
+    mesh = scenes.blob_mesh(24)
+    G = capi.HostRaytracer(device=0)
+    for sigma in (0.5, 0.4, 1.0, 0.8, 0.5):
+        cfg = scenes.config_c1(64, 40, 3)
+        cfg.sigma_filter = sigma
+        O = Oracle()
+        O.apply_config(cfg)
+        O.add_mesh(mesh)
+        O.prepare()
+        G.apply_config(cfg)
+        if sigma == 0.5 and G.num_objects() < 4:
+            G.add_mesh(mesh)
+        G.prepare()
+        img, cnt = G.render()
+        oimg, ocnt = O.render_seeded()
+        assert_bits(cnt, ocnt, f"splat weights at sigma {sigma}")
+        assert_bits(img, oimg, f"image at sigma {sigma}")
+
+
+def test_pass_is_sized_for_the_free_memory():
+    """A pass never asks for more state than the device has free (hipMemGetInfo; here a pretended 24 MB through the
+    test hook): the render splits into more passes instead of failing, and the image only changes in summation order."""
+    g = load_golden("scene_blob32.npz")
+    rt, (mesh, cfg, oid) = gpu("blob32")
+    img0, cnt0 = rt.render()
+    assert rt.stats()["passes"] == 1
+    slots = ((cfg.W + 7) // 8) * ((cfg.H + 7) // 8) * 64
+    rt.set_option("pass_memory_limit", int((2.5 * slots * 160 + 240000) / 0.8))     # room for about two samples per pixel and pass (160 B of state per path)
+    img, cnt = rt.render()
+    assert 1 < rt.stats()["passes"] < cfg.spp
+    assert np.abs(normalised(img, cnt) - normalised(img0, cnt0)).max() < 1e-5
+    rt.set_option("pass_memory_limit", 1)                                 # not even one sample fits: one sample per pass is still tried
+    img, cnt = rt.render()
+    assert rt.stats()["passes"] == cfg.spp
+    assert np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max() < 1e-5
+    rt.set_option("pass_memory_limit", 0)

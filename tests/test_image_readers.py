@@ -194,3 +194,123 @@ def test_jpeg_kinds_outside_the_decoder_are_refused(tmp_path):
     q.write_bytes(b"\xff\xd8\xff\xdb\x00")
     with pytest.raises(capi.MiptError):
         host_read(q)
+
+
+def host_write(path, rgb):
+    mipt, host = capi.load()
+    err = C.create_string_buffer(256)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    host.mh_save_image.restype = C.c_int
+    rc = host.mh_save_image(str(path).encode(), rgb.ctypes.data_as(C.POINTER(C.c_ubyte)), rgb.shape[1], rgb.shape[0], err, 256)
+    if rc != 0:
+        raise capi.MiptError(err.value.decode())
+
+
+@pytest.mark.parametrize("name", ["out.png", "OUT.PNG", "frame.bmp", "frame.ppm"])
+def test_save_image_by_extension_round_trips(tmp_path, name):
+    """save_image's rule (utils.cpp:178-234): the container follows the extension (lower-cased).  What the writer
+    produces, the host mirror's own readers decode to the same pixels; a PNG is also a valid file for zlib + the PNG
+    chunk layout (checked independently here)."""
+    rng = np.random.default_rng(len(name))
+    img = rng.integers(0, 256, (23, 37, 3), dtype=np.uint8)
+    img[5:12, 3:30] = img[5:6, 3:4]                    # a flat patch and a gradient: exercises the row filters
+    img[14:20] = (np.arange(37)[None, :, None] * 6 + np.arange(3)).astype(np.uint8)
+    p = tmp_path / name
+    host_write(p, img)
+    assert np.array_equal(host_read(p), img)
+    data = p.read_bytes()
+    if name.lower().endswith(".png"):
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, seen = 8, b"", []
+        while pos < len(data):
+            n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+            seen.append(tag)
+            if tag == b"IHDR":
+                assert struct.unpack(">IIBBBBB", body) == (37, 23, 8, 2, 0, 0, 0)
+            if tag == b"IDAT":
+                idat += body
+            pos += 12 + n
+        assert seen[0] == b"IHDR" and seen[-1] == b"IEND"
+        assert len(zlib.decompress(idat)) == 23 * (37 * 3 + 1)
+    elif name.endswith(".bmp"):
+        assert data[:2] == b"BM" and struct.unpack("<I", data[2:6])[0] == len(data)
+    else:
+        assert data.startswith(b"P6\n37 23\n255\n")
+
+
+def test_save_image_tga_and_refused_extensions(tmp_path):
+    img = np.random.default_rng(3).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    host_write(tmp_path / "a.tga", img)
+    d = (tmp_path / "a.tga").read_bytes()
+    assert d[2] == 2 and struct.unpack("<HH", d[12:16]) == (7, 5) and d[16] == 24
+    assert np.array_equal(np.frombuffer(d[18:], np.uint8).reshape(5, 7, 3)[..., ::-1], img)
+    for bad, what in (("a.jpg", "JPEG"), ("a.hdr", "hdr"), ("a.xyz", "extension"), ("noext", "extension")):
+        with pytest.raises(capi.MiptError, match=what):
+            host_write(tmp_path / bad, img)
+        assert not (tmp_path / bad).exists()           # never another format under that name
+
+
+def _jpeg_segments(data):
+    """(marker, start, end) of the marker segments in front of the first scan."""
+    pos, out = 2, []
+    while pos + 4 <= len(data) and data[pos] == 0xff:
+        m = data[pos + 1]
+        n = struct.unpack(">H", data[pos + 2:pos + 4])[0]
+        out.append((m, pos, pos + 2 + n))
+        if m == 0xda:
+            break
+        pos += 2 + n
+    return out
+
+
+def test_malformed_jpeg_is_refused_not_trusted(tmp_path):
+    """Crafted files: a scan naming a Huffman table no DHT defined, a DC table whose symbols are categories above 15,
+    sampling factors that do not divide the largest one (3 under 4).  Each is an error, never a read out of bounds."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_cases.npz"))
+    done = set()
+    for n in range(int(g["count"])):
+        data = g[f"file{n}"].tobytes()
+        segs = _jpeg_segments(data)
+        # (1) no DHT at all
+        stripped = bytearray(data[:2])
+        for m, a, b in segs:
+            if m != 0xc4:
+                stripped += data[a:b]
+        stripped += data[segs[-1][2]:]
+        p = tmp_path / f"nodht{n}.jpg"
+        p.write_bytes(bytes(stripped))
+        with pytest.raises(capi.MiptError, match="never defined"):
+            host_read(p)
+        done.add("nodht")
+        # (2) every symbol of the DC tables becomes category 31
+        evil = bytearray(data)
+        for m, a, b in segs:
+            if m != 0xc4:
+                continue
+            q = a + 4
+            while q < b:
+                tc, cnt = evil[q] >> 4, sum(evil[q + 1:q + 17])
+                if tc == 0:
+                    for k in range(q + 17, q + 17 + cnt):
+                        evil[k] = 31
+                    done.add("dc31")
+                q += 17 + cnt
+        p = tmp_path / f"dc31_{n}.jpg"
+        p.write_bytes(bytes(evil))
+        with pytest.raises(capi.MiptError, match="huffman"):
+            host_read(p)
+        # (3) 3-component frames: component 0 sampled 4x1, component 1 sampled 3x1
+        for m, a, b in segs:
+            if m in (0xc0, 0xc2) and data[a + 9] == 3:
+                bad = bytearray(data)
+                bad[a + 11] = 0x41
+                bad[a + 14] = 0x31
+                p = tmp_path / f"samp{n}.jpg"
+                p.write_bytes(bytes(bad))
+                with pytest.raises(capi.MiptError, match="divide"):
+                    host_read(p)
+                done.add("samp")
+    assert done == {"nodht", "dc31", "samp"}

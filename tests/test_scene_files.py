@@ -84,6 +84,31 @@ def test_unsupported_scene_features_are_refused(tmp_path):
         H.load_scene(os.path.join(str(tmp_path), "missing.scn"))
 
 
+def test_load_scene_name_substitution(tmp_path):
+    """Raytracer::load_scene(filename, replacedNames) (Raytracer.cpp:1149, 1214; Geometry.h:524-526; the third argument
+    of the reference's command line, mainApp.cpp:41-42): the '#' in a mesh name is replaced before the mesh file is read."""
+    scn = stage(tmp_path)
+    text = open(scn).read()
+    mesh_line = [l for l in text.splitlines() if l.startswith("name:") and l.strip().endswith(".obj")]
+    assert len(mesh_line) == 1
+    fname = mesh_line[0].split(":", 1)[1].strip()
+    stem = fname[:-4]
+    templ = os.path.join(str(tmp_path), "templ.scn")
+    open(templ, "w").write(text.replace(mesh_line[0], "name: " + stem[:-3] + "#" + stem[-1:] + ".obj", 1))
+    H = capi.HostRaytracer()
+    H.load_scene(templ, stem[-3:-1])
+    check_state(H, np.load(GOLD))
+    a = H.mesh_dump(3)
+    H2 = capi.HostRaytracer()
+    H2.load_scene(scn)
+    for key in ("perm", "nodes_i", "nodes_bb", "groups"):
+        assert_bits(a[key], H2.mesh_dump(3)[key], "mesh." + key)
+    with pytest.raises(capi.MiptError):                 # wrong substitution: the file does not exist
+        H.load_scene(templ, "zz")
+    with pytest.raises(capi.MiptError, match="#"):      # no '#' to substitute: the reference's std::string::replace throws
+        H.load_scene(scn, "x")
+
+
 @pytest.mark.gpu
 def test_scene_file_radiance_and_cli(tmp_path):
     """scene.scn -> host mirror -> C ABI -> HIP path: per-sample radiance of the reference, bit for bit; and the
@@ -108,3 +133,12 @@ def test_scene_file_radiance_and_cli(tmp_path):
     data = out.read_bytes()
     assert data.startswith(header)
     assert np.array_equal(np.frombuffer(data[len(header):], np.uint8).reshape(H.H, H.W, 3), u8)
+    # the reference's command line: `scene.scn out.png [nameSubst]` writes a PNG (save_image dispatches on the extension)
+    from test_image_readers import host_read
+    png = tmp_path / "out.png"
+    r = subprocess.run([exe, scn, str(png)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    assert np.array_equal(host_read(png), u8)
+    r = subprocess.run([exe, scn, str(tmp_path / "out.jpg")], capture_output=True, text=True)
+    assert r.returncode != 0 and "JPEG" in r.stderr and not (tmp_path / "out.jpg").exists()
