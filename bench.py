@@ -8,24 +8,38 @@ Workload (config.workload): the configuration BASELINE.json's metric is quoted o
 "the 2.5M-triangle scene") = configs[2]: 2 508 800-triangle blob with a 2048x2048 Kd texture and a
 4096x2048 environment map, Phong BRDF, 1920x1080, depth 4, default loadScene() light and camera; it
 fits one GPU.  --workload c1 / c3 / c4 select the other configs (c1 = 133 128-triangle diffuse blob).
-One STEP = one pass of the hot path (camera rays -> getColor -> splat) over the whole frame at
---spp-per-step samples per pixel (default 256: 531 M paths, ~85 GB of path state in flight — sized for
-288 GB of HBM; the per-launch ramp and drain of the persistent kernels is amortised over a large batch: 3.72 Grays/s
-at 64 spp per step, 3.82 at 128, 3.94 at 256, 3.98 at 512);
-the default K = 4 steps x 256 spp is exactly the 1024 spp of the config.  With N GPUs the frame's
-32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated), a step
-renders N x --spp-per-step samples per pixel so that every rank keeps the same number of paths in
-flight per pass as the single-GPU run ("scaling": "weak": per-GPU work per step is fixed), and the
-per-rank accumulators are summed by ONE all-reduce at the end (RCCL).
+One STEP = the hot path (camera rays -> getColor -> splat) over the whole frame at --spp-per-step samples per pixel.
+With N GPUs the frame's 32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
+the per-rank accumulators are summed by ONE all-reduce at the end (RCCL).
+  --scaling strong (default)  the job is fixed: a step is the metric's frame, 1024 spp at 1080p (256 at 4K), whatever N is;
+        a rank renders all samples of its 1/N of the tiles.  The library cuts a step into passes of at most 2^29 paths
+        (~86 GB of path state, sized for 288 GB of HBM): 4 passes of 256 spp on one GPU, one pass of 1024 spp on its
+        eighth of the frame on each of 8 — every pass stays large (the per-launch ramp and drain of the persistent
+        kernels is amortised over a large batch: 3.72 Grays/s at 64 spp per pass, 3.82 at 128, 3.94 at 256, 3.98 at 512).
+  --scaling weak              the job grows with N: a step renders N x 256 spp, so every rank keeps one 531 M-path pass per
+        step as in the single-GPU run.
+At N > 1 the line of the other mode (two steps, measured after the timed region) is attached as "other_scaling".
+--in-process N drives N devices from ONE process through mipt_create(device_ids, N) (the C++ host's way: worker threads and
+the RCCL reduce inside the library) instead of one process per GPU; "0,0" lists a device twice (one-GPU functional test).
 
 value = rays (closest-hit + shadow, counted like the oracle counts them) of all ranks / wall time
 of the K timed steps (+ the final reduce), inputs resident in HBM, barrier + synchronize on both
 sides, max over ranks.
 
-roofline: the dominant kernel's ALGORITHMIC bytes per launch / its mean launch duration (HIP events
-on the render stream, measured here).  Algorithmic bytes per ray come from the CPU oracle's counters
-of the reference's ordered traversal on a bounded sample of the same scene and camera
-(B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.
+roofline (dominant kernel = the closest-hit traversal, k_wf_traverse<0>; its mean launch duration is measured here with
+HIP events on the render stream).  Three fractions, none of which can exceed 1 by construction except the first:
+  frac_algorithmic_hbm  ALGORITHMIC bytes per launch / duration / 8 TB/s.  Bytes per ray come from the CPU
+                        oracle's counters of the reference's ordered traversal on a bounded sample of the same scene and
+                        camera (B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.  It exceeds 1:
+                        the BVH is served by L2 and the Infinity Cache, those bytes never cross HBM.
+  frac_hbm_measured     HBM bytes the kernel really moved (rocprofv3 PMC, profiles/r2_pmc_counters.json, per ray of the
+                        profiled run x the rays of this run; FETCH_SIZE corrected with the gather factor measured by
+                        tools/fetch_calibration.py) / duration / 8 TB/s
+  frac                  the most utilised hardware resource the counters show for this kernel: vector-L1 (TCP) line
+                        lookups, one 64-byte line per CU and cycle at most.  achieved = TCP_TOTAL_CACHE_ACCESSES per ray
+                        (same PMC file) x rays per launch x 64 B / duration; peak = CUs x 64 B x 2.4 GHz.  Beside it:
+                        the lookups per ray the kernel makes and the algorithmic minimum (one per inner node visited, one
+                        per triangle record tested, oracle counters).
 
 cpu_baseline (rank 0, N=1 only): the compiled reference's own render_image_nopreviz() on all host
 cores when oracle/_ref/libptref.so is present (kind "reference"), otherwise the oracle's threaded
@@ -40,7 +54,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_STEP = 256          # at 1080p; scaled down with the pixel count so that a pass keeps <= 2^29 paths (~86 GB of path state)
+SPP_PER_PASS = 256          # at 1080p; scaled down with the pixel count so that a pass keeps <= 2^29 paths (~86 GB of path state)
+SEED_STRIDE = 65536         # sample k of pixel p draws from pcg32(p * 65536 + k): a run may use at most 65536 samples per pixel
 
 
 def parse():
@@ -49,7 +64,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c1", "c1g", "c2", "c3", "c4"], help="BASELINE.json configs[1..4]")
-    ap.add_argument("--spp-per-step", type=int, default=0, help="samples per pixel per step (default: 256 at 1080p, 64 at 4K)")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="samples per pixel per step (default: strong 1024 at 1080p / 256 at 4K; weak 256 / 64 per rank)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="strong: the job per step is fixed (default); weak: it grows with the number of GPUs")
+    ap.add_argument("--in-process", default="", help="device list, e.g. 0,1,2,3: ONE process drives them through mipt_create(ids, n) (world size must be 1)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--grid", type=int, default=None, help="override the blob tessellation n (2 n^2 triangles)")
@@ -79,7 +96,10 @@ def oracle_bytes_per_ray(mesh, mat, cfg_full):
     c = O.counters().astype(float)
     b_closest = (24 * c[0] + 8 * c[1] + 64 * c[2]) / max(1.0, float(rays[0]))
     b_shadow = (24 * c[3] + 8 * c[4] + 64 * c[5]) / max(1.0, float(rays[1]))
-    return dict(bytes_closest=b_closest, bytes_shadow=b_shadow, rays_per_path=float(rays[0] + rays[1]) / (cfg.W * cfg.H * cfg.spp),
+    # one 64-byte line per inner node visited (it holds both children's boxes: two box tests) and one per triangle record
+    l_closest = (c[0] / 2 + c[2]) / max(1.0, float(rays[0]))
+    l_shadow = (c[3] / 2 + c[5]) / max(1.0, float(rays[1]))
+    return dict(bytes_closest=b_closest, bytes_shadow=b_shadow, lines_closest=l_closest, lines_shadow=l_shadow, rays_per_path=float(rays[0] + rays[1]) / (cfg.W * cfg.H * cfg.spp),
                 sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp")
 
 
@@ -153,18 +173,31 @@ def main():
         dist.barrier()
     from pathtracer_amd import capi, scenes
 
-    if args.spp_per_step <= 0:
-        dims = {"c4": (3840, 2160)}.get(args.workload, (1920, 1080))
-        npx = (args.width or dims[0]) * (args.height or dims[1])
-        args.spp_per_step = SPP_PER_STEP
-        while args.spp_per_step > 1 and npx * args.spp_per_step > (1 << 29) + (1 << 24):
-            args.spp_per_step //= 2
-    SPS = args.spp_per_step * world     # weak scaling: a rank owns 1/world of the pixels and renders world x the samples per step
-    total_spp = SPS * (args.steps + args.warmup)
+    in_process = [int(x) for x in args.in_process.split(",")] if args.in_process else []
+    if in_process and world > 1:
+        raise SystemExit("--in-process drives its devices from one process: do not launch it under torch.distributed.run")
+    job_gpus = len(in_process) if in_process else world
+    dims = {"c4": (3840, 2160)}.get(args.workload, (1920, 1080))
+    npx = (args.width or dims[0]) * (args.height or dims[1])
+    spp_pass = SPP_PER_PASS
+    while spp_pass > 1 and npx * spp_pass > (1 << 29) + (1 << 24):
+        spp_pass //= 2
+
+    def samples_per_step(scaling):
+        if args.spp_per_step > 0:
+            return args.spp_per_step * (job_gpus if scaling == "weak" else 1)
+        return spp_pass * job_gpus if scaling == "weak" else 4 * spp_pass      # strong: the metric's frame (1024 spp at 1080p)
+
+    SPS = samples_per_step(args.scaling)
+    other = "weak" if args.scaling == "strong" else "strong"
+    OTHER_STEPS = 2 if job_gpus > 1 else 0
+    total_spp = SPS * (args.steps + args.warmup) + samples_per_step(other) * (OTHER_STEPS + 1)
+    if total_spp > SEED_STRIDE:
+        raise SystemExit(f"{total_spp} samples per pixel in this run, but the streams of neighbouring pixels are {SEED_STRIDE} apart: use fewer steps")
     mesh, cfg, mat, wl_text = scenes.workload(args.workload, args.width, args.height, total_spp, args.grid)
     args.width, args.height = cfg.W, cfg.H
 
-    rt = capi.HostRaytracer(device=local_rank)
+    rt = capi.HostRaytracer(device=in_process if in_process else local_rank)
     rt.apply_config(cfg)
     rt.set_partition(32, rank, world)
     t0 = time.time()
@@ -176,7 +209,6 @@ def main():
     t_prepare = time.time() - t0
     if args.pipeline >= 0:
         rt.set_option("pipeline", args.pipeline)
-    rt.set_option("paths_per_pass", args.width * args.height * SPS)
     for kv in args.opt:
         k, v = kv.split("=")
         rt.set_option(k, int(v))
@@ -185,10 +217,12 @@ def main():
     accum = torch.zeros(args.width * args.height * 4, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     P = rt.params       # live view of the host mirror's mipt_render_params; patched per step
-    assert P.W == args.width and P.nrays == total_spp and P.seed_stride == 65536 and P.tile_nranks == world
+    assert P.W == args.width and P.nrays == total_spp and P.seed_stride == SEED_STRIDE and P.tile_nranks == world
+    assert total_spp <= P.seed_stride
 
-    def step(s):
-        P.sample_begin, P.sample_end = s * SPS, (s + 1) * SPS
+    def step(s, sps=None, base=0):
+        sps = sps or SPS
+        P.sample_begin, P.sample_end = base + s * sps, base + (s + 1) * sps
         rt.render_device(accum.data_ptr(), stream)
         st = rt.stats()    # synchronises; cheap next to a step
         return st
@@ -204,7 +238,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     rays = paths = 0
-    kern_ms = sh_ms = shade_ms = 0.0
+    kern_ms = sh_ms = shade_ms = resolve_ms = 0.0
     launches = sh_launches = 0
     rays_c = rays_s = 0
     pipeline = -1
@@ -213,15 +247,39 @@ def main():
         st = step(s)
         rays_c += st["rays_closest"]; rays_s += st["rays_shadow"]; paths += st["paths"]
         kern_ms += st["traverse_ms"]; launches += st["traverse_launches"]
-        sh_ms += st["shadow_ms"]; sh_launches += st["shadow_launches"]; shade_ms += st["shade_ms"]
+        sh_ms += st["shadow_ms"]; sh_launches += st["shadow_launches"]; shade_ms += st["shade_ms"]; resolve_ms += st["resolve_ms"]
         pipeline = st["pipeline"]; merged = st["traverse_merged"]
-    if world > 1:                                        # the framebuffer reduce (RCCL over xGMI)
-        if on_device:
-            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
-        else:
-            host = accum.cpu(); dist.all_reduce(host, op=dist.ReduceOp.SUM); accum.copy_(host)
+    def reduce_frame():
+        if world > 1:                                    # the framebuffer reduce (RCCL over xGMI); --in-process: done inside the library
+            if on_device:
+                dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+            else:
+                host = accum.cpu(); dist.all_reduce(host, op=dist.ReduceOp.SUM); accum.copy_(host)
+
+    reduce_frame()
     sync()
     elapsed = time.perf_counter() - t0
+    other_line = None
+    if OTHER_STEPS:                                      # the other scaling mode, beside the timed region
+        o_sps, base = samples_per_step(other), SPS * (args.steps + args.warmup)
+        accum2 = accum.clone()
+        step(0, o_sps, base)
+        sync()
+        t1 = time.perf_counter()
+        o_rays = 0
+        for s2 in range(1, OTHER_STEPS + 1):
+            st = step(s2, o_sps, base)
+            o_rays += st["rays_closest"] + st["rays_shadow"]
+        reduce_frame()
+        sync()
+        o_el = time.perf_counter() - t1
+        tt = torch.tensor([o_el, float(o_rays)], dtype=torch.float64, device=dev if on_device else "cpu")
+        if world > 1:
+            tm = tt.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ts = tt.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            o_el, o_rays = float(tm[0]), float(ts[1])
+        other_line = {"scaling": other, "value": o_rays / o_el / 1e6, "unit": "Mrays/s", "steps": OTHER_STEPS, "spp_per_step": o_sps, "ms_per_step": 1e3 * o_el / OTHER_STEPS}
+        accum = accum2
     t = torch.tensor([elapsed, float(rays_c), float(rays_s), float(paths), kern_ms, float(launches)], dtype=torch.float64, device=dev if on_device else "cpu")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,20 +293,24 @@ def main():
         out = {
             "metric": "Msamples/s (primary+secondary rays) at 1080p\u00d71024spp; 1/2/4/8-GPU scaling",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": job_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
-                       "parallelism": f"tiles32x{world}", "pipeline": int(pipeline)},
+                       "parallelism": f"tiles32x{job_gpus}" + (f", one process, mipt_create(n={job_gpus}): {rt.group_reduce_kind()}" if in_process else (", one process per GPU, RCCL all-reduce of the framebuffers" if world > 1 else "")),
+                       "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
             "host_bvh_build_s": t_build,   # TriMesh::init as a whole (axis swap, BVH, triangle soup, tangents)
             "bvh_build": {"builder": bvh_who, "seconds": round(bvh_s, 4), "device_seconds": round(bvh_dev_s, 4), "triangles": int(mesh.ntri)},
             "prepare_s": t_prepare, "finite": finite,
+            "launch_stats": {"rays_closest": rays_c, "rays_shadow": rays_s, "extend_launches": int(launches), "shadow_launches": int(sh_launches)},
         }
+        if other_line:
+            out["other_scaling"] = other_line
         if world == 1 and args.pmc and pipeline == 1:
-            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
-        if world == 1 and not args.pmc:
+            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
+        if world == 1 and not in_process and not args.pmc:
             ob = oracle_bytes_per_ray(mesh, mat, cfg)
             my_launches = max(1, launches)
             ms_per_launch = kern_ms / my_launches
@@ -261,29 +323,53 @@ def main():
             else:                 # dominant kernel = closest-hit traversal
                 kernel = "k_wf_traverse<0> (closest-hit / extend stage)"
                 bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
-            achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            alg_hbm = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            rays_per_launch = (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches
             try:
                 stream = rt.measure_stream_read(8 << 30, 5)      # achievable read bandwidth of this device
             except Exception:
                 stream = None
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "peak_measured_stream_read": stream, "frac_of_measured": (achieved / stream) if stream else None,
-                               "traffic": None, "kernel": kernel,
-                               "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
-                               "ms_per_launch": ms_per_launch, "launches": int(launches), "oracle_sample": ob["sample"],
-                               "rays_per_launch": (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches}
-            try:   # HBM bytes per launch of the dominant kernel from the committed PMC run (same workload)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))[args.workload]
-                tr = tj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_high"]
-                out["roofline"]["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of this kernel on this workload, " + tj["source"]
+            n_cus = 256
+            try:
+                n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
             except Exception:
                 pass
+            peak_l1 = n_cus * 64 * 2.4                            # GB/s: one 64-byte line lookup per CU and cycle at 2.4 GHz
+            rf = {"bound": "l1", "achieved": None, "peak": peak_l1, "unit": "GB/s", "frac": None, "traffic": None,
+                  "bound_note": "vector-L1 (TCP) line lookups, 64 B per CU-cycle: the most utilised resource the PMC counters show for this kernel; "
+                                "the algorithmic-HBM fraction of SURVEY 8d is > 1 (BVH served by L2 / Infinity Cache) and measured HBM traffic is far from its peak",
+                  "kernel": kernel, "ms_per_launch": ms_per_launch, "launches": int(launches), "rays_per_launch": rays_per_launch,
+                  "frac_algorithmic_hbm": alg_hbm / 8000.0, "algorithmic_hbm_gb_per_s": alg_hbm, "hbm_peak_gb_per_s": 8000.0,
+                  "peak_measured_stream_read": stream, "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
+                  "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"]}
+            try:   # per-ray counter values of the dominant kernel from the committed PMC run of the same workload
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_counters.json")))[args.workload]
+                pk = pj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
+                lookups = pk["tcp_accesses_per_ray"] * rays_per_launch
+                rf["achieved"] = lookups * 64 / (ms_per_launch * 1e-3) / 1e9
+                rf["frac"] = rf["achieved"] / peak_l1
+                rf["l1_lookups_per_cu_cycle_at_2.4GHz"] = lookups / (n_cus * 2.4e9 * ms_per_launch * 1e-3)
+                rf["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
+                rf["traffic"] = pk["hbm_bytes_per_ray"] * rays_per_launch
+                rf["frac_hbm_measured"] = rf["traffic"] / (ms_per_launch * 1e-3) / 8e12
+                rf["pmc_source"] = pj["source"]
+            except Exception as e:
+                rf["pmc_note"] = "profiles/r2_pmc_counters.json has no entry for this workload / kernel (%s)" % type(e).__name__
+            out["roofline"] = rf
             if pipeline == 1 and sh_launches:
-                sh_ach = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
-                out["roofline_shadow_kernel"] = {"kernel": "k_wf_traverse<true> (any-hit / shadow stage)", "achieved": sh_ach, "frac": sh_ach / 8000.0, "ms_per_launch": sh_ms / sh_launches,
-                                                 "launches": int(sh_launches)}
-            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps}
+                sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
+                rs = {"kernel": "k_wf_traverse<1> (any-hit / shadow stage)", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
+                      "launches": int(sh_launches), "rays_per_launch": rays_s / sh_launches, "l1_lookups_per_ray_algorithmic": ob["lines_shadow"]}
+                try:
+                    pk = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_counters.json")))[args.workload]["kernels"]["k_wf_traverse<1>"]
+                    lk = pk["tcp_accesses_per_ray"] * rays_s / sh_launches
+                    rs["frac"] = lk * 64 / (sh_ms / sh_launches * 1e-3) / 1e9 / peak_l1
+                    rs["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
+                    rs["frac_hbm_measured"] = pk["hbm_bytes_per_ray"] * rays_s / sh_launches / (sh_ms / sh_launches * 1e-3) / 8e12
+                except Exception:
+                    pass
+                out["roofline_shadow_kernel"] = rs
+            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(mesh, mat, cfg, ob["rays_per_path"])
         print(json.dumps(out))

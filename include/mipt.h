@@ -13,8 +13,10 @@
  *
  * Conventions: plain C, pointers + sizes, no C++/torch types.  Every function returns an int
  * status (MIPT_OK = 0); mipt_last_error() gives the text.  Host arrays passed in are copied
- * before the call returns; the library never keeps a caller pointer.  One context = one GPU =
- * one host thread at a time; several contexts may coexist (one process per GPU under RCCL).
+ * before the call returns; the library never keeps a caller pointer.  One context = one host
+ * thread at a time; it drives one GPU, or several (mipt_create with n > 1: one worker thread and one
+ * stream per device inside the library, partial framebuffers summed by one RCCL reduce); several
+ * contexts may coexist (one process per GPU with the caller's own collective is the other way to scale).
  * There is NO CPU fallback: without a usable HIP device mipt_create fails with
  * MIPT_ERR_NO_DEVICE.
  */
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 1
+#define MIPT_ABI_VERSION 2
 
 enum {
 	MIPT_OK = 0,
@@ -191,19 +193,36 @@ typedef struct mipt_stats {
 	                                 kernel (scenes with ghost objects, a background photo, fog or subsurface colours) */
 	uint32_t traverse_merged;     /* 1 = option "merge_traverse" was in effect (see traverse_ms) */
 	uint32_t reserved;
+	double   resolve_ms;          /* summed over the splat (resolve) launches */
 } mipt_stats;
 
 typedef void (*mipt_progress_cb)(void* user, int samples_done, int samples_total);
 
 /* ---- entry points ------------------------------------------------------------------------ */
 
-/* Opens device `device_ids[0]` (n must be 1: multi-GPU = one process and one context per GPU,
- * partitioned by mipt_render_params::tile_*).  Replaces nothing in the reference (it has no
- * device); called from Raytracer::Raytracer(). */
+/* Opens the n devices `device_ids[0..n)` as ONE context.  Replaces nothing in the reference (it has no device); called
+ * from Raytracer::Raytracer().
+ *   n == 1  one GPU.
+ *   n  > 1  the reference's model — one process, its threads render disjoint pixel batches into per-thread framebuffers
+ *           that are summed at the end (Raytracer.cpp:1581-1685) — with devices in place of threads: the scene is
+ *           replicated (mipt_upload_scene uploads to every device), mipt_render / mipt_render_device give member i the
+ *           tiles t % (n * tile_nranks) == tile_rank * n + i, every member renders all samples of its tiles into its own
+ *           full-size partial framebuffer on its own stream and host thread, and ONE reduce (RCCL ncclReduce, sum, fp32,
+ *           root = device_ids[0], over xGMI) forms the frame, which is added to the caller's buffer.  Progress calls and
+ *           cancellation work as with one device (the reduce then runs after every pass-sized chunk).  The ray-level and
+ *           per-sample entry points (mipt_trace*, mipt_sample_*, mipt_render_denoiser_inputs) run on device_ids[0].
+ *           RCCL (librccl.so.1) is loaded with dlopen when the first group is created; mipt_group_reduce_kind() tells
+ *           whether it is in use.  A device may be listed more than once (a one-GPU box exercising this path): such a
+ *           group sums its framebuffers with device copies and adds instead, as does option "reduce" = 2. */
 int mipt_create(const int* device_ids, int n, mipt_ctx** out);
 void mipt_destroy(mipt_ctx* ctx);
 const char* mipt_last_error(const mipt_ctx* ctx);
 int mipt_abi_version(void);
+int mipt_group_size(const mipt_ctx* ctx);                  /* number of devices behind the context */
+const char* mipt_group_reduce_kind(const mipt_ctx* ctx);   /* "" for one device, else how the partial framebuffers are summed */
+/* Loads RCCL and runs one single-rank ncclReduce on the context's device (checks the dlopen'ed symbols and their
+ * signatures on a box with one GPU).  MIPT_ERR_UNSUPPORTED if the library cannot be loaded. */
+int mipt_rccl_selftest(mipt_ctx* ctx);
 
 /* Copies the scene to HBM and converts it to the traversal layout.  Called where
  * the reference calls Scene::prepare_render (Geometry.cpp:280-307), i.e. after every
@@ -223,9 +242,10 @@ int mipt_render(mipt_ctx* ctx, const mipt_render_params* p, float* accum_rgb, fl
                 mipt_progress_cb cb, void* cb_user, volatile int* cancel);
 
 /* Same, but accumulates into a DEVICE buffer of W*H*4 floats ([W*H*3 rgb | W*H weights], same
- * pixel order) on HIP stream `hip_stream` (a hipStream_t, NULL = default stream) and returns
- * without synchronising the host; used for the multi-GPU framebuffer reduce (RCCL on the same
- * buffer), which replaces the per-thread buffer sum of Raytracer.cpp:1669-1685. */
+ * pixel order; on device_ids[0]) on HIP stream `hip_stream` (a hipStream_t, NULL = default stream) and returns
+ * without synchronising the host.  One process per GPU: the caller reduces these buffers itself (bench.py: one RCCL
+ * all-reduce), which replaces the per-thread buffer sum of Raytracer.cpp:1669-1685.  A group (n > 1) has already
+ * summed its members' framebuffers into the buffer when the work queued on `hip_stream` completes. */
 int mipt_render_device(mipt_ctx* ctx, const mipt_render_params* p, float* d_accum_rgbw, void* hip_stream);
 
 /* Scene::intersection (Geometry.cpp:589-688) on n rays. */
@@ -258,6 +278,10 @@ int mipt_tile_owner(int W, int tile_size, int tile_nranks, int i, int j);
 /* Measurement aid (bench.py): achievable HBM read bandwidth of the context's device, a grid-stride sum over `bytes` of
  * device memory with 16-byte loads, `repeats` launches timed with HIP events.  Not part of the reference's surface. */
 int mipt_measure_stream_read(mipt_ctx* ctx, uint64_t bytes, int repeats, double* gb_per_s);
+/* The same for the traversal kernels' access pattern: `records` 64-byte records (four 16-byte loads per lane, like a fat BVH
+ * node) gathered at pseudo-random 64-byte-aligned offsets of a `buffer_bytes` buffer; gb_per_s counts 64 bytes per record.
+ * Under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter for gathers (tools/fetch_calibration.py). */
+int mipt_measure_gather_read(mipt_ctx* ctx, uint64_t buffer_bytes, uint64_t records, int repeats, double* gb_per_s);
 
 /* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
  * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes
@@ -290,6 +314,9 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "lane_limit"      measurement probe: the persistent traversal hands rays to the first N lanes of a wave only (0 = all 64)
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
  *                     every ray (normally only for rays with a zero direction component)
+ *   "reduce"          groups only: 0 = RCCL when its communicators exist (default), 1 = RCCL or fail, 2 = device copies + adds
+ *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
+ *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
  *   "paths_per_pass"  upper bound on paths in flight per pass (default 2^29, ~86 GB of path state).  Whatever its value, a pass
  *                     is sized so that its state fits in ~80 % of the device memory that is free when the render starts

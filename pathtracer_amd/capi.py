@@ -27,7 +27,7 @@ MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
                 "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs"]
 
 _f = C.c_float
@@ -39,7 +39,7 @@ class MiptStats(C.Structure):
                 ("mesh_casts_closest", C.c_uint64), ("mesh_casts_shadow", C.c_uint64),
                 ("render_ms", C.c_double), ("traverse_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("traverse_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("passes", C.c_uint32), ("pipeline", C.c_uint32),
-                ("traverse_merged", C.c_uint32), ("reserved", C.c_uint32)]
+                ("traverse_merged", C.c_uint32), ("reserved", C.c_uint32), ("resolve_ms", C.c_double)]
 
 
 class MiptTexture(C.Structure):
@@ -113,6 +113,10 @@ def load():
     mipt.mipt_last_error.restype = C.c_char_p
     mipt.mipt_last_error.argtypes = [C.c_void_p]
     mipt.mipt_build_bvh_error.restype = C.c_char_p
+    mipt.mipt_group_reduce_kind.restype = C.c_char_p
+    mipt.mipt_group_reduce_kind.argtypes = [C.c_void_p]
+    mipt.mipt_group_size.argtypes = [C.c_void_p]
+    mipt.mipt_rccl_selftest.argtypes = [C.c_void_p]
     host.mh_create.restype = C.c_void_p
     host.mh_last_error.restype = C.c_char_p
     for name in ("mh_ctx", "mh_scene_desc", "mh_render_params", "mh_imagedouble", "mh_sample_count", "mh_image"):
@@ -170,9 +174,10 @@ class HostRaytracer:
         self.device = device
         self._uploaded = False
         if device is not None:
-            rc = self.host.mh_open_device(self.h, int(device))
+            ids = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+            rc = self.host.mh_open_devices(self.h, (C.c_int * len(ids))(*ids), len(ids))     # mipt_create(device_ids, n)
             if rc != MIPT_OK:
-                raise MiptError(f"mipt_create(device={device}) failed with status {rc}: {self.host.mh_last_error(self.h).decode()}")
+                raise MiptError(f"mipt_create(devices={ids}) failed with status {rc}: {self.host.mh_last_error(self.h).decode()}")
 
     def close(self):
         if self.h:
@@ -515,6 +520,21 @@ class HostRaytracer:
         """Achievable HBM read bandwidth of the device in GB/s (mipt_measure_stream_read)."""
         out = C.c_double(0.0)
         self._check(self.mipt.mipt_measure_stream_read(self.ctx, C.c_uint64(nbytes), int(repeats), C.byref(out)), "mipt_measure_stream_read")
+        return out.value
+
+    def group_size(self):
+        return self.mipt.mipt_group_size(self.ctx)
+
+    def group_reduce_kind(self):
+        return self.mipt.mipt_group_reduce_kind(self.ctx).decode()
+
+    def rccl_selftest(self):
+        self._check(self.mipt.mipt_rccl_selftest(self.ctx), "mipt_rccl_selftest")
+
+    def measure_gather_read(self, buffer_bytes=8 << 30, records=1 << 28, repeats=3):
+        """GB/s of 64-byte records gathered at random 64-byte-aligned offsets (mipt_measure_gather_read)."""
+        out = C.c_double(0.0)
+        self._check(self.mipt.mipt_measure_gather_read(self.ctx, C.c_uint64(buffer_bytes), C.c_uint64(records), int(repeats), C.byref(out)), "mipt_measure_gather_read")
         return out.value
 
     def stats(self):

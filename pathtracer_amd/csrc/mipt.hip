@@ -14,6 +14,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <dlfcn.h>
 
 #include "../../include/mipt.h"
 #include "mipt_shade.h"
@@ -42,11 +43,12 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned int v
 // traversal stack of the calling lane: private memory for the simple kernels ...
 #define MIPT_DECLARE_STACK(stk) ScratchStack stk;
 // ... and the block's LDS slab (+ global spill columns) for the persistent traversal kernels
-#define MIPT_DECLARE_LDS_STACK(stk, spill_buf) \
-	__shared__ uint2 lds_stack_[MIPT_LDS_STACK * MIPT_BLOCK]; \
-	__shared__ unsigned char lds_leafmap_[4 * MIPT_BLOCK];   /* per wave: owner lane + triangle slot of each packed leaf test */ \
-	LdsStack stk; stk.base = (lds_uint2*)lds_stack_ + threadIdx.x; stk.stride = MIPT_BLOCK; \
-	stk.spill = (glb_uint2*)(spill_buf) + (size_t)blockIdx.x * MIPT_BLOCK + threadIdx.x; stk.spill_stride = (int)(gridDim.x * MIPT_BLOCK);
+// (the traversal kernels may run with larger blocks than the other stages: MIPT_TRAV_BLOCK, mipt_persistent.h)
+#define MIPT_DECLARE_LDS_STACK(stk, spill_buf, BLOCK) \
+	__shared__ uint2 lds_stack_[MIPT_LDS_STACK * (BLOCK)]; \
+	__shared__ unsigned char lds_leafmap_[4 * (BLOCK)];   /* per wave: owner lane + triangle slot of each packed leaf test */ \
+	LdsStack stk; stk.base = (lds_uint2*)lds_stack_ + threadIdx.x; stk.stride = (BLOCK); \
+	stk.spill = (glb_uint2*)(spill_buf) + (size_t)blockIdx.x * (BLOCK) + threadIdx.x; stk.spill_stride = (int)(gridDim.x * (BLOCK));
 
 // Scene::intersection on a ray list (mipt_trace).
 __global__ void __launch_bounds__(MIPT_BLOCK) k_trace(const DScene* __restrict__ sc, const mipt_ray* __restrict__ rays, int n, mipt_hit* __restrict__ hits) {
@@ -191,6 +193,82 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 #include "mipt_build.h"
 #include "mipt_compositing.h"
 
+// The same splat with a third of the reads.  In the gather above every sample is fetched by each of its (2 fs + 1)^2
+// destination pixels (9 at the default sigma), by different waves and thousands of iterations apart: no cache holds it in
+// between (measured: 2 % L2 hit rate, 6-13x the algorithmic bytes).  Here a thread owns a destination COLUMN of a band of
+// `rows` destination rows and scans the source rows of that band from top to bottom with one rolling accumulator per
+// destination row a source row reaches (2 fs + 1 of them): a sample is then fetched once per column offset and serves
+// 2 fs + 1 destination pixels at each fetch — (2 fs + 1) x (1 + 2 fs / rows) reads per sample instead of (2 fs + 1)^2.
+// What cannot be removed without changing the result is the column re-read: a destination pixel takes ALL samples of the
+// source to its left before the first sample of the source above it (Raytracer.cpp:1477-1497 run serially), so the three
+// visits of a sample lie a whole pass of samples apart.  Every destination pixel still receives its terms in the
+// reference's scan order (source row, source column, sample): the single-pass image stays bit-exact.
+#ifndef MIPT_RESOLVE_UNROLL
+#define MIPT_RESOLVE_UNROLL 8           // sample loads in flight per thread: the kernel runs ~2 waves per SIMD and lives on memory-level parallelism
+#endif
+template <int FS>
+__global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSamples in, float denom2, int rows, float* __restrict__ accum) {
+	const int W = R.W, H = R.H, ftw = 2 * FS + 1;
+	const int j2 = blockIdx.x * blockDim.x + threadIdx.x;
+	const int r0 = blockIdx.y * rows, r1 = min(H, r0 + rows);          // destination rows [r0, r1)
+	if (j2 >= W) return;
+	const int nk = ps.k1 - ps.k0;
+	const size_t npx = (size_t)W * H;
+	float acc[ftw][4];                                                  // acc[di + FS] = destination row i + di while source row i is scanned
+	auto load_acc = [&](int i2, float* a) {
+		if (i2 >= r0 && i2 < r1) { const size_t d = (size_t)(H - i2 - 1) * W + j2; a[0] = accum[3 * d]; a[1] = accum[3 * d + 1]; a[2] = accum[3 * d + 2]; a[3] = accum[3 * npx + d]; }
+		else { a[0] = a[1] = a[2] = a[3] = 0.f; }
+	};
+	const int i_first = max(0, r0 - FS), i_last = min(H - 1, r1 - 1 + FS);
+#pragma unroll
+	for (int k = 0; k < ftw; k++) load_acc(i_first - FS + k, acc[k]);
+	for (int i = i_first; i <= i_last; i++) {
+		bool live[ftw];
+#pragma unroll
+		for (int k = 0; k < ftw; k++) { const int i2 = i - FS + k; live[k] = i2 >= r0 && i2 < r1; }
+		for (int dj = -FS; dj <= FS; dj++) {
+			const int j = j2 + dj;
+			if (j < 0 || j >= W) continue;
+			const int slot = ps.pix2slot[i * W + j];
+			if (slot < 0) continue;
+			const int bmin_i = max(0, i - FS), bmax_i = min(i + FS, H - 1), bmin_j = max(0, j - FS), bmax_j = min(j + FS, W - 1);
+			const float ratio = 1.f / sum_area_table(R.filter_integral, ftw, bmin_i - i + FS, bmax_i - i + FS, bmin_j - j + FS, bmax_j - j + FS);
+			const float denom1 = (float)((double)ratio / ((double)(R.sigma_filter * R.sigma_filter) * 2. * MIPT_PI));
+			const float fdj = (float)(-dj);                             // j2 - j
+			const float2* __restrict__ pj = in.dxdy + slot;
+			const float4* __restrict__ pc = in.col + slot;
+			const size_t stride = (size_t)ps.npix_slots;
+#pragma unroll MIPT_RESOLVE_UNROLL
+			for (int kk = 0; kk < nk; kk++) {
+				const float2 jit = pj[(size_t)kk * stride];
+				const float4 c = pc[(size_t)kk * stride];
+				const float sb = sqr(fdj - jit.x);
+#pragma unroll
+				for (int k = 0; k < ftw; k++) {
+					if (!live[k]) continue;                             // uniform over the block
+					const float w = (float)(fast_exp((double)(-(sqr((float)(k - FS) - jit.y) + sb) * denom2)) * (double)denom1);   // i2 - i = k - FS
+					acc[k][0] += c.x * w; acc[k][1] += c.y * w; acc[k][2] += c.z * w; acc[k][3] += w;
+				}
+			}
+		}
+		// destination row i - FS has seen its last source row
+		{
+			const int i2 = i - FS;
+			if (i2 >= r0 && i2 < r1) { const size_t d = (size_t)(H - i2 - 1) * W + j2; accum[3 * d] = acc[0][0]; accum[3 * d + 1] = acc[0][1]; accum[3 * d + 2] = acc[0][2]; accum[3 * npx + d] = acc[0][3]; }
+		}
+#pragma unroll
+		for (int k = 0; k + 1 < ftw; k++) { acc[k][0] = acc[k + 1][0]; acc[k][1] = acc[k + 1][1]; acc[k][2] = acc[k + 1][2]; acc[k][3] = acc[k + 1][3]; }
+		load_acc(i + FS + 1, acc[ftw - 1]);
+	}
+	// rows whose lower neighbours lie outside the image (or the band ends at the image border): flush what is left
+#pragma unroll
+	for (int k = 0; k + 1 < ftw; k++) {
+		const int i2 = i_last + 1 - FS + k;
+		if (i2 >= r0 && i2 < r1) { const size_t d = (size_t)(H - i2 - 1) * W + j2; accum[3 * d] = acc[k][0]; accum[3 * d + 1] = acc[k][1]; accum[3 * d + 2] = acc[k][2]; accum[3 * npx + d] = acc[k][3]; }
+	}
+}
+
+
 // ---- denoiser inputs (has_denoiser branch of render_image_nopreviz, Raytracer.cpp:1631-1645) ---------------------------
 // getColor hands back the shading normal and Kd of the first hit (Raytracer.cpp:255-258).  They are read off the hit
 // records of depth 0 by a stage of their own, launched only when the caller asked for them: the tuned shade kernels
@@ -243,8 +321,11 @@ __global__ void __launch_bounds__(256) k_resolve_aov(DRender R, DPass ps, DSampl
 // host side: context, upload, C-ABI
 // =====================================================================================
 
+struct mipt_group;
 struct mipt_ctx {
 	int device = -1;
+	mipt_group* group = nullptr;      // mipt_create with n > 1: the devices that share this context's work (this context is member 0)
+	bool is_member = false;           // a context owned by a group (members 1..n-1), not handed to the caller
 	std::string err;
 	std::vector<void*> scene_allocs;
 	DScene* d_scene = nullptr;
@@ -267,7 +348,7 @@ struct mipt_ctx {
 	DCounters* d_cnt = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	std::vector<hipEvent_t> kev;      // begin/end event pairs around the timed kernel launches
-	std::vector<int> kev_kind;        // 0 = dominant (per-path / extend), 1 = shadow, 2 = generate / shade
+	std::vector<int> kev_kind;        // 0 = dominant (per-path / extend), 1 = shadow, 2 = generate / shade, 3 = resolve (splat)
 	unsigned kev_used = 0;
 	int n_cus = 256;
 	mipt_stats stats{};
@@ -287,6 +368,7 @@ struct mipt_ctx {
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
+	int64_t opt_resolve_rows = 12;          // splat: destination rows per band of the column-scan kernel (0 = the per-pixel gather kernel)
 	int64_t opt_pass_memory_limit = 0;      // test hook: > 0 = size the pass as if only this many bytes were free on the device
 	int64_t opt_paths_per_pass = 1 << 29;   // 537 M paths (259 spp at 1080p), ~86 GB of path state: sized for 288 GB of HBM
 };
@@ -303,15 +385,20 @@ extern "C" int mipt_abi_version(void) { return MIPT_ABI_VERSION; }
 
 extern "C" const char* mipt_last_error(const mipt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
-	if (!out) return MIPT_ERR_INVALID;
+static void free_scene(mipt_ctx* c) {
+	for (void* p : c->scene_allocs) hipFree(p);
+	c->scene_allocs.clear();
+	c->d_scene = nullptr;
+	c->has_scene = false;
+}
+
+static int create_one(int device, mipt_ctx** out) {
 	*out = nullptr;
-	if (n != 1 || !device_ids) return MIPT_ERR_INVALID;
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MIPT_ERR_NO_DEVICE;   // no CPU fallback
-	if (device_ids[0] < 0 || device_ids[0] >= count) return MIPT_ERR_NO_DEVICE;
+	if (device < 0 || device >= count) return MIPT_ERR_NO_DEVICE;
 	mipt_ctx* c = new mipt_ctx;
-	c->device = device_ids[0];
+	c->device = device;
 	if (hipSetDevice(c->device) != hipSuccess) { delete c; return MIPT_ERR_NO_DEVICE; }
 	if (hipMalloc((void**)&c->d_cnt, sizeof(DCounters) * MIPT_COUNTER_SHARDS) != hipSuccess) { delete c; return MIPT_ERR_HIP; }
 	hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
@@ -321,17 +408,120 @@ extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
 	return MIPT_OK;
 }
 
-static void free_scene(mipt_ctx* c) {
-	for (void* p : c->scene_allocs) hipFree(p);
-	c->scene_allocs.clear();
-	c->d_scene = nullptr;
-	c->has_scene = false;
+// ---- several GPUs behind one context (mipt_create with n > 1) -----------------------------------------------------------
+// The reference is ONE process whose threads render disjoint pixel batches into per-thread framebuffers that are summed at
+// the end (Raytracer.cpp:1669-1685).  Here the threads are devices: member i of the group renders the tiles
+// t % (n * tile_nranks) == tile_rank * n + i into its own full-size partial framebuffer, on its own stream, driven by its
+// own host thread; the partial framebuffers are then summed into member 0's by ONE reduce (RCCL ncclReduce over xGMI, sum,
+// fp32, root 0) and added to the caller's buffer.  No collective in the data path.  RCCL is loaded with dlopen when the
+// first group is created, so a single-GPU process never depends on it.
+typedef struct ncclComm* mipt_nccl_comm;
+struct RcclApi {
+	void* lib = nullptr;
+	int (*CommInitAll)(mipt_nccl_comm*, int, const int*) = nullptr;
+	int (*CommDestroy)(mipt_nccl_comm) = nullptr;
+	int (*Reduce)(const void*, void*, size_t, int, int, int, mipt_nccl_comm, hipStream_t) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	std::string why;                  // why RCCL is not usable, when lib == nullptr
+};
+static RcclApi& rccl_api() {
+	static RcclApi api;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		void* h = nullptr;
+		for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+		if (!h) { api.why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+		api.CommInitAll = (decltype(api.CommInitAll))dlsym(h, "ncclCommInitAll");
+		api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+		api.Reduce = (decltype(api.Reduce))dlsym(h, "ncclReduce");
+		api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+		api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
+		api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+		if (!api.CommInitAll || !api.CommDestroy || !api.Reduce || !api.GroupStart || !api.GroupEnd || !api.GetErrorString) { api.why = "librccl.so.1 lacks an expected symbol"; dlclose(h); return; }
+		api.lib = h;
+	});
+	return api;
+}
+enum { MIPT_NCCL_FLOAT32 = 7, MIPT_NCCL_SUM = 0 };          // ncclFloat32, ncclSum (rccl.h)
+
+struct mipt_group {
+	std::vector<mipt_ctx*> member;            // member[0] = the context the caller holds
+	std::vector<hipStream_t> stream;          // one render stream per member
+	std::vector<hipEvent_t> done;             // "this member's partial framebuffer is complete"
+	std::vector<float*> acc; std::vector<size_t> acc_bytes;   // partial framebuffers, W*H*4 floats
+	float* tmp0 = nullptr; size_t tmp0_bytes = 0;             // staging on member 0's device for the copy reduce
+	std::vector<mipt_nccl_comm> comm;         // one communicator per member, or empty: copy reduce
+	std::string reduce_note;                  // how the framebuffers are summed, for mipt_last_error-style diagnostics
+	int64_t opt_reduce = 0;                   // 0 = RCCL when the communicators exist, 2 = peer copies + add
+};
+
+// acc[i] += src[i]
+__global__ void __launch_bounds__(256) k_accumulate(float* __restrict__ acc, const float* __restrict__ src, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] += src[i];
+}
+
+extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
+	if (!out) return MIPT_ERR_INVALID;
+	*out = nullptr;
+	if (n < 1 || n > 64 || !device_ids) return MIPT_ERR_INVALID;
+	mipt_ctx* c = nullptr;
+	int rc = create_one(device_ids[0], &c);
+	if (rc) return rc;
+	if (n > 1) {
+		mipt_group* g = new mipt_group;
+		c->group = g;
+		g->member.push_back(c);
+		for (int i = 1; i < n; i++) {
+			mipt_ctx* m = nullptr;
+			if ((rc = create_one(device_ids[i], &m))) { mipt_destroy(c); return rc; }
+			m->is_member = true;
+			g->member.push_back(m);
+		}
+		g->stream.assign(n, nullptr); g->done.assign(n, nullptr); g->acc.assign(n, nullptr); g->acc_bytes.assign(n, 0);
+		for (int i = 0; i < n; i++) {
+			if (hipSetDevice(g->member[i]->device) != hipSuccess || hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking) != hipSuccess ||
+			    hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) { mipt_destroy(c); return MIPT_ERR_HIP; }
+		}
+		// one RCCL communicator per member; a device listed twice (a single-GPU box exercising the group path) cannot have
+		// two ranks in one communicator: the framebuffers are then summed by device copies + adds
+		bool distinct = true;
+		for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (device_ids[i] == device_ids[j]) distinct = false;
+		RcclApi& api = rccl_api();
+		if (!distinct) g->reduce_note = "copy reduce: a device is listed more than once";
+		else if (!api.lib) g->reduce_note = "copy reduce: " + api.why;
+		else {
+			g->comm.assign(n, nullptr);
+			const int r = api.CommInitAll(g->comm.data(), n, device_ids);
+			if (r != 0) { g->reduce_note = std::string("copy reduce: ncclCommInitAll failed: ") + api.GetErrorString(r); g->comm.clear(); }
+			else g->reduce_note = "RCCL ncclReduce(sum, fp32, root 0)";
+		}
+		hipSetDevice(c->device);
+	}
+	*out = c;
+	return MIPT_OK;
 }
 
 extern "C" void mipt_destroy(mipt_ctx* c) {
 	if (!c) return;
-	if (c->queue_buf) hipFree(c->queue_buf);
+	if (c->group) {
+		mipt_group* g = c->group;
+		c->group = nullptr;
+		if (!g->comm.empty()) for (mipt_nccl_comm cm : g->comm) if (cm) rccl_api().CommDestroy(cm);
+		for (size_t i = 0; i < g->member.size(); i++) {
+			hipSetDevice(g->member[i]->device);
+			if (i < g->acc.size() && g->acc[i]) hipFree(g->acc[i]);
+			if (i < g->stream.size() && g->stream[i]) hipStreamDestroy(g->stream[i]);
+			if (i < g->done.size() && g->done[i]) hipEventDestroy(g->done[i]);
+			if (i == 0 && g->tmp0) hipFree(g->tmp0);
+			if (i > 0) mipt_destroy(g->member[i]);
+		}
+		delete g;
+	}
 	hipSetDevice(c->device);
+	if (c->queue_buf) hipFree(c->queue_buf);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
 	if (c->tab_buf) hipFree(c->tab_buf);
@@ -346,8 +536,17 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 
 extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!c || !name) return MIPT_ERR_INVALID;
+	if (c->group) {
+		if (!strcmp(name, "reduce")) {
+			if (value != 0 && value != 1 && value != 2) return fail(c, MIPT_ERR_INVALID, "reduce must be 0 (RCCL when available), 1 (RCCL or fail) or 2 (device copies)");
+			if (value == 1 && c->group->comm.empty()) return fail(c, MIPT_ERR_UNSUPPORTED, "no RCCL communicator: %s", c->group->reduce_note.c_str());
+			c->group->opt_reduce = value; return MIPT_OK;
+		}
+		for (size_t i = 1; i < c->group->member.size(); i++) { int rc = mipt_set_option(c->group->member[i], name, value); if (rc) return fail(c, rc, "%s", c->group->member[i]->err.c_str()); }
+	}
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
 	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
@@ -390,7 +589,8 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 // staging of all meshes' traversal records (one device buffer each)
 // (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
 struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; };
-struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; };
+struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; int top_nodes = 0; };
+#define MIPT_TOP_RESERVE 255             // inner nodes stored breadth-first in front of a mesh's node range (>= MIPT_TOP_NODES of any build)
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
@@ -404,7 +604,22 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	const uint32_t node_base = (uint32_t)stg.nfat_total, tri_base = (uint32_t)stg.nt_total;
 	std::vector<int> fat_index(nn, -1);
 	int nfat = 0;
-	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) fat_index[i] = nfat++;
+	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) nfat++;
+	// Position of the inner nodes in the buffer: the first MIPT_TOP_RESERVE of them in BREADTH-first order (the levels every
+	// ray crosses: the traversal kernels keep a copy of that prefix in LDS), the others behind them in the reference's
+	// depth-first order.  Child references are indices, so the order in memory is free.
+	{
+		std::vector<int> bfs;
+		if (nn > 0 && !m->nodes[0].isleaf) bfs.push_back(0);
+		for (size_t h = 0; h < bfs.size() && bfs.size() < MIPT_TOP_RESERVE; h++) {
+			const int kids[2] = {m->nodes[bfs[h]].fg, m->nodes[bfs[h]].fd};
+			for (int kid : kids) if (kid > bfs[h] && kid < nn && !m->nodes[kid].isleaf && bfs.size() < MIPT_TOP_RESERVE) bfs.push_back(kid);
+		}
+		int next = 0;
+		for (int i : bfs) fat_index[i] = next++;
+		for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf && fat_index[i] < 0) fat_index[i] = next++;
+		if (stg.chunks.empty()) stg.top_nodes = (int)bfs.size();
+	}
 	auto child_ref = [&](int node, uint32_t& ref) -> int {
 		if (node < 0 || node >= nn) return fail(c, MIPT_ERR_INVALID, "BVH child index out of range");
 		const mipt_bvh_node& n = m->nodes[node];
@@ -509,7 +724,23 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	return MIPT_OK;
 }
 
+static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s);
 extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
+	if (!c || !s || !s->objects) return fail(c, MIPT_ERR_INVALID, "null scene");
+	if (!c->group) return upload_scene_one(c, s);
+	// the scene is replicated: every member converts and uploads its own copy, on its own host thread
+	mipt_group* g = c->group;
+	const size_t n = g->member.size();
+	std::vector<int> rcs(n, MIPT_OK);
+	std::vector<std::thread> th;
+	for (size_t i = 1; i < n; i++) th.emplace_back([&, i] { rcs[i] = upload_scene_one(g->member[i], s); });
+	rcs[0] = upload_scene_one(c, s);
+	for (auto& t : th) t.join();
+	for (size_t i = 1; i < n; i++) if (rcs[i]) return fail(c, rcs[i], "device %d: %s", g->member[i]->device, g->member[i]->err.c_str());
+	hipSetDevice(c->device);
+	return rcs[0];
+}
+static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	if (!c || !s || !s->objects) return fail(c, MIPT_ERR_INVALID, "null scene");
 	if (s->n_objects < 2 || s->n_objects > MIPT_MAX_OBJECTS) return fail(c, MIPT_ERR_INVALID, "n_objects must be in [2,%d]", MIPT_MAX_OBJECTS);
 	HIPCHK(c, hipSetDevice(c->device));
@@ -596,6 +827,7 @@ extern "C" int mipt_upload_scene(mipt_ctx* c, const mipt_scene_desc* s) {
 			on += ch.nfat; ot += ch.nt;
 		}
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
+		H.top_nodes = stg.top_nodes;
 	}
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
@@ -934,14 +1166,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
-			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], grid_all)); };
+			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], k < 3 ? (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK) : grid_all)); };
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (!merge || b == 0) {                                  // closest hits of depth b (merged mode: done by the launch of depth b-1)
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 					else hipLaunchKernelGGL(k_wf_extend, G(6), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
@@ -954,15 +1186,23 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
-				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
+				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
 				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
 			c->stats.traverse_merged = merge ? 1u : 0u;
 		}
 		if (!dump && d_aov) hipLaunchKernelGGL(k_resolve_aov, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, aov_n, aov_kd, d_accum, d_aov);
-		else if (!dump) hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+		else if (!dump) {
+			if (timed_begin(3)) return fail(c, MIPT_ERR_HIP, "event record failed");
+			const int rows = (int)c->opt_resolve_rows;
+			const dim3 sgrid((unsigned)((R.W + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)));
+			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum);
+			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum);
+			else hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+		}
 		HIPCHK(c, hipGetLastError());
 		if (dump) {
 			HIPCHK(c, hipStreamSynchronize(st));
@@ -1014,7 +1254,7 @@ static int collect_stats(mipt_ctx* c) {
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder
 	float ms = 0;
 	if (c->stats.passes && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.render_ms = ms;
-	double ms_kind[3] = {0, 0, 0}; unsigned n_kind[3] = {0, 0, 0};
+	double ms_kind[4] = {0, 0, 0, 0}; unsigned n_kind[4] = {0, 0, 0, 0};
 	for (unsigned k = 0; k < c->kev_used; k++) {
 		float t = 0;
 		if (hipEventElapsedTime(&t, c->kev[2 * k], c->kev[2 * k + 1]) == hipSuccess) { ms_kind[c->kev_kind[k]] += t; n_kind[c->kev_kind[k]]++; }
@@ -1022,12 +1262,105 @@ static int collect_stats(mipt_ctx* c) {
 	c->stats.traverse_ms = ms_kind[0]; c->stats.traverse_launches = n_kind[0];
 	c->stats.shadow_ms = ms_kind[1]; c->stats.shadow_launches = n_kind[1];
 	c->stats.shade_ms = ms_kind[2];
+	c->stats.resolve_ms = ms_kind[3];
+	return MIPT_OK;
+}
+
+// Samples [k0, k1) on every member of the group, each on its share of the tiles, summed into d_accum (member 0's device) on `st`.
+static int group_render_range(mipt_ctx* c, const mipt_render_params* p, int k0, int k1, float* d_accum, hipStream_t st) {
+	mipt_group* g = c->group;
+	const int n = (int)g->member.size();
+	const size_t count = (size_t)p->W * p->H * 4, bytes = count * sizeof(float);
+	const int nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
+	if (p->tile_rank < 0 || p->tile_rank >= nr) return fail(c, MIPT_ERR_INVALID, "tile_rank outside [0,tile_nranks)");
+	std::vector<int> rcs(n, MIPT_OK);
+	auto work = [&](int i) {
+		mipt_ctx* m = g->member[i];
+		if (hipSetDevice(m->device) != hipSuccess) { rcs[i] = fail(m, MIPT_ERR_HIP, "hipSetDevice(%d) failed", m->device); return; }
+		if (g->acc_bytes[i] < bytes) {
+			if (g->acc[i]) { hipFree(g->acc[i]); g->acc[i] = nullptr; g->acc_bytes[i] = 0; }
+			if (hipMalloc((void**)&g->acc[i], bytes) != hipSuccess) { rcs[i] = fail(m, MIPT_ERR_HIP, "hipMalloc of a partial framebuffer failed"); return; }
+			g->acc_bytes[i] = bytes;
+		}
+		if (hipMemsetAsync(g->acc[i], 0, bytes, g->stream[i]) != hipSuccess) { rcs[i] = fail(m, MIPT_ERR_HIP, "hipMemsetAsync failed"); return; }
+		mipt_render_params q = *p;
+		q.sample_begin = k0; q.sample_end = k1;
+		q.tile_nranks = nr * n; q.tile_rank = p->tile_rank * n + i;      // the caller's own partition (one process per node, say) is refined by the group's
+		rcs[i] = render_impl(m, &q, g->acc[i], g->stream[i], nullptr, nullptr, nullptr, nullptr);
+		if (rcs[i] == MIPT_OK && hipEventRecord(g->done[i], g->stream[i]) != hipSuccess) rcs[i] = fail(m, MIPT_ERR_HIP, "hipEventRecord failed");
+	};
+	{
+		std::vector<std::thread> th;
+		for (int i = 1; i < n; i++) th.emplace_back(work, i);
+		work(0);
+		for (auto& t : th) t.join();
+	}
+	for (int i = 0; i < n; i++) if (rcs[i]) { if (i) fail(c, rcs[i], "device %d: %s", g->member[i]->device, g->member[i]->err.c_str()); hipSetDevice(c->device); return rcs[i]; }
+	// the framebuffer reduce: the analogue of the per-thread buffer sum of Raytracer.cpp:1669-1685
+	if (!g->comm.empty() && g->opt_reduce != 2) {
+		RcclApi& api = rccl_api();
+		int r = api.GroupStart();
+		for (int i = 0; i < n && r == 0; i++) {
+			hipSetDevice(g->member[i]->device);
+			r = api.Reduce(g->acc[i], g->acc[i], count, MIPT_NCCL_FLOAT32, MIPT_NCCL_SUM, 0, g->comm[i], g->stream[i]);
+		}
+		const int r2 = api.GroupEnd();
+		hipSetDevice(c->device);
+		if (r != 0 || r2 != 0) return fail(c, MIPT_ERR_HIP, "ncclReduce failed: %s", api.GetErrorString(r ? r : r2));
+	} else {
+		HIPCHK(c, hipSetDevice(c->device));
+		if (g->tmp0_bytes < bytes) {
+			if (g->tmp0) { hipFree(g->tmp0); g->tmp0 = nullptr; g->tmp0_bytes = 0; }
+			HIPCHK(c, hipMalloc((void**)&g->tmp0, bytes));
+			g->tmp0_bytes = bytes;
+		}
+		for (int i = 1; i < n; i++) {
+			HIPCHK(c, hipStreamWaitEvent(g->stream[0], g->done[i], 0));
+			HIPCHK(c, hipMemcpyPeerAsync(g->tmp0, c->device, g->acc[i], g->member[i]->device, bytes, g->stream[0]));
+			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)c->n_cus * 4u), dim3(256), 0, g->stream[0], g->acc[0], (const float*)g->tmp0, count);
+		}
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipEventRecord(g->done[0], g->stream[0]));
+	HIPCHK(c, hipStreamWaitEvent(st, g->done[0], 0));
+	hipLaunchKernelGGL(k_accumulate, dim3((unsigned)c->n_cus * 4u), dim3(256), 0, st, d_accum, (const float*)g->acc[0], count);
+	HIPCHK(c, hipGetLastError());
+	// member 0's partial framebuffer is reused by the next range: its stream waits until the caller's stream has read it
+	HIPCHK(c, hipEventRecord(g->done[0], st));
+	HIPCHK(c, hipStreamWaitEvent(g->stream[0], g->done[0], 0));
+	return MIPT_OK;
+}
+
+// mipt_render* on a group: the whole sample range at once, or — when the caller wants progress calls or may cancel — in
+// chunks of about one pass per device with the reduce after each chunk, so that the caller's buffer always holds complete sums.
+static int group_render(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel) {
+	if (!p) return fail(c, MIPT_ERR_INVALID, "null render params");
+	if (p->W <= 0 || p->H <= 0 || p->nrays <= 0) return fail(c, MIPT_ERR_INVALID, "bad image size / sample count");
+	int kb = p->sample_begin, ke = p->sample_end;
+	if (kb == 0 && ke == 0) ke = p->nrays;
+	if (kb < 0 || ke > p->nrays || kb > ke) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays]");
+	if (kb == ke) return MIPT_OK;
+	const int n = (int)c->group->member.size(), nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
+	int chunk = ke - kb;
+	if (cb || cancel) {
+		const int64_t px_per_device = std::max<int64_t>(64, (int64_t)p->W * p->H / ((int64_t)nr * n));
+		chunk = (int)std::max<int64_t>(1, std::min<int64_t>(chunk, c->opt_paths_per_pass / px_per_device));
+		if (c->opt_samples_per_pass > 0) chunk = (int)std::min<int64_t>(chunk, c->opt_samples_per_pass);
+	}
+	for (int k0 = kb; k0 < ke; k0 += chunk) {
+		if (cancel && *cancel) { hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled"); }
+		const int k1 = std::min(ke, k0 + chunk);
+		int rc = group_render_range(c, p, k0, k1, d_accum, st);
+		if (rc) return rc;
+		if (cb) { hipStreamSynchronize(st); cb(cb_user, k1 - kb, ke - kb); }
+	}
 	return MIPT_OK;
 }
 
 extern "C" int mipt_render_device(mipt_ctx* c, const mipt_render_params* p, float* d_accum_rgbw, void* hip_stream) {
 	if (!c || !p || !d_accum_rgbw) return fail(c, MIPT_ERR_INVALID, "bad arguments");
 	HIPCHK(c, hipSetDevice(c->device));
+	if (c->group) return group_render(c, p, d_accum_rgbw, (hipStream_t)hip_stream, nullptr, nullptr, nullptr);
 	return render_impl(c, p, d_accum_rgbw, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
@@ -1057,7 +1390,8 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	const bool pin_rgb = cb && hipHostRegister(accum_rgb, npx * 3 * sizeof(float), hipHostRegisterDefault) == hipSuccess;
 	const bool pin_w = cb && hipHostRegister(accum_w, npx * sizeof(float), hipHostRegisterDefault) == hipSuccess;
 	if (cb) (void)hipGetLastError();
-	int rc = render_impl(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel, nullptr);
+	int rc = c->group ? group_render(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel)
+	                  : render_impl(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel, nullptr);
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
 	if (rc == MIPT_OK || rc == MIPT_ERR_CANCELLED) {
@@ -1137,6 +1471,43 @@ extern "C" int mipt_measure_stream_read(mipt_ctx* c, uint64_t bytes, int repeats
 	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipFree(sink);
 	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
 	*gb_per_s = (double)bytes * repeats / (ms * 1e-3) / 1e9;
+	return MIPT_OK;
+}
+
+// The access pattern of the traversal kernels on its own, with a known byte count: every lane reads whole 64-byte records
+// (four 16-byte loads, like a fat BVH node) at pseudo-random 64-byte-aligned offsets of a buffer far larger than the
+// Infinity Cache.  Run under `rocprofv3 --pmc FETCH_SIZE` it tells how many bytes that counter reports per gathered byte
+// (tools/fetch_calibration.py): for wide streaming reads the factor is 1/2 (MI355X_MICROARCH.md), for gathers it was unknown.
+__global__ void __launch_bounds__(256) k_gather_read(const float4* __restrict__ src, unsigned long long nrec, int iters, float* __restrict__ sink) {
+	float acc = 0.f;
+	unsigned long long x = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+	for (int it = 0; it < iters; it++) {
+		x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;   // splitmix64
+		const float4* q = src + 4 * (x % nrec);
+		const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+		acc += a.x + b.y + c.z + d.w;
+	}
+	if (acc == 123.456f) *sink = acc;
+}
+extern "C" int mipt_measure_gather_read(mipt_ctx* c, uint64_t buffer_bytes, uint64_t records, int repeats, double* gb_per_s) {
+	if (!c || !gb_per_s || buffer_bytes < (1u << 20) || records < 1 || repeats < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	float4* buf = nullptr; float* sink = nullptr;
+	HIPCHK(c, hipMalloc(&buf, buffer_bytes));
+	if (hipMalloc(&sink, 4) != hipSuccess) { hipFree(buf); return fail(c, MIPT_ERR_HIP, "hipMalloc failed"); }
+	hipMemset(buf, 0, buffer_bytes);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const unsigned grid = (unsigned)c->n_cus * 8u;
+	const int iters = (int)std::max<uint64_t>(1, records / ((uint64_t)grid * 256));
+	hipLaunchKernelGGL(k_gather_read, dim3(grid), dim3(256), 0, 0, buf, (unsigned long long)(buffer_bytes / 64), std::min(iters, 8), sink);   // warm-up
+	hipEventRecord(e0, 0);
+	for (int r = 0; r < repeats; r++) hipLaunchKernelGGL(k_gather_read, dim3(grid), dim3(256), 0, 0, buf, (unsigned long long)(buffer_bytes / 64), iters, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipFree(sink);
+	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
+	*gb_per_s = (double)grid * 256.0 * iters * 64.0 * repeats / (ms * 1e-3) / 1e9;
 	return MIPT_OK;
 }
 
@@ -1307,5 +1678,58 @@ extern "C" int mipt_get_stats(mipt_ctx* c, mipt_stats* out) {
 	int rc = collect_stats(c);
 	if (rc) return rc;
 	*out = c->stats;
+	if (c->group) {     // counters: sums over the devices; times: the slowest device (they run side by side)
+		for (size_t i = 1; i < c->group->member.size(); i++) {
+			mipt_ctx* m = c->group->member[i];
+			HIPCHK(c, hipSetDevice(m->device));
+			HIPCHK(c, hipDeviceSynchronize());
+			if ((rc = collect_stats(m))) { hipSetDevice(c->device); return fail(c, rc, "device %d: %s", m->device, m->err.c_str()); }
+			const mipt_stats& t = m->stats;
+			out->paths += t.paths; out->rays_closest += t.rays_closest; out->rays_shadow += t.rays_shadow;
+			out->mesh_casts_closest += t.mesh_casts_closest; out->mesh_casts_shadow += t.mesh_casts_shadow;
+			out->render_ms = std::max(out->render_ms, t.render_ms); out->traverse_ms = std::max(out->traverse_ms, t.traverse_ms);
+			out->shadow_ms = std::max(out->shadow_ms, t.shadow_ms); out->shade_ms = std::max(out->shade_ms, t.shade_ms); out->resolve_ms = std::max(out->resolve_ms, t.resolve_ms);
+			out->passes = std::max(out->passes, t.passes);
+		}
+		HIPCHK(c, hipSetDevice(c->device));
+	}
 	return MIPT_OK;
+}
+
+// How a group sums its partial framebuffers ("RCCL ncclReduce(sum, fp32, root 0)" or "copy reduce: <why>"); "" for a single device.
+extern "C" const char* mipt_group_reduce_kind(const mipt_ctx* c) { return (c && c->group) ? c->group->reduce_note.c_str() : ""; }
+extern "C" int mipt_group_size(const mipt_ctx* c) { return !c ? 0 : (c->group ? (int)c->group->member.size() : 1); }
+
+// Loads RCCL and runs one single-rank ncclReduce on the context's device: checks, on a box with one GPU, that the library
+// the group path depends on can be loaded and called with the signatures used here.
+extern "C" int mipt_rccl_selftest(mipt_ctx* c) {
+	if (!c) return MIPT_ERR_INVALID;
+	RcclApi& api = rccl_api();
+	if (!api.lib) return fail(c, MIPT_ERR_UNSUPPORTED, "%s", api.why.c_str());
+	HIPCHK(c, hipSetDevice(c->device));
+	mipt_nccl_comm cm = nullptr;
+	int dev = c->device;
+	int r = api.CommInitAll(&cm, 1, &dev);
+	if (r != 0) return fail(c, MIPT_ERR_HIP, "ncclCommInitAll: %s", api.GetErrorString(r));
+	const size_t count = 1 << 20;
+	float *a = nullptr, *b = nullptr;
+	hipStream_t st = nullptr;
+	int rc = MIPT_OK;
+	std::vector<float> h(count), back(count);
+	for (size_t i = 0; i < count; i++) h[i] = (float)(i % 977) * 0.25f;
+	if (hipMalloc((void**)&a, count * 4) != hipSuccess || hipMalloc((void**)&b, count * 4) != hipSuccess || hipStreamCreate(&st) != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "allocation failed");
+	if (!rc && (hipMemcpy(a, h.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(b, 0, count * 4) != hipSuccess)) rc = fail(c, MIPT_ERR_HIP, "copy failed");
+	if (!rc) {
+		api.GroupStart();
+		r = api.Reduce(a, b, count, MIPT_NCCL_FLOAT32, MIPT_NCCL_SUM, 0, cm, st);
+		const int r2 = api.GroupEnd();
+		if (r != 0 || r2 != 0) rc = fail(c, MIPT_ERR_HIP, "ncclReduce: %s", api.GetErrorString(r ? r : r2));
+	}
+	if (!rc && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(back.data(), b, count * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail(c, MIPT_ERR_HIP, "reduce did not complete");
+	if (!rc && memcmp(h.data(), back.data(), count * 4) != 0) rc = fail(c, MIPT_ERR_HIP, "single-rank ncclReduce returned other bytes");
+	if (a) hipFree(a);
+	if (b) hipFree(b);
+	if (st) hipStreamDestroy(st);
+	api.CommDestroy(cm);
+	return rc;
 }

@@ -23,6 +23,16 @@
 #ifndef MIPT_DERIVE_EXTEND
 #define MIPT_DERIVE_EXTEND 1           // the closest-hit traversal too, at 6 waves per SIMD (84 registers; at 7 waves / 72 registers deriving spills: +15 %)
 #endif
+// Top of the tree in LDS: the first MIPT_TOP_NODES inner nodes of the scene's first mesh in breadth-first order (mipt_upload_scene
+// stores them in front of the node buffer) are copied into LDS by every block; a lane whose current node is one of them reads
+// its 64 bytes with four ds_read_b128 instead of four global_load_dwordx4.  0 = off.  The blocks are then MIPT_TRAV_BLOCK threads
+// so that the copy is shared by more waves (LDS per block: stack 80 B + leaf map 4 B per thread + 64 B per cached node).
+#ifndef MIPT_TOP_NODES
+#define MIPT_TOP_NODES 0
+#endif
+#ifndef MIPT_TRAV_BLOCK
+#define MIPT_TRAV_BLOCK (MIPT_TOP_NODES ? 512 : 256)
+#endif
 #ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 1024u           // ids reserved per global atomic (sub-allocated wave-locally)
 #endif
@@ -84,7 +94,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 // queue is drained and all rays this wave fetched are finished.
 template <bool SHADOW>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
+                                               int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
@@ -95,9 +105,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
 	// ids reserved per global atomic: large enough to keep the same-address atomic rate low (one costs ~11 ns
 	// chip-wide), small enough that every wave of the grid gets several chunks (tail balance)
-	const unsigned nwaves = gridDim.x * (MIPT_BLOCK / 64), wave_id = blockIdx.x * (MIPT_BLOCK / 64) + (threadIdx.x >> 6);
+	const unsigned nwaves = gridDim.x * (MIPT_TRAV_BLOCK / 64), wave_id = blockIdx.x * (MIPT_TRAV_BLOCK / 64) + (threadIdx.x >> 6);
 	bool first_pull = true;
-	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u));
+	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_TRAV_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u));
 	const unsigned lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -215,8 +225,17 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
 				if (!inner) continue;
 				MIPT_PROF_COUNT(0)
-				const float4* q = nodes + 4 * (size_t)st.cur;
-				float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+				float4 q0, q1, q2, q3;
+				if (MIPT_TOP_NODES && st.cur < ntop) {
+					// piece p of node n sits at slot (p + (n >> 2)) & 3 of its 64 bytes: the 16 lanes one LDS cycle serves then
+					// spread over all 16 bank quads instead of the 4 that "piece p of any node" maps to
+					const lds_float4* l = top + 4 * st.cur;
+					const unsigned r = st.cur >> 2;
+					q0 = lds_ld4(l + (r & 3)); q1 = lds_ld4(l + ((r + 1) & 3)); q2 = lds_ld4(l + ((r + 2) & 3)); q3 = lds_ld4(l + ((r + 3) & 3));
+				} else {
+					const float4* q = nodes + 4 * (size_t)st.cur;
+					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+				}
 				uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 				float tl, tr;
 				bool goleft, goright;
@@ -358,10 +377,22 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
 template <int MODE>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
-	MIPT_DECLARE_LDS_STACK(stk, wf.spill);
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
+	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min_flags, stk, leafmap);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min_flags, stk, leafmap);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min_flags, stk, leafmap);
+	uint32_t ntop = 0;
+	const lds_float4* top = nullptr;
+#if MIPT_TOP_NODES
+	__shared__ float4 lds_top_[4 * MIPT_TOP_NODES];
+	ntop = min((uint32_t)sc->top_nodes, (uint32_t)MIPT_TOP_NODES);
+	for (uint32_t k = threadIdx.x; k < 4 * ntop; k += MIPT_TRAV_BLOCK) {
+		const uint32_t n = k >> 2, piece = k & 3;
+		lds_top_[4 * n + ((piece + (n >> 2)) & 3)] = nodes[k];
+	}
+	__syncthreads();
+	top = (const lds_float4*)lds_top_;
+#endif
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
 }

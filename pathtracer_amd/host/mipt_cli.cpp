@@ -5,7 +5,8 @@
 // the container follows the extension of the output name (utils.cpp:178-234; .png / .bmp / .tga / .ppm are written, any
 // other extension is an error, never another format under that name).
 //
-//   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device]
+//   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device[,device...]] [-g gpus]
+//        -d 0,1,2,3 or -g 4: the devices rendering the frame (tiles dealt to them, one RCCL reduce; mipt_create with n > 1)
 //        the reference's command line (mainApp.cpp:38-49): loadScene(), load_scene(argv[1][, argv[3]]), render_image_nopreviz(),
 //        save_image(argv[2]); nameSubst replaces the '#' in the mesh file names of the scene (Geometry.h:524-526); options override the file
 //   mipt_render mesh.obj out.png [-s WxH] [-n spp] [-b bounces] [-d device] [--merl file.binary] [--mirror]
@@ -20,7 +21,8 @@ using namespace mipt_host;
 
 int main(int argc, char** argv) {
 	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.ppm [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
-	int W = 1000, H = 800, spp = 100, bounces = 3, device = 0;
+	int W = 1000, H = 800, spp = 100, bounces = 3;
+	int devices[64] = {0}, ndev = 1;
 	const char* merl = nullptr;
 	bool mirror = false;
 	const char* name_subst = nullptr;                    // argv[3] of the reference's command line, when it is not an option
@@ -36,14 +38,19 @@ int main(int argc, char** argv) {
 		if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { fprintf(stderr, "bad size\n"); return 2; } }
 		else if (!strcmp(argv[i], "-n") && i + 1 < argc) spp = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-b") && i + 1 < argc) bounces = atoi(argv[++i]);
-		else if (!strcmp(argv[i], "-d") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-d") && i + 1 < argc) {          // one device or a comma-separated list
+			ndev = 0;
+			for (const char* q = argv[++i]; *q && ndev < 64;) { devices[ndev++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; }
+			if (ndev == 0) { fprintf(stderr, "bad device list\n"); return 2; }
+		}
+		else if (!strcmp(argv[i], "-g") && i + 1 < argc) { ndev = atoi(argv[++i]); if (ndev < 1 || ndev > 64) { fprintf(stderr, "bad GPU count\n"); return 2; } for (int k = 0; k < ndev; k++) devices[k] = k; }
 		else if (!strcmp(argv[i], "--merl") && i + 1 < argc) merl = argv[++i];
 		else if (!strcmp(argv[i], "--mirror")) mirror = true;
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
 	}
 	mh_raytracer* h = mh_create();                                       // new Raytracer + loadScene()
-	int rc = mh_open_device(h, device);
-	if (rc != MIPT_OK) { fprintf(stderr, "cannot open GPU %d (status %d): %s\n", device, rc, mh_last_error(h)); return 1; }   // no CPU fallback
+	int rc = mh_open_devices(h, devices, ndev);
+	if (rc != MIPT_OK) { fprintf(stderr, "cannot open GPU %d%s (status %d): %s\n", devices[0], ndev > 1 ? ", ..." : "", rc, mh_last_error(h)); return 1; }   // no CPU fallback
 	auto t0 = std::chrono::steady_clock::now();
 	const size_t len = strlen(argv[1]);
 	if (len > 4 && !strcmp(argv[1] + len - 4, ".scn")) {                   // Raytracer::load_scene; explicit options override the file

@@ -1288,12 +1288,15 @@ void Raytracer::clear_image() {
 	sample_count.assign((size_t)W * H, 0.f);
 }
 
-int Raytracer::open_device(int device_id) {
+int Raytracer::open_device(int device_id) { return open_devices(&device_id, 1); }
+// Several devices behind the one context: render_image / render_image_nopreviz then use all of them (tiles dealt to the
+// devices, one RCCL reduce of the partial framebuffers inside mipt_render) with no other change on this side.
+int Raytracer::open_devices(const int* device_ids, int n) {
 	if (ctx) { mipt_destroy(ctx); ctx = nullptr; }
 	uploaded_ = false;
-	last_status = mipt_create(&device_id, 1, &ctx);
+	last_status = mipt_create(device_ids, n, &ctx);
 	if (last_status != MIPT_OK) err_ = "mipt_create failed (no usable HIP device: this library has no CPU path)";
-	else g_bvh_builder_device = device_id;   // meshes loaded by this process build their BVH on the GPU it renders on
+	else g_bvh_builder_device = device_ids[0];   // meshes loaded by this process build their BVH on the (first) GPU it renders on
 	return last_status;
 }
 const char* Raytracer::last_error() const { return (ctx && last_status != MIPT_OK && err_.empty()) ? mipt_last_error(ctx) : err_.c_str(); }
@@ -1516,6 +1519,7 @@ extern "C" {
 mh_raytracer* mh_create(void) { mh_raytracer* h = new mh_raytracer; h->rt.loadScene(); return h; }
 void mh_destroy(mh_raytracer* h) { delete h; }
 int mh_open_device(mh_raytracer* h, int device_id) { return h->rt.open_device(device_id); }
+int mh_open_devices(mh_raytracer* h, const int* device_ids, int n) { return h->rt.open_devices(device_ids, n); }
 void mh_set_partition(mh_raytracer* h, int ts, int rank, int nranks) { h->rt.set_partition(ts, rank, nranks); }
 void mh_set_render(mh_raytracer* h, int W, int H, int nrays, int nb_bounces, float sigma) {
 	Raytracer& r = h->rt; r.W = W; r.H = H; r.nrays = nrays; r.nb_bounces = nb_bounces; r.sigma_filter = sigma;

@@ -191,6 +191,7 @@ public:
 	void scene_changed() { uploaded_ = false; }
 	// the GPU this Raytracer renders on, and its share of the image (multi-GPU: one process per GPU)
 	int open_device(int device_id);
+	int open_devices(const int* device_ids, int n);   // mipt_create(device_ids, n)
 	int upload_scene_if_changed();    // mipt_upload_scene unless the resident copy is current; returns the mipt status
 	void set_partition(int tile_size, int rank, int nranks) { tile_size_ = tile_size; tile_rank_ = rank; tile_nranks_ = nranks; }
 	const char* last_error() const;
@@ -247,6 +248,7 @@ typedef struct mh_raytracer mh_raytracer;
 mh_raytracer* mh_create(void);                           // new Raytracer + loadScene()
 void mh_destroy(mh_raytracer*);
 int  mh_open_device(mh_raytracer*, int device_id);        // mipt_create; returns mipt status
+int  mh_open_devices(mh_raytracer*, const int* device_ids, int n);   // mipt_create(device_ids, n): n > 1 = every render call uses all of them
 void mh_set_partition(mh_raytracer*, int tile_size, int rank, int nranks);
 void mh_set_render(mh_raytracer*, int W, int H, int nrays, int nb_bounces, float sigma_filter);
 void mh_set_camera(mh_raytracer*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);

@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     assert declared == set(capi.MIPT_SYMBOLS), declared ^ set(capi.MIPT_SYMBOLS)
     for s in declared:
         assert hasattr(mipt, s), s
-    assert mipt.mipt_abi_version() == 1
+    assert mipt.mipt_abi_version() == 2
 
 
 def test_no_device_means_error_not_fallback():
@@ -35,6 +35,10 @@ def test_no_device_means_error_not_fallback():
     dev = (C.c_int * 1)(0)
     assert mipt.mipt_create(dev, 1, C.byref(ctx)) == capi.MIPT_ERR_NO_DEVICE
     assert not ctx.value
+    two = (C.c_int * 2)(0, 1)
+    assert mipt.mipt_create(two, 2, C.byref(ctx)) == capi.MIPT_ERR_NO_DEVICE and not ctx.value      # a group needs its devices too
+    assert mipt.mipt_create(two, 0, C.byref(ctx)) == 1
+    assert mipt.mipt_group_size(None) == 0 and mipt.mipt_group_reduce_kind(None) == b""
     with pytest.raises(capi.MiptError):
         capi.HostRaytracer(device=0)
     rt = capi.HostRaytracer()          # host-only use is fine ...
