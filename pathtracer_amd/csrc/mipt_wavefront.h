@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 // shade: material of the hit, emission, next-event-estimation request, continuation sampling.
 // TIER 0: every vertex with the general code.  TIER 1: fast tier over the same queue; vertices it cannot
 // handle go to list_slow.  TIER 2: the general code over list_slow for scenes without a measured BRDF, TIER 3: with.
+#ifndef MIPT_SHADE_ROLLED
+#define MIPT_SHADE_ROLLED 1
+#endif
 #ifndef MIPT_SHADE_WAVES
 #define MIPT_SHADE_WAVES 3
 #endif
@@ -298,6 +301,27 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	};
 	while (q.pull(head, n, base)) {
 		unsigned cont_bits = 0, cast_bits = 0, slow_bits = 0;
+#if MIPT_SHADE_ROLLED
+		// The loop over the sub-chunks is NOT unrolled: one copy of the vertex code is ~4 600 instructions (37 KB), four copies
+		// do not fit the 64 KB instruction cache two CUs share.  The path id of sub-chunk u+2 and the state of sub-chunk
+		// u+1 are requested while sub-chunk u is shaded.
+		auto load_id = [&](int u) -> unsigned {
+			const unsigned idx = base + 64u * (unsigned)u + lane_id();
+			return (u < (int)MIPT_WF_UNROLL && idx < n) ? (identity ? idx : list[idx]) : 0xffffffffu;
+		};
+		unsigned id_cur = load_id(0), id_nxt = load_id(1), id_nn = 0xffffffffu;
+		In cur, nxt;
+		cur.w = cur.o = cur.d = cur.hr = cur.col = make_float4(0.f, 0.f, 0.f, 0.f); cur.rs = make_uint2(0u, 0u); nxt = cur;
+		fetch(id_cur, id_cur != 0xffffffffu, cur);
+#pragma unroll 1
+		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
+			const unsigned id = id_cur;
+			id_nn = load_id(u + 2);
+			fetch(id_nxt, id_nxt != 0xffffffffu, nxt);       // in flight while this sub-chunk is shaded; moved into `cur` at the end of the body
+			const In sin = cur;
+			do {
+			if (id == 0xffffffffu) break;
+#else
 		unsigned ids[MIPT_WF_UNROLL];
 #pragma unroll
 		for (int u = 0; u < MIPT_WF_UNROLL; u++) {
@@ -313,11 +337,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			if (u + 1 < MIPT_WF_UNROLL) fetch(ids[u + 1], ids[u + 1] != 0xffffffffu, nxt);
 			const In sin = cur;
 			cur = nxt;
-			if (id == 0xffffffffu) continue;
+			do {
+			if (id == 0xffffffffu) break;
+#endif
 			const float4 w = sin.w, o = sin.o, d = sin.d, hr = sin.hr, col = sin.col;
 			const uint2 rs = sin.rs;
 			unsigned fl = __float_as_uint(w.w);
-			if (identity && !(fl & MIPT_WF_VALID)) continue;
+			if (identity && !(fl & MIPT_WF_VALID)) break;
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
 			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
@@ -339,7 +365,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			bool c;
 			if (TIER == 1) {
 				int r = path_vertex_fast(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
-				if (r == VERTEX_DEFER) { slow_bits |= 1u << u; continue; }
+				if (r == VERTEX_DEFER) { slow_bits |= 1u << u; break; }
 				c = r == VERTEX_CONTINUE;
 			} else c = path_vertex<TIER != 2>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
@@ -380,6 +406,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				wf_st(&wf.rng[id], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 			if (c) cont_bits |= 1u << u;
+			} while (0);
+#if MIPT_SHADE_ROLLED
+			cur = nxt; id_cur = id_nxt; id_nxt = id_nn;
+#endif
 		}
 		const unsigned* src = identity ? nullptr : list;
 		queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);

@@ -102,3 +102,35 @@ def test_default_builder_on_a_gpu_box_is_the_gpu():
     H.apply_config(scenes.config_c1(16, 16, 1))
     obj = H.add_mesh(scenes.blob_mesh(24))
     assert H.mesh_bvh_builder(obj)[0] == "gpu"
+
+
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout", "merl"])
+def test_gpu_bvh_against_the_reference_goldens(name):
+    """The GPU-built tree of every golden scene, compared DIRECTLY with what the compiled reference's TriMesh::build_bvh
+    produced (tests/golden/scene_*.npz: perm / nodes_i / nodes_bb / root_bb / soup written by tests/golden/make_golden.py
+    from oracle/_ref) — not through the host recursion."""
+    from helpers import load_golden, setup_scene
+    g = load_golden(f"scene_{name}.npz")
+    capi.set_bvh_builder("gpu", 0)
+    try:
+        H = capi.HostRaytracer()
+        mesh, cfg, oid = setup_scene_no_device(H, name)
+        assert H.mesh_bvh_builder(oid)[0] == "gpu"
+        d = H.mesh_dump(oid)
+    finally:
+        capi.set_bvh_builder("auto", 0)
+    assert np.array_equal(d["perm"], g["perm"]), "triangle order"
+    assert np.array_equal(d["nodes_i"], g["nodes_i"]), "node topology / numbering"
+    assert np.array_equal(d["nodes_bb"], g["nodes_bb"]), "node boxes (compared as floats: +0 == -0)"
+    assert np.array_equal(d["root_bb"], g["root_bb"])
+    assert np.array_equal(d["soup"][:, :16].view(np.uint32), g["soup16"].view(np.uint32)), "triangle records in tree order"
+    assert np.array_equal(d["groups"], g["groups"])
+
+
+def setup_scene_no_device(H, name):
+    """tests/golden/make_golden.py's setup() without the upload at the end (the context has no device; only TriMesh::init runs)."""
+    from make_golden import golden_scene
+    mesh, cfg, mat = golden_scene(name)
+    H.apply_config(cfg)
+    oid = H.add_mesh(mesh)
+    return mesh, cfg, oid

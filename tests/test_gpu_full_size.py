@@ -193,3 +193,42 @@ def test_every_pixel_full_size_queue_kernel(feature):
     assert err < 1e-4 and same > 0.99999, (feature, same, err)      # the fp64 exp of the subsurface weight is the device library's
     assert out[1].stats()["pipeline"] == 2
     assert 0.01 < want.mean() / WHITE < 2.0
+
+
+def test_c4_real_geometry_oracle_subset():
+    """configs[4] with its REAL geometry: 23 697 288 triangles (15 M nodes: the one config whose BVH exceeds the Infinity
+    Cache), the tree built on the GPU (mipt_build_bvh), MERL table, thin-lens depth of field, 3840x2160.  The oracle builds
+    its own tree with the reference's serial recursion and evaluates 2 000 random (pixel, sample) pairs; both schedulers
+    must return the same radiance bit for bit.  (About two minutes, nearly all of it the oracle's serial BVH build.)"""
+    from oracle.binding import Oracle
+    mesh, cfg, mat, text = scenes.workload("c4", spp=SPP)
+    assert mesh.ntri > 23_000_000, text
+    rng = np.random.default_rng(14)
+    pix = np.stack([rng.integers(0, cfg.H, 1000), rng.integers(0, cfg.W, 1000)], 1).astype(np.int32)      # x SPP = 2 000 samples
+    capi.set_bvh_builder("gpu", 0)
+    try:
+        rt = capi.HostRaytracer(device=0)
+        rt.apply_config(cfg)
+        oid = scenes.install(rt, mesh, mat)
+        who, secs, dev_secs = rt.mesh_bvh_builder(oid)
+        assert who == "gpu" and dev_secs < 1.0
+        rt.prepare()
+        got = {}
+        for pipeline in (1, 0):
+            rt.set_option("pipeline", pipeline)
+            got[pipeline] = rt.sample_radiance(pix, 0, SPP)
+        rt.close()
+    finally:
+        capi.set_bvh_builder("auto", 0)
+    O = Oracle()
+    O.apply_config(cfg)
+    scenes.install(O, mesh, mat)
+    O.prepare()
+    want, want_j = O.getcolor_samples(pix, 0, SPP)
+    for pipeline in (1, 0):
+        g, gj = got[pipeline]
+        assert_bits(gj, want_j, "jitter")
+        err = np.abs(g.astype(np.float64) - want).max() / WHITE
+        assert err < 1e-4, (pipeline, err)
+        assert_bits(g, want, f"c4 real geometry: per-sample radiance, pipeline {pipeline}")
+    assert 0.005 < want.mean() / WHITE < 2.0
