@@ -192,7 +192,8 @@ typedef struct mipt_stats {
 	uint32_t pipeline;            /* pipeline that produced these numbers: 0 per-path kernel, 1 wavefront stages, 2 the contribution-queue
 	                                 kernel (scenes with ghost objects, a background photo, fog or subsurface colours) */
 	uint32_t traverse_merged;     /* 1 = option "merge_traverse" was in effect (see traverse_ms) */
-	uint32_t reserved;
+	uint32_t reserved;            /* contribution-queue pipeline: samples of the last pass that needed more pending contributions than the
+	                                 wavefront stages keep per sample and were rendered by the one-thread-per-sample loop instead */
 	double   resolve_ms;          /* summed over the splat (resolve) launches */
 } mipt_stats;
 
@@ -314,6 +315,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "lane_limit"      measurement probe: the persistent traversal hands rays to the first N lanes of a wave only (0 = all 64)
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for
  *                     every ray (normally only for rays with a zero direction component)
+ *   "queue_wavefront" scenes with ghost objects / a background photo / fog / subsurface colours: 1 = getColor's contribution queue as
+ *                     wavefront stages (default), 0 = one thread per sample with the queue in HBM (the round-1 kernel; same results)
  *   "reduce"          groups only: 0 = RCCL when its communicators exist (default), 1 = RCCL or fail, 2 = device copies + adds
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
  *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order

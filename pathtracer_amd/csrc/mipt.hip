@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 #include "mipt_persistent.h"
 #include "mipt_build.h"
 #include "mipt_compositing.h"
+#include "mipt_queue_wave.h"
 
 // The same splat with a third of the reads.  In the gather above every sample is fetched by each of its (2 fs + 1)^2
 // destination pixels (9 at the default sigma), by different waves and thousands of iterations apart: no cache holds it in
@@ -335,11 +336,17 @@ struct mipt_ctx {
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
 	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
 	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
+	void* overflow_buf = nullptr; size_t overflow_buf_bytes = 0;     // 200-entry rings of the samples the wavefront queue abandoned
+	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
+	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
+	unsigned grid_qlogic[2] = {0, 0};
+	unsigned grid_qtrav[2] = {0, 0};  // resident blocks of k_q_traverse<false / true>
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
 	unsigned grid_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of: traverse<0,1,2>, shade<0,1,2>, extend, shadow
 	int n_mesh_objects = 0;
 	uint64_t host_paths = 0;
+	bool paths_from_host = false;
 	bool has_scene = false;
 	// render-time buffers (grown on demand)
 	void* pass_buf = nullptr; size_t pass_buf_bytes = 0;
@@ -522,6 +529,7 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	}
 	hipSetDevice(c->device);
 	if (c->queue_buf) hipFree(c->queue_buf);
+	if (c->overflow_buf) hipFree(c->overflow_buf);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
 	if (c->tab_buf) hipFree(c->tab_buf);
@@ -546,6 +554,8 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	}
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "queue_wavefront")) { c->opt_queue_wavefront = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
 	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
@@ -751,7 +761,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false, scene_ghost = false;
+	bool scene_merl = false, scene_ghost = false, scene_subs = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -779,7 +789,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			const mipt_texture& t = o.subsurface[k];
 			if (t.W > 0 || t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0) {
 				if (o.type == MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: subsurface scattering on a sphere", i);
-				scene_ghost = true;
+				scene_ghost = true; scene_subs = true;
 			}
 		}
 		for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) {
@@ -841,6 +851,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
+	c->scene_has_subsurface = scene_subs;
 	c->d_background = nullptr; c->backgroundW = c->backgroundH = 0;
 	if (s->background && s->backgroundW > 0 && s->backgroundH > 0) {
 		int rc = upload(c, s->background, (size_t)s->backgroundW * s->backgroundH * 3, &c->d_background);
@@ -852,6 +863,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	if (s->fog_density > 1E-8f && (s->n_objects < 3 || s->fog_type < 0 || s->fog_type > 1 || s->fog_phase_type < 0 || s->fog_phase_type > 2)) return fail(c, MIPT_ERR_INVALID, "bad fog description");
 	c->scene_has_ghost = scene_ghost || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
+	c->grid_qlogic[0] = 0;
 	return MIPT_OK;
 }
 
@@ -1066,7 +1078,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
-	if (c->scene_has_ghost) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
+	const bool queue_wave = c->scene_has_ghost && c->opt_queue_wavefront;
+	if (c->scene_has_ghost && !queue_wave) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
 	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass);
 	spp_pass = std::min(spp_pass, ke - kb);
 	const bool want_aov = d_aov || (dump && dump->out_normal);
@@ -1077,7 +1090,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	size_t per_path = sizeof(float4) + sizeof(float2), fixed_bytes = 4096;
 	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES; fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned); }
 	if (want_aov) per_path += 2 * sizeof(float4);
-	const size_t per_path_queue = pipeline == 2 ? MIPT_SIZE_CIRC_ARRAY * sizeof(QContrib) : 0;
+	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
+		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 5 * sizeof(unsigned);
+		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
+	}
+	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? MIPT_QW_FIFO : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
 	// The pass is sized for the memory that is actually free (the default of 2^29 paths is ~86 GB of state, sized for an
 	// otherwise empty 288 GB device): at most ~80 % of free + what this context already holds for passes, path ids < 2^31.
 	{
@@ -1122,6 +1139,33 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	float4 *aov_n = nullptr, *aov_kd = nullptr;
 	if (want_aov) { aov_n = (float4*)carve(N * sizeof(float4)); aov_kd = (float4*)carve(N * sizeof(float4)); }
 	QContrib* queues = pipeline == 2 ? (QContrib*)c->queue_buf : nullptr;
+	DQueueWave qw{};
+	if (pipeline == 2 && queue_wave) {
+		wf.ray_o = (float4*)carve(N * sizeof(float4)); wf.ray_d = (float4*)carve(N * sizeof(float4)); wf.hit = (float4*)carve(N * sizeof(float4));
+		wf.sh_o = (float4*)carve(N * sizeof(float4)); wf.sh_d = (float4*)carve(N * sizeof(float4));
+		wf.rng = (uint2*)carve(N * sizeof(uint2));
+		wf.out = S;
+		qw.cur_w = (float4*)carve(N * sizeof(float4)); qw.cur_o = (float4*)carve(N * sizeof(float4)); qw.cur_d = (float4*)carve(N * sizeof(float4));
+		qw.acc = (float4*)carve(N * sizeof(float4));
+		qw.ctl = (unsigned*)carve(N * sizeof(unsigned));
+		qw.fr = (float4*)carve(N * MIPT_QW_FRAME * sizeof(float4));
+		qw.vis = (float*)carve(N * sizeof(float));
+		qw.live[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.live[1] = (unsigned*)carve(N * sizeof(unsigned));
+		qw.shl[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.shl[1] = (unsigned*)carve(N * sizeof(unsigned));
+		qw.overflow = (unsigned*)carve(N * sizeof(unsigned));
+		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
+		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
+		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
+		wf.spill = (uint2*)c->spill_buf;
+		if (c->grid_qtrav[0] == 0) {
+			const void* kern[2] = {(const void*)k_q_traverse<false>, (const void*)k_q_traverse<true>};
+			for (int k = 0; k < 2; k++) {
+				int nb = 0;
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+				c->grid_qtrav[k] = std::min((unsigned)c->n_cus * 8u, (unsigned)c->n_cus * (unsigned)nb);
+			}
+		}
+	}
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;
@@ -1157,6 +1201,67 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_render_paths, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+		} else if (pipeline == 2 && queue_wave) {
+			// the contribution queue as rounds of stage kernels (mipt_queue_wave.h): every round the host learns how many
+			// samples still have a query pending (one 8-byte read; the round loop ends when none has)
+			HIPCHK(c, hipMemsetAsync(qw.counters, 0, MIPT_QW_COUNTERS * sizeof(unsigned), st));
+			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
+			hipLaunchKernelGGL(k_q_begin, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, R, P, wf, qw);
+			typedef void (*logic_fn)(const DScene*, DRender, DPass, DWave, DQueueWave, const unsigned*, const unsigned*, unsigned, unsigned*, int, int, DCounters*);
+			const logic_fn logic_k[2] = {c->scene_has_subsurface ? (logic_fn)k_q_logic<true, false> : (logic_fn)k_q_logic<false, false>,      // over a closest-hit list (or all samples)
+			                             c->scene_has_subsurface ? (logic_fn)k_q_logic<true, true> : (logic_fn)k_q_logic<false, true>};       // over an any-hit list
+			if (c->grid_qlogic[0] == 0) {                                 // resident blocks of the logic stage
+				for (int k = 0; k < 2; k++) {
+					int nb = 0;
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)logic_k[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+					c->grid_qlogic[k] = (unsigned)c->n_cus * (unsigned)nb;
+				}
+			}
+			auto launch_logic = [&](int shadow_list, const unsigned* list, const unsigned* n_ptr, unsigned n_imm, unsigned n_host, unsigned* head, int out_slot, int out_parity) {
+				if (n_host == 0) return;
+				const dim3 g(std::max(1u, std::min(c->grid_qlogic[shadow_list], (n_host + MIPT_BLOCK - 1) / MIPT_BLOCK)));
+				hipLaunchKernelGGL(logic_k[shadow_list], g, dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, list, n_ptr, n_imm, head, out_slot, out_parity, c->d_cnt);
+			};
+			launch_logic(0, nullptr, nullptr, (unsigned)total, (unsigned)total, &qw.counters[MIPT_QW_HEAD_LOGIC_A(0)], 0, 0);
+			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+			const float4* d_nodes = (const float4*)c->d_all_nodes;
+			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
+			for (int r = 0;; r++) {
+				if (r > 100000) return fail(c, MIPT_ERR_HIP, "the contribution queue did not drain");
+				const int slot = r & 3, par = r & 1;
+				unsigned pair[2] = {0, 0};                                  // {n_shadow, n_closest} requested by the logic stage of this round
+				HIPCHK(c, hipMemcpyAsync(pair, &qw.counters[MIPT_QW_PAIR(slot)], 8, hipMemcpyDeviceToHost, st));
+				HIPCHK(c, hipStreamSynchronize(st));
+				if (pair[0] == 0 && pair[1] == 0) break;
+				unsigned* pair_dev = &qw.counters[MIPT_QW_PAIR(slot)];
+				if (pair[1]) {
+					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = pair_dev + 1; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
+					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					hipLaunchKernelGGL(k_q_traverse<false>, dim3(std::max(1u, std::min(c->grid_qtrav[0], (pair[1] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				}
+				if (pair[0]) {
+					TravQueue tq; tq.list = qw.shl[par]; tq.n_ptr = pair_dev; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW(slot)]; tq.identity = false; tq.vis = qw.vis; tq.skip_ghosts = true;
+					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					hipLaunchKernelGGL(k_q_traverse<true>, dim3(std::max(1u, std::min(c->grid_qtrav[1], (pair[0] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				}
+				// the logic stage of the next round, over both lists of this one; its counters (used four rounds ago) are cleared first
+				const int nslot = (r + 1) & 3, npar = (r + 1) & 1;
+				HIPCHK(c, hipMemsetAsync(&qw.counters[MIPT_QW_PAIR(nslot)], 0, MIPT_QW_SLOT_WORDS * sizeof(unsigned), st));
+				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
+				launch_logic(0, qw.live[par], pair_dev + 1, 0, pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
+				launch_logic(1, qw.shl[par], pair_dev, 0, pair[0], &qw.counters[MIPT_QW_HEAD_LOGIC_B(nslot)], nslot, npar);
+				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+			}
+			unsigned n_over = 0;
+			HIPCHK(c, hipMemcpyAsync(&n_over, &qw.counters[MIPT_QW_N_OVERFLOW], 4, hipMemcpyDeviceToHost, st));
+			HIPCHK(c, hipStreamSynchronize(st));
+			if (n_over) {   // samples that needed more than MIPT_QW_FIFO pending contributions: the reference's 200-entry ring, one thread each
+				if ((rc = ensure(c, &c->overflow_buf, &c->overflow_buf_bytes, (size_t)n_over * MIPT_SIZE_CIRC_ARRAY * sizeof(QContrib)))) return rc;
+				hipLaunchKernelGGL(k_render_paths_queue_list, dim3((n_over + MIPT_BLOCK - 1) / MIPT_BLOCK), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt, (QContrib*)c->overflow_buf, qw.overflow, n_over, aov_n, aov_kd);
+			}
+			c->stats.reserved = n_over;
 		} else if (pipeline == 2) {
 			if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_render_paths_queue, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, S, c->d_cnt, queues, aov_n, aov_kd);
@@ -1239,6 +1344,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	c->stats.passes = passes;
 	c->host_paths = c->blk_valid_pixels * (uint64_t)(ke - kb);
 	c->stats.pipeline = (uint32_t)pipeline;
+	c->paths_from_host = pipeline == 2 && queue_wave;
 	c->kev_used = nev;
 	return MIPT_OK;
 }
@@ -1248,7 +1354,7 @@ static int collect_stats(mipt_ctx* c) {
 	HIPCHK(c, hipMemcpy(hs.data(), c->d_cnt, sizeof(DCounters) * MIPT_COUNTER_SHARDS, hipMemcpyDeviceToHost));
 	DCounters h{};
 	for (const DCounters& x : hs) { h.paths += x.paths; h.rays_closest += x.rays_closest; h.rays_shadow += x.rays_shadow; }
-	if (c->stats.pipeline == 1) h.paths = c->host_paths;     // the wavefront generate stage does not count on the device
+	if (c->stats.pipeline == 1 || c->paths_from_host) h.paths = c->host_paths;     // the wavefront stages do not count paths on the device
 	c->stats.paths = h.paths; c->stats.rays_closest = h.rays_closest; c->stats.rays_shadow = h.rays_shadow;
 	c->stats.mesh_casts_closest = h.rays_closest * (uint64_t)c->n_mesh_objects;
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder

@@ -59,7 +59,8 @@ struct LaneState {
 // (i is wave-uniform, so the object's description is fetched with scalar loads).  Returns true when
 // the lane has to start traversing mesh i (its traversal state is then set up).
 template <bool SHADOW>
-__device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 rd, LaneState& st) {
+__device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 rd, LaneState& st, bool skip_ghosts) {
+	if (SHADOW && skip_ghosts && o.ghost) return false;          // getColor's shadow rays pass through ghost objects (Geometry.cpp:722, Raytracer.cpp:513)
 	f3 d = xf_dir(o.inv, rd);
 	f3 org = xf_point(o.inv, ro);
 	if (o.type != 0) {
@@ -89,19 +90,30 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 #ifndef MIPT_TRAVERSE_WAVES
 #define MIPT_TRAVERSE_WAVES 7
 #endif
+// Which rays a launch works on and where an any-hit result goes.
+struct TravQueue {
+	const unsigned* list;        // path ids (ignored when identity)
+	const unsigned* n_ptr;       // number of entries, read on the device (nullptr: n_imm)
+	unsigned n_imm;
+	unsigned* head;              // shared chunk counter of this queue
+	bool identity;               // entry k is path id k (depth 0 of the wavefront pipeline)
+	float* vis;                  // shadow rays: nullptr = add the pending direct term to the path's colour when the light sample is
+	                             // visible (wavefront pipeline); else write 1.f (visible) / 0.f (occluded) to vis[id] (contribution-queue pipeline)
+	bool skip_ghosts;            // shadow rays ignore ghost objects
+};
 // One queue of one depth: SHADOW = false the closest-hit rays of depth b (Scene::intersection), SHADOW = true the
 // light-sample rays of depth b (Scene::intersection_shadow).  Called by every wave of the grid; returns when the
 // queue is drained and all rays this wave fetched are finished.
 template <bool SHADOW>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               int b, unsigned n0, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
+                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
-	const unsigned n = SHADOW ? MIPT_N_SHADOW(wf, b) : MIPT_N_EXTEND(wf, b, n0);
-	unsigned* head = &wf.counters[SHADOW ? MIPT_CNT_SH_HEAD(b) : MIPT_CNT_EXT_HEAD(b)];
-	const unsigned* __restrict__ list = SHADOW ? wf.list_sh : wf.list[b & 1];
-	const bool identity = !SHADOW && b == 0;
+	const unsigned n = tq.n_ptr ? *tq.n_ptr : tq.n_imm;
+	unsigned* head = tq.head;
+	const unsigned* __restrict__ list = tq.list;
+	const bool identity = tq.identity;
 	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
 	// ids reserved per global atomic: large enough to keep the same-address atomic rate low (one costs ~11 ns
 	// chip-wide), small enough that every wave of the grid gets several chunks (tail balance)
@@ -183,14 +195,15 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			if (need) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {
 				if (need && st.obj == i) {
-					if (visit_object<SHADOW>(sc->obj[i], i, ro, rd, st)) { need = false; alive = true; }
+					if (visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts)) { need = false; alive = true; }
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
 					else st.obj = i + 1;
 				}
 			}
 			if (need) {                                               // object list exhausted: the ray is decided
 				if (SHADOW) {
-					if (!st.best) {
+					if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
+					else if (!st.best) {
 						float4 c = wf.out.col[st.id], pc = wf.sh_c[st.id];
 						wf.out.col[st.id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
 					}
@@ -392,7 +405,18 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 	__syncthreads();
 	top = (const lds_float4*)lds_top_;
 #endif
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, b, 0u, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, b, n0, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, b + 1, n0, refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
+	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+}
+
+// The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
+// (SHADOW = false: wf.ray_o / ray_d -> wf.hit) or any hits (SHADOW = true: wf.sh_o / sh_d -> tq.vis).
+template <bool SHADOW>
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
+	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
 }

@@ -41,6 +41,9 @@ MIPT_DEV f3 tangent_of(f3 N) {            // getTangent
 	return normalize(t);
 }
 MIPT_DEV f3 random_cos(f3 N, float r1, float r2) {
+#if defined(MIPT_PERTURB) && MIPT_PERTURB == 3
+	return N;                                                               // measurement probe: no sampling frame
+#endif
 	float sr2 = sqrtf(1.f - r2);
 	const float twopi = (float)(2. * MIPT_PI);
 	f3 loc = mk3(pt_cosf(twopi * r1) * sr2, pt_sinf(twopi * r1) * sr2, sqrtf(r2));

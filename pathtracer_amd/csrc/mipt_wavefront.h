@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 // shade: material of the hit, emission, next-event-estimation request, continuation sampling.
 // TIER 0: every vertex with the general code.  TIER 1: fast tier over the same queue; vertices it cannot
 // handle go to list_slow.  TIER 2: the general code over list_slow for scenes without a measured BRDF, TIER 3: with.
+#ifndef MIPT_PERTURB
+#define MIPT_PERTURB 0                  // measurement builds only (tools/build_variant.sh): leaves a piece of the shade stage out to price it
+#endif
 #ifndef MIPT_SHADE_ROLLED
 #define MIPT_SHADE_ROLLED 1
 #endif
@@ -376,10 +379,14 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			bool sh_queue = false;
 			if (sh.diffuse && sh.cast) {
 				n_shadow++;                                               // counted like the reference counts intersection_shadow calls
+#if MIPT_PERTURB == 1
+				sh_queue = true;                                          // measurement probe: no analytic / root tests for the shadow request
+#else
 				if (!analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
 					if (MIPT_SHADE_ROOT_TEST && meshes_missed(sc, sh.ray.o, sh.ray.d, sh.dist)) p.color = p.color + wv * sh.contrib;
 					else sh_queue = true;
 				}
+#endif
 			}
 			if (TIER == 1) {
 				// the vertex ran with colour 0, so p.color is exactly the term it adds (0 + x = x); on a non-emissive surface
@@ -399,7 +406,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
 			if (c) {
 				float t0; unsigned best0;
+#if MIPT_PERTURB == 2
+				t0 = __int_as_float(0x7f800000); best0 = MIPT_HIT_MISS;         // measurement probe: no analytic prefix for the continuation ray
+#else
 				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);       // rides in the unused .w of the ray's two float4s
+#endif
 				wf_st(&wf.ray_o[id], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
 				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
 				wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes   # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+opts = dict(kv.split("=") for kv in sys.argv[2:])        # e.g. queue_wavefront=0 : the one-thread-per-sample kernel
 for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
     mesh, cfg, mat, text = scenes.workload("c1", 1920, 1080, spp, None)
     H = capi.HostRaytracer(device=0)
@@ -25,6 +26,8 @@ for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
     if feature == "subsurface":
         H.set_group_subsurface(oid, 0, (0.8, 0.5, 0.3))
     H.prepare()
+    for kopt, v in opts.items():
+        H.set_option(kopt, int(v))
     H.render()                                    # warm-up (code object load, buffers)
     t0 = time.time()
     img, cnt = H.render()
@@ -32,4 +35,4 @@ for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
     st = H.stats()
     rays = st["rays_closest"] + st["rays_shadow"]
     print(json.dumps({"feature": feature, "pipeline": st["pipeline"], "spp": spp, "Mrays_per_s": round(rays / dt / 1e6, 1), "seconds": round(dt, 3),
-                      "rays_per_path": round(rays / max(1, st["paths"]), 2), "finite": bool(np.isfinite(img).all())}), flush=True)
+                      "rays_per_path": round(rays / max(1, st["paths"]), 2), "passes": st["passes"], "samples_through_the_fallback": st["reserved"], "kernel_ms": {"closest": round(st["traverse_ms"], 1), "shadow": round(st["shadow_ms"], 1), "logic": round(st["shade_ms"], 1), "splat": round(st["resolve_ms"], 1)}, "finite": bool(np.isfinite(img).all())}), flush=True)
