@@ -317,6 +317,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     every ray (normally only for rays with a zero direction component)
  *   "queue_wavefront" scenes with ghost objects / a background photo / fog / subsurface colours: 1 = getColor's contribution queue as
  *                     wavefront stages (default), 0 = one thread per sample with the queue in HBM (the round-1 kernel; same results)
+ *   "queue_ring"      test hook: pending contributions a sample may hold in the wavefront stages (default and maximum 32); samples that
+ *                     need more are rendered by the one-thread-per-sample loop with the reference's 200-entry ring (same results)
  *   "reduce"          groups only: 0 = RCCL when its communicators exist (default), 1 = RCCL or fail, 2 = device copies + adds
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
  *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order

@@ -338,6 +338,7 @@ struct mipt_ctx {
 	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
 	void* overflow_buf = nullptr; size_t overflow_buf_bytes = 0;     // 200-entry rings of the samples the wavefront queue abandoned
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
+	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
 	unsigned grid_qlogic[2] = {0, 0};
 	unsigned grid_qtrav[2] = {0, 0};  // resident blocks of k_q_traverse<false / true>
@@ -554,6 +555,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	}
 	if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail(c, MIPT_ERR_INVALID, "pipeline must be 0 or 1"); c->opt_pipeline = value; return MIPT_OK; }
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
+	if (!strcmp(name, "queue_ring")) { if (value < 1) return fail(c, MIPT_ERR_INVALID, "queue_ring must be >= 1"); c->opt_queue_ring = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_wavefront")) { c->opt_queue_wavefront = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
@@ -1155,6 +1157,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		qw.overflow = (unsigned*)carve(N * sizeof(unsigned));
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
+		qw.ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
 		if (c->grid_qtrav[0] == 0) {

@@ -57,6 +57,7 @@ struct DQueueWave {
 	unsigned* counters;
 	float4 *aov_n, *aov_kd;          // denoiser inputs or null
 	unsigned N;
+	unsigned ring;                   // pending contributions a sample may hold here (<= MIPT_QW_FIFO; smaller: test hook for the fallback)
 };
 
 // shadow rays of getColor ignore ghost objects (avoid_ghosts = true, Raytracer.cpp:513; Geometry.cpp:722)
@@ -151,7 +152,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	const int pix = pi * R.W + pj, k = ps.k0 + kk;
 
 	auto push = [&](f3 w, const Ray& r, int depth, bool lights, bool env, bool hadSS) {
-		if (S.count >= MIPT_QW_FIFO) { S.overflow = true; return; }
+		if (S.count >= qw.ring) { S.overflow = true; return; }
 		QContrib c;
 		c.w = make_float4(w.x, w.y, w.z, __uint_as_float((unsigned)(depth & 0xffff) | (lights ? 0x10000u : 0u) | (env ? 0x20000u : 0u) | (hadSS ? 0x40000u : 0u)));
 		c.o = make_float4(r.o.x, r.o.y, r.o.z, 0.f); c.d = make_float4(r.d.x, r.d.y, r.d.z, 0.f);

@@ -67,3 +67,31 @@ def test_gpu_fog_image_against_the_oracle():
         outs.append(X.render_seeded())
     assert_bits(outs[1][0], outs[0][0], "splatted image in exponential fog")
     assert_bits(outs[1][1], outs[0][1], "sample_count")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ghostfog", "glassfog", "exp"])
+def test_gpu_queue_forms_agree_and_overflow_falls_back(kind):
+    """The three ways the contribution queue can run give the same bits: the wavefront stages (default), the wavefront stages
+    with a ring of 2 pending contributions per sample — most samples of a fog scene need more and are then rendered by the
+    one-thread-per-sample loop with the reference's 200-entry ring — and that loop alone."""
+    g = np.load(GOLD)
+    want = g[kind + "_rgb"]
+    seen = {}
+    for name, opts in (("wavefront", {}), ("ring2", {"queue_ring": 2}), ("thread", {"queue_wavefront": 0})):
+        H = capi.HostRaytracer(device=0)
+        cfg = fog_scene(H, kind)
+        for k, v in opts.items():
+            H.set_option(k, v)
+        rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+        st = H.stats()
+        assert st["pipeline"] == 2
+        seen[name] = st["reserved"]
+        assert_bits(rgb, want, f"per-sample radiance, fog scene {kind}, {name}")
+        img, cnt = H.render()                               # and through the splat
+        if name == "wavefront":
+            first = (img, cnt)
+        else:
+            assert_bits(img, first[0], f"image, {name}")
+            assert_bits(cnt, first[1], f"weights, {name}")
+    assert seen["wavefront"] == 0 and seen["thread"] == 0 and seen["ring2"] > 0, seen
