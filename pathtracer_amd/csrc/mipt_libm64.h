@@ -1,0 +1,258 @@
+// mipt_libm64.h — double-precision exp / pow / sincos bit-exact with the host libm the reference links (glibc 2.35, x86-64).
+//
+// The reference's path calls them in three places: `exp` in the subsurface profile weight (Raytracer.cpp:381), `cos` / `sin` /
+// `pow` in random_Phong (BRDF.h:41-46), `cos` / `sin` in the MERL half / difference-angle transform (MERLBRDFRead.cpp:49-127).
+// Every cos / sin there comes as a pair on one argument, which GCC compiles to ONE call of sincos() (the compiled reference
+// and the oracle import sincos, pow, exp, acos, atan2 from libm and nothing else of this kind: objdump -d | grep call).
+// glibc picks, through ifunc, the variants of exp and pow built with -mfma on every x86-64 CPU that has FMA and AVX2
+// (__exp_fma, __pow_fma: sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, Szabolcs Nagy's table-driven routines, with the
+// contractions GCC chose); sincos has no such variant and is the plain build of IBM's accurate kernels (s_sincos.c).
+// What is below restates those algorithms with every fused operation written as an explicit fma(), in the places the
+// disassembly of the installed libm.so.6 has them (objdump -d: 0x76470 and 0x768b0 of Ubuntu's 2.35-0ubuntu3.x build), and
+// with none in sincos; the tables come out of the same file (tests/native/gen_libm64_tables.py -> mipt_libm64_tables.h).
+// Plain C++ (no HIP intrinsics), compiled without FP contraction, so that tests/native/libm64_check.cpp builds the SAME
+// source with g++ and compares it with libm on billions of arguments.
+//
+// Coverage: the main paths and the argument ranges the path can reach; whatever is outside (|x| > 1.05e8 for sincos,
+// non-finite or non-positive bases and out-of-range exponents for pow) returns false from the *_main() form and the caller
+// uses the device library, whose results for those exact special values are not in question.
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#define MIPT_L64 __host__ __device__ __forceinline__
+#define MIPT_L64_TABLE static __device__ const
+#else
+#define MIPT_L64 static inline
+#define MIPT_L64_TABLE static const
+#endif
+#include "mipt_libm64_tables.h"
+
+MIPT_L64 uint64_t l64_bits(double x) { return __builtin_bit_cast(uint64_t, x); }
+MIPT_L64 double l64_dbl(uint64_t u) { return __builtin_bit_cast(double, u); }
+MIPT_L64 double l64_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+MIPT_L64 double l64_abs(double x) { return l64_dbl(l64_bits(x) & 0x7fffffffffffffffull); }
+MIPT_L64 double l64_copysign(double mag, double sgn) { return l64_dbl((l64_bits(mag) & 0x7fffffffffffffffull) | (l64_bits(sgn) & 0x8000000000000000ull)); }
+
+// ---------------------------------------------------------------- exp (e_exp.c: N = 128, degree-5 polynomial)
+#define L64_INVLN2N 0x1.71547652b82fep+7
+#define L64_SHIFT 0x1.8p+52
+#define L64_NEGLN2HIN (-0x1.62e42fefa0000p-8)
+#define L64_NEGLN2LON (-0x1.cf79abc9e3b3ap-47)
+#define L64_C2 0x1.ffffffffffdbdp-2
+#define L64_C3 0x1.555555555543cp-3
+#define L64_C4 0x1.55555cf172b91p-5
+#define L64_C5 0x1.1111167a4d017p-7
+
+// specialcase() of e_exp.c: the result's exponent would over- or underflow the scale factor
+MIPT_L64 double l64_exp_special(double tmp, uint64_t sbits, uint64_t ki) {
+	if ((ki & 0x80000000ull) == 0) {                     // k > 0
+		sbits -= 1009ull << 52;
+		const double scale = l64_dbl(sbits);
+		return 0x1p1009 * l64_fma(scale, tmp, scale);
+	}
+	sbits += 1022ull << 52;                              // k < 0: care in the subnormal range
+	const double scale = l64_dbl(sbits);
+	const double st = scale * tmp;
+	double y = scale + st;
+	if (y < 1.0) {
+		double lo = (scale - y) + st;
+		const double hi = 1.0 + y;
+		lo = ((1.0 - hi) + y) + lo;
+		y = (hi + lo) - 1.0;
+		if (y == 0.0) y = 0.0;
+	}
+	return 0x1p-1022 * y;
+}
+// exp_inline() of e_pow.c == the body of exp() with xtail = 0 and sign_bias = 0
+MIPT_L64 double l64_exp_core(double x, double xtail, bool with_tail) {
+	uint32_t abstop = (uint32_t)(l64_bits(x) >> 52) & 0x7ffu;
+	if (abstop - 0x3c9u >= 0x3fu) {
+		if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;                         // |x| < 2^-54
+		if (abstop >= 0x409u) {                                                      // |x| >= 1024, inf, nan
+			if (l64_bits(x) == 0xfff0000000000000ull) return 0.0;
+			if (abstop >= 0x7ffu) return 1.0 + x;
+			return (l64_bits(x) >> 63) ? 0x1p-767 * 0x1p-767 : 0x1p769 * 0x1p769;    // __math_uflow / __math_oflow
+		}
+		abstop = 0;                                                                  // 512 <= |x| < 1024: special-cased below
+	}
+	double kd = l64_fma(x, L64_INVLN2N, L64_SHIFT);
+	const uint64_t ki = l64_bits(kd);
+	kd -= L64_SHIFT;
+	double r = l64_fma(kd, L64_NEGLN2HIN, x);
+	r = l64_fma(kd, L64_NEGLN2LON, r);
+	if (with_tail) r = xtail + r;
+	const uint64_t idx = 2 * (ki % 128);
+	const uint64_t top = ki << 45;
+	const double tail = l64_dbl(mipt_l64_exp_tab[idx]);
+	const uint64_t sbits = mipt_l64_exp_tab[idx + 1] + top;
+	const double p = l64_fma(L64_C3, r, L64_C2);
+	const double q = r + tail;
+	const double r2 = r * r;
+	const double s = l64_fma(r, L64_C5, L64_C4);
+	const double t = l64_fma(p, r2, q);
+	const double r4 = r2 * r2;
+	const double tmp = l64_fma(r4, s, t);
+	if (abstop == 0) return l64_exp_special(tmp, sbits, ki);
+	const double scale = l64_dbl(sbits);
+	return l64_fma(scale, tmp, scale);
+}
+MIPT_L64 double mipt_exp64(double x) { return l64_exp_core(x, 0.0, false); }
+
+// ---------------------------------------------------------------- pow (e_pow.c: log_inline with a 128-entry table, then exp_inline)
+#define L64_LN2HI 0x1.62e42fefa3800p-1
+#define L64_LN2LO 0x1.ef35793c76730p-45
+#define L64_A0 (-0x1.0000000000000p-1)
+#define L64_A1 (-0x1.5555555555560p-1)
+#define L64_A2 0x1.0000000000006p-1
+#define L64_A3 0x1.999999959554ep-1
+#define L64_A4 (-0x1.555555529a47ap-1)
+#define L64_A5 (-0x1.2495b9b4845e9p+0)
+#define L64_A6 0x1.0002b8b263fc3p+0
+// x positive and normal, |y| in [2^-65, 2^63): everything the path can ask for (x in (0, 1], y in (0, 1]).  false otherwise.
+MIPT_L64 bool mipt_pow64_main(double x, double y, double& out) {
+	const uint64_t ix = l64_bits(x), iy = l64_bits(y);
+	const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
+	if (topx - 1u >= 0x7ffu - 1u || (topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu) return false;
+	const uint64_t tmp = ix - 0x3fe6955500000000ull;
+	const int i = (int)((tmp >> 45) % 128);
+	const int k = (int)((int64_t)tmp >> 52);
+	const uint64_t iz = ix - (tmp & (0xfffull << 52));
+	const double z = l64_dbl(iz), kd = (double)k;
+	const double invc = l64_dbl(mipt_l64_pow_log_tab[4 * i]), logc = l64_dbl(mipt_l64_pow_log_tab[4 * i + 2]), logctail = l64_dbl(mipt_l64_pow_log_tab[4 * i + 3]);
+	const double r = l64_fma(z, invc, -1.0);
+	const double t1 = l64_fma(kd, L64_LN2HI, logc);
+	const double lo1 = l64_fma(kd, L64_LN2LO, logctail);
+	const double ar = L64_A0 * r;
+	const double p1 = l64_fma(r, L64_A2, L64_A1);
+	const double p2 = l64_fma(r, L64_A4, L64_A3);
+	const double t2 = t1 + r;
+	const double ar2 = r * ar;
+	const double lo2a = t1 - t2;
+	const double ar3 = r * ar2;
+	const double lo3 = l64_fma(ar, r, -ar2);
+	const double lo2 = lo2a + r;
+	const double p3 = l64_fma(r, L64_A6, L64_A5);
+	const double hi = t2 + ar2;
+	const double hd = t2 - hi;
+	const double p23 = l64_fma(p3, ar2, p2);
+	const double lo4 = hd + ar2;
+	const double pin = l64_fma(ar2, p23, p1);
+	double lo = lo1 + lo2;
+	lo = lo + lo3;
+	lo = lo + lo4;
+	lo = l64_fma(ar3, pin, lo);
+	const double lhi = hi + lo;
+	const double ltail = (hi - lhi) + lo;
+	const double ehi = y * lhi;
+	const double et = l64_fma(lhi, y, -ehi);
+	const double elo = l64_fma(y, ltail, et);
+	out = l64_exp_core(ehi, elo, true);
+	return true;
+}
+
+// ---------------------------------------------------------------- sin / cos (s_sin.c, the IBM Accurate Mathematical Library routines)
+#define L64_BIG 0x1.8p+45
+#define L64_TOINT 0x1.8p+52
+#define L64_HPINV 0x1.45f306dc9c883p-1
+#define L64_MP1 0x1.921fb58000000p+0
+#define L64_MP2 (-0x1.dde973c000000p-27)
+#define L64_PP3 (-0x1.cb3b398000000p-55)
+#define L64_PP4 (-0x1.d747f23e32ed7p-83)
+#define L64_HP0 0x1.921fb54442d18p+0
+#define L64_HP1 0x1.1a62633145c07p-54
+#define L64_S1 (-0x1.5555555555555p-3)
+#define L64_S2 0x1.1111111110ecep-7
+#define L64_S3 (-0x1.a01a019db08b8p-13)
+#define L64_S4 0x1.71de27b9a7ed9p-19
+#define L64_S5 (-0x1.addffc2fcdf59p-26)
+#define L64_SN3 (-0x1.5555555555515p-3)
+#define L64_SN5 0x1.11110e829872fp-7
+#define L64_CS2 0x1.0p-1
+#define L64_CS4 (-0x1.5555555555535p-5)
+#define L64_CS6 0x1.6c16bedd9e239p-10
+
+struct L64Tab { double sn, ssn, cs, ccs; };
+MIPT_L64 L64Tab l64_lookup(double u) {
+	const int k = (int)(uint32_t)l64_bits(u) * 4;        // u.i[LOW_HALF] * 4
+	L64Tab t;
+	t.sn = l64_dbl(mipt_l64_sincos_tab[k]); t.ssn = l64_dbl(mipt_l64_sincos_tab[k + 1]);
+	t.cs = l64_dbl(mipt_l64_sincos_tab[k + 2]); t.ccs = l64_dbl(mipt_l64_sincos_tab[k + 3]);
+	return t;
+}
+// ---------------------------------------------------------------- sincos (s_sincos.c)
+// glibc's sincos() is not sin() next to cos(): it has no FMA variant (sysdeps/x86_64/fpu/multiarch has none for
+// s_sincos.c), so it is the plain-SSE2 build of IBM's kernels — no fused operation anywhere — and it takes the
+// 0.855 <= |x| < 2.426 range through a renormalised (a, da) pair for BOTH results, where sin() uses (hp0 - |x|, hp1)
+// directly.  About 2 results in 10 000 differ from those of sin() / cos() in the last bit (tests/native/libm64_check.cpp
+// counts them), so it is sincos that is restated here.
+MIPT_L64 double l64p_do_cos(double x, double dx) {
+	if (x < 0) dx = -dx;
+	const double ax = l64_abs(x);
+	const double u = L64_BIG + ax;
+	const double xr = (ax - (u - L64_BIG)) + dx;
+	const double xx = xr * xr;
+	const double s = xr + (xr * xx) * (L64_SN3 + xx * L64_SN5);
+	const double c = xx * (L64_CS2 + xx * (L64_CS4 + xx * L64_CS6));
+	const L64Tab T = l64_lookup(u);
+	const double cor = ((T.ccs - s * T.ssn) - T.cs * c) - T.sn * s;
+	return T.cs + cor;
+}
+MIPT_L64 double l64p_do_sin(double x, double dx) {
+	const double xold = x;
+	const double ax = l64_abs(x);
+	if (ax < 0.126) {
+		const double xx = x * x;
+		const double poly = ((((L64_S5 * xx + L64_S4) * xx + L64_S3) * xx + L64_S2) * xx) + L64_S1;
+		const double t = (poly * x - 0.5 * dx) * xx + dx;
+		return x + t;
+	}
+	if (!(0.0 < x)) dx = -dx;
+	const double u = L64_BIG + ax;
+	const double xr = ax - (u - L64_BIG);
+	const double xx = xr * xr;
+	const double s = xr + (dx + (xr * xx) * (L64_SN3 + xx * L64_SN5));
+	const double c = xr * dx + xx * (L64_CS2 + xx * (L64_CS4 + xx * L64_CS6));
+	const L64Tab T = l64_lookup(u);
+	const double cor = ((T.ssn + s * T.ccs) - T.sn * c) + T.cs * s;
+	return l64_copysign(T.sn + cor, xold);
+}
+MIPT_L64 int l64p_reduce(double x, double& a, double& da) {
+	const double t = x * L64_HPINV + L64_TOINT;
+	const double xn = t - L64_TOINT;
+	const double y = (x - xn * L64_MP1) - xn * L64_MP2;
+	const int n = (int)(uint32_t)l64_bits(t) & 3;
+	double t1 = xn * L64_PP3;
+	const double t2 = y - t1;
+	double db = (y - t2) - t1;
+	t1 = xn * L64_PP4;
+	const double b = t2 - t1;
+	db += (t2 - b) - t1;
+	a = b; da = db;
+	return n;
+}
+MIPT_L64 double l64p_do_sincos(double a, double da, int n) {
+	const double r = (n & 1) ? l64p_do_cos(a, da) : l64p_do_sin(a, da);
+	return (n & 2) ? -r : r;
+}
+// sincos(x, &s, &c) for |x| < 105414350; false for larger, infinite or NaN arguments
+MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs) {
+	const int32_t k = (int32_t)(l64_bits(x) >> 32) & 0x7fffffff;
+	if (k < 0x400368fd) {
+		if (k < 0x3e400000) { sn = x; cs = 1.0; return true; }
+		if (k < 0x3feb6000) { sn = l64p_do_sin(x, 0.0); cs = l64p_do_cos(x, 0.0); return true; }
+		const double y = L64_HP0 - l64_abs(x);
+		const double a = y + L64_HP1;
+		const double da = (y - a) + L64_HP1;
+		sn = l64_copysign(l64p_do_cos(a, da), x);
+		cs = l64p_do_sin(a, da);
+		return true;
+	}
+	if (k < 0x419921fb) {
+		double a, da;
+		const int n = l64p_reduce(x, a, da);
+		sn = l64p_do_sincos(a, da, n);
+		cs = l64p_do_sincos(a, da, n + 1);
+		return true;
+	}
+	return false;
+}

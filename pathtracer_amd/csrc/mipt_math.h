@@ -5,19 +5,19 @@
 // spells the evaluation order and the promotion points of the reference expression it cites.
 // The translation unit is compiled with -ffp-contract=off: IEEE + - * / sqrt are correctly
 // rounded on gfx950 exactly as on x86-64 SSE, so those expressions are bit-identical.
-// Transcendentals: sinf / cosf / powf / acosf / atanf / atan2f are re-implemented with the algorithms of the
-// host libm the reference links against (mipt_sincos.h, mipt_powf.h, mipt_invtrig.h; each verified
-// against libm on billions of inputs by tests/native/), so that direction sampling, the Phong lobe, the
-// Fresnel term and the environment-map lookup are bit-identical too; the fp64 cos / sin / pow / acos /
-// atan2 of random_Phong and of the MERL evaluation go through the ROCm device library and may differ
-// from glibc in the last ulp of a DOUBLE, which survives the rounding to float about once in 1e8
-// (stated tolerance: DESIGN.md §5).
+// Transcendentals: sinf / cosf / powf / acosf / atanf / atan2f and the double-precision exp / pow / sincos are
+// re-implemented with the algorithms of the host libm the reference links against (mipt_sincos.h, mipt_powf.h,
+// mipt_invtrig.h, mipt_libm64.h; each verified against libm on billions of inputs by tests/native/), so that direction
+// sampling, the Phong lobe and its fp64 sampling frame, the Fresnel term, the subsurface weight and the environment-map
+// lookup are bit-identical too.  Only the fp64 acos / atan2 of the MERL half / difference-angle transform still go
+// through the ROCm device library; they feed nothing but table indices.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mipt_sincos.h"
 #include "mipt_powf.h"
 #include "mipt_invtrig.h"
+#include "mipt_libm64.h"
 
 #define MIPT_DEV __device__ __forceinline__
 
@@ -73,6 +73,14 @@ MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.
 // Bit-exact with the host libm (see mipt_sincos.h; checked on every float of the range the path uses).
 MIPT_DEV float pt_sinf(float y) { return mipt_sincosf<false>(y); }
 MIPT_DEV float pt_cosf(float y) { return mipt_sincosf<true>(y); }
+
+// double-precision exp / pow / sincos of the host libm (mipt_libm64.h; 1.6 G arguments checked against libm by
+// tests/native/libm64_check.cpp).  Arguments outside the restated ranges (never reached by the path) go to the device library.
+__device__ __attribute__((noinline)) void sincos64_special(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+__device__ __attribute__((noinline)) double pow64_special(double x, double y) { return pow(x, y); }
+MIPT_DEV void pt_sincos64(double a, double& s, double& c) { if (!mipt_sincos64_main(a, s, c)) sincos64_special(a, s, c); }
+MIPT_DEV double pt_pow64(double x, double y) { double r; if (mipt_pow64_main(x, y, r)) return r; return pow64_special(x, y); }
+MIPT_DEV double pt_exp64(double x) { return mipt_exp64(x); }
 
 // powf: the host libm's algorithm, bit for bit (mipt_powf.h), for positive finite x and finite non-zero y; the exact
 // special values (pow(x,0) = 1, pow(1,y) = 1, zero / inf / NaN / negative bases) come from the device library.

@@ -367,7 +367,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 						f3 localP2; Mat subsmat;
 						subsmat.shadingN = mk3(0, 1, 0); subsmat.Kd = mk3(0.5f, 0.5f, 0.5f); subsmat.Ks = mk3(0, 0, 0); subsmat.Ne = mk3(100, 100, 100); subsmat.Ke = mk3(0, 0, 0); subsmat.transp = false; subsmat.refr_index = 0;
 						hit_material_obj(obj, probe, sh, localP2, subsmat);
-						const float chris = (float)exp((double)(-norm2(P - localP2)) / (2. * (double)sigmasub * (double)sigmasub));
+						const float chris = (float)pt_exp64((double)(-norm2(P - localP2)) / (2. * (double)sigmasub * (double)sigmasub));
 						const double d0 = 0.5 * (double)dot(subsmat.shadingN, Nn), d1 = 0.25 * (double)dot(subsmat.shadingN, Tg), d2 = 0.25 * (double)dot(subsmat.shadingN, Tg2);
 						const float sumpdfs = (float)((d0 * d0 + d1 * d1) + d2 * d2);
 						const float pdfdisk = wAxis * fabsf(dot(axis, subsmat.shadingN)) / sumpdfs;

@@ -56,7 +56,9 @@ MIPT_DEV f3 random_cos(f3 N, float r1, float r2) {
 __device__ __attribute__((noinline)) f3 random_phong(f3 R, float phong_exponent, float r1, float r2) {
 	float facteur = sqrtf(1 - pt_powf(r2, 2.f / (phong_exponent + 1.f)));
 	double ang = 2 * MIPT_PI * (double)r1;
-	f3 loc = mk3((float)(cos(ang) * (double)facteur), (float)(sin(ang) * (double)facteur), (float)pow((double)r2, 1. / (double)(phong_exponent + 1)));
+	double ca, sa;
+	pt_sincos64(ang, sa, ca);                 // cos(ang), sin(ang): one sincos() call in the compiled reference
+	f3 loc = mk3((float)(ca * (double)facteur), (float)(sa * (double)facteur), (float)pt_pow64((double)r2, 1. / (double)(phong_exponent + 1)));
 	f3 t1 = tangent_of(R);
 	f3 t2 = cross(t1, R);
 	return loc.z * R + loc.x * t1 + loc.y * t2;
@@ -85,11 +87,12 @@ MIPT_DEV f3 phong_eval(const Mat& mat, f3 wi, f3 wo, f3 N) {
 }
 
 // ---------------------------------------------------------------- IsoMERLBRDF (BRDF.h:192-247, MERLBRDFRead.cpp:29-206)
-// fp64 half/difference-angle transform and table lookup, as the reference.  The trigonometric calls go
-// through the ROCm device library: a last-ulp difference from glibc can move a sample into the
-// neighbouring table cell, so MERL scenes are held to the stated tolerance, not to bit equality.
+// fp64 half/difference-angle transform and table lookup, as the reference.  cos / sin are the host libm's sincos()
+// (mipt_libm64.h); acos / atan2 still go through the ROCm device library: a last-ulp difference from glibc there could
+// move a sample into the neighbouring table cell only when an angle lies within an ulp of a cell boundary.
 MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, double* out) {   // rotate_vector :49-72
-	double ca = cos(angle), sa = sin(angle);
+	double ca, sa;
+	pt_sincos64(angle, sa, ca);
 	out[0] = v[0] * ca; out[1] = v[1] * ca; out[2] = v[2] * ca;
 	double temp = axis[0] * v[0] + axis[1] * v[1] + axis[2] * v[2];
 	temp = temp * (1.0 - ca);
@@ -114,12 +117,16 @@ __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ dat
 	if (phii < 0) phii = (float)((double)phii + 2 * MIPT_PI);
 	// std_coords_to_half_diff_coords (:76-127)
 	double theta_in = thetai, fi_in = phii, theta_out = thetao, fi_out = phio;
-	double in_z = cos(theta_in), pin = sin(theta_in);
-	double in_x = pin * cos(fi_in), in_y = pin * sin(fi_in);
+	double in_z, pin, cfi, sfi;
+	pt_sincos64(theta_in, pin, in_z);
+	pt_sincos64(fi_in, sfi, cfi);
+	double in_x = pin * cfi, in_y = pin * sfi;
 	double in[3] = {in_x, in_y, in_z};
 	{ double len = sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]); in[0] = in[0] / len; in[1] = in[1] / len; in[2] = in[2] / len; }
-	double out_z = cos(theta_out), pout = sin(theta_out);
-	double out_x = pout * cos(fi_out), out_y = pout * sin(fi_out);
+	double out_z, pout, cfo, sfo;
+	pt_sincos64(theta_out, pout, out_z);
+	pt_sincos64(fi_out, sfo, cfo);
+	double out_x = pout * cfo, out_y = pout * sfo;
 	double half[3] = {(in_x + out_x) / 2.0, (in_y + out_y) / 2.0, (in_z + out_z) / 2.0};
 	{ double len = sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]); half[0] = half[0] / len; half[1] = half[1] / len; half[2] = half[2] / len; }
 	double theta_half = acos(half[2]);

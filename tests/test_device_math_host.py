@@ -52,3 +52,48 @@ def test_expf_logf_tanf_bit_exact_with_libm(tmp_path):
     n, bad = int(out[0]), [int(v) for v in out[1:4]]
     assert n > 5_000_000_000
     assert bad == [0, 0, 0], bad
+
+
+def _cpu_has_fma_avx2():
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return False
+    return "fma" in flags and "avx2" in flags
+
+
+def test_exp_pow_sincos_double_bit_exact_with_libm(tmp_path):
+    """csrc/mipt_libm64.h (subsurface weight, random_Phong's sampling frame, the MERL transform) against the host libm's
+    double-precision exp / pow / sincos: the whole finite range of exp incl. subnormal results, pow over the Phong lobe's
+    domain and wide log-uniform ones, sincos over the path's domains (2 pi x float, float angles) and everything below
+    1.05e8 — 500 M evaluations here (1.6 G with 0 mismatches: `libm64_check 60000000`).  glibc runs its FMA builds of exp
+    and pow on CPUs with FMA + AVX2, which is what the header restates: on other CPUs the comparison is void."""
+    import pytest
+    if not _cpu_has_fma_avx2():
+        pytest.skip("host CPU without FMA + AVX2: glibc selects other variants of exp / pow than the ones restated")
+    exe = str(tmp_path / "libm64_check")
+    subprocess.run(["g++", "-O2", "-fopenmp", "-ffp-contract=off", "-mfma", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "libm64_check.cpp"), "-lm"], check=True)
+    out = subprocess.run([exe, "20000000"], check=True, capture_output=True, text=True).stdout.split()
+    n, bad_exp, bad_pow, bad_sincos, sincos_vs_sin_cos = (int(v) for v in out[:5])
+    assert n > 300_000_000
+    assert (bad_exp, bad_pow, bad_sincos) == (0, 0, 0)
+    assert sincos_vs_sin_cos > 0        # libm's sincos() is not its sin() next to its cos(): the reason sincos is what is restated
+
+
+def test_libm64_tables_are_those_of_the_installed_libm(tmp_path):
+    """csrc/mipt_libm64_tables.h is generated from the .rodata of libm.so.6 (tests/native/gen_libm64_tables.py): where the
+    installed libm is the build the addresses were taken from, regenerating gives the committed file."""
+    import pytest
+    import shutil
+    libm = "/lib/x86_64-linux-gnu/libm.so.6"
+    gen = os.path.join(ROOT, "tests", "native", "gen_libm64_tables.py")
+    committed = os.path.join(ROOT, "pathtracer_amd", "csrc", "mipt_libm64_tables.h")
+    if not os.path.exists(libm) or os.path.getsize(libm) != 940560:
+        pytest.skip("another build of libm.so.6 than Ubuntu GLIBC 2.35-0ubuntu3.x")
+    work = tmp_path / "tree" / "tests" / "native"
+    os.makedirs(work)
+    os.makedirs(tmp_path / "tree" / "pathtracer_amd" / "csrc")
+    shutil.copy(gen, work / "gen_libm64_tables.py")
+    subprocess.run(["python3", str(work / "gen_libm64_tables.py"), libm], check=True, capture_output=True)
+    assert open(tmp_path / "tree" / "pathtracer_amd" / "csrc" / "mipt_libm64_tables.h").read() == open(committed).read()

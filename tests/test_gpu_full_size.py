@@ -188,9 +188,9 @@ def test_every_pixel_full_size_queue_kernel(feature):
     pix = np.stack(np.meshgrid(np.arange(cfg.H), np.arange(cfg.W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
     want, _ = out[0].getcolor_samples(pix, 0, 1)
     got, _ = out[1].sample_radiance(pix, 0, 1)
-    same = bits_equal(got, want).all(-1).mean()
     err = np.abs(got.astype(np.float64) - want).max() / WHITE
-    assert err < 1e-4 and same > 0.99999, (feature, same, err)      # the fp64 exp of the subsurface weight is the device library's
+    assert err < 1e-4, (feature, err)
+    assert_bits(got, want, f"per-sample radiance of all 2 073 600 pixels, {feature}")      # the fp64 exp of the subsurface weight is glibc's (csrc/mipt_libm64.h)
     assert out[1].stats()["pipeline"] == 2
     assert 0.01 < want.mean() / WHITE < 2.0
 

@@ -46,8 +46,8 @@ def test_oracle_subsurface_against_live_reference():
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", SSS_KINDS)
 def test_gpu_subsurface_per_sample(kind):
-    """One fp64 exp of the branch (the profile weight `chris`, Raytracer.cpp:381) comes from the ROCm device library, not
-    from glibc: the bar is the stated tolerance, and the fraction of bit-identical samples is reported."""
+    """The fp64 exp of the branch (the profile weight `chris`, Raytracer.cpp:381) is glibc's algorithm (csrc/mipt_libm64.h):
+    every sample bit for bit."""
     g = np.load(GOLD)
     H = capi.HostRaytracer(device=0)
     cfg = subsurface_scene(H, kind)
@@ -56,7 +56,7 @@ def test_gpu_subsurface_per_sample(kind):
     same = (rgb.view(np.uint32) == want.view(np.uint32)).all(-1).mean()
     err = np.abs(rgb.astype(np.float64) - want).max() / WHITE
     print("%s: bit-identical fraction %.6f, max |err|/white %.3e" % (kind, same, err))
-    assert same > 0.9999 and err < 1e-4, (same, err)
+    assert same == 1.0 and err == 0.0, (same, err)
 
 
 @pytest.mark.gpu
