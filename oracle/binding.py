@@ -336,6 +336,17 @@ class Ref(_Base):
         hdr = self.scene_header()
         self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])
 
+    # ---- key-framed transforms
+    def set_frame(self, frame):
+        self.lib.ref_set_frame(self.ctx, int(frame))
+
+    def add_keyframe(self, obj, frame):
+        self.lib.ref_add_keyframe(self.ctx, int(obj), int(frame))
+
+    def set_object_transform(self, obj, translation, rotation9, scale):
+        t = np.ascontiguousarray(translation, np.float32); r = np.ascontiguousarray(rotation9, np.float32).reshape(9)
+        self.lib.ref_set_object_transform(self.ctx, int(obj), _p(t, _f), _p(r, _f), _f(scale))
+
     def num_objects(self):
         return self.lib.ref_num_objects(self.ctx)
 

@@ -77,6 +77,15 @@ void ref_load_scene(RefCtx* c, const char* file) {
 	rt->last_nrays = -1; rt->lastfilter = -1; rt->randomPerPixel.clear();
 	rt->has_denoiser = false;
 }
+// key-framed transforms (Geometry.h:258-320): the frame they are evaluated at, Object::add_keyframe, the transform it records
+void ref_set_frame(RefCtx* c, int frame) { c->rt->s.current_frame = frame; }
+void ref_add_keyframe(RefCtx* c, int obj, int frame) { c->rt->s.objects[obj]->add_keyframe(frame); }
+void ref_set_object_transform(RefCtx* c, int obj, const float* t, const float* r, float scale) {
+	Object* o = c->rt->s.objects[obj];
+	o->max_translation = Vector(t[0], t[1], t[2]);
+	for (int k = 0; k < 9; k++) o->mat_rotation[k] = r[k];
+	o->scale = scale;
+}
 int ref_num_objects(RefCtx* c) { return (int)c->rt->s.objects.size(); }
 void ref_get_scene_header(RefCtx* c, float* o) {
 	Raytracer& r = *c->rt;

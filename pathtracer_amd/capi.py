@@ -235,6 +235,17 @@ class HostRaytracer:
         hdr = self.scene_header()
         self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])
 
+    # ---- key-framed transforms (Geometry.h:258-320)
+    def set_frame(self, frame):
+        self.host.mh_set_frame(self.h, int(frame))
+
+    def add_keyframe(self, obj, frame):
+        self.host.mh_add_keyframe(self.h, int(obj), int(frame))
+
+    def set_object_transform(self, obj, translation, rotation9, scale):
+        t = np.ascontiguousarray(translation, np.float32); r = np.ascontiguousarray(rotation9, np.float32).reshape(9)
+        self.host.mh_set_object_transform(self.h, int(obj), _p(t, _f), _p(r, _f), _f(scale))
+
     def save_scene(self, path):
         self.host.mh_save_scene.restype = C.c_int
         if self.host.mh_save_scene(self.h, str(path).encode()) != 0:

@@ -5,7 +5,8 @@
 // the container follows the extension of the output name (utils.cpp:178-234; .png / .bmp / .tga / .ppm are written, any
 // other extension is an error, never another format under that name).
 //
-//   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device[,device...]] [-g gpus]
+//   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-f frame] [-d device[,device...]] [-g gpus]
+//        -f: Scene::current_frame, the time the scene's key-framed transforms are evaluated at (default 0)
 //        -d 0,1,2,3 or -g 4: the devices rendering the frame (tiles dealt to them, one RCCL reduce; mipt_create with n > 1)
 //        the reference's command line (mainApp.cpp:38-49): loadScene(), load_scene(argv[1][, argv[3]]), render_image_nopreviz(),
 //        save_image(argv[2]); nameSubst replaces the '#' in the mesh file names of the scene (Geometry.h:524-526); options override the file
@@ -20,8 +21,8 @@
 using namespace mipt_host;
 
 int main(int argc, char** argv) {
-	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.ppm [nameSubst] [-s WxH] [-n spp] [-b bounces] [-d device] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
-	int W = 1000, H = 800, spp = 100, bounces = 3;
+	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.ppm [nameSubst] [-s WxH] [-n spp] [-b bounces] [-f frame] [-d device,...] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
+	int W = 1000, H = 800, spp = 100, bounces = 3, frame = 0;
 	int devices[64] = {0}, ndev = 1;
 	const char* merl = nullptr;
 	bool mirror = false;
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
 		if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { fprintf(stderr, "bad size\n"); return 2; } }
 		else if (!strcmp(argv[i], "-n") && i + 1 < argc) spp = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-b") && i + 1 < argc) bounces = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-f") && i + 1 < argc) frame = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-d") && i + 1 < argc) {          // one device or a comma-separated list
 			ndev = 0;
 			for (const char* q = argv[++i]; *q && ndev < 64;) { devices[ndev++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; }
@@ -69,6 +71,7 @@ int main(int argc, char** argv) {
 		if (mirror) mh_set_object_flags(h, obj, 1, 0);
 		if (merl && mh_set_brdf_merl_file(h, obj, merl) != 0) { fprintf(stderr, "%s\n", mh_last_error(h)); return 1; }
 	}
+	mh_set_frame(h, frame);
 	auto t1 = std::chrono::steady_clock::now();
 	rc = mh_render_image_nopreviz(h);
 	auto t2 = std::chrono::steady_clock::now();

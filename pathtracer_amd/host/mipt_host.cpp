@@ -71,12 +71,98 @@ Object::Object() {
 	memset(trans_matrix, 0, sizeof trans_matrix); memset(inv_trans_matrix, 0, sizeof inv_trans_matrix); memset(rot_matrix, 0, sizeof rot_matrix);
 }
 
-void Object::build_matrix() {   // Geometry.h:322-360
-	const float* m = mat_rotation;
+// Key frames (Geometry.h:258-320).  std::map::upper_bound and the arithmetic are the reference's; the rotation goes through
+// Matrix::toQuaternion / Slerp / fromQuaternion (Vector.h:104-158, 223-269) with T = float: the unsuffixed literals make the
+// square roots and the products of fromQuaternion double expressions narrowed on assignment, acos / sin of a float are the
+// float overloads.
+float Object::get_scale(float frame) const {
+	auto it1 = scale_keyframes.upper_bound(frame);
+	auto it2 = it1;
+	if (it1 == scale_keyframes.end()) return scale_keyframes.size() != 0 ? scale_keyframes.rbegin()->second : scale;
+	if (it1 == scale_keyframes.begin()) return it1->second;
+	it1--;
+	const float t = (frame - it1->first) / (it2->first - it1->first);
+	return (1.f - t) * it1->second + t * it2->second;
+}
+Vector Object::get_translation(float frame) const {
+	auto it1 = translation_keyframes.upper_bound(frame);
+	auto it2 = it1;
+	if (it1 == translation_keyframes.end()) return translation_keyframes.size() != 0 ? translation_keyframes.rbegin()->second : max_translation;
+	if (it1 == translation_keyframes.begin()) return it1->second;
+	it1--;
+	const float t = (frame - it1->first) / (it2->first - it1->first);
+	const float a = 1 - t;                                      // (1 - t) * v1 + t * v2, component-wise (Vector.h:499, 491)
+	return Vector(a * it1->second[0] + t * it2->second[0], a * it1->second[1] + t * it2->second[1], a * it1->second[2] + t * it2->second[2]);
+}
+namespace {
+struct Quat { float w, x, y, z; };
+Quat to_quaternion(const float* v) {                            // Matrix::toQuaternion: (*this)(i, j) = values[i * 3 + j]
+	const float m00 = v[0], m01 = v[3], m02 = v[6], m10 = v[1], m11 = v[4], m12 = v[7], m20 = v[2], m21 = v[5], m22 = v[8];
+	const float tr = m00 + m11 + m22;
+	Quat q;
+	if (tr > 0) {
+		const float S = (float)(std::sqrt(tr + 1.0) * 2);
+		q.w = (float)(0.25 * S); q.x = (m21 - m12) / S; q.y = (m02 - m20) / S; q.z = (m10 - m01) / S;
+	} else if ((m00 > m11) & (m00 > m22)) {
+		const float S = (float)(std::sqrt(1.0 + m00 - m11 - m22) * 2);
+		q.w = (m21 - m12) / S; q.x = (float)(0.25 * S); q.y = (m01 + m10) / S; q.z = (m02 + m20) / S;
+	} else if (m11 > m22) {
+		const float S = (float)(std::sqrt(1.0 + m11 - m00 - m22) * 2);
+		q.w = (m02 - m20) / S; q.x = (m01 + m10) / S; q.y = (float)(0.25 * S); q.z = (m12 + m21) / S;
+	} else {
+		const float S = (float)(std::sqrt(1.0 + m22 - m00 - m11) * 2);
+		q.w = (m10 - m01) / S; q.x = (m02 + m20) / S; q.y = (m12 + m21) / S; q.z = (float)(0.25 * S);
+	}
+	return q;
+}
+Quat slerp(Quat q1, Quat q2, float t) {                         // Vector.h:223-258
+	float w2 = q2.w, x2 = q2.x, y2 = q2.y, z2 = q2.z;
+	const float w1 = q1.w, x1 = q1.x, y1 = q1.y, z1 = q1.z;
+	if (w1 * w2 + x1 * x2 + y1 * y2 + z1 * z2 < 0) { w2 = -w2; x2 = -x2; y2 = -y2; z2 = -z2; }
+	const float theta = std::acos(w1 * w2 + x1 * x2 + y1 * y2 + z1 * z2);
+	float mult1, mult2;
+	if (theta > 0.000001) { mult1 = std::sin((1 - t) * theta) / std::sin(theta); mult2 = std::sin(t * theta) / std::sin(theta); }
+	else { mult1 = 1 - t; mult2 = t; }
+	Quat r;
+	r.w = mult1 * w1 + mult2 * w2; r.x = mult1 * x1 + mult2 * x2; r.y = mult1 * y1 + mult2 * y2; r.z = mult1 * z1 + mult2 * z2;
+	return r;
+}
+void from_quaternion(Quat q, float* v) {                        // Matrix::fromQuaternion
+	const float w = q.w, x = q.x, y = q.y, z = q.z;
+	v[0] = w * w + x * x - y * y - z * z;
+	v[1] = (float)(2.0 * x * y + 2.0 * w * z);
+	v[2] = (float)(2.0 * x * z - 2.0 * y * w);
+	v[3] = (float)(2.0 * x * y - 2.0 * w * z);
+	v[4] = w * w - x * x + y * y - z * z;
+	v[5] = (float)(2.0 * y * z + 2.0 * w * x);
+	v[6] = (float)(2.0 * x * z + 2.0 * w * y);
+	v[7] = (float)(2.0 * y * z - 2.0 * w * x);
+	v[8] = w * w - x * x - y * y + z * z;
+}
+}  // namespace
+void Object::get_rotation(float frame, float out9[9]) const {
+	auto it1 = rotation_keyframes.upper_bound(frame);
+	auto it2 = it1;
+	if (it1 == rotation_keyframes.end()) { memcpy(out9, rotation_keyframes.size() != 0 ? rotation_keyframes.rbegin()->second.data() : mat_rotation, 36); return; }
+	if (it1 == rotation_keyframes.begin()) { memcpy(out9, it1->second.data(), 36); return; }
+	it1--;
+	const float t = (frame - it1->first) / (it2->first - it1->first);
+	from_quaternion(slerp(to_quaternion(it1->second.data()), to_quaternion(it2->second.data()), t), out9);
+}
+void Object::add_keyframe(int frame) {
+	std::array<float, 9> r; memcpy(r.data(), mat_rotation, 36);
+	rotation_keyframes[(float)frame] = r;
+	translation_keyframes[(float)frame] = max_translation;
+	scale_keyframes[(float)frame] = scale;
+}
+
+void Object::build_matrix(float frame) {   // Geometry.h:322-360
+	float m[9];
+	get_rotation(frame, m);
 	float mt[9];
 	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) mt[j * 3 + i] = m[i * 3 + j];
-	const float s = scale;
-	const Vector tr = max_translation;
+	const float s = get_scale(frame);
+	const Vector tr = get_translation(frame);
 	for (int i = 0; i < 3; i++) {
 		Vector v2(m[0 * 3 + i], m[1 * 3 + i], m[2 * 3 + i]);
 		trans_matrix[0 * 4 + i] = v2[0] * s; trans_matrix[1 * 4 + i] = v2[1] * s; trans_matrix[2 * 4 + i] = v2[2] * s;
@@ -906,7 +992,7 @@ void TriMesh::setup_tangents() {
 
 // ---------------------------------------------------------------- Scene
 Scene::~Scene() { for (Object* o : objects) delete o; }
-void Scene::prepare_render() { for (Object* o : objects) o->build_matrix(); }
+void Scene::prepare_render() { for (Object* o : objects) o->build_matrix((float)current_frame); }   // Geometry.cpp:280-284
 
 bool Scene::intersection(const mipt_ray& d, Vector& P, int& sphere_id, float& min_t, mipt_hit& mat, int& triangle_id) const {
 	mipt_hit h;
@@ -1084,8 +1170,17 @@ bool scn_object_common(ScnReader& R, Object* o, const std::string& dir, const ch
 	o->flip_normals = b != 0;
 	if (!R.next()) return R.fail("truncated object");
 	bool have_count = true;
-	if (R.starts("nb_transforms:")) {
-		if (strtoul(R.after("nb_transforms:"), nullptr, 10) != 0) return R.fail("key-framed transforms are outside the hot path");
+	o->scale_keyframes.clear(); o->translation_keyframes.clear(); o->rotation_keyframes.clear();
+	if (R.starts("nb_transforms:")) {                   // Geometry.h:549-571: n scales, n translations, n rotations, each behind its frame
+		const int n = (int)strtoul(R.after("nb_transforms:"), nullptr, 10);
+		float kv[10];
+		for (int i = 0; i < n; i++) { if (!R.next() || !R.floats(R.line, kv, 2)) return R.fail("bad scale key frame"); o->scale_keyframes[kv[0]] = kv[1]; }
+		for (int i = 0; i < n; i++) { if (!R.next() || !R.floats(R.line, kv, 4)) return R.fail("bad translation key frame"); o->translation_keyframes[kv[0]] = Vector(kv[1], kv[2], kv[3]); }
+		for (int i = 0; i < n; i++) {
+			if (!R.next() || !R.floats(R.line, kv, 10)) return R.fail("bad rotation key frame");
+			std::array<float, 9> r; for (int k = 0; k < 9; k++) r[k] = kv[1 + k];
+			o->rotation_keyframes[kv[0]] = r;
+		}
 		have_count = false;
 	} else if (!R.starts("nb_textures:")) return R.fail("expected nb_textures");
 	bool ok = true;
@@ -1116,7 +1211,7 @@ bool Raytracer::load_scene(const char* filename, const char* replacedNames) {
 	W = (int)v[0]; H = (int)v[1];
 	if (!R.getu("nrays:", nrays)) return bail("");
 	if (!R.next()) return bail("truncated header");
-	if (R.starts("nbframes:")) { if (!R.expect("Cam:")) return bail(""); }
+	if (R.starts("nbframes:")) { s.nbframes = (int)strtoul(R.after("nbframes:"), nullptr, 10); if (!R.expect("Cam:")) return bail(""); }
 	else if (!R.starts("Cam:")) return bail("expected Cam");
 	if (!R.floats(R.after("Cam:"), v, 9)) return bail("bad Cam");
 	cam.position = Vector(v[0], v[1], v[2]); cam.direction = Vector(v[3], v[4], v[5]); cam.up = Vector(v[6], v[7], v[8]);
@@ -1197,6 +1292,7 @@ bool Raytracer::load_scene(const char* filename, const char* replacedNames) {
 			g->name = tmp.name; g->miroir = tmp.miroir; g->ghost = tmp.ghost; g->flip_normals = tmp.flip_normals; g->interp_normals = true;
 			g->scale = tmp.scale; g->max_translation = tmp.max_translation; g->rotation_center = tmp.rotation_center;
 			memcpy(g->mat_rotation, tmp.mat_rotation, sizeof tmp.mat_rotation);
+			g->scale_keyframes = tmp.scale_keyframes; g->translation_keyframes = tmp.translation_keyframes; g->rotation_keyframes = tmp.rotation_keyframes;
 			g->textures = tmp.textures; g->normal_map = tmp.normal_map; g->subsurface = tmp.subsurface; g->specularmap = tmp.specularmap;
 			g->alphamap = tmp.alphamap; g->roughnessmap = tmp.roughnessmap; g->transparent_map = tmp.transparent_map; g->refr_index_map = tmp.refr_index_map;
 			s.addObject(g);
@@ -1225,7 +1321,7 @@ bool Raytracer::save_scene(const char* filename) const {
 	if (!f) return false;
 	fprintf(f, "W,H: %u, %u\n", W, H);
 	fprintf(f, "nrays: %u\n", nrays);
-	fprintf(f, "nbframes: %u\n", 1u);
+	fprintf(f, "nbframes: %u\n", (unsigned)s.nbframes);
 	fprintf(f, "Cam: (%f, %f, %f), (%f, %f, %f), (%f, %f, %f)\n", cam.position[0], cam.position[1], cam.position[2], cam.direction[0], cam.direction[1], cam.direction[2], cam.up[0], cam.up[1], cam.up[2]);
 	fprintf(f, "fov: %f\nfocus: %f\naperture: %f\nsigma_filter: %f\ngamma: %f\n", cam.fov, cam.focus_distance, cam.aperture, sigma_filter, gamma);
 	fprintf(f, "is_lenticular: %u\nlenticular_nb_images: %u\nlenticular_max_angle: %f\nlenticular_pixel_width: %u\nisArray: %u\nnbviewX: %u\nnbviewY: %u\nmaxSpacingX: %f\nmaxSpacingY: %f\n",
@@ -1250,7 +1346,10 @@ bool Raytracer::save_scene(const char* filename) const {
 		const float* m = o->mat_rotation;
 		fprintf(f, "rotation: (%f, %f, %f, %f, %f, %f, %f, %f, %f)\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]);
 		fprintf(f, "center: (%f, %f, %f)\n", o->rotation_center[0], o->rotation_center[1], o->rotation_center[2]);
-		fprintf(f, "scale: %f\ndisplay_edges: 0\ninterp_normals: %u\nflip_normals: %u\nnb_transforms: 0\n", o->scale, o->interp_normals ? 1 : 0, o->flip_normals ? 1 : 0);
+		fprintf(f, "scale: %f\ndisplay_edges: 0\ninterp_normals: %u\nflip_normals: %u\nnb_transforms: %u\n", o->scale, o->interp_normals ? 1 : 0, o->flip_normals ? 1 : 0, (unsigned)o->translation_keyframes.size());
+		for (const auto& kf : o->scale_keyframes) fprintf(f, "%f %f\n", kf.first, kf.second);                                  // Geometry.h:467-475
+		for (const auto& kf : o->translation_keyframes) fprintf(f, "%f %f, %f, %f\n", kf.first, kf.second[0], kf.second[1], kf.second[2]);
+		for (const auto& kf : o->rotation_keyframes) { const float* q = kf.second.data(); fprintf(f, "%f %f, %f, %f, %f, %f, %f, %f, %f, %f\n", kf.first, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]); }
 		list3("nb_textures", o->textures); list3("nb_normalmaps", o->normal_map); list3("nb_subsurfaces", o->subsurface); list3("nb_specularmaps", o->specularmap);
 		list3("nb_alphamaps", o->alphamap); list3("nb_expmaps", o->roughnessmap); list1("nb_transpmaps", o->transparent_map); list1("nb_refrindexmaps", o->refr_index_map);
 		if (o->type == OT_SPHERE) {
@@ -1301,7 +1400,7 @@ int Raytracer::open_devices(const int* device_ids, int n) {
 }
 const char* Raytracer::last_error() const { return (ctx && last_status != MIPT_OK && err_.empty()) ? mipt_last_error(ctx) : err_.c_str(); }
 
-void Raytracer::prepare_render(float) {   // Raytracer.cpp:1321-1391
+void Raytracer::prepare_render(float time) {   // Raytracer.cpp:1321-1391
 	pcg32 engine0(0);                       // engine[0] = pcg32(0) (:1325-1327)
 	const float invmax = 1.f / 4294967296.f;   // Raytracer.h:28
 	if (randomPerPixel.size() != (size_t)W * H) {
@@ -1332,7 +1431,7 @@ void Raytracer::prepare_render(float) {   // Raytracer.cpp:1321-1391
 	}
 	s.prepare_render();
 	centerLight = s.lumiere->apply_transformation(s.lumiere->O);   // :1377-1380
-	lum_scale = s.lumiere->scale;
+	lum_scale = s.lumiere->get_scale(time);
 	radiusLight = lum_scale * s.lumiere->R;
 	lightPower = s.intensite_lumiere / (lum_scale * lum_scale);
 	std::fill(sample_count.begin(), sample_count.end(), 0.f);
@@ -1398,7 +1497,7 @@ void Raytracer::build_descs() {
 	scene_desc.backgroundW = has_bg ? s.backgroundW : 0; scene_desc.backgroundH = has_bg ? s.backgroundH : 0;
 	scene_desc.fog_density = s.fog_density; scene_desc.fog_absorption = s.fog_absorption; scene_desc.fog_density_decay = s.fog_density_decay;
 	scene_desc.fog_absorption_decay = s.fog_absorption_decay; scene_desc.phase_aniso = s.phase_aniso; scene_desc.fog_type = s.fog_type; scene_desc.fog_phase_type = s.fog_phase_type;
-	scene_desc.fog_ground_level = n > 2 ? s.objects[2]->max_translation[1] : 0.f;   // objects[2]->get_translation(time, is_recording)[1], no key frames (Raytracer.cpp:55)
+	scene_desc.fog_ground_level = n > 2 ? s.objects[2]->get_translation((float)s.current_frame)[1] : 0.f;   // objects[2]->get_translation(time, is_recording)[1] (Raytracer.cpp:55)
 	mipt_render_params& p = render_params;
 	memset(&p, 0, sizeof p);
 	p.W = W; p.H = H; p.nrays = nrays; p.nb_bounces = nb_bounces;
@@ -1573,6 +1672,12 @@ int mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W
 	return 0;
 }
 int mh_load_scene(mh_raytracer* h, const char* scn) { return h->rt.load_scene(scn) ? 0 : -1; }
+void mh_set_frame(mh_raytracer* h, int frame) { h->rt.s.current_frame = frame; }
+void mh_add_keyframe(mh_raytracer* h, int obj, int frame) { h->rt.s.objects[obj]->add_keyframe(frame); }
+void mh_set_object_transform(mh_raytracer* h, int obj, const float* t, const float* r, float scale) {
+	Object* o = h->rt.s.objects[obj];
+	o->max_translation = Vector(t[0], t[1], t[2]); memcpy(o->mat_rotation, r, 36); o->scale = scale;
+}
 int mh_load_scene_subst(mh_raytracer* h, const char* scn, const char* replacedNames) { return h->rt.load_scene(scn, replacedNames) ? 0 : -1; }
 int mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char* err, int errlen) {
 	std::string why;

@@ -59,7 +59,17 @@ class Object {                        // Geometry.h:240-735
 public:
 	virtual ~Object() {}
 	Object();
-	void build_matrix();              // Geometry.h:322-360 (no keyframes, is_recording = false)
+	void build_matrix(float frame = 0.f);   // Geometry.h:322-360 (is_recording = false): scale / translation / rotation of the key frames at `frame`
+	// key-framed transforms (Geometry.h:258-320): the value of the last key frame at or after the end, of the first one before
+	// the beginning, linear (scale, translation) or quaternion-slerp (rotation) interpolation in between; no key frames: the
+	// object's own scale / max_translation / mat_rotation
+	float get_scale(float frame) const;
+	Vector get_translation(float frame) const;
+	void get_rotation(float frame, float out9[9]) const;
+	void add_keyframe(int frame);     // Geometry.h:316-320: the current transform becomes the key frame of `frame`
+	std::map<float, float> scale_keyframes;
+	std::map<float, Vector> translation_keyframes;
+	std::map<float, std::array<float, 9>> rotation_keyframes;
 	Vector apply_transformation(const Vector& v) const;
 	void add_col_texture(const Vector& c) { textures.push_back(constant(c)); }
 	void add_col_specular(const Vector& c) { specularmap.push_back(constant(c)); }
@@ -168,7 +178,7 @@ public:
 	Sphere* lumiere = nullptr;
 	float intensite_lumiere = 0, envmap_intensity = 1;
 	float double_frustum_start_t = 0;
-	int current_frame = 0;
+	int current_frame = 0, nbframes = 1;
 	Raytracer* owner = nullptr;
 };
 
@@ -256,6 +266,9 @@ void mh_set_light(mh_raytracer*, const float* center, float R, float intensite_l
 void mh_set_envmap_intensity(mh_raytracer*, float v);
 int  mh_read_image(const char* file, unsigned char* rgb_out, int capacity, int* W, int* H, char* err, int errlen);   // PPM / PNG as stb_image delivers them (3 channels)
 int  mh_load_scene(mh_raytracer*, const char* scn_file);   // Raytracer::load_scene; 0 or -1 (mh_last_error)
+void mh_set_frame(mh_raytracer*, int frame);                 // Scene::current_frame: the time key-framed transforms are evaluated at
+void mh_add_keyframe(mh_raytracer*, int obj, int frame);      // Object::add_keyframe(frame)
+void mh_set_object_transform(mh_raytracer*, int obj, const float* translation3, const float* rotation9, float scale);   // max_translation, mat_rotation, scale
 int  mh_load_scene_subst(mh_raytracer*, const char* scn_file, const char* replacedNames);   // Raytracer::load_scene(filename, replacedNames): the '#' of mesh names
 int  mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char* err, int errlen);   // save_image (utils.cpp:178-234) for 8-bit RGB: .png / .bmp / .tga / .ppm by extension; -1 + text otherwise
 int  mh_save_scene(mh_raytracer*, const char* scn_file);   // Raytracer::save_scene

@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
+if __name__ == "__main__" and "--keyframes" not in sys.argv and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
     main()
 
 
@@ -444,3 +444,73 @@ def main_lenticular():
 
 if __name__ == "__main__" and "--lenticular" in sys.argv:
     main_lenticular()
+
+
+# ---- key-framed transforms (Geometry.h:258-320): scale / translation interpolated linearly, rotation by quaternion slerp
+KEYFRAME_FRAMES = (0, 2, 3, 5, 7, 9, 12, 40)
+
+
+def _rot(axis, angle):
+    a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return (np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K).astype(np.float32).reshape(9)
+
+
+def keyframe_scene(X, objfile):
+    """The OBJ scene with key frames on the mesh (three rotations that take Matrix::toQuaternion through its four branches,
+    translations, scales), on the light (translation + scale: centerLight, radiusLight, lightPower follow) and on the
+    ground plane (translation: the fog's ground level follows).  X: the compiled reference or the host mirror."""
+    cfg = scenes.config_c1(48, 30, 2)
+    cfg.nb_bounces = 3
+    X.apply_config(cfg)
+    oid = X.add_mesh_obj(objfile)
+    ident = np.eye(3, dtype=np.float32).reshape(9)
+    for frame, (t, r, sc) in ((2, ((0, 0, 0), _rot((0, 1, 0), 0.3), 30.0)), (5, ((4, 1, -3), _rot((1, 0, 0), 3.0), 24.0)),
+                              (9, ((-2, 3, 5), _rot((0, 1, 0), 3.1), 33.0)), (12, ((0, 6, 0), _rot((0.2, 0.1, 1), 2.9), 27.0))):
+        base, _ = X.object_state(oid)
+        X.set_object_transform(oid, np.asarray(t, np.float32) + base[:3] * (frame == 2), r, sc)
+        X.add_keyframe(oid, frame)
+    for frame, (t, sc) in ((2, ((0, 0, 0), 1.0)), (9, ((5, 2, -4), 1.5))):
+        X.set_object_transform(0, t, ident, sc)
+        X.add_keyframe(0, frame)
+    for frame, ty in ((0, 0.0), (12, -3.0)):
+        X.set_object_transform(2, (0, ty, 0), ident, 1.0)
+        X.add_keyframe(2, frame)
+    return cfg, oid
+
+
+def main_keyframes():
+    import tempfile
+    d = tempfile.mkdtemp(prefix="ptref_keyframes_")
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        scenes.write_obj_scene(d)
+        R = Ref()
+        cfg, oid = keyframe_scene(R, "scene.obj")
+        R.set_fog(0.3, 0.2, 0.02, 0.03, 1, 0, 0.0)
+        R.save_scene("keyframes.scn")
+        text = open("keyframes.scn").read()
+        R2 = Ref()                               # what a second instance makes of the file: the expected values
+        R2.load_scene("keyframes.scn")
+        g = {}
+        for frame in KEYFRAME_FRAMES:
+            R2.set_frame(frame)
+            R2.prepare()
+            g[f"light_{frame}"] = R2.light()
+            for k in range(R2.num_objects()):
+                t, inv, r = R2.object_matrices(k)
+                g[f"f{frame}_obj{k}_trans"], g[f"f{frame}_obj{k}_inv"], g[f"f{frame}_obj{k}_rot"] = t, inv, r
+        for frame in (3, 7):
+            R2.set_frame(frame)
+            R2.prepare()
+            g[f"rgb_{frame}"] = R2.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0]
+    finally:
+        os.chdir(cwd)
+    open(os.path.join(OUT, "keyframes.scn"), "w").write(text)
+    np.savez_compressed(os.path.join(OUT, "keyframes.npz"), **g)
+    print("keyframes goldens written; mean radiance / white at frame 3:", float(g["rgb_3"].mean() / 196964.7))
+
+
+if __name__ == "__main__" and "--keyframes" in sys.argv:
+    main_keyframes()

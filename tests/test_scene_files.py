@@ -75,7 +75,8 @@ def test_unsupported_scene_features_are_refused(tmp_path):
     scn = stage(tmp_path)
     text = open(scn).read()
     H = capi.HostRaytracer()
-    for old, new, what in (("nb_transforms: 0", "nb_transforms: 2", "key-framed"),):
+    for old, new, what in (("nb_transforms: 0", "nb_transforms: 2", "key frame"),          # two key frames announced, none given
+                           ("has_csv: 0", "has_csv: 1", "per-face colour"), ("NEW MESH", "NEW POINTSET", "outside the hot path")):
         bad = os.path.join(str(tmp_path), "bad.scn")
         open(bad, "w").write(text.replace(old, new, 1))
         with pytest.raises(capi.MiptError, match=what):
