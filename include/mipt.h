@@ -34,7 +34,7 @@ enum {
 	MIPT_ERR_INVALID = 1,      /* bad argument / inconsistent description */
 	MIPT_ERR_NO_DEVICE = 2,    /* no HIP device, or device id out of range */
 	MIPT_ERR_HIP = 3,          /* a HIP runtime call failed (text in mipt_last_error) */
-	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature that is not built (textured or extra spheres ...) */
+	MIPT_ERR_UNSUPPORTED = 4,  /* scene uses a feature that is not built (a subsurface colour on a sphere, object types other than the three ...) */
 	MIPT_ERR_NO_SCENE = 5,     /* render/trace before mipt_upload_scene */
 	MIPT_ERR_CANCELLED = 6     /* *cancel became non-zero between passes (Raytracer::stopRender) */
 };
@@ -112,7 +112,10 @@ typedef struct mipt_object {
 } mipt_object;
 
 /* Scene (Geometry.h:1238-1400).  As in Raytracer::loadScene (Raytracer.cpp:1257-1269) object 0
- * is the light sphere (Scene::lumiere), object 1 the environment sphere, object 2.. the rest. */
+ * is the light sphere (Scene::lumiere), object 1 the environment sphere, object 2.. the rest.  A sphere among
+ * "the rest" needs material lists of its own or the mirror flag: without them the reference shades it with the
+ * material of whichever object Scene::intersection tested before it (one `localmat` for the loop, Geometry.cpp:596);
+ * mipt_upload_scene refuses that case with MIPT_ERR_UNSUPPORTED. */
 typedef struct mipt_scene_desc {
 	int32_t n_objects;
 	const mipt_object* objects;

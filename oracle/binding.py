@@ -96,6 +96,11 @@ class _Base:
     def set_envmap_intensity(self, v):
         self.lib.ref_set_envmap_intensity(self.ctx, _f(v))
 
+    def add_sphere(self, center, R, mirror=False, flip_normals=False):
+        """s.addObject(new Sphere(center, R, mirror, normal_swapped)): a sphere beside the light (0) and the environment (1)."""
+        o = np.ascontiguousarray(center, np.float32)
+        return self.lib.ref_add_sphere(self.ctx, _p(o, _f), _f(R), int(mirror), int(flip_normals))
+
     def set_object_flags(self, obj, miroir=False, flip_normals=False):
         self.lib.ref_set_object_flags(self.ctx, obj, int(miroir), int(flip_normals))
 

@@ -1515,6 +1515,14 @@ o_ctx* o_create(void) {
 	return c;
 }
 
+/* s.addObject(new Sphere(O, R, mirror, normal_swapped)) (Geometry.h:849-873) */
+int o_add_sphere(o_ctx* c, const float* O, float R, int mirror, int flip_normals) {
+	o_obj* sp = push_obj(c);
+	sp->type = OT_SPHERE; sp->O = V(O[0], O[1], O[2]); sp->R = R; sp->R2 = R * R; sp->rotation_center = sp->O;
+	sp->miroir = mirror != 0; sp->flip_normals = flip_normals != 0;
+	return c->nobj - 1;
+}
+
 static void free_mesh(o_mesh* g) {
 	if (!g) return;
 	free(g->vertices); free(g->normals); free(g->uvs); free(g->indices); free(g->soup); free(g->tangent_soup); free(g->perm); free(g->nodes); free(g);

@@ -27,6 +27,7 @@ void   o_set_render(o_ctx*, int W, int H, int nrays, int nb_bounces, float sigma
 void   o_set_camera(o_ctx*, const float* pos, const float* dir, const float* up, float fov, float focus, float aperture);
 void   o_set_light(o_ctx*, const float* center, float R, float intensite_lumiere);
 void   o_set_envmap_intensity(o_ctx*, float v);
+int    o_add_sphere(o_ctx*, const float* O3, float R, int mirror, int flip_normals);   /* another Sphere object; returns its index */
 /* TriMesh::TriMesh(scene, obj, 1, (0,0,0), false, NULL, false, center) on in-memory OBJ arrays,
  * followed by the GUI placement (mainApp.cpp:2402-2410).  ft/uvs may be NULL. Returns object id. */
 int    o_add_mesh(o_ctx*, int nv, const float* verts, int nn, const float* normals, int nt, const float* uvs,

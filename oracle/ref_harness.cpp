@@ -180,6 +180,10 @@ int ref_write_obj(const char* path, int nv, const float* v, int nn, const float*
 
 // Per-object switches the GUI exposes (mirror flag, constant transparency / refraction index
 // / Kd / Ks / Ne multipliers for one material group).
+int ref_add_sphere(RefCtx* c, const float* O, float R, int mirror, int flip_normals) {
+	c->rt->s.addObject(new Sphere(Vector(O[0], O[1], O[2]), R, mirror != 0, flip_normals != 0));
+	return (int)c->rt->s.objects.size() - 1;
+}
 void ref_set_object_flags(RefCtx* c, int obj, int miroir, int flip_normals) {
 	c->rt->s.objects[obj]->miroir = miroir != 0;
 	c->rt->s.objects[obj]->flip_normals = flip_normals != 0;

@@ -235,6 +235,11 @@ class HostRaytracer:
         hdr = self.scene_header()
         self.W, self.H, self.spp = int(hdr[0]), int(hdr[1]), int(hdr[2])
 
+    def add_sphere(self, center, R, mirror=False, flip_normals=False):
+        """s.addObject(new Sphere(center, R, mirror, normal_swapped)): a sphere beside the light (0) and the environment (1)."""
+        o = np.ascontiguousarray(center, np.float32)
+        return self.host.mh_add_sphere(self.h, _p(o, _f), _f(R), int(mirror), int(flip_normals))
+
     # ---- key-framed transforms (Geometry.h:258-320)
     def set_frame(self, frame):
         self.host.mh_set_frame(self.h, int(frame))

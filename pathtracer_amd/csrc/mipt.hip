@@ -763,7 +763,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false, scene_ghost = false, scene_subs = false;
+	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -801,8 +801,17 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			if (rc) return rc;
 		}
 		if (o.type == MIPT_OBJ_SPHERE) {
-			if (i >= 2) return fail(c, MIPT_ERR_UNSUPPORTED, "spheres other than the light (0) and the environment (1) are outside the hot path");
-			for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) if (counts[sl]) return fail(c, MIPT_ERR_UNSUPPORTED, "textured spheres are outside the hot path");
+			// material lists on a sphere are looked up at the spherical coordinates of its normal (Geometry.h:975-981); normal and
+			// alpha maps are read by TriMesh only (a sphere ignores them), a subsurface colour on a sphere was refused above
+			if (o.has_envmap && i != 1) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: an environment map on a sphere other than object 1", i);
+			// Scene::intersection keeps ONE MaterialValues for all objects of its loop (`localmat`, Geometry.cpp:596), and a sphere
+			// without material lists writes only the normal and Ke into it: such a sphere is shaded with whatever the object tested
+			// before it left there (the ground plane's colour if the ray also crosses the plane, a mesh's material at a hit further
+			// away ...).  That is an accident of the loop, not a material; the light and the environment never reach the BRDF, a
+			// mirror does not read the material, every other sphere needs lists of its own.
+			if (i >= 2 && !o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR]))
+				return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: a sphere without material lists (it would be shaded with the material of whichever object Scene::intersection tested before it)", i);
+			if (i >= 2) sphere_extra = true;
 			memcpy(d.O, o.O, 12); d.R = o.R; d.R2 = o.R * o.R;
 			d.has_envmap = o.has_envmap; d.envW = o.envW; d.envH = o.envH; d.envtex = nullptr;
 			if (o.has_envmap) {
@@ -854,6 +863,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
 	c->scene_has_subsurface = scene_subs;
+	if (scene_subs && sphere_extra) return fail(c, MIPT_ERR_UNSUPPORTED, "spheres beside the light and the environment in a scene with subsurface colours (a sphere leaves the Ksub of the object tested before it in place)");
 	c->d_background = nullptr; c->backgroundW = c->backgroundH = 0;
 	if (s->background && s->backgroundW > 0 && s->backgroundH > 0) {
 		int rc = upload(c, s->background, (size_t)s->backgroundW * s->backgroundH * 3, &c->d_background);

@@ -409,6 +409,14 @@ MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
 		else mat.Ke = mk3((float)s.envtex[idx], (float)s.envtex[idx + 1], (float)s.envtex[idx + 2]) * (100000.f / 255.f);
 		return;
 	}
+	// a sphere with material lists (Geometry.h:975-981): the lists are looked up at the spherical coordinates of the NORMALISED
+	// normal, which then is the one handed on (a sphere without lists keeps P - O as it is: Scene::intersection normalises later)
+	if (s.ntex[MT_KD] != 0 || s.ntex[MT_KS] != 0 || s.ntex[MT_NE] != 0 || s.ntex[MT_TRANSP] != 0 || s.ntex[MT_REFR] != 0) {
+		N = fast_normalize(N);
+		float theta = 1.f - mipt_acosf(N.y) / (float)MIPT_PI;
+		float phi = (mipt_atan2f(-N.z, N.x) + (float)MIPT_PI) / (2.f * (float)MIPT_PI);
+		query_material(s, 0, theta, phi, mat);
+	}
 	mat.shadingN = s.flip_normals ? -N : N;
 	mat.Ke = mk3(0, 0, 0);
 }

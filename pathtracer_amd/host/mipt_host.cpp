@@ -1722,9 +1722,12 @@ int mh_add_mesh_obj(mh_raytracer* h, const char* obj_file, float scale, int cent
 // multipliers of one material group: Kd, Ks, Ne (3 each), alpha, refr, transp (1 each) + W, H of the Kd / Ks / normal / alpha images
 void mh_get_group_material(mh_raytracer* h, int obj, int grp, float* out12, int* wh8) {
 	Object* o = h->rt.s.objects[obj];
-	for (int k = 0; k < 3; k++) { out12[k] = o->textures[grp].multiplier[k]; out12[3 + k] = o->specularmap[grp].multiplier[k]; out12[6 + k] = o->roughnessmap[grp].multiplier[k]; }
-	out12[9] = o->alphamap[grp].multiplier[0]; out12[10] = o->refr_index_map[grp].multiplier[0]; out12[11] = o->transparent_map[grp].multiplier[0];
-	const Texture* t[4] = {&o->textures[grp], &o->specularmap[grp], &o->normal_map[grp], &o->alphamap[grp]};
+	// (an object that is not a mesh has only the lists that were given to it: a missing entry reads as zeros)
+	static const Texture none = [] { Texture t; t.multiplier = Vector(0, 0, 0); return t; }();
+	auto at = [&](const std::vector<Texture>& l) -> const Texture& { return grp >= 0 && grp < (int)l.size() ? l[grp] : none; };
+	for (int k = 0; k < 3; k++) { out12[k] = at(o->textures).multiplier[k]; out12[3 + k] = at(o->specularmap).multiplier[k]; out12[6 + k] = at(o->roughnessmap).multiplier[k]; }
+	out12[9] = at(o->alphamap).multiplier[0]; out12[10] = at(o->refr_index_map).multiplier[0]; out12[11] = at(o->transparent_map).multiplier[0];
+	const Texture* t[4] = {&at(o->textures), &at(o->specularmap), &at(o->normal_map), &at(o->alphamap)};
 	for (int k = 0; k < 4; k++) { wh8[2 * k] = (int)t[k]->W; wh8[2 * k + 1] = (int)t[k]->H; }
 }
 int mh_num_groups(mh_raytracer* h, int obj) { return (int)h->rt.s.objects[obj]->textures.size(); }
@@ -1755,6 +1758,12 @@ void mh_set_group_material(mh_raytracer* h, int obj, int grp, const float* Kd, c
 	if (grp < (int)o->roughnessmap.size()) o->roughnessmap[grp].multiplier = Vector(Ne[0], Ne[1], Ne[2]);
 	if (grp < (int)o->transparent_map.size()) o->transparent_map[grp].multiplier = Vector(transp_col, transp_col, transp_col);
 	if (grp < (int)o->refr_index_map.size()) o->refr_index_map[grp].multiplier = Vector(refr, refr, refr);
+}
+int mh_add_sphere(mh_raytracer* h, const float* O, float R, int mirror, int flip_normals) {   // s.addObject(new Sphere(O, R, mirror, normal_swapped))
+	Sphere* sp = new Sphere(Vector(O[0], O[1], O[2]), R);
+	sp->miroir = mirror != 0; sp->flip_normals = flip_normals != 0;
+	h->rt.s.addObject(sp);
+	return (int)h->rt.s.objects.size() - 1;
 }
 void mh_add_group_material(mh_raytracer* h, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr) {
 	Object* o = h->rt.s.objects[obj];

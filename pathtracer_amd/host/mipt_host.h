@@ -287,6 +287,7 @@ int  mh_mesh_bvh_builder(mh_raytracer*, int obj, double* seconds, double* device
 void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks
 void mh_set_object_flags(mh_raytracer*, int obj, int miroir, int flip_normals);
 void mh_set_group_material(mh_raytracer*, int obj, int grp, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
+int  mh_add_sphere(mh_raytracer*, const float* O3, float R, int mirror, int flip_normals);   // another Sphere object (Geometry.h:849-873); returns its index
 void mh_add_group_material(mh_raytracer*, int obj, const float* Kd, const float* Ks, const float* Ne, float transp_col, float refr);
 void mh_set_group_texture(mh_raytracer*, int obj, int grp, int slot, int W, int H, const unsigned char* rgb);
 void mh_set_envmap(mh_raytracer*, int W, int H, const unsigned char* rgb);

@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--keyframes" not in sys.argv and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
+if __name__ == "__main__" and "--spheres" not in sys.argv and "--keyframes" not in sys.argv and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
     main()
 
 
@@ -514,3 +514,45 @@ def main_keyframes():
 
 if __name__ == "__main__" and "--keyframes" in sys.argv:
     main_keyframes()
+
+
+# ---- spheres beside the light (0) and the environment (1) (Geometry.h:849-992)
+SPHERE_KINDS = ("mixed", "glossy", "nomesh")
+
+
+def sphere_scene(X, kind):
+    """Spheres as ordinary scene objects, in front of and behind the mesh in the object list: a constant diffuse one, a mirror,
+    an image-textured glossy one (lists looked up at the spherical coordinates of the normal), glass; `nomesh`: no TriMesh
+    at all, flipped normals.  (A sphere WITHOUT material lists is not a case: Scene::intersection would shade it with the
+    material of whichever object it tested before, Geometry.cpp:596.)"""
+    cfg = scenes.config_c1(48, 30, 3)
+    cfg.nb_bounces = 5 if kind == "mixed" else 4
+    X.apply_config(cfg)
+    a = X.add_sphere((-12, -17, 8), 9.0)
+    X.add_group_material(a, (0.2, 0.6, 0.9), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
+    if kind != "nomesh":
+        X.add_mesh(scenes.blob_mesh(16), scale=20.0)
+    b = X.add_sphere((14, -14, 2), 8.0, mirror=(kind != "glossy"))
+    if kind == "glossy":
+        X.add_group_material(b, (0.5, 0.5, 0.1), (0.4, 0.4, 0.4), (50, 50, 50), 1.0, 1.3)
+    c = X.add_sphere((0, -20, 18), 6.0, flip_normals=(kind == "nomesh"))
+    X.add_group_material(c, (0.9, 0.2, 0.1), (0.3, 0.3, 0.3) if kind != "mixed" else (0.0, 0.0, 0.0), (20, 20, 20), 1.0, 1.3)
+    X.set_group_texture(c, 0, 0, scenes.checker_texture(32, 16, 5, 4))
+    d = X.add_sphere((-20, -18, -6), 7.0)
+    X.add_group_material(d, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, 1.5)      # transparent_map < 0.5: glass
+    X.prepare()
+    return cfg
+
+
+def main_spheres():
+    g = {}
+    for kind in SPHERE_KINDS:
+        R = Ref()
+        cfg = sphere_scene(R, kind)
+        g[kind + "_rgb"] = R.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0]
+        print(kind, "mean radiance / white =", float(g[kind + "_rgb"].mean() / 196964.7))
+    np.savez_compressed(os.path.join(OUT, "spheres.npz"), **g)
+
+
+if __name__ == "__main__" and "--spheres" in sys.argv:
+    main_spheres()

@@ -2,7 +2,8 @@
 camera, light, aperture, depth, materials incl. glossy / mirror / dielectric / textures / MERL), per-sample radiance
 compared bit for bit on both pipelines.  usage: python tests/tools/fuzz_parity.py [n_scenes] [seed] [--queue]   (test infrastructure: the oracle is the checker)
 --queue: every scene also draws from the features of the contribution-queue kernel (ghost objects, background photo, fog in
-both media with the three phase functions, subsurface colours), alone and combined."""
+both media with the three phase functions, subsurface colours), alone and combined.
+--spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -11,6 +12,7 @@ from pathtracer_amd import capi, scenes
 from oracle.binding import Oracle
 
 QUEUE = "--queue" in sys.argv
+SPHERES = "--spheres" in sys.argv
 argv = [a for a in sys.argv if not a.startswith("--")]
 n_scenes = int(argv[1]) if len(argv) > 1 else 20
 rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
@@ -34,9 +36,26 @@ for it in range(n_scenes):
         mesh = scenes.fat_leaf_mesh(int(rng.integers(8, 30)))
     scale = float(rng.choice([30.0, 5.0, 0.5, 80.0]))
     out = []
+    sph = []
+    if SPHERES:
+        for k in range(int(rng.integers(1, 4))):
+            sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 5)),
+                            first=bool(rng.random() < 0.3), flip=bool(rng.random() < 0.15), Kd=rng.uniform(0.05, 1, 3), Ks=rng.uniform(0, 0.6, 3), Ne=rng.uniform(1, 200, 3)))
+    def put_spheres(X, first):
+        for q in sph:
+            if q["first"] != first: continue
+            o = X.add_sphere(q["c"], q["r"], mirror=(q["kind"] == 1), flip_normals=q["flip"])
+            if q["kind"] == 0: X.add_group_material(o, q["Kd"], (0, 0, 0), (0, 0, 0), 1.0, 1.3)
+            if q["kind"] == 2: X.add_group_material(o, q["Kd"], q["Ks"], q["Ne"], 1.0, 1.3)
+            if q["kind"] == 3:
+                X.add_group_material(o, (1, 1, 1), q["Ks"] * 0.5, q["Ne"], 1.0, 1.3)
+                X.set_group_texture(o, 0, 0, scenes.checker_texture(32, 16, 5, 4))
+            if q["kind"] == 4: X.add_group_material(o, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, float(1.1 + q["Ks"][0]))
     for X in (Oracle(), capi.HostRaytracer(device=0)):
         X.apply_config(cfg)
+        put_spheres(X, True)
         oid = X.add_mesh(mesh, scale=scale)
+        put_spheres(X, False)
         out.append((X, oid))
     # materials must be identical on both sides: draw once, apply twice
     Kd, Ks, Ne = rng.uniform(0, 1, 3), rng.uniform(0, 0.9, 3), rng.uniform(0, 300, 3)
@@ -68,15 +87,15 @@ for it in range(n_scenes):
             if pick[1] < 0.25: X.set_object_ghost(oid, True)
             if pick[2] < 0.6: X.set_background(photo)
             if pick[3] < 0.5: X.set_fog(*fog)
-            if pick[4] < 0.4 and kind not in ("two",): X.set_group_subsurface(oid, 0, ksub)
-        feats = [n for n, on in (("ghostfloor", pick[0] < 0.45), ("ghostmesh", pick[1] < 0.25), ("photo", pick[2] < 0.6), ("fog%d/%d" % (fog[4], fog[5]), pick[3] < 0.5), ("sss", pick[4] < 0.4 and kind != "two")) if on]
+            if pick[4] < 0.4 and kind not in ("two",) and not sph: X.set_group_subsurface(oid, 0, ksub)
+        feats = [n for n, on in (("ghostfloor", pick[0] < 0.45), ("ghostmesh", pick[1] < 0.25), ("photo", pick[2] < 0.6), ("fog%d/%d" % (fog[4], fog[5]), pick[3] < 0.5), ("sss", pick[4] < 0.4 and kind != "two" and not sph)) if on]
     for X, oid in out:
         X.prepare()
     O, G = out[0][0], out[1][0]
     pix = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
     want = O.getcolor_samples(pix, 0, spp)[0]
     line = "%2d %-8s n=%-3d scale %-5g %3dx%-3d spp %d depth %d aperture %-4g" % (it, kind, n, scale, W, H, spp, cfg.nb_bounces, cfg.aperture)
-    line += " " + "+".join(feats)
+    line += " " + "+".join(feats) + (" spheres " + "".join("cmgtd"[q["kind"]] for q in sph) if sph else "")
     for pipeline in ((1,) if feats else (1, 0)):
         G.set_option("pipeline", pipeline)
         got = G.getcolor_samples(pix, 0, spp)[0]
