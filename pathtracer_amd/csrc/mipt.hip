@@ -1103,7 +1103,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES; fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned); }
 	if (want_aov) per_path += 2 * sizeof(float4);
 	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
-		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 5 * sizeof(unsigned);
+		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 9 * sizeof(unsigned);
 		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
 	}
 	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? MIPT_QW_FIFO : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
@@ -1154,16 +1154,18 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	DQueueWave qw{};
 	if (pipeline == 2 && queue_wave) {
 		wf.ray_o = (float4*)carve(N * sizeof(float4)); wf.ray_d = (float4*)carve(N * sizeof(float4)); wf.hit = (float4*)carve(N * sizeof(float4));
-		wf.sh_o = (float4*)carve(N * sizeof(float4)); wf.sh_d = (float4*)carve(N * sizeof(float4));
+		wf.sh_o = (float4*)carve(N * sizeof(float4)); wf.sh_d = (float4*)carve(N * sizeof(float4)); wf.sh_c = (float4*)carve(N * sizeof(float4));
 		wf.rng = (uint2*)carve(N * sizeof(uint2));
 		wf.out = S;
 		qw.cur_w = (float4*)carve(N * sizeof(float4)); qw.cur_o = (float4*)carve(N * sizeof(float4)); qw.cur_d = (float4*)carve(N * sizeof(float4));
-		qw.acc = (float4*)carve(N * sizeof(float4));
+		qw.acc = S.col;                     // the colour of a sample accumulates in place (w: attenuationFactor while it lives)
 		qw.ctl = (unsigned*)carve(N * sizeof(unsigned));
 		qw.fr = (float4*)carve(N * MIPT_QW_FRAME * sizeof(float4));
 		qw.vis = (float*)carve(N * sizeof(float));
 		qw.live[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.live[1] = (unsigned*)carve(N * sizeof(unsigned));
 		qw.shl[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.shl[1] = (unsigned*)carve(N * sizeof(unsigned));
+		qw.prl[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.prl[1] = (unsigned*)carve(N * sizeof(unsigned));
+		qw.sha[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.sha[1] = (unsigned*)carve(N * sizeof(unsigned));
 		qw.overflow = (unsigned*)carve(N * sizeof(unsigned));
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
@@ -1242,11 +1244,19 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			for (int r = 0;; r++) {
 				if (r > 100000) return fail(c, MIPT_ERR_HIP, "the contribution queue did not drain");
 				const int slot = r & 3, par = r & 1;
-				unsigned pair[2] = {0, 0};                                  // {n_shadow, n_closest} requested by the logic stage of this round
+				unsigned pair[2] = {0, 0}, more[2] = {0, 0};                // {n_shadow, n_closest}, {subsurface probes, any-hit requests nobody waits for} of this round's logic stage
 				HIPCHK(c, hipMemcpyAsync(pair, &qw.counters[MIPT_QW_PAIR(slot)], 8, hipMemcpyDeviceToHost, st));
+				HIPCHK(c, hipMemcpyAsync(more, &qw.counters[MIPT_QW_N_PROBE(slot)], 8, hipMemcpyDeviceToHost, st));
 				HIPCHK(c, hipStreamSynchronize(st));
-				if (pair[0] == 0 && pair[1] == 0) break;
+				const unsigned n_probe = more[0], n_add = more[1];
+				if (pair[0] == 0 && pair[1] == 0 && n_probe == 0 && n_add == 0) break;
 				unsigned* pair_dev = &qw.counters[MIPT_QW_PAIR(slot)];
+				if (n_probe) {
+					TravQueue tq; tq.list = qw.prl[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_PROBE(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_PROBE(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
+					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				}
 				if (pair[1]) {
 					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = pair_dev + 1; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
@@ -1259,12 +1269,19 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					hipLaunchKernelGGL(k_q_traverse<true>, dim3(std::max(1u, std::min(c->grid_qtrav[1], (pair[0] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
-				// the logic stage of the next round, over both lists of this one; its counters (used four rounds ago) are cleared first
+				if (n_add) {
+					TravQueue tq; tq.list = qw.sha[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_SHADOW_ADD(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW_ADD(slot)]; tq.identity = false; tq.vis = (R.fog_density > 1E-8) ? qw.vis : nullptr; tq.skip_ghosts = true;   // fog: the logic stage reads the answer later
+					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					hipLaunchKernelGGL(k_q_traverse<true>, dim3(std::max(1u, std::min(c->grid_qtrav[1], (n_add + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				}
+				// the logic stage of the next round, over the lists of this one; its counters (used four rounds ago) are cleared first
 				const int nslot = (r + 1) & 3, npar = (r + 1) & 1;
 				HIPCHK(c, hipMemsetAsync(&qw.counters[MIPT_QW_PAIR(nslot)], 0, MIPT_QW_SLOT_WORDS * sizeof(unsigned), st));
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				launch_logic(0, qw.live[par], pair_dev + 1, 0, pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
 				launch_logic(1, qw.shl[par], pair_dev, 0, pair[0], &qw.counters[MIPT_QW_HEAD_LOGIC_B(nslot)], nslot, npar);
+				launch_logic(0, qw.prl[par], &qw.counters[MIPT_QW_N_PROBE(slot)], 0, n_probe, &qw.counters[MIPT_QW_HEAD_LOGIC_C(nslot)], nslot, npar);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			}
 			unsigned n_over = 0;

@@ -51,6 +51,8 @@ struct LaneState {
 	int obj;                // object being traversed / next object to visit
 	int best;               // closest: packed best hit (MIPT_HIT_MISS = none); shadow: 1 = occluded
 	unsigned id;            // path id
+	uint64_t rng;           // reservoir: the engine of the sample that asked
+	int count;              // reservoir: intersections accepted so far
 };
 
 #define MIPT_NONE 0x7fffffffu
@@ -104,7 +106,12 @@ struct TravQueue {
 // One queue of one depth: SHADOW = false the closest-hit rays of depth b (Scene::intersection), SHADOW = true the
 // light-sample rays of depth b (Scene::intersection_shadow).  Called by every wave of the grid; returns when the
 // queue is drained and all rays this wave fetched are finished.
-template <bool SHADOW>
+// RESV (with SHADOW = false): the subsurface probes of the contribution-queue pipeline, TriMesh::reservoir_sampling_intersection
+// (TriangleMesh.cpp:1321-1426, restated per thread as mesh_reservoir in mipt_compositing.h): the request is a ray in the
+// frame of ONE mesh (wf.ray_o.w = max_t, wf.ray_d.w = the object), the traversal is the closest-hit one with the far bound
+// fixed at max_t, and every triangle hit in [0, max_t) draws one number from the sample's engine (wf.rng) in visiting order and
+// replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
+template <bool SHADOW, bool RESV = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
                                                const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
 	const int inner_min = inner_min_flags & 0xffff;
@@ -124,7 +131,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	const unsigned long long below = (1ull << lane) - 1ull;
 
 	LaneState st;
-	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0;
+	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0; st.rng = 0; st.count = 0;
 	st.o_xy = (mipt_f2){0.f, 0.f}; st.i_xy = (mipt_f2){0.f, 0.f}; st.oz_iz = (mipt_f2){0.f, 0.f}; st.d = mk3(0, 0, 0);
 	bool alive = false;                  // the lane holds a ray that is inside a mesh traversal
 	bool need = false;                   // the lane holds a ray that must visit its next object(s)
@@ -176,7 +183,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						// arrive only if no sphere / plane occludes them
 						st.id = id; st.obj = first_mesh; need = true;
 						if (SHADOW) { st.dist = wf.sh_o[id].w; st.best = 0; }
-						else { st.beta = 0; st.gamma = 0; }                          // st.t / st.best arrive with the ray (object loop below)
+						else if (!RESV) { st.beta = 0; st.gamma = 0; }               // st.t / st.best arrive with the ray (object loop below)
 					}
 				}
 			}
@@ -184,7 +191,25 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		}
 		// ---- object loop (wave-uniform index): new rays start at object 0, rays that just left a mesh
 		//      continue behind it; a ray stops at the first mesh it has to traverse
-		if (__ballot(need)) {
+		if (RESV) {
+			if (need) {
+				const float4 o4 = wf.ray_o[st.id], d4 = wf.ray_d[st.id];
+				const DObject& o = sc->obj[__float_as_uint(d4.w)];
+				const f3 org = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+				const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+				float t_root;
+				bool enter = box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
+				if (enter && t_root > o4.w) enter = false;
+				need = false;
+				if (enter) {
+					st.o_xy = (mipt_f2){org.x, org.y}; st.i_xy = (mipt_f2){invd.x, invd.y}; st.oz_iz = (mipt_f2){org.z, invd.z}; st.d = d;
+					st.t = o4.w; st.cur = o.root_ref; st.sp = 0; st.obj = (int)__float_as_uint(d4.w);
+					st.count = 0; st.best = (int)MIPT_HIT_MISS; st.dist = 0.f; st.beta = 0.f; st.gamma = 0.f;
+					{ const uint2 rs = wf.rng[st.id]; st.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
+					alive = true;
+				} else wf.hit[st.id] = make_float4(0.f, 0.f, 0.f, __uint_as_float(MIPT_HIT_MISS));      // no draw: the engine stays as it is
+			}
+		} else if (__ballot(need)) {
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
 			if (need) {
 				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
@@ -322,7 +347,13 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						for (int k = 0; k < 4; k++) {
 							const int jj = prefix + k - base;
 							const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(min(max(jj, 0), 63) << 2, __float_as_int(lt)));
-							if (k < cnt && jj >= 0 && jj < 64 && v < cur_t) {
+							if (RESV) {
+								if (k < cnt && jj >= 0 && jj < 64 && v < cur_t && v >= 0.f) {                       // TriangleMesh.cpp:1399-1412
+									st.count++;
+									const float r1 = pcg_uniform(st.rng);
+									if ((double)r1 < 1. / (double)st.count) { st.dist = v; win = k; wj = jj; upd = true; }
+								}
+							} else if (k < cnt && jj >= 0 && jj < 64 && v < cur_t) {
 								cur_t = v; win = k; wj = jj; upd = true;
 								if (SHADOW && ((double)v < (double)st.dist * 0.999)) decided = true;               // TriangleMesh.cpp:1309
 							}
@@ -336,7 +367,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					if (cnt > 0) {
 						per_lane = false;
 						if (win >= 0) {
-							st.t = cur_t;
+							if (!RESV) st.t = cur_t;
 							if (!SHADOW) {
 								const int local = first + win - (int)sc->obj[st.obj].tri_base;
 								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg;
@@ -353,14 +384,18 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
 					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
-						bool accept = lt < st.t;
+						bool accept = lt < st.t && (!RESV || lt >= 0.f);
 						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 						if (accept) {
 							const DObject& o = sc->obj[st.obj];
 							local = i - (int)o.tri_base;
 							if (o.alpha_test) accept = !alpha_rejects(o, local, 1 - lb - lg, lb, lg);
 						}
-						if (accept) {
+						if (accept && RESV) {
+							st.count++;
+							const float r1 = pcg_uniform(st.rng);
+							if ((double)r1 < 1. / (double)st.count) { st.dist = lt; st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg; }
+						} else if (accept) {
 							st.t = lt;
 							if (SHADOW) {
 								if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
@@ -377,7 +412,14 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		MIPT_PROF_CLOCK(c3);
 		MIPT_PROF_CYCLES(14, c2, c3)
 		// ---- mesh finished: the ray goes on with the objects behind it (next iteration's object loop)
-		if (alive && st.cur == MIPT_NONE) {
+		if (RESV) {
+			if (alive && st.cur == MIPT_NONE) {
+				alive = false;
+				const unsigned tri = (unsigned)st.best == MIPT_HIT_MISS ? MIPT_HIT_MISS : ((unsigned)st.best & MIPT_HIT_NOTRI);
+				wf.hit[st.id] = make_float4(st.dist, st.beta, st.gamma, __uint_as_float(tri));
+				wf.rng[st.id] = make_uint2((unsigned)st.rng, (unsigned)(st.rng >> 32));
+			}
+		} else if (alive && st.cur == MIPT_NONE) {
 			alive = false; need = true;
 			// shadow: a hit with t >= 0.999*dist is not an occluder (Geometry.cpp:736) -> next object
 			st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
@@ -419,4 +461,11 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
 	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
+}
+
+// The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_EXTEND_WAVES))) k_q_probe(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
+	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	traverse_queue<false, true>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
 }

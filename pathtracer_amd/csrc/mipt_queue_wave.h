@@ -18,8 +18,11 @@
 //   to recompute than to store.  The arithmetic of every segment is the statement sequence of trace_path_queue.
 // * The queries run on the persistent traversal kernels of pipeline 1 (k_q_traverse: the same traverse_queue, explicit
 //   queue descriptor; shadow rays skip ghost objects, Geometry.cpp:722).  As there, the stage that creates a ray
-//   tests the analytic objects itself.  The subsurface probe (TriMesh::reservoir_sampling_intersection draws from the
-//   engine inside its leaf loop) stays a call inside the logic stage.
+//   tests the analytic objects itself.
+// * The subsurface probe of a mesh (TriMesh::reservoir_sampling_intersection draws from the sample's engine inside its leaf
+//   loop) is a third kind of query: A1 stops where getColor calls get_random_intersection, k_q_probe (the persistent
+//   traversal in its reservoir mode, mipt_persistent.h) runs it with the sample's engine and A1 is entered again: it recomputes the deterministic head of the vertex from the saved closest hit,
+//   takes the numbers it had drawn from the frame and goes on behind the call.
 // * The reference's FIFO has 200 entries (Raytracer.h:114); 200 x 48 B per sample would cap a pass at 2 M samples and
 //   the persistent kernels need far larger batches.  A sample gets a ring of MIPT_QW_FIFO entries here; the rare sample
 //   that needs more is abandoned (nothing of it is kept) and rendered afterwards by trace_path_queue with the full
@@ -33,26 +36,34 @@
 #define MIPT_QW_LOGIC_WAVES 2
 #endif
 #define MIPT_QW_FRAME 13                  // float4 slots of the per-sample frame
-enum { QW_POP = 0, QW_A1 = 1, QW_A2 = 2, QW_F1 = 3, QW_DONE = 4 };
+enum { QW_POP = 0, QW_A1 = 1, QW_A2 = 2, QW_F1 = 3, QW_DONE = 4, QW_PROBE = 5, QW_T5 = 6 };
 // counters of one round (cyclic, 4 round slots): every word on its own 128-byte line
-#define MIPT_QW_SLOT_WORDS (8 * 32)
+#define MIPT_QW_SLOT_WORDS (10 * 32)
 #define MIPT_QW_PAIR(s) ((s) * MIPT_QW_SLOT_WORDS)                // 64-bit {n_shadow, n_closest} of the round's request lists
 #define MIPT_QW_HEAD_CLOSEST(s) ((s) * MIPT_QW_SLOT_WORDS + 32)
 #define MIPT_QW_HEAD_SHADOW(s) ((s) * MIPT_QW_SLOT_WORDS + 64)
 #define MIPT_QW_HEAD_LOGIC_A(s) ((s) * MIPT_QW_SLOT_WORDS + 96)   // logic stage over the previous round's closest list
 #define MIPT_QW_HEAD_LOGIC_B(s) ((s) * MIPT_QW_SLOT_WORDS + 128)  // ... and over its shadow list
+#define MIPT_QW_N_PROBE(s) ((s) * MIPT_QW_SLOT_WORDS + 160)       // entries of the round's probe list; the next word: entries of the list of
+#define MIPT_QW_N_SHADOW_ADD(s) ((s) * MIPT_QW_SLOT_WORDS + 161)  // any-hit requests nobody waits for (the traversal adds the pending term)
+#define MIPT_QW_HEAD_SHADOW_ADD(s) ((s) * MIPT_QW_SLOT_WORDS + 224)
+#define MIPT_QW_HEAD_PROBE(s) ((s) * MIPT_QW_SLOT_WORDS + 256)
+#define MIPT_QW_HEAD_LOGIC_C(s) ((s) * MIPT_QW_SLOT_WORDS + 192)  // logic stage over the previous round's probe list
 #define MIPT_QW_N_OVERFLOW (4 * MIPT_QW_SLOT_WORDS)
 #define MIPT_QW_COUNTERS (4 * MIPT_QW_SLOT_WORDS + 32)
 
 struct DQueueWave {
 	QContrib* fifo;                  // [N][MIPT_QW_FIFO]
 	float4 *cur_w, *cur_o, *cur_d;   // the contribution being processed (w.w: its depth / flag bits)
-	float4* acc;                     // xyz: the sample's colour so far; w: attenuationFactor (Raytracer.cpp:206, kept across contributions)
+	float4* acc;                     // xyz: the sample's colour so far; w: attenuationFactor (Raytracer.cpp:206, kept across contributions).
+	                                 // The same array as wf.out.col: the any-hit stage adds a pending direct term to it (below)
 	unsigned* ctl;                   // head | count << 8 | phase << 16 | fog site << 24
 	float4* fr;                      // frame, slot-major: fr[slot * N + id]
 	float* vis;                      // any-hit results
 	unsigned* live[2];               // ids with a closest-hit request, by round parity
 	unsigned* shl[2];                // ids with an any-hit request
+	unsigned* prl[2];                // ids with a subsurface probe request
+	unsigned* sha[2];                // ids with an any-hit request whose answer only decides whether wf.sh_c is added to the colour
 	unsigned* overflow;              // ids whose ring overflowed
 	unsigned* counters;
 	float4 *aov_n, *aov_kd;          // denoiser inputs or null
@@ -90,11 +101,6 @@ MIPT_DEV bool qw_meshes_missed(const DScene* __restrict__ sc, f3 ro, f3 rd, floa
 	return missed;
 }
 
-struct QwNoStack {};
-MIPT_DEV bool qw_mesh_reservoir(const DObject&, f3, f3, float, float, uint64_t&, float&, int&, float&, float&, QwNoStack&) { return false; }   // never reached: the build without the probe
-template <class STK> MIPT_DEV bool qw_mesh_reservoir(const DObject& o, f3 org, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out, int& tri_out, float& beta_out, float& gamma_out, STK& stk) {
-	return mesh_reservoir(o, org, d, min_t, max_t, rng, t_out, tri_out, beta_out, gamma_out, stk);
-}
 // First round: the camera contribution of every sample.
 __global__ void __launch_bounds__(MIPT_BLOCK) k_q_begin(DRender R, DPass ps, DWave wf, DQueueWave qw) {
 	const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,11 +132,22 @@ struct QwSample {
 	bool overflow;
 };
 
-// One sample: run segments until the next ray query.  Returns 0 (finished or abandoned), 1 (closest-hit request in
-// wf.ray_o / ray_d), 2 (any-hit request in wf.sh_o / sh_d).
-template <bool SUBS, bool SHADOW_LIST, class STK>
+// One sample: run segments until the next ray query.  Returns -1 (abandoned) or the requests it made as bits: 1 (closest
+// hit, wf.ray_o / ray_d), 2 (any hit, wf.sh_o / sh_d, the sample waits for the answer), 4 (subsurface probe, wf.ray_o /
+// ray_d: origin and direction in the object's frame, .w = tmax / the object), 8 (any hit, wf.sh_o / sh_d, nobody waits:
+// the traversal stage adds wf.sh_c to the colour if the light sample is visible); 0 = finished.
+//
+// With fog the same request is made early too (bit 8 with the closest-hit request of the fog event, both answered in one
+// round; qw.vis is read where the direct term is added, TAIL of site 5), so a vertex costs two rounds instead of three.
+// Bit 8 without fog is the common vertex: an opaque, non-ghost surface.  The answer of its light-sample query decides
+// nothing but whether the direct term is added (Raytracer.cpp:538-566; the env flag of the continuation, :626-629, reads
+// isShadowed only for ghosts) and the query draws no random numbers, so the vertex goes on to its continuation in the same
+// call and its any-hit query runs in the same round as the closest-hit query of the next contribution; the term is added
+// to the colour by the any-hit stage, i.e. before the next vertex adds anything: the order of the additions is the
+// reference's.
+template <bool SUBS, bool SHADOW_LIST>
 __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const DRender& R, const DPass& ps, const DWave& wf, const DQueueWave& qw, const unsigned id,
-                                       unsigned& n_closest, unsigned& n_shadow, STK& stk) {
+                                       unsigned& n_closest, unsigned& n_shadow) {
 	const unsigned N = qw.N;
 	unsigned ctl = qw.ctl[id];
 	int phase = (int)((ctl >> 16) & 0xffu);
@@ -164,7 +181,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 		qw.acc[id] = make_float4(S.color.x, S.color.y, S.color.z, S.att);
 		qw.ctl[id] = (S.head & 0xffu) | ((S.count & 0xffu) << 8) | ((unsigned)ph << 16) | ((unsigned)st << 24);
 	};
-	auto finish = [&]() { wf.out.col[id] = make_float4(S.color.x, S.color.y, S.color.z, 0.f); save(QW_DONE, 0); };
+	auto finish = [&]() { S.att = 0.f; save(QW_DONE, 0); };       // qw.acc IS wf.out.col
 	auto request_closest = [&](const Ray& r) {
 		float t0; unsigned best0;
 		analytic_prefix_closest(sc, r.o, r.d, t0, best0);
@@ -189,9 +206,11 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	Mat m; m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
 	float t_main = 0.f, d_light2 = 0.f;
 	int objid = 0; bool sub_interaction = false, isShadowed = false;
+	int pending_add = 0;                  // 8: this call left an any-hit request whose term the traversal stage adds
+	bool deferred = false;                // fog: the any-hit request of the vertex is in flight, its answer (qw.vis) is read where the direct term is added
 	auto save_vertex = [&]() {
 		FR(0) = make_float4(P.x, P.y, P.z, t_main);
-		FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u)));
+		FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u)));
 		FR(2) = make_float4(rayDirection.x, rayDirection.y, rayDirection.z, d_light2);
 		FR(3) = make_float4(m.Kd.x, m.Kd.y, m.Kd.z, m.Ks.x);
 		FR(4) = make_float4(m.Ks.y, m.Ks.z, m.Ne.x, m.Ne.y);
@@ -203,7 +222,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	auto load_vertex = [&]() {
 		const float4 a = FR(0), b = FR(1), c = FR(2), d = FR(3), e = FR(4), f = FR(5), g = FR(6), h = FR(7), i2 = FR(8);
 		P = mk3(a.x, a.y, a.z); t_main = a.w;
-		Nn = mk3(b.x, b.y, b.z); { const unsigned fl = __float_as_uint(b.w); objid = (int)(fl & 0xffu); sub_interaction = (fl & 0x100u) != 0; isShadowed = (fl & 0x200u) != 0; }
+		Nn = mk3(b.x, b.y, b.z); { const unsigned fl = __float_as_uint(b.w); objid = (int)(fl & 0xffu); sub_interaction = (fl & 0x100u) != 0; isShadowed = (fl & 0x200u) != 0; deferred = (fl & 0x400u) != 0; }
 		rayDirection = mk3(c.x, c.y, c.z); d_light2 = c.w;
 		m.Kd = mk3(d.x, d.y, d.z); m.Ks = mk3(d.w, e.x, e.y); m.Ne = mk3(e.z, e.w, f.x); Ksub = mk3(f.y, f.z, f.w);
 		subsW = mk3(g.x, g.y, g.z); dir_l = mk3(h.x, h.y, h.z); wi = mk3(i2.x, i2.y, i2.z);
@@ -277,10 +296,11 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	// TAIL (what follows a fog call at its site) -> A3 -> POP.  Every transfer goes forward, so each segment is one block
 	// of straight-line code and what it computes dies with it unless a later segment of the same call uses it.
 	enum { ST_A1 = 1, ST_A2 = 2, ST_F1Q = 3, ST_TAIL = 4, ST_A3 = 5, ST_POP = 6 };
-	int st = phase == QW_A1 ? ST_A1 : (phase == QW_A2 ? ST_A2 : (phase == QW_F1 ? ST_F1Q : ST_POP));
+	int st = (phase == QW_A1 || phase == QW_PROBE) ? ST_A1 : (phase == QW_A2 ? ST_A2 : (phase == QW_F1 ? ST_F1Q : (phase == QW_T5 ? ST_TAIL : ST_POP)));
 	const bool a2_from_query = phase == QW_A2;
+	const bool a1_from_probe = SUBS && phase == QW_PROBE;      // the answer of the subsurface probe: the head of A1 again (deterministic), from the saved hit
 	if (!SHADOW_LIST && st == ST_A1) do {
-			const float4 hr = wf.hit[id];
+			const float4 hr = a1_from_probe ? FR(12) : wf.hit[id];
 			const unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
 			const bool hit = packed != MIPT_HIT_MISS;
@@ -329,22 +349,27 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				const float subsProba = (hadSS || !is_subsurface) ? 0.f : 0.6f; // :318
 				const float inv1MSubsProba = 1.f / (1.f - subsProba);
 				subsW = mk3(inv1MSubsProba, inv1MSubsProba, inv1MSubsProba);
-				if (is_subsurface && (pcg_uniform(S.rng) < subsProba)) {        // :324-404
+				if (a1_from_probe || (is_subsurface && (pcg_uniform(S.rng) < subsProba))) {        // :324-404
 					sub_interaction = true;
 					const float invSubsProba = 1.f / subsProba;
 					subsW = mk3(invSubsProba, invSubsProba, invSubsProba);
 					const float sigmasub = 1.5f;
 					const float diskR = sqrtf(12.46f) * sigmasub;
 					const float integ = 1.f - mipt_expf(-diskR * diskR / (2.f * sigmasub * sigmasub));
-					const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(S.rng) * integ));
-					const float randangle = pcg_uniform(S.rng) * 2.f * (float)MIPT_PI;
-					const float gauss0 = randR * pt_sinf(randangle), gauss1 = randR * pt_cosf(randangle), gauss2 = randR;
+					float gauss0, gauss1, gauss2, r1s;
+					bool r2_low = false;
+					if (a1_from_probe) { const float4 g = FR(6); gauss0 = g.x; gauss1 = g.y; gauss2 = g.z; r1s = g.w; r2_low = FR(7).x != 0.f; }
+					else {
+						const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(S.rng) * integ));
+						const float randangle = pcg_uniform(S.rng) * 2.f * (float)MIPT_PI;
+						gauss0 = randR * pt_sinf(randangle); gauss1 = randR * pt_cosf(randangle); gauss2 = randR;
+						r1s = pcg_uniform(S.rng);
+					}
 					const float gaussval = (float)((1. / (double)(sigmasub * sigmasub * 2.f * (float)MIPT_PI)) * (double)mipt_expf(-(gauss2 * gauss2) / (2.f * sigmasub * sigmasub)));
 					const float pdfgauss = gaussval / integ;
 					const f3 Tg = tangent_of(Nn);
 					const f3 Tg2 = cross(Nn, Tg);
 					const f3 PtaboveP = ((P + gauss0 * Tg) + gauss1 * Tg2) + Nn * diskR;
-					const float r1s = pcg_uniform(S.rng);
 					f3 axis = -Nn;
 					float tmax;
 					const float hh = sqrtf(diskR * diskR - gauss2 * gauss2);
@@ -355,14 +380,27 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 						wAxis = 0.25f;
 						tmax = 2.f * gauss2;
 						if (r1s < 0.75f) axis = Tg; else axis = Tg2;
-						const float r2s = pcg_uniform(S.rng);
-						if (r2s < 0.5f) subsOrigin = subsOrigin - hh * Nn;
+						if (!a1_from_probe) r2_low = pcg_uniform(S.rng) < 0.5f;
+						if (r2_low) subsOrigin = subsOrigin - hh * Nn;
 					}
 					Ray probe; probe.o = subsOrigin; probe.d = axis;
 					Hit sh; sh.obj = h.obj; sh.tri = -1; sh.t = 0; sh.beta = sh.gamma = 0;
 					const f3 po = xf_point(obj.inv, probe.o), pd = xf_dir(obj.inv, probe.d);
-					const bool subsinter = obj.type == 2 ? plane_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t)
-					                                     : qw_mesh_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t, sh.tri, sh.beta, sh.gamma, stk);
+					if (obj.type != 2 && !a1_from_probe) {                       // a mesh: get_random_intersection is the probe stage's
+						FR(12) = hr;
+						FR(6) = make_float4(gauss0, gauss1, gauss2, r1s);
+						FR(7) = make_float4(r2_low ? 1.f : 0.f, 0.f, 0.f, 0.f);
+						wf.ray_o[id] = make_float4(po.x, po.y, po.z, tmax);
+						wf.ray_d[id] = make_float4(pd.x, pd.y, pd.z, __uint_as_float((unsigned)h.obj));
+						save(QW_PROBE, 0);
+						return 4;
+					}
+					bool subsinter;
+					if (a1_from_probe) {
+						const float4 pr = wf.hit[id];
+						subsinter = __float_as_uint(pr.w) != MIPT_HIT_MISS;
+						sh.t = pr.x; sh.beta = pr.y; sh.gamma = pr.z; sh.tri = (int)__float_as_uint(pr.w);
+					} else subsinter = plane_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t);
 					if (subsinter) {
 						f3 localP2; Mat subsmat;
 						subsmat.shadingN = mk3(0, 1, 0); subsmat.Kd = mk3(0.5f, 0.5f, 0.5f); subsmat.Ks = mk3(0, 0, 0); subsmat.Ne = mk3(100, 100, 100); subsmat.Ke = mk3(0, 0, 0); subsmat.transp = false; subsmat.refr_index = 0;
@@ -444,8 +482,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					yield_shadow = true;
 				}
 			}
-			save_vertex();
-			if (yield_shadow) { save(QW_A2, 0); return 2; }
+			if (yield_shadow && obj.ghost) { save_vertex(); save(QW_A2, 0); return 2; }   // a ghost queues the path going straight on only if the light is visible
+			if (yield_shadow && has_fog) deferred = true;
+			else if (yield_shadow) pending_add = 8;
+			if (has_fog) save_vertex();                                         // the fog event of site 5 comes back through the frame
 			st = ST_A2;
 	} while (0);
 	if (st == ST_A2) do {
@@ -472,12 +512,14 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			}
 			if (has_fog) {                                                      // :557-565
 				FR(9) = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
-				FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u)));
+				FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u)));
 				site = 5;
-				if (fog_begin(site, currentRay, pt_l)) return 1;
+				if (fog_begin(site, currentRay, pt_l)) return 1 | (deferred ? 8 : 0);
+				if (deferred) { save(QW_T5, site); return 2; }                   // no event: the answer is needed now
 				st = ST_TAIL; break;
 			}
-			S.color = S.color + pathWeight * contrib;                          // :566
+			if (pending_add) { const f3 pc = pathWeight * contrib; wf.sh_c[id] = make_float4(pc.x, pc.y, pc.z, 0.f); }
+			else S.color = S.color + pathWeight * contrib;                     // :566
 			st = ST_A3;
 	} while (0);
 	if (!SHADOW_LIST && st == ST_F1Q) {
@@ -534,9 +576,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				st = ST_POP; break;
 			}
 			// site 5: the diffuse vertex goes on (:565)
-			if (phase == QW_F1) {                                               // entered from the fog query: the vertex is in the frame
+			if (phase == QW_F1 || phase == QW_T5) {                             // entered from a query: the vertex is in the frame
 				load_vertex();
 				const float4 c9 = FR(9); contrib = mk3(c9.x, c9.y, c9.z);
+				if (deferred && qw.vis[id] == 0.f) { isShadowed = true; contrib = mk3(0, 0, 0); }   // :538 was assumed visible
 			}
 			S.color = S.color + (S.att * pathWeight) * contrib;
 			st = ST_A3;
@@ -572,7 +615,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	// ---- POP: the next contribution that is still alive asks for its closest hit
 	if (S.overflow) { save(QW_DONE, 0); return -1; }
 	for (;;) {
-			if (S.count == 0) { finish(); return 0; }
+			if (S.count == 0) { finish(); return pending_add; }
 			const QContrib c = fifo[S.head];
 			S.head = (S.head + 1) % MIPT_QW_FIFO; S.count--;
 			const unsigned bits = __float_as_uint(c.w.w);
@@ -582,36 +625,39 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			Ray r; r.o = mk3(c.o.x, c.o.y, c.o.z); r.d = mk3(c.d.x, c.d.y, c.d.z);
 			request_closest(r);
 			save(QW_A1, 0);
-			return 1;
+			return 1 | pending_add;
 		}
 }
 
-template <bool SUBS> struct QwStack { typedef ScratchStack type; };
-template <> struct QwStack<false> { typedef QwNoStack type; };
 // One round of the logic stage over one id list of the previous round (or, round 0, over all path slots).
 template <bool SUBS, bool SHADOW_LIST>
 __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_QW_LOGIC_WAVES))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
                                                                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, unsigned n_imm,
                                                                                                 unsigned* __restrict__ head, int out_slot, int out_parity, DCounters* __restrict__ cnt) {
-	typename QwStack<SUBS>::type stk;                 // the traversal stack of the subsurface probe, only in the build that has the probe
 	const unsigned n = n_ptr ? *n_ptr : n_imm;
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
 	QueuePuller q; q.init();
 	while (q.pull(head, n, base)) {
-		unsigned closest_bits = 0, shadow_bits = 0, over_bits = 0;
+		unsigned closest_bits = 0, shadow_bits = 0, over_bits = 0, probe_bits = 0, add_bits = 0;
 #pragma unroll 1
 		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			if (idx >= n) continue;
 			const unsigned id = list ? list[idx] : idx;
-			const int r = qw_advance<SUBS, SHADOW_LIST>(sc, R, ps, wf, qw, id, n_closest, n_shadow, stk);
-			if (r == 1) closest_bits |= 1u << u;
-			else if (r == 2) shadow_bits |= 1u << u;
-			else if (r < 0) over_bits |= 1u << u;
+			const int r = qw_advance<SUBS, SHADOW_LIST>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
+			if (r < 0) over_bits |= 1u << u;
+			else {
+				if (r & 1) closest_bits |= 1u << u;
+				if (r & 2) shadow_bits |= 1u << u;
+				if (r & 4) probe_bits |= 1u << u;
+				if (r & 8) add_bits |= 1u << u;
+			}
 		}
 		queue_push2(qw.shl[out_parity], qw.live[out_parity], reinterpret_cast<unsigned long long*>(&qw.counters[MIPT_QW_PAIR(out_slot)]), shadow_bits, closest_bits, list, base);
 		queue_push(qw.overflow, &qw.counters[MIPT_QW_N_OVERFLOW], over_bits, list, base);
+		if (SUBS && !SHADOW_LIST) queue_push(qw.prl[out_parity], &qw.counters[MIPT_QW_N_PROBE(out_slot)], probe_bits, list, base);
+		if (!SHADOW_LIST) queue_push(qw.sha[out_parity], &qw.counters[MIPT_QW_N_SHADOW_ADD(out_slot)], add_bits, list, base);
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);
