@@ -348,6 +348,7 @@ struct mipt_ctx {
 	int n_mesh_objects = 0;
 	uint64_t host_paths = 0;
 	bool paths_from_host = false;
+	bool primary_from_host = false;       // the camera rays of the contribution-queue stages are requested by k_q_begin, which does not count
 	bool has_scene = false;
 	// render-time buffers (grown on demand)
 	void* pass_buf = nullptr; size_t pass_buf_bytes = 0;
@@ -1158,6 +1159,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.rng = (uint2*)carve(N * sizeof(uint2));
 		wf.out = S;
 		qw.cur_w = (float4*)carve(N * sizeof(float4)); qw.cur_o = (float4*)carve(N * sizeof(float4)); qw.cur_d = (float4*)carve(N * sizeof(float4));
+		wf.wgt = qw.cur_w;                  // round 0 walks the identity queue: bit 31 of cur_w.w marks the slots that hold a sample
 		qw.acc = S.col;                     // the colour of a sample accumulates in place (w: attenuationFactor while it lives)
 		qw.ctl = (unsigned*)carve(N * sizeof(unsigned));
 		qw.fr = (float4*)carve(N * MIPT_QW_FRAME * sizeof(float4));
@@ -1221,7 +1223,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			// samples still have a query pending (one 8-byte read; the round loop ends when none has)
 			HIPCHK(c, hipMemsetAsync(qw.counters, 0, MIPT_QW_COUNTERS * sizeof(unsigned), st));
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-			hipLaunchKernelGGL(k_q_begin, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, R, P, wf, qw);
+			hipLaunchKernelGGL(k_q_begin, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, c->d_cnt);
 			typedef void (*logic_fn)(const DScene*, DRender, DPass, DWave, DQueueWave, const unsigned*, const unsigned*, unsigned, unsigned*, int, int, DCounters*);
 			const logic_fn logic_k[2] = {c->scene_has_subsurface ? (logic_fn)k_q_logic<true, false> : (logic_fn)k_q_logic<false, false>,      // over a closest-hit list (or all samples)
 			                             c->scene_has_subsurface ? (logic_fn)k_q_logic<true, true> : (logic_fn)k_q_logic<false, true>};       // over an any-hit list
@@ -1237,7 +1239,6 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				const dim3 g(std::max(1u, std::min(c->grid_qlogic[shadow_list], (n_host + MIPT_BLOCK - 1) / MIPT_BLOCK)));
 				hipLaunchKernelGGL(logic_k[shadow_list], g, dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, list, n_ptr, n_imm, head, out_slot, out_parity, c->d_cnt);
 			};
-			launch_logic(0, nullptr, nullptr, (unsigned)total, (unsigned)total, &qw.counters[MIPT_QW_HEAD_LOGIC_A(0)], 0, 0);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
@@ -1245,9 +1246,13 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (r > 100000) return fail(c, MIPT_ERR_HIP, "the contribution queue did not drain");
 				const int slot = r & 3, par = r & 1;
 				unsigned pair[2] = {0, 0}, more[2] = {0, 0};                // {n_shadow, n_closest}, {subsurface probes, any-hit requests nobody waits for} of this round's logic stage
-				HIPCHK(c, hipMemcpyAsync(pair, &qw.counters[MIPT_QW_PAIR(slot)], 8, hipMemcpyDeviceToHost, st));
-				HIPCHK(c, hipMemcpyAsync(more, &qw.counters[MIPT_QW_N_PROBE(slot)], 8, hipMemcpyDeviceToHost, st));
-				HIPCHK(c, hipStreamSynchronize(st));
+				const bool first = r == 0;                                   // round 0: the camera rays of all path slots (k_q_begin), identity queue
+				if (first) pair[1] = p->nb_bounces > 0 ? (unsigned)total : 0u;
+				else {
+					HIPCHK(c, hipMemcpyAsync(pair, &qw.counters[MIPT_QW_PAIR(slot)], 8, hipMemcpyDeviceToHost, st));
+					HIPCHK(c, hipMemcpyAsync(more, &qw.counters[MIPT_QW_N_PROBE(slot)], 8, hipMemcpyDeviceToHost, st));
+					HIPCHK(c, hipStreamSynchronize(st));
+				}
 				const unsigned n_probe = more[0], n_add = more[1];
 				if (pair[0] == 0 && pair[1] == 0 && n_probe == 0 && n_add == 0) break;
 				unsigned* pair_dev = &qw.counters[MIPT_QW_PAIR(slot)];
@@ -1258,7 +1263,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[1]) {
-					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = pair_dev + 1; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
+					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = first ? nullptr : pair_dev + 1; tq.n_imm = pair[1]; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = first; tq.vis = nullptr; tq.skip_ghosts = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					hipLaunchKernelGGL(k_q_traverse<false>, dim3(std::max(1u, std::min(c->grid_qtrav[0], (pair[1] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
@@ -1279,7 +1284,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				const int nslot = (r + 1) & 3, npar = (r + 1) & 1;
 				HIPCHK(c, hipMemsetAsync(&qw.counters[MIPT_QW_PAIR(nslot)], 0, MIPT_QW_SLOT_WORDS * sizeof(unsigned), st));
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				launch_logic(0, qw.live[par], pair_dev + 1, 0, pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
+				if (first) launch_logic(0, nullptr, nullptr, pair[1], pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
+				else launch_logic(0, qw.live[par], pair_dev + 1, 0, pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
 				launch_logic(1, qw.shl[par], pair_dev, 0, pair[0], &qw.counters[MIPT_QW_HEAD_LOGIC_B(nslot)], nslot, npar);
 				launch_logic(0, qw.prl[par], &qw.counters[MIPT_QW_N_PROBE(slot)], 0, n_probe, &qw.counters[MIPT_QW_HEAD_LOGIC_C(nslot)], nslot, npar);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
@@ -1375,6 +1381,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	c->host_paths = c->blk_valid_pixels * (uint64_t)(ke - kb);
 	c->stats.pipeline = (uint32_t)pipeline;
 	c->paths_from_host = pipeline == 2 && queue_wave;
+	c->primary_from_host = c->paths_from_host && p->nb_bounces > 0;
 	c->kev_used = nev;
 	return MIPT_OK;
 }
@@ -1385,6 +1392,7 @@ static int collect_stats(mipt_ctx* c) {
 	DCounters h{};
 	for (const DCounters& x : hs) { h.paths += x.paths; h.rays_closest += x.rays_closest; h.rays_shadow += x.rays_shadow; }
 	if (c->stats.pipeline == 1 || c->paths_from_host) h.paths = c->host_paths;     // the wavefront stages do not count paths on the device
+	if (c->primary_from_host) h.rays_closest += c->host_paths;
 	c->stats.paths = h.paths; c->stats.rays_closest = h.rays_closest; c->stats.rays_shadow = h.rays_shadow;
 	c->stats.mesh_casts_closest = h.rays_closest * (uint64_t)c->n_mesh_objects;
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder

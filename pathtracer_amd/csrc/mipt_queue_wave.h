@@ -36,6 +36,17 @@
 #define MIPT_QW_LOGIC_WAVES 2
 #endif
 #define MIPT_QW_FRAME 13                  // float4 slots of the per-sample frame
+// The per-sample state (1.9 KB) is touched once per call: streaming cache policy, as the path state of pipeline 1
+#ifndef MIPT_QW_STREAM
+#define MIPT_QW_STREAM 1
+#endif
+#if MIPT_QW_STREAM
+#define QW_LD(p) wf_ld(p)
+#define QW_ST(p, v) wf_st((p), (v))
+#else
+#define QW_LD(p) (*(p))
+#define QW_ST(p, v) (*(p) = (v))
+#endif
 enum { QW_POP = 0, QW_A1 = 1, QW_A2 = 2, QW_F1 = 3, QW_DONE = 4, QW_PROBE = 5, QW_T5 = 6 };
 // counters of one round (cyclic, 4 round slots): every word on its own 128-byte line
 #define MIPT_QW_SLOT_WORDS (10 * 32)
@@ -101,8 +112,11 @@ MIPT_DEV bool qw_meshes_missed(const DScene* __restrict__ sc, f3 ro, f3 rd, floa
 	return missed;
 }
 
-// First round: the camera contribution of every sample.
-__global__ void __launch_bounds__(MIPT_BLOCK) k_q_begin(DRender R, DPass ps, DWave wf, DQueueWave qw) {
+// The camera contribution of every sample, already popped (Raytracer.cpp:231-246 for the first entry of the FIFO: depth and
+// weight pass the tests of :240-241 by construction) and with its closest-hit request made: round 0 is the closest-hit
+// traversal over all path slots (identity queue; bit 31 of cur_w.w marks the slots that hold a sample, as MIPT_WF_VALID of
+// pipeline 1's wgt — wf.wgt IS qw.cur_w here).
+__global__ void __launch_bounds__(MIPT_BLOCK) k_q_begin(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw, DCounters* __restrict__ cnt) {
 	const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	if (tid >= total) return;
@@ -111,17 +125,21 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_q_begin(DRender R, DPass ps, DWa
 	const int i = ps.blocks[2 * blk] + (in >> 3), j = ps.blocks[2 * blk + 1] + (in & 7);
 	if (qw.aov_n) { qw.aov_n[tid] = make_float4(0.f, 0.f, 0.f, 0.f); qw.aov_kd[tid] = make_float4(0.f, 0.f, 0.f, 0.f); }
 	wf.out.col[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (!(i < R.H && j < R.W)) { qw.ctl[tid] = (unsigned)QW_DONE << 16; wf.out.dxdy[tid] = make_float2(0.f, 0.f); return; }
+	if (!(i < R.H && j < R.W)) { qw.ctl[tid] = (unsigned)QW_DONE << 16; qw.cur_w[tid] = make_float4(0.f, 0.f, 0.f, 0.f); wf.out.dxdy[tid] = make_float2(0.f, 0.f); return; }
 	PathState p; float dx, dy;
 	path_begin(R, i, j, ps.k0 + kk, p, dx, dy);
 	wf.out.dxdy[tid] = make_float2(dx, dy);
-	QContrib c;
-	c.w = make_float4(1.f, 1.f, 1.f, __uint_as_float((unsigned)(R.nb_bounces & 0xffff) | 0x10000u | 0x20000u));
-	c.o = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f); c.d = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
-	qw.fifo[(size_t)tid * MIPT_QW_FIFO] = c;
-	qw.acc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 	wf.rng[tid] = make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32));
-	qw.ctl[tid] = 0u | (1u << 8) | ((unsigned)QW_POP << 16);
+	const bool dead = (R.nb_bounces & 0xffff) == 0;                  // :240 (depth 0: nothing is traced)
+	qw.cur_w[tid] = make_float4(1.f, 1.f, 1.f, __uint_as_float((unsigned)(R.nb_bounces & 0xffff) | 0x10000u | 0x20000u | (dead ? 0u : MIPT_WF_VALID)));
+	if (dead) { qw.ctl[tid] = (unsigned)QW_DONE << 16; return; }
+	qw.cur_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f); qw.cur_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
+	float t0; unsigned best0;
+	analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
+	wf.ray_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0);
+	wf.ray_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0));
+	qw.ctl[tid] = (unsigned)QW_A1 << 16;                             // empty ring, waiting for the closest hit
+	(void)cnt;                                                       // the camera rays are counted on the host (valid pixels x samples)
 }
 
 // The state of one sample while its segments run.
@@ -154,11 +172,12 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	int site = (int)(ctl >> 24);
 	if (phase == QW_DONE) return 0;
 	QwSample S;
-	{ const uint2 rs = wf.rng[id]; S.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
-	{ const float4 a = qw.acc[id]; S.color = mk3(a.x, a.y, a.z); S.att = a.w; }
+	{ const uint2 rs = QW_LD(&wf.rng[id]); S.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
+	{ const float4 a = QW_LD(&qw.acc[id]); S.color = mk3(a.x, a.y, a.z); S.att = a.w; }
 	S.head = ctl & 0xffu; S.count = (ctl >> 8) & 0xffu; S.overflow = false;
 	QContrib* const fifo = qw.fifo + (size_t)id * MIPT_QW_FIFO;
-	auto FR = [&](int slot) -> float4& { return qw.fr[(size_t)slot * N + id]; };
+	auto FRL = [&](int slot) -> float4 { return QW_LD(&qw.fr[(size_t)slot * N + id]); };
+	auto FRS = [&](int slot, float4 v) { QW_ST(&qw.fr[(size_t)slot * N + id], v); };
 	const bool has_bg = R.backgroundW > 0 && R.background != nullptr;       // :220
 	const bool has_fog = R.fog_density > 1E-8;                              // :207
 	const f3 cl = ld3(R.centerLight);
@@ -168,25 +187,29 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	const int pi = ps.blocks[2 * blk] + (in_ >> 3), pj = ps.blocks[2 * blk + 1] + (in_ & 7);
 	const int pix = pi * R.W + pj, k = ps.k0 + kk;
 
+	QContrib front; front.w = front.o = front.d = make_float4(0.f, 0.f, 0.f, 0.f);
+	bool have_front = false;
 	auto push = [&](f3 w, const Ray& r, int depth, bool lights, bool env, bool hadSS) {
 		if (S.count >= qw.ring) { S.overflow = true; return; }
 		QContrib c;
 		c.w = make_float4(w.x, w.y, w.z, __uint_as_float((unsigned)(depth & 0xffff) | (lights ? 0x10000u : 0u) | (env ? 0x20000u : 0u) | (hadSS ? 0x40000u : 0u)));
 		c.o = make_float4(r.o.x, r.o.y, r.o.z, 0.f); c.d = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
-		fifo[(S.head + S.count) % MIPT_QW_FIFO] = c;
+		if (S.count == 0) { front = c; have_front = true; }         // into an empty ring: handed to POP in registers (written by save() if the call ends first)
+		else { QContrib* const e = fifo + (S.head + S.count) % MIPT_QW_FIFO; QW_ST(&e->w, c.w); QW_ST(&e->o, c.o); QW_ST(&e->d, c.d); }
 		S.count++;
 	};
 	auto save = [&](int ph, int st) {
-		wf.rng[id] = make_uint2((unsigned)S.rng, (unsigned)(S.rng >> 32));
-		qw.acc[id] = make_float4(S.color.x, S.color.y, S.color.z, S.att);
+		if (have_front) { QContrib* const e = fifo + S.head; QW_ST(&e->w, front.w); QW_ST(&e->o, front.o); QW_ST(&e->d, front.d); have_front = false; }
+		QW_ST(&wf.rng[id], make_uint2((unsigned)S.rng, (unsigned)(S.rng >> 32)));
+		QW_ST(&qw.acc[id], make_float4(S.color.x, S.color.y, S.color.z, S.att));
 		qw.ctl[id] = (S.head & 0xffu) | ((S.count & 0xffu) << 8) | ((unsigned)ph << 16) | ((unsigned)st << 24);
 	};
 	auto finish = [&]() { S.att = 0.f; save(QW_DONE, 0); };       // qw.acc IS wf.out.col
 	auto request_closest = [&](const Ray& r) {
 		float t0; unsigned best0;
 		analytic_prefix_closest(sc, r.o, r.d, t0, best0);
-		wf.ray_o[id] = make_float4(r.o.x, r.o.y, r.o.z, t0);
-		wf.ray_d[id] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(best0));
+		QW_ST(&wf.ray_o[id], make_float4(r.o.x, r.o.y, r.o.z, t0));
+		QW_ST(&wf.ray_d[id], make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(best0)));
 		n_closest++;
 	};
 
@@ -194,7 +217,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	f3 pathWeight = mk3(0, 0, 0); Ray currentRay; currentRay.o = mk3(0, 0, 0); currentRay.d = mk3(0, 0, 1);
 	int nbrebonds = 0; bool show_lights = false, show_envmap = false, hadSS = false;
 	auto load_cur = [&]() {
-		const float4 w = qw.cur_w[id], o = qw.cur_o[id], d = qw.cur_d[id];
+		const float4 w = QW_LD(&qw.cur_w[id]), o = QW_LD(&qw.cur_o[id]), d = QW_LD(&qw.cur_d[id]);
 		const unsigned bits = __float_as_uint(w.w);
 		pathWeight = mk3(w.x, w.y, w.z); currentRay.o = mk3(o.x, o.y, o.z); currentRay.d = mk3(d.x, d.y, d.z);
 		nbrebonds = (int)(bits & 0xffffu); show_lights = (bits & 0x10000u) != 0; show_envmap = (bits & 0x20000u) != 0; hadSS = (bits & 0x40000u) != 0;
@@ -209,18 +232,18 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	int pending_add = 0;                  // 8: this call left an any-hit request whose term the traversal stage adds
 	bool deferred = false;                // fog: the any-hit request of the vertex is in flight, its answer (qw.vis) is read where the direct term is added
 	auto save_vertex = [&]() {
-		FR(0) = make_float4(P.x, P.y, P.z, t_main);
-		FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u)));
-		FR(2) = make_float4(rayDirection.x, rayDirection.y, rayDirection.z, d_light2);
-		FR(3) = make_float4(m.Kd.x, m.Kd.y, m.Kd.z, m.Ks.x);
-		FR(4) = make_float4(m.Ks.y, m.Ks.z, m.Ne.x, m.Ne.y);
-		FR(5) = make_float4(m.Ne.z, Ksub.x, Ksub.y, Ksub.z);
-		FR(6) = make_float4(subsW.x, subsW.y, subsW.z, 0.f);
-		FR(7) = make_float4(dir_l.x, dir_l.y, dir_l.z, 0.f);
-		FR(8) = make_float4(wi.x, wi.y, wi.z, 0.f);
+		FRS(0, make_float4(P.x, P.y, P.z, t_main));
+		FRS(1, make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u))));
+		FRS(2, make_float4(rayDirection.x, rayDirection.y, rayDirection.z, d_light2));
+		FRS(3, make_float4(m.Kd.x, m.Kd.y, m.Kd.z, m.Ks.x));
+		FRS(4, make_float4(m.Ks.y, m.Ks.z, m.Ne.x, m.Ne.y));
+		FRS(5, make_float4(m.Ne.z, Ksub.x, Ksub.y, Ksub.z));
+		FRS(6, make_float4(subsW.x, subsW.y, subsW.z, 0.f));
+		FRS(7, make_float4(dir_l.x, dir_l.y, dir_l.z, 0.f));
+		FRS(8, make_float4(wi.x, wi.y, wi.z, 0.f));
 	};
 	auto load_vertex = [&]() {
-		const float4 a = FR(0), b = FR(1), c = FR(2), d = FR(3), e = FR(4), f = FR(5), g = FR(6), h = FR(7), i2 = FR(8);
+		const float4 a = FRL(0), b = FRL(1), c = FRL(2), d = FRL(3), e = FRL(4), f = FRL(5), g = FRL(6), h = FRL(7), i2 = FRL(8);
 		P = mk3(a.x, a.y, a.z); t_main = a.w;
 		Nn = mk3(b.x, b.y, b.z); { const unsigned fl = __float_as_uint(b.w); objid = (int)(fl & 0xffu); sub_interaction = (fl & 0x100u) != 0; isShadowed = (fl & 0x200u) != 0; deferred = (fl & 0x400u) != 0; }
 		rayDirection = mk3(c.x, c.y, c.z); d_light2 = c.w;
@@ -286,21 +309,22 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 		else if (R.fog_phase_type == 2) phase_func = (float)(3 / (16 * MIPT_PI) * (double)(1 + sqr(dot(random_dir, rd))));
 		Ray L; L.o = random_P; L.d = random_dir;
 		request_closest(L);
-		FR(10) = make_float4(T, proba_t, int_ext_partielle, phase_func);
-		FR(11) = make_float4(point_aleatoire.x, point_aleatoire.y, point_aleatoire.z, is_uniform ? 1.f : 0.f);
+		FRS(10, make_float4(T, proba_t, int_ext_partielle, phase_func));
+		FRS(11, make_float4(point_aleatoire.x, point_aleatoire.y, point_aleatoire.z, is_uniform ? 1.f : 0.f));
 		save(QW_F1, st);
 		return true;
 	};
 
-	// The segments in the order control can flow through them within one call: A1 -> A2 -> [F1: answer of the fog query] ->
+	// The segments in the order control can flow through them within one call: A1 -> A2 -> [FOG: the fog call] -> [F1: answer of the fog query] ->
 	// TAIL (what follows a fog call at its site) -> A3 -> POP.  Every transfer goes forward, so each segment is one block
 	// of straight-line code and what it computes dies with it unless a later segment of the same call uses it.
-	enum { ST_A1 = 1, ST_A2 = 2, ST_F1Q = 3, ST_TAIL = 4, ST_A3 = 5, ST_POP = 6 };
+	enum { ST_A1 = 1, ST_A2 = 2, ST_FOG = 3, ST_F1Q = 4, ST_TAIL = 5, ST_A3 = 6, ST_POP = 7 };
+	f3 fog_light = cl;                     // sampleLightPos of the fog call of the site
 	int st = (phase == QW_A1 || phase == QW_PROBE) ? ST_A1 : (phase == QW_A2 ? ST_A2 : (phase == QW_F1 ? ST_F1Q : (phase == QW_T5 ? ST_TAIL : ST_POP)));
 	const bool a2_from_query = phase == QW_A2;
 	const bool a1_from_probe = SUBS && phase == QW_PROBE;      // the answer of the subsurface probe: the head of A1 again (deterministic), from the saved hit
 	if (!SHADOW_LIST && st == ST_A1) do {
-			const float4 hr = a1_from_probe ? FR(12) : wf.hit[id];
+			const float4 hr = a1_from_probe ? FRL(12) : QW_LD(&wf.hit[id]);
 			const unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
 			const bool hit = packed != MIPT_HIT_MISS;
@@ -321,21 +345,19 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			objid = h.obj;
 			if (h.obj == 1) {                                                   // :275-301
 				if (has_fog) {
-					FR(9) = make_float4(m.Ke.x, m.Ke.y, m.Ke.z, 0.f);
-					FR(0) = make_float4(P.x, P.y, P.z, t_main);
+					FRS(9, make_float4(m.Ke.x, m.Ke.y, m.Ke.z, 0.f));
+					FRS(0, make_float4(P.x, P.y, P.z, t_main));
 					site = show_envmap ? 1 : 0;
-					if (fog_begin(site, currentRay, cl)) return 1;
-					st = ST_TAIL; break;              // no event: straight to what follows the fog call
+					st = ST_FOG; break;              // no event: straight to what follows the fog call
 				}
 				if (show_envmap) S.color = S.color + (pathWeight * R.envmap_intensity) * m.Ke;
 				st = ST_POP; break;
 			}
 			if (h.obj == 0) {                                                   // :303-316
 				if (has_fog) {
-					FR(0) = make_float4(P.x, P.y, P.z, t_main);
+					FRS(0, make_float4(P.x, P.y, P.z, t_main));
 					site = 2;
-					if (fog_begin(site, currentRay, cl)) return 1;
-					st = ST_TAIL; break;
+					st = ST_FOG; break;
 				}
 				const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f);
 				S.color = S.color + pathWeight * cc;
@@ -358,7 +380,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					const float integ = 1.f - mipt_expf(-diskR * diskR / (2.f * sigmasub * sigmasub));
 					float gauss0, gauss1, gauss2, r1s;
 					bool r2_low = false;
-					if (a1_from_probe) { const float4 g = FR(6); gauss0 = g.x; gauss1 = g.y; gauss2 = g.z; r1s = g.w; r2_low = FR(7).x != 0.f; }
+					if (a1_from_probe) { const float4 g = FRL(6); gauss0 = g.x; gauss1 = g.y; gauss2 = g.z; r1s = g.w; r2_low = FRL(7).x != 0.f; }
 					else {
 						const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(S.rng) * integ));
 						const float randangle = pcg_uniform(S.rng) * 2.f * (float)MIPT_PI;
@@ -387,17 +409,17 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					Hit sh; sh.obj = h.obj; sh.tri = -1; sh.t = 0; sh.beta = sh.gamma = 0;
 					const f3 po = xf_point(obj.inv, probe.o), pd = xf_dir(obj.inv, probe.d);
 					if (obj.type != 2 && !a1_from_probe) {                       // a mesh: get_random_intersection is the probe stage's
-						FR(12) = hr;
-						FR(6) = make_float4(gauss0, gauss1, gauss2, r1s);
-						FR(7) = make_float4(r2_low ? 1.f : 0.f, 0.f, 0.f, 0.f);
-						wf.ray_o[id] = make_float4(po.x, po.y, po.z, tmax);
-						wf.ray_d[id] = make_float4(pd.x, pd.y, pd.z, __uint_as_float((unsigned)h.obj));
+						FRS(12, hr);
+						FRS(6, make_float4(gauss0, gauss1, gauss2, r1s));
+						FRS(7, make_float4(r2_low ? 1.f : 0.f, 0.f, 0.f, 0.f));
+						QW_ST(&wf.ray_o[id], make_float4(po.x, po.y, po.z, tmax));
+						QW_ST(&wf.ray_d[id], make_float4(pd.x, pd.y, pd.z, __uint_as_float((unsigned)h.obj)));
 						save(QW_PROBE, 0);
 						return 4;
 					}
 					bool subsinter;
 					if (a1_from_probe) {
-						const float4 pr = wf.hit[id];
+						const float4 pr = QW_LD(&wf.hit[id]);
 						subsinter = __float_as_uint(pr.w) != MIPT_HIT_MISS;
 						sh.t = pr.x; sh.beta = pr.y; sh.gamma = pr.z; sh.tri = (int)__float_as_uint(pr.w);
 					} else subsinter = plane_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t);
@@ -424,11 +446,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			if (obj.miroir) {                                                   // :413-436
 				Ray rm; rm.o = P + 0.001f * Nn; rm.d = reflect(rayDirection, Nn);
 				if (has_fog) {
-					FR(0) = make_float4(P.x, P.y, P.z, t_main);
-					FR(7) = make_float4(rm.o.x, rm.o.y, rm.o.z, 0.f); FR(8) = make_float4(rm.d.x, rm.d.y, rm.d.z, 0.f);
+					FRS(0, make_float4(P.x, P.y, P.z, t_main));
+					FRS(7, make_float4(rm.o.x, rm.o.y, rm.o.z, 0.f)); FRS(8, make_float4(rm.d.x, rm.d.y, rm.d.z, 0.f));
 					site = 3;
-					if (fog_begin(site, currentRay, cl)) return 1;
-					st = ST_TAIL; break;
+					st = ST_FOG; break;
 				}
 				push(pathWeight, rm, nbrebonds - 1, show_lights, true, hadSS);
 				st = ST_POP; break;
@@ -450,11 +471,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					else { nr.o = P - 0.001f * nt; nr.d = refr; }
 				} else { nr.o = P + 0.001f * nt; nr.d = reflect(rayDirection, Nn); }
 				if (has_fog) {
-					FR(0) = make_float4(P.x, P.y, P.z, t_main);
-					FR(7) = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.f); FR(8) = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.f);
+					FRS(0, make_float4(P.x, P.y, P.z, t_main));
+					FRS(7, make_float4(nr.o.x, nr.o.y, nr.o.z, 0.f)); FRS(8, make_float4(nr.d.x, nr.d.y, nr.d.z, 0.f));
 					site = 4;
-					if (fog_begin(site, currentRay, cl)) return 1;
-					st = ST_TAIL; break;
+					st = ST_FOG; break;
 				}
 				push(pathWeight, nr, nbrebonds - 1, show_lights, true, hadSS);
 				st = ST_POP; break;
@@ -477,8 +497,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				if (qw_analytic_occluded(sc, rl.o, rl.d, dist)) isShadowed = true;
 				else if (qw_meshes_missed(sc, rl.o, rl.d, dist)) isShadowed = false;
 				else {
-					wf.sh_o[id] = make_float4(rl.o.x, rl.o.y, rl.o.z, dist);
-					wf.sh_d[id] = make_float4(rl.d.x, rl.d.y, rl.d.z, 0.f);
+					QW_ST(&wf.sh_o[id], make_float4(rl.o.x, rl.o.y, rl.o.z, dist));
+					QW_ST(&wf.sh_d[id], make_float4(rl.d.x, rl.d.y, rl.d.z, 0.f));
 					yield_shadow = true;
 				}
 			}
@@ -501,8 +521,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					currentRay.o = (P + rayDirection * 0.001f) + offset * 0.001f;
 					currentRay.d = rayDirection;
 					push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap, hadSS);
-					qw.cur_o[id] = make_float4(currentRay.o.x, currentRay.o.y, currentRay.o.z, 0.f);      // currentRay itself is replaced (the fog event below uses it)
-					qw.cur_d[id] = make_float4(currentRay.d.x, currentRay.d.y, currentRay.d.z, 0.f);
+					QW_ST(&qw.cur_o[id], make_float4(currentRay.o.x, currentRay.o.y, currentRay.o.z, 0.f));      // currentRay itself is replaced (the fog event below uses it)
+					QW_ST(&qw.cur_d[id], make_float4(currentRay.d.x, currentRay.d.y, currentRay.d.z, 0.f));
 				} else {                                                        // :538-553
 					const f3 brdf = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, wi, -rayDirection, Nn) : phong_eval(m, wi, -rayDirection, Nn));
 					const float J = dot(dir_l, -wi) / d_light2;
@@ -511,22 +531,27 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				}
 			}
 			if (has_fog) {                                                      // :557-565
-				FR(9) = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
-				FR(1) = make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u)));
-				site = 5;
-				if (fog_begin(site, currentRay, pt_l)) return 1 | (deferred ? 8 : 0);
-				if (deferred) { save(QW_T5, site); return 2; }                   // no event: the answer is needed now
-				st = ST_TAIL; break;
+				FRS(9, make_float4(contrib.x, contrib.y, contrib.z, 0.f));
+				FRS(1, make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u))));
+				site = 5; fog_light = pt_l;
+				st = ST_FOG; break;
 			}
-			if (pending_add) { const f3 pc = pathWeight * contrib; wf.sh_c[id] = make_float4(pc.x, pc.y, pc.z, 0.f); }
+			if (pending_add) { const f3 pc = pathWeight * contrib; QW_ST(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f)); }
 			else S.color = S.color + pathWeight * contrib;                     // :566
 			st = ST_A3;
 	} while (0);
+	// ---- the fog call of the site (one instance for the six sites: fogContribution up to its visibility query is ~2500
+	//      instructions of exact expf / logf / atan2f / tanf)
+	if (st == ST_FOG) {
+			if (fog_begin(site, currentRay, fog_light)) return 1 | (deferred ? 8 : 0);
+			if (deferred) { save(QW_T5, site); return 2; }                       // no event: the answer of the light-sample query is needed now
+			st = ST_TAIL;
+	}
 	if (!SHADOW_LIST && st == ST_F1Q) {
 			// the second half of fogContribution, once the closest hit along the in-scattering direction is known
 			{
-				const float4 lo = wf.ray_o[id], ld = wf.ray_d[id], hr = wf.hit[id], f10 = FR(10), f11 = FR(11);
-				t_main = FR(0).w;
+				const float4 lo = QW_LD(&wf.ray_o[id]), ld = QW_LD(&wf.ray_d[id]), hr = QW_LD(&wf.hit[id]), f10 = FRL(10), f11 = FRL(11);
+				t_main = FRL(0).w;
 				Ray L; L.o = mk3(lo.x, lo.y, lo.z); L.d = mk3(ld.x, ld.y, ld.z);
 				const f3 random_P = L.o, random_dir = L.d, point_aleatoire = mk3(f11.x, f11.y, f11.z);
 				const bool is_uniform = f11.w != 0.f;
@@ -567,10 +592,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	if (st == ST_TAIL) do {
 			// the statements after the fog call of the site
 			if (site == 0) { st = ST_POP; break; }
-			if (site == 1) { const float4 ke = FR(9); S.color = S.color + ((S.att * pathWeight) * R.envmap_intensity) * mk3(ke.x, ke.y, ke.z); st = ST_POP; break; }
+			if (site == 1) { const float4 ke = FRL(9); S.color = S.color + ((S.att * pathWeight) * R.envmap_intensity) * mk3(ke.x, ke.y, ke.z); st = ST_POP; break; }
 			if (site == 2) { const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f); S.color = S.color + (S.att * pathWeight) * cc; st = ST_POP; break; }
 			if (site == 3 || site == 4) {
-				const float4 ro = FR(7), rd = FR(8);
+				const float4 ro = FRL(7), rd = FRL(8);
 				Ray nr; nr.o = mk3(ro.x, ro.y, ro.z); nr.d = mk3(rd.x, rd.y, rd.z);
 				push(S.att * pathWeight, nr, nbrebonds - 1, show_lights, true, hadSS);
 				st = ST_POP; break;
@@ -578,7 +603,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			// site 5: the diffuse vertex goes on (:565)
 			if (phase == QW_F1 || phase == QW_T5) {                             // entered from a query: the vertex is in the frame
 				load_vertex();
-				const float4 c9 = FR(9); contrib = mk3(c9.x, c9.y, c9.z);
+				const float4 c9 = FRL(9); contrib = mk3(c9.x, c9.y, c9.z);
 				if (deferred && qw.vis[id] == 0.f) { isShadowed = true; contrib = mk3(0, 0, 0); }   // :538 was assumed visible
 			}
 			S.color = S.color + (S.att * pathWeight) * contrib;
@@ -616,12 +641,14 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	if (S.overflow) { save(QW_DONE, 0); return -1; }
 	for (;;) {
 			if (S.count == 0) { finish(); return pending_add; }
-			const QContrib c = fifo[S.head];
+			QContrib c;
+			if (have_front) { c = front; have_front = false; }
+			else { const QContrib* const e = fifo + S.head; c.w = QW_LD(&e->w); c.o = QW_LD(&e->o); c.d = QW_LD(&e->d); }
 			S.head = (S.head + 1) % MIPT_QW_FIFO; S.count--;
 			const unsigned bits = __float_as_uint(c.w.w);
 			if ((int)(bits & 0xffffu) == 0) continue;                            // :240
 			if (norm2(mk3(c.w.x, c.w.y, c.w.z)) < sqr(0.01f)) continue;          // :241
-			qw.cur_w[id] = c.w; qw.cur_o[id] = c.o; qw.cur_d[id] = c.d;
+			QW_ST(&qw.cur_w[id], c.w); QW_ST(&qw.cur_o[id], c.o); QW_ST(&qw.cur_d[id], c.d);
 			Ray r; r.o = mk3(c.o.x, c.o.y, c.o.z); r.d = mk3(c.d.x, c.d.y, c.d.z);
 			request_closest(r);
 			save(QW_A1, 0);

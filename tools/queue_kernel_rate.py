@@ -1,6 +1,6 @@
 """Throughput of the contribution-queue kernel (ghost / photo / fog / subsurface scenes): configs[1]'s scene at 1080p with
 the feature switched on, N spp through mipt_render_device-equivalent host call; prints Mrays/s from the ABI's counters.
-usage: python tools/queue_kernel_rate.py [spp]"""
+usage: python tools/queue_kernel_rate.py [spp] [option=value ...] [only=feature]"""
 import json
 import os
 import sys
@@ -12,8 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes   # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-opts = dict(kv.split("=") for kv in sys.argv[2:])        # e.g. queue_wavefront=0 : the one-thread-per-sample kernel
+opts = dict(kv.split("=") for kv in sys.argv[2:])        # e.g. queue_wavefront=0 : the one-thread-per-sample kernel; only=fog : one feature
+only = opts.pop("only", None)
 for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
+    if only and only not in feature:
+        continue
     mesh, cfg, mat, text = scenes.workload("c1", 1920, 1080, spp, None)
     H = capi.HostRaytracer(device=0)
     H.apply_config(cfg)
