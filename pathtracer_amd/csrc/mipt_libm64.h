@@ -1,21 +1,25 @@
-// mipt_libm64.h — double-precision exp / pow / sincos bit-exact with the host libm the reference links (glibc 2.35, x86-64).
+// mipt_libm64.h — double-precision exp / pow / sincos / acos / atan2 bit-exact with the host libm the reference links (glibc 2.35, x86-64).
 //
 // The reference's path calls them in three places: `exp` in the subsurface profile weight (Raytracer.cpp:381), `cos` / `sin` /
-// `pow` in random_Phong (BRDF.h:41-46), `cos` / `sin` in the MERL half / difference-angle transform (MERLBRDFRead.cpp:49-127).
+// `pow` in random_Phong (BRDF.h:41-46), `cos` / `sin` / `acos` / `atan2` in the MERL half / difference-angle transform
+// (MERLBRDFRead.cpp:49-127).
 // Every cos / sin there comes as a pair on one argument, which GCC compiles to ONE call of sincos() (the compiled reference
 // and the oracle import sincos, pow, exp, acos, atan2 from libm and nothing else of this kind: objdump -d | grep call).
 // glibc picks, through ifunc, the variants of exp and pow built with -mfma on every x86-64 CPU that has FMA and AVX2
 // (__exp_fma, __pow_fma: sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c, Szabolcs Nagy's table-driven routines, with the
-// contractions GCC chose); sincos has no such variant and is the plain build of IBM's accurate kernels (s_sincos.c).
+// contractions GCC chose), and likewise __ieee754_acos_fma / __ieee754_atan2_fma (e_asin.c, e_atan2.c, IBM's accurate
+// library as of glibc 2.34+: the multi-precision fall-backs are gone, every range returns its first estimate); sincos
+// has no such variant and is the plain build of IBM's accurate kernels (s_sincos.c).
 // What is below restates those algorithms with every fused operation written as an explicit fma(), in the places the
-// disassembly of the installed libm.so.6 has them (objdump -d: 0x76470 and 0x768b0 of Ubuntu's 2.35-0ubuntu3.x build), and
+// disassembly of the installed libm.so.6 has them (objdump -d: 0x76470, 0x768b0, 0x77960, 0x78060 of Ubuntu's 2.35-0ubuntu3.x build), and
 // with none in sincos; the tables come out of the same file (tests/native/gen_libm64_tables.py -> mipt_libm64_tables.h).
 // Plain C++ (no HIP intrinsics), compiled without FP contraction, so that tests/native/libm64_check.cpp builds the SAME
 // source with g++ and compares it with libm on billions of arguments.
 //
 // Coverage: the main paths and the argument ranges the path can reach; whatever is outside (|x| > 1.05e8 for sincos,
 // non-finite or non-positive bases and out-of-range exponents for pow) returns false from the *_main() form and the caller
-// uses the device library, whose results for those exact special values are not in question.
+// uses the device library, whose results for those exact special values are not in question.  acos and atan2 are complete
+// (every argument, special values included).
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
@@ -255,4 +259,208 @@ MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs) {
 		return true;
 	}
 	return false;
+}
+
+// ---------------------------------------------------------------- acos (e_asin.c, IBM Accurate Mathematical Library; glibc 2.35 = after
+// the multi-precision fall-backs were removed: every range returns its first estimate)
+// __ieee754_acos_fma at 0x77960 of the installed libm: the interval [0.125, 0.96875) is cut into pieces with a Taylor
+// expansion of asin around the piece's x0 stored in `asncs` (rows of 11 .. 15 doubles by range), acos = pi/2 -+ asin;
+// |x| < 0.125 is a polynomial, |x| >= 0.96875 goes through 2 asin(sqrt((1 - |x|) / 2)) with a table-started square root.
+#define L64_AC_F1 0x1.55555555554f9p-3
+#define L64_AC_F2 0x1.333333336127dp-4
+#define L64_AC_F3 0x1.6db6dae42c0e4p-5
+#define L64_AC_F4 0x1.f1c7e04f4ad99p-6
+#define L64_AC_F5 0x1.6e442c822d419p-6
+#define L64_AC_F6 0x1.292d80f453c72p-6
+#define L64_AC_RT0 0x1.fffffffecc1ddp-1
+#define L64_AC_RT1 0x1.fffffff757304p-2
+#define L64_AC_RT2 0x1.800496769c91ap-2
+#define L64_AC_RT3 0x1.4006318d1dab9p-2
+#define L64_PI 0x1.921fb54442d18p+1
+#define L64_PI_LO 0x1.1a62633145c07p-53
+MIPT_L64 double l64_asn(int i) { return l64_dbl(mipt_l64_asncs_tab[i]); }
+// one piece of [0.125, 0.96875): row n of `stride` doubles = {x0, c1, c2 .. c(stride-5), c_xx, asin(x0) tail, asin(x0)}
+MIPT_L64 double l64_acos_piece(double x, bool positive, int n, int stride) {
+	const double xx = (positive ? x : -x) - l64_asn(n);
+	double p = l64_asn(n + stride - 5);
+	for (int j = stride - 6; j >= 2; j--) p = l64_fma(xx, p, l64_asn(n + j));
+	p = l64_fma(xx * xx, p, l64_asn(n + stride - 4));
+	const double t = l64_fma(xx, l64_asn(n + 1), p);
+	const double y = l64_asn(n + stride - 3);
+	if (positive) return (L64_HP1 - t) + (L64_HP0 - y);
+	return (t + L64_HP1) + (y + L64_HP0);
+}
+MIPT_L64 double mipt_acos64(double x) {
+	const uint64_t bits = l64_bits(x);
+	const int32_t m = (int32_t)(bits >> 32);
+	const int32_t k = m & 0x7fffffff;
+	const uint32_t lx = (uint32_t)bits;
+	if (k <= 0x3c87ffff) return L64_HP0;                                    // |x| < 2^-55
+	if (k <= 0x3fbfffff) {                                                  // |x| < 0.125
+		const double x2 = x * x;
+		double p = l64_fma(x2, L64_AC_F6, L64_AC_F5);
+		p = l64_fma(x2, p, L64_AC_F4); p = l64_fma(x2, p, L64_AC_F3); p = l64_fma(x2, p, L64_AC_F2); p = l64_fma(x2, p, L64_AC_F1);
+		const double r = L64_HP0 - x;
+		const double c = ((L64_HP0 - r) - x) + L64_HP1;
+		const double cor = l64_fma(-p, x * x2, c);
+		return r + cor;
+	}
+	const bool pos = m > 0;
+	if (k <= 0x3fdfffff) {                                                  // < 0.5
+		if (k <= 0x3fcfffff) return l64_acos_piece(x, pos, 11 * ((k >> 15) & 0x1f), 11);
+		return l64_acos_piece(x, pos, 11 * ((k >> 14) & 0x3f) + 352, 11);
+	}
+	if (k <= 0x3fe7ffff) return l64_acos_piece(x, pos, 12 * ((k >> 13) & 0x7f) + 1056, 12);   // < 0.75
+	if (k <= 0x3fed7fff) return l64_acos_piece(x, pos, 13 * ((k >> 13) & 0x7f) + 992, 13);    // < 0.921875
+	if (k <= 0x3fee7fff) return l64_acos_piece(x, pos, 14 * ((k >> 13) & 0x7f) + 884, 14);    // < 0.953125
+	if (k <= 0x3feeffff) return l64_acos_piece(x, pos, 15 * ((k >> 13) & 0x7f) + 768, 15);    // < 0.96875
+	if (k <= 0x3fefffff) {                                                  // < 1
+		const double z = (pos ? 1.0 - x : x + 1.0) * 0.5;
+		const uint64_t zb = l64_bits(z);
+		double t = l64_dbl(mipt_l64_inroot_tab[(zb >> 46) & 0x7f]) * l64_dbl((uint64_t)(1023 + (0x1ff - (int)(zb >> 53))) << 52);   // inroot[] * powtwo[]
+		const double r = l64_fma(-(t * t), z, 1.0);
+		double q = l64_fma(r, L64_AC_RT3, L64_AC_RT2);
+		q = l64_fma(r, q, L64_AC_RT1); q = l64_fma(r, q, L64_AC_RT0);
+		t = q * t;
+		const double c = z * t;
+		const double e = l64_fma(-c, t * 0.5, 1.5);
+		const double y0 = l64_fma(c, 0x1.0p+27, c);
+		const double y = l64_fma(-0x1.0p+27, c, y0);
+		const double den = l64_fma(e, c, y);
+		const double cc = l64_fma(-y, y, z) / den;
+		double p = l64_fma(z, L64_AC_F6, L64_AC_F5);
+		p = l64_fma(z, p, L64_AC_F4); p = l64_fma(z, p, L64_AC_F3); p = l64_fma(z, p, L64_AC_F2); p = l64_fma(z, p, L64_AC_F1);
+		const double w = (p * z) * (y + cc);
+		if (m < 0) { const double s = ((L64_HP1 - cc) - w) + (L64_HP0 - y); return s + s; }
+		const double s = (cc + w) + y;
+		return s + s;
+	}
+	if (k == 0x3ff00000 && lx == 0) return pos ? 0.0 : L64_PI;              // +-1
+	if (k > 0x7ff00000 || (k == 0x7ff00000 && lx != 0)) return x + x;      // NaN
+	const double u = x - x;                                                 // |x| > 1 (or infinite): invalid
+	return u / u;
+}
+
+// ---------------------------------------------------------------- atan2 (e_atan2.c, same library, same state: first estimates only)
+// __ieee754_atan2_fma at 0x78060: u = min(|x|,|y|) / max(|x|,|y|) with its rounding error du (one fused multiply), then
+// atan(u + du) from a degree-13 polynomial for u < 1/16 or from the Taylor expansion around the nearest of 241 points
+// (`cij`), combined with 0, pi/2 or pi in two parts.  The rounding-mode bracket of the original is a no-op here (the
+// reference never leaves round-to-nearest).
+#define L64_AT_D3 (-0x1.5555555555555p-2)
+#define L64_AT_D5 0x1.99999999997fdp-3
+#define L64_AT_D7 (-0x1.24924923f7603p-3)
+#define L64_AT_D9 0x1.c71c6e5129a3bp-4
+#define L64_AT_D11 (-0x1.7458022b13c25p-4)
+#define L64_AT_D13 0x1.375f08b31cbcep-4
+MIPT_L64 double l64_at_poly(double v) {          // d3 + v (d5 + v (d7 + v (d9 + v (d11 + v d13))))
+	double p = l64_fma(v, L64_AT_D13, L64_AT_D11);
+	p = l64_fma(v, p, L64_AT_D9); p = l64_fma(v, p, L64_AT_D7); p = l64_fma(v, p, L64_AT_D5);
+	return l64_fma(v, p, L64_AT_D3);
+}
+MIPT_L64 const uint64_t* l64_at_row(double u) {  // i = (TWO52 + 256 u) - TWO52 (round to nearest even), row i - 16
+	const double r = l64_fma(u, 256.0, 0x1.0p+52) - 0x1.0p+52;
+	return mipt_l64_cij_tab + 7 * ((int)r - 16);
+}
+MIPT_L64 double l64_at_tail(const uint64_t* row, double v) {   // c2 + v (c3 + v (c4 + v (c5 + v c6)))
+	double p = l64_fma(v, l64_dbl(row[6]), l64_dbl(row[5]));
+	p = l64_fma(v, p, l64_dbl(row[4])); p = l64_fma(v, p, l64_dbl(row[3]));
+	return l64_fma(v, p, l64_dbl(row[2]));
+}
+MIPT_L64 double mipt_atan264(double y, double x) {
+	const uint64_t xb = l64_bits(x), yb = l64_bits(y);
+	const int32_t ux = (int32_t)(xb >> 32), uy = (int32_t)(yb >> 32);
+	const uint32_t dx = (uint32_t)xb, dy = (uint32_t)yb;
+	const double mhpi = -L64_HP0, mopi = -L64_PI;
+	const bool x_inf = (ux & 0x7ff00000) == 0x7ff00000, y_inf = (uy & 0x7ff00000) == 0x7ff00000;
+	if (x_inf && (((ux & 0x000fffff) | dx) != 0)) return x + y;            // x is NaN
+	if (y_inf && (((uy & 0x000fffff) | dy) != 0)) return y + y;            // y is NaN
+	if (dy == 0 && uy == 0) return ux < 0 ? L64_PI : 0.0;                   // y = +0
+	if (dy == 0 && (uint32_t)uy == 0x80000000u) return ux < 0 ? mopi : -0.0;   // y = -0
+	if (x == 0.0) return uy < 0 ? mhpi : L64_HP0;
+	if (x_inf) {
+		if (ux > 0) return y_inf ? (uy < 0 ? -0x1.921fb54442d18p-1 : 0x1.921fb54442d18p-1) : (uy < 0 ? -0.0 : 0.0);       // x = +inf
+		return y_inf ? (uy < 0 ? -0x1.2d97c7f3321d2p+1 : 0x1.2d97c7f3321d2p+1) : (uy < 0 ? mopi : L64_PI);                 // x = -inf
+	}
+	if (y_inf) return uy < 0 ? mhpi : L64_HP0;
+	double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+	const int32_t de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+	if (de > 0x038fffff) return (0.0 < y) ? L64_HP0 : mhpi;                 // |y/x| > 2^57
+	if (de < (int32_t)0xfc700001) {                                         // |y/x| < 2^-57
+		if (!(x > 0.0)) return (0.0 < y) ? L64_PI : mopi;
+		return l64_copysign(ay / ax, y);
+	}
+	if (ax < 0x1.0p-500 || ay < 0x1.0p-500) { ax *= 0x1.0p+500; ay *= 0x1.0p+500; }
+	if (ax > 0x1.0p+500 || ay > 0x1.0p+500) { ax *= 0x1.0p-500; ay *= 0x1.0p-500; }
+	double u, du, z;
+	if (ax > ay) {
+		u = ay / ax;
+		const double v = ax * u, vv = l64_fma(ax, u, -v);
+		du = ((ay - v) - vv) / ax;
+		if (x > 0.0) {                                                      // (i) atan(ay / ax)
+			if (0.0625 > u) {
+				const double v2 = u * u;
+				z = u + l64_fma(u * v2, l64_at_poly(v2), du);
+			} else {
+				const uint64_t* row = l64_at_row(u);
+				const double t3 = u - l64_dbl(row[0]);
+				const double w = du + t3;
+				const double dw = (l64_abs(t3) > l64_abs(du)) ? (t3 - w) + du : (du - w) + t3;
+				const double t2 = l64_dbl(row[2]);
+				double p = l64_fma(w, l64_dbl(row[6]), l64_dbl(row[5]));
+				p = l64_fma(w, p, l64_dbl(row[4])); p = l64_fma(w, p, l64_dbl(row[3]));
+				p = (w * w) * p;
+				p = l64_fma(dw, t2, p);
+				z = l64_fma(w, t2, p) + l64_dbl(row[1]);
+			}
+			return l64_copysign(z, y);
+		}
+	} else {
+		u = ax / ay;
+		const double v = ay * u, vv = l64_fma(ay, u, -v);
+		du = ((ax - v) - vv) / ay;
+		if (x > 0.0) {                                                      // (ii) pi/2 - atan(ax / ay)
+			if (0.0625 > u) {
+				const double v2 = u * u;
+				const double zz = (u * v2) * l64_at_poly(v2);
+				const double t2 = L64_HP0 - u;
+				const double cor = (L64_HP0 > l64_abs(u)) ? (L64_HP0 - t2) - u : L64_HP0 - (u + t2);
+				z = ((((cor + L64_HP1) - du) - zz)) + t2;
+			} else {
+				const uint64_t* row = l64_at_row(u);
+				const double w = (u - l64_dbl(row[0])) + du;
+				const double zz = l64_fma(-w, l64_at_tail(row, w), L64_HP1);
+				z = (L64_HP0 - l64_dbl(row[1])) + zz;
+			}
+			return l64_copysign(z, y);
+		}
+	}
+	if (ay > ax) {                                                          // (iii) x < 0: pi/2 + atan(ax / ay)
+		if (0.0625 > u) {
+			const double v2 = u * u;
+			const double p = l64_at_poly(v2);
+			const double t2 = u + L64_HP0;
+			const double zz = (v2 * u) * p;
+			const double cor = (L64_HP0 > l64_abs(u)) ? (L64_HP0 - t2) + u : (u - t2) + L64_HP0;
+			z = (((cor + L64_HP1) + du) + zz) + t2;
+		} else {
+			const uint64_t* row = l64_at_row(u);
+			const double w = (u - l64_dbl(row[0])) + du;
+			const double zz = l64_fma(w, l64_at_tail(row, w), L64_HP1);
+			z = (L64_HP0 + l64_dbl(row[1])) + zz;
+		}
+		return l64_copysign(z, y);
+	}
+	if (0.0625 > u) {                                                       // (iv) x < 0: pi - atan(ay / ax)
+		const double v2 = u * u;
+		const double zz = (v2 * u) * l64_at_poly(v2);
+		const double t2 = L64_PI - u;
+		const double cor = (L64_PI > l64_abs(u)) ? (L64_PI - t2) - u : L64_PI - (t2 + u);
+		z = (((cor + L64_PI_LO) - du) - zz) + t2;
+	} else {
+		const uint64_t* row = l64_at_row(u);
+		const double w = (u - l64_dbl(row[0])) + du;
+		const double zz = l64_fma(-w, l64_at_tail(row, w), L64_PI_LO);
+		z = (L64_PI - l64_dbl(row[1])) + zz;
+	}
+	return l64_copysign(z, y);
 }

@@ -87,9 +87,9 @@ MIPT_DEV f3 phong_eval(const Mat& mat, f3 wi, f3 wo, f3 N) {
 }
 
 // ---------------------------------------------------------------- IsoMERLBRDF (BRDF.h:192-247, MERLBRDFRead.cpp:29-206)
-// fp64 half/difference-angle transform and table lookup, as the reference.  cos / sin are the host libm's sincos()
-// (mipt_libm64.h); acos / atan2 still go through the ROCm device library: a last-ulp difference from glibc there could
-// move a sample into the neighbouring table cell only when an angle lies within an ulp of a cell boundary.
+// fp64 half/difference-angle transform and table lookup, as the reference.  cos / sin / acos / atan2 are the host libm's
+// sincos(), acos(), atan2() restated (mipt_libm64.h): the angles, and with them the table cells, are the reference's by
+// construction.
 MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, double* out) {   // rotate_vector :49-72
 	double ca, sa;
 	pt_sincos64(angle, sa, ca);
@@ -129,14 +129,14 @@ __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ dat
 	double out_x = pout * cfo, out_y = pout * sfo;
 	double half[3] = {(in_x + out_x) / 2.0, (in_y + out_y) / 2.0, (in_z + out_z) / 2.0};
 	{ double len = sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]); half[0] = half[0] / len; half[1] = half[1] / len; half[2] = half[2] / len; }
-	double theta_half = acos(half[2]);
-	double fi_half = atan2(half[1], half[0]);
+	double theta_half = pt_acos64(half[2]);
+	double fi_half = pt_atan264(half[1], half[0]);
 	const double bi_normal[3] = {0.0, 1.0, 0.0}, normal[3] = {0.0, 0.0, 1.0};
 	double temp[3], diff[3];
 	merl_rotate(in, normal, -fi_half, temp);
 	merl_rotate(temp, bi_normal, -theta_half, diff);
-	double theta_diff = acos(diff[2]);
-	double fi_diff = atan2(diff[1], diff[0]);
+	double theta_diff = pt_acos64(diff[2]);
+	double fi_diff = pt_atan264(diff[1], diff[0]);
 	// index functions (:134-180)
 	int th_idx;
 	if (theta_half <= 0.0) th_idx = 0;

@@ -62,12 +62,14 @@ def _cpu_has_fma_avx2():
     return "fma" in flags and "avx2" in flags
 
 
-def test_exp_pow_sincos_double_bit_exact_with_libm(tmp_path):
+def test_exp_pow_sincos_acos_atan2_double_bit_exact_with_libm(tmp_path):
     """csrc/mipt_libm64.h (subsurface weight, random_Phong's sampling frame, the MERL transform) against the host libm's
-    double-precision exp / pow / sincos: the whole finite range of exp incl. subnormal results, pow over the Phong lobe's
-    domain and wide log-uniform ones, sincos over the path's domains (2 pi x float, float angles) and everything below
-    1.05e8 — 500 M evaluations here (1.6 G with 0 mismatches: `libm64_check 60000000`).  glibc runs its FMA builds of exp
-    and pow on CPUs with FMA + AVX2, which is what the header restates: on other CPUs the comparison is void."""
+    double-precision exp / pow / sincos / acos / atan2: the whole finite range of exp incl. subnormal results, pow over the
+    Phong lobe's domain and wide log-uniform ones, sincos over the path's domains (2 pi x float, float angles) and
+    everything below 1.05e8, acos over [-1, 1] (uniform, towards 0, towards +-1, components of unit vectors) and outside,
+    atan2 over all quadrants, ratios, magnitudes and every pair of special values — 580 M evaluations here (8.7 G with 0
+    mismatches: `libm64_check 300000000`).  glibc runs its FMA builds of exp, pow, acos and atan2 on CPUs with FMA + AVX2,
+    which is what the header restates: on other CPUs the comparison is void."""
     import pytest
     if not _cpu_has_fma_avx2():
         pytest.skip("host CPU without FMA + AVX2: glibc selects other variants of exp / pow than the ones restated")
@@ -75,9 +77,9 @@ def test_exp_pow_sincos_double_bit_exact_with_libm(tmp_path):
     subprocess.run(["g++", "-O2", "-fopenmp", "-ffp-contract=off", "-mfma", "-o", exe,
                     os.path.join(ROOT, "tests", "native", "libm64_check.cpp"), "-lm"], check=True)
     out = subprocess.run([exe, "20000000"], check=True, capture_output=True, text=True).stdout.split()
-    n, bad_exp, bad_pow, bad_sincos, sincos_vs_sin_cos = (int(v) for v in out[:5])
-    assert n > 300_000_000
-    assert (bad_exp, bad_pow, bad_sincos) == (0, 0, 0)
+    n, bad_exp, bad_pow, bad_sincos, sincos_vs_sin_cos, bad_acos, bad_atan2 = (int(v) for v in out[:7])
+    assert n > 500_000_000
+    assert (bad_exp, bad_pow, bad_sincos, bad_acos, bad_atan2) == (0, 0, 0, 0, 0)
     assert sincos_vs_sin_cos > 0        # libm's sincos() is not its sin() next to its cos(): the reason sincos is what is restated
 
 

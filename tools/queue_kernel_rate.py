@@ -32,10 +32,13 @@ for feature in ("none", "photo+ghostfloor", "fog", "subsurface"):
     for kopt, v in opts.items():
         H.set_option(kopt, int(v))
     H.render()                                    # warm-up (code object load, buffers)
-    t0 = time.time()
-    img, cnt = H.render()
-    dt = time.time() - t0
-    st = H.stats()
+    dt, st = 1e30, None
+    for rep in range(3):                          # best of three (the host side of a render is ~10 ms of Python + readback)
+        t0 = time.time()
+        img, cnt = H.render()
+        d = time.time() - t0
+        if d < dt:
+            dt, st = d, H.stats()
     rays = st["rays_closest"] + st["rays_shadow"]
     print(json.dumps({"feature": feature, "pipeline": st["pipeline"], "spp": spp, "Mrays_per_s": round(rays / dt / 1e6, 1), "seconds": round(dt, 3),
                       "rays_per_path": round(rays / max(1, st["paths"]), 2), "passes": st["passes"], "samples_through_the_fallback": st["reserved"], "kernel_ms": {"closest": round(st["traverse_ms"], 1), "shadow": round(st["shadow_ms"], 1), "logic": round(st["shade_ms"], 1), "splat": round(st["resolve_ms"], 1)}, "finite": bool(np.isfinite(img).all())}), flush=True)
