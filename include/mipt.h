@@ -313,6 +313,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "refill"          pipeline 1: 1 = traversal stages refill idle lanes from the queue (default), 0 = one ray per lane
  *   "merge_traverse"  pipeline 1: 1 = the shadow rays of depth b and the closest-hit rays of depth b+1 share one
  *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
+ *   "sort_rays"       pipeline 1: 1 = the closest-hit queue of every depth >= 1 is reordered by direction octant before it is
+ *                     traversed (a measured negative, DESIGN.md §4: -11 %; same results), 0 = path-id order (default)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
  *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
  *   "lane_limit"      measurement probe: the persistent traversal hands rays to the first N lanes of a wave only (0 = all 64)

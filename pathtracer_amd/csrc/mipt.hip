@@ -373,6 +373,7 @@ struct mipt_ctx {
 	int64_t opt_inner_min = 16;
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
+	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
@@ -566,6 +567,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
@@ -1101,7 +1103,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
 	// Bytes of pass state per path id, and the part that does not depend on the pass size
 	size_t per_path = sizeof(float4) + sizeof(float2), fixed_bytes = 4096;
-	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES; fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned); }
+	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES + (c->opt_sort_rays ? sizeof(unsigned) : 0); fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned) + MIPT_SORT_BINS * 2048 * sizeof(unsigned) + 64; }
 	if (want_aov) per_path += 2 * sizeof(float4);
 	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
 		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 9 * sizeof(unsigned);
@@ -1138,6 +1140,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	DSamples S;
 	S.col = (float4*)carve(N * sizeof(float4)); S.dxdy = (float2*)carve(N * sizeof(float2));
 	DWave wf{};
+	unsigned *sort_list = nullptr, *sort_hist = nullptr;
 	if (pipeline == 1) {
 		wf.ray_o = (float4*)carve(N * sizeof(float4)); wf.ray_d = (float4*)carve(N * sizeof(float4));
 		wf.wgt = (float4*)carve(N * sizeof(float4)); wf.hit = (float4*)carve(N * sizeof(float4));
@@ -1145,6 +1148,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.rng = (uint2*)carve(N * sizeof(uint2));
 		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned)); wf.list_slow = (unsigned*)carve(N * sizeof(unsigned));
 		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
+		if (c->opt_sort_rays) { sort_list = (unsigned*)carve(N * sizeof(unsigned)); sort_hist = (unsigned*)carve(MIPT_SORT_BINS * 2048 * sizeof(unsigned)); }
 		wf.out = S;
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
@@ -1311,7 +1315,18 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
+			unsigned* const list_mem[2] = {wf.list[0], wf.list[1]};
 			for (int b = 0; b < p->nb_bounces; b++) {
+				if (c->opt_sort_rays && !merge && b > 0) {                // reorder the closest-hit queue of this depth (written by shade(b-1))
+					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
+					const unsigned sg = std::min(2048u, (unsigned)c->n_cus * 4u);
+					const unsigned* nq = &wf.counters[MIPT_CNT_PAIR(b - 1) + 1];
+					hipLaunchKernelGGL(k_sort_hist, dim3(sg), dim3(MIPT_SORT_BLOCK), 0, st, wf, (const unsigned*)list_mem[b & 1], nq, sort_hist);
+					hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, sort_hist, sg * MIPT_SORT_BINS);
+					hipLaunchKernelGGL(k_sort_scatter, dim3(sg), dim3(MIPT_SORT_BLOCK), 0, st, wf, (const unsigned*)list_mem[b & 1], nq, (const unsigned*)sort_hist, sort_list);
+					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+					wf.list[b & 1] = sort_list;                           // this depth's traversal and shade read the reordered queue
+				}
 				if (!merge || b == 0) {                                  // closest hits of depth b (merged mode: done by the launch of depth b-1)
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
@@ -1331,6 +1346,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
 				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+				wf.list[b & 1] = list_mem[b & 1];
 			}
 			c->stats.traverse_merged = merge ? 1u : 0u;
 		}

@@ -454,3 +454,91 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_shadow(const DScene* __restri
 		}
 	}
 }
+
+// ---------------------------------------------------------------- ray reordering (option sort_rays)
+// The closest-hit queue of depth b+1 is written by shade(b) in path-id order: neighbouring entries start at neighbouring
+// surface points but leave in unrelated directions.  A stable counting sort by the octant of the direction (8 bins, order
+// inside a bin kept) puts rays that take the same near / far decisions at every node side by side, so the lanes of a wave
+// walk the tree together for longer.  Which lane runs a ray never changes its result (mipt_persistent.h).
+#define MIPT_SORT_BINS 8
+#define MIPT_SORT_BLOCK 256
+MIPT_DEV unsigned sort_key(const DWave& wf, unsigned id) {
+	const float4 d = wf.ray_d[id];
+	return (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+}
+MIPT_DEV void sort_segment(unsigned n, unsigned& lo, unsigned& hi) {
+	const unsigned seg = ((n + gridDim.x - 1) / gridDim.x + MIPT_SORT_BLOCK - 1) / MIPT_SORT_BLOCK * MIPT_SORT_BLOCK;
+	lo = min(n, blockIdx.x * seg); hi = min(n, lo + seg);
+}
+__global__ void __launch_bounds__(MIPT_SORT_BLOCK) k_sort_hist(DWave wf, const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, unsigned* __restrict__ hist) {
+	__shared__ unsigned cnt[MIPT_SORT_BINS];
+	if (threadIdx.x < MIPT_SORT_BINS) cnt[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned lo, hi;
+	sort_segment(*n_ptr, lo, hi);
+	for (unsigned i = lo + threadIdx.x; i < hi; i += MIPT_SORT_BLOCK) {
+		const unsigned k = sort_key(wf, list[i]);
+#pragma unroll
+		for (unsigned b = 0; b < MIPT_SORT_BINS; b++) {
+			const unsigned long long m = __ballot(k == b);
+			if (lane_id() == 0 && m) atomicAdd(&cnt[b], (unsigned)__popcll(m));
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < MIPT_SORT_BINS) hist[threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];     // bin-major
+}
+// exclusive scan of the bin-major histogram (one block)
+__global__ void __launch_bounds__(1024) k_sort_scan(unsigned* __restrict__ hist, unsigned total) {
+	__shared__ unsigned part[1024];
+	__shared__ unsigned carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (unsigned base = 0; base < total; base += 1024) {
+		const unsigned i = base + threadIdx.x;
+		const unsigned v = i < total ? hist[i] : 0u;
+		part[threadIdx.x] = v;
+		__syncthreads();
+		for (unsigned ofs = 1; ofs < 1024; ofs <<= 1) {
+			const unsigned a = threadIdx.x >= ofs ? part[threadIdx.x - ofs] : 0u;
+			__syncthreads();
+			part[threadIdx.x] += a;
+			__syncthreads();
+		}
+		if (i < total) hist[i] = carry + part[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry += part[1023];
+		__syncthreads();
+	}
+}
+__global__ void __launch_bounds__(MIPT_SORT_BLOCK) k_sort_scatter(DWave wf, const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, const unsigned* __restrict__ offsets, unsigned* __restrict__ out) {
+	__shared__ unsigned base[MIPT_SORT_BINS];
+	__shared__ unsigned wcnt[MIPT_SORT_BLOCK / 64][MIPT_SORT_BINS];
+	if (threadIdx.x < MIPT_SORT_BINS) base[threadIdx.x] = offsets[threadIdx.x * gridDim.x + blockIdx.x];
+	__syncthreads();
+	unsigned lo, hi;
+	sort_segment(*n_ptr, lo, hi);
+	const unsigned w = threadIdx.x >> 6, lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (unsigned t = lo; t < hi; t += MIPT_SORT_BLOCK) {
+		const unsigned i = t + threadIdx.x;
+		const bool on = i < hi;
+		const unsigned id = on ? list[i] : 0u;
+		const unsigned k = on ? sort_key(wf, id) : 0xffu;
+		unsigned rank = 0;
+#pragma unroll
+		for (unsigned b = 0; b < MIPT_SORT_BINS; b++) {
+			const unsigned long long m = __ballot(k == b);
+			if (k == b) rank = (unsigned)__popcll(m & below);
+			if (lane == 0) wcnt[w][b] = (unsigned)__popcll(m);
+		}
+		__syncthreads();
+		if (on) {
+			unsigned o = base[k] + rank;
+			for (unsigned ww = 0; ww < w; ww++) o += wcnt[ww][k];
+			out[o] = id;
+		}
+		__syncthreads();
+		if (threadIdx.x < MIPT_SORT_BINS) { unsigned s = 0; for (unsigned ww = 0; ww < MIPT_SORT_BLOCK / 64; ww++) s += wcnt[ww][threadIdx.x]; base[threadIdx.x] += s; }
+		__syncthreads();
+	}
+}

@@ -195,11 +195,11 @@ def test_two_meshes_fat_leaves_ties_and_literal_slab():
     assert (leaves[:, 2] - leaves[:, 1]).max() > 4
     pix = all_pixels(cfg)
     want = O.getcolor_samples(pix, 0, cfg.spp)[0]
-    for opts in ({"pipeline": 1}, {"pipeline": 1, "literal_slab": 1}, {"pipeline": 1, "refill": 0}, {"pipeline": 0}):
+    for opts in ({"pipeline": 1}, {"pipeline": 1, "literal_slab": 1}, {"pipeline": 1, "refill": 0}, {"pipeline": 1, "sort_rays": 1}, {"pipeline": 0}):
         for k, v in opts.items():
             G.set_option(k, v)
         assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, f"per-sample radiance {opts}")
-        G.set_option("literal_slab", 0); G.set_option("refill", 1)
+        G.set_option("literal_slab", 0); G.set_option("refill", 1); G.set_option("sort_rays", 0)
 
 
 def test_progress_callback_and_cancel():
