@@ -141,16 +141,24 @@ MIPT_DEV int tex_index(const DTex& t, float u, float v) {     // BRDF.h:296-298
 	int y = (int)(v * (float)(uint64_t)(t.H - 1));
 	return (y * t.W + x) * 3;
 }
-MIPT_DEV f3 tex_getVec(const DTex& t, float u, float v) {     // BRDF.h:293-308
-	if (t.W > 0) { int idx = tex_index(t, u, v); return mk3(t.values[idx] * t.mult[0], t.values[idx + 1] * t.mult[1], t.values[idx + 2] * t.mult[2]); }
-	return mk3(t.mult[0], t.mult[1], t.mult[2]);
+// (the texture descriptors and their texels are reached through pointers loaded from memory, which the compiler has to
+// treat as generic: read through global-address-space views they are global_load instead of flat_load instructions)
+typedef const __attribute__((address_space(1))) DTex glb_DTex;
+typedef const __attribute__((address_space(1))) float glb_cfloat;
+MIPT_DEV f3 tex_getVec(const DTex& tg, float u, float v) {     // BRDF.h:293-308
+	glb_DTex& t = (glb_DTex&)tg;
+	const float m0 = t.mult[0], m1 = t.mult[1], m2 = t.mult[2];
+	if (t.W > 0) { DTex d; d.W = t.W; d.H = t.H; int idx = tex_index(d, u, v); glb_cfloat* val = (glb_cfloat*)t.values; return mk3(val[idx] * m0, val[idx + 1] * m1, val[idx + 2] * m2); }
+	return mk3(m0, m1, m2);
 }
-MIPT_DEV float tex_getValRed(const DTex& t, float u, float v) {   // BRDF.h:379-391
-	if (t.W > 0) { int idx = tex_index(t, u, v); return t.values[idx] * t.mult[0]; }
+MIPT_DEV float tex_getValRed(const DTex& tg, float u, float v) {   // BRDF.h:379-391
+	glb_DTex& t = (glb_DTex&)tg;
+	if (t.W > 0) { DTex d; d.W = t.W; d.H = t.H; int idx = tex_index(d, u, v); return ((glb_cfloat*)t.values)[idx] * t.mult[0]; }
 	return t.mult[0];
 }
-MIPT_DEV f3 tex_getNormal(const DTex& t, float u, float v) {  // BRDF.h:347-357
-	if (t.W > 0) { int idx = tex_index(t, u, v); return mk3(t.values[idx], t.values[idx + 1], t.values[idx + 2]); }
+MIPT_DEV f3 tex_getNormal(const DTex& tg, float u, float v) {  // BRDF.h:347-357
+	glb_DTex& t = (glb_DTex&)tg;
+	if (t.W > 0) { DTex d; d.W = t.W; d.H = t.H; int idx = tex_index(d, u, v); glb_cfloat* val = (glb_cfloat*)t.values; return mk3(val[idx], val[idx + 1], val[idx + 2]); }
 	return mk3(0.f, 0.f, 1.f);
 }
 // Object::queryMaterial (Geometry.h:399-445).  idx is compared as size_t in the reference, so a
@@ -355,8 +363,10 @@ MIPT_DEV bool plane_test(const DObject& p, f3 o, f3 d, float& t) {
 
 // ---------------------------------------------------------------- TriMesh::getMaterial (TriangleMesh.cpp:919-970)
 MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, float gamma, Mat& mat) {
-	const float4* q = reinterpret_cast<const float4*>(o.shade + tri);
-	float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	typedef float v4f_ __attribute__((ext_vector_type(4)));
+	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(o.shade + tri);
+	const v4f_ r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
+	const float4 q0 = make_float4(r0.x, r0.y, r0.z, r0.w), q1 = make_float4(r1.x, r1.y, r1.z, r1.w), q2 = make_float4(r2.x, r2.y, r2.z, r2.w), q3 = make_float4(r3.x, r3.y, r3.z, r3.w);
 	f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
 	float uv00 = q2.y, uv01 = q2.z, uv10 = q2.w, uv11 = q3.x, uv20 = q3.y, uv21 = q3.z;
 	// group word: bit 30 = "the first UV index of the triangle is valid" (TriangleMesh.cpp:934), set at upload so that
