@@ -125,3 +125,20 @@ def test_gpu_compositing_image_and_passes():
     H2.prepare()
     H2.render()
     assert H2.stats()["pipeline"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 1])
+def test_gpu_compositing_depth_zero_and_one(depth):
+    """nb_bounces = 0: the camera contribution is dropped by the depth test of the loop head (Raytracer.cpp:240), nothing is
+    traced and the sample is black — k_q_begin decides that itself since it pops the camera contribution; nb_bounces = 1: one
+    vertex, whose successors die at the same test."""
+    from oracle.binding import Oracle
+    outs = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        cfg = compositing_scene(X, "both")
+        X.set_render(cfg.W, cfg.H, cfg.spp, depth)
+        X.prepare()
+        outs.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
+    assert_bits(outs[1], outs[0], f"per-sample radiance at depth {depth}")
+    assert outs[1].any() == (depth > 0)
