@@ -133,7 +133,6 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_q_begin(const DScene* __restrict
 	const bool dead = (R.nb_bounces & 0xffff) == 0;                  // :240 (depth 0: nothing is traced)
 	qw.cur_w[tid] = make_float4(1.f, 1.f, 1.f, __uint_as_float((unsigned)(R.nb_bounces & 0xffff) | 0x10000u | 0x20000u | (dead ? 0u : MIPT_WF_VALID)));
 	if (dead) { qw.ctl[tid] = (unsigned)QW_DONE << 16; return; }
-	qw.cur_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, 0.f); qw.cur_d[tid] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, 0.f);
 	float t0; unsigned best0;
 	analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);
 	wf.ray_o[tid] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0);
@@ -150,6 +149,7 @@ struct QwSample {
 	bool overflow;
 };
 
+MIPT_DEV bool has_fog_early(const DRender& R) { return R.fog_density > 1E-8; }
 // One sample: run segments until the next ray query.  Returns -1 (abandoned) or the requests it made as bits: 1 (closest
 // hit, wf.ray_o / ray_d), 2 (any hit, wf.sh_o / sh_d, the sample waits for the answer), 4 (subsurface probe, wf.ray_o /
 // ray_d: origin and direction in the object's frame, .w = tmax / the object), 8 (any hit, wf.sh_o / sh_d, nobody waits:
@@ -173,7 +173,19 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	if (phase == QW_DONE) return 0;
 	QwSample S;
 	{ const uint2 rs = QW_LD(&wf.rng[id]); S.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
-	{ const float4 a = QW_LD(&qw.acc[id]); S.color = mk3(a.x, a.y, a.z); S.att = a.w; }
+	// The colour is read when something is added to it and written back when it has changed.  Adding a zero vector never
+	// changes it, not even in the sign of a zero: the colour starts as +0 and x + y is -0 only for (-0) + (-0), so no
+	// component is ever -0 and c + (+-0) == c bit for bit; most vertices add m.Ke = 0 (:411) and nothing else in their call.
+	// attenuationFactor lives in .w and matters with fog only (read and written with the colour there).
+	S.color = mk3(0, 0, 0); S.att = 0.f;
+	bool color_loaded = false, color_dirty = false;
+	auto load_color = [&]() { if (!color_loaded) { const float4 a = QW_LD(&qw.acc[id]); S.color = mk3(a.x, a.y, a.z); S.att = a.w; color_loaded = true; } };
+	auto add_color = [&](f3 v) {
+		if (v.x == 0.f && v.y == 0.f && v.z == 0.f) return;
+		load_color();
+		S.color = S.color + v; color_dirty = true;
+	};
+	if (has_fog_early(R)) load_color();
 	S.head = ctl & 0xffu; S.count = (ctl >> 8) & 0xffu; S.overflow = false;
 	QContrib* const fifo = qw.fifo + (size_t)id * MIPT_QW_FIFO;
 	auto FRL = [&](int slot) -> float4 { return QW_LD(&qw.fr[(size_t)slot * N + id]); };
@@ -201,10 +213,10 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	auto save = [&](int ph, int st) {
 		if (have_front) { QContrib* const e = fifo + S.head; QW_ST(&e->w, front.w); QW_ST(&e->o, front.o); QW_ST(&e->d, front.d); have_front = false; }
 		QW_ST(&wf.rng[id], make_uint2((unsigned)S.rng, (unsigned)(S.rng >> 32)));
-		QW_ST(&qw.acc[id], make_float4(S.color.x, S.color.y, S.color.z, S.att));
+		if (color_dirty) QW_ST(&qw.acc[id], make_float4(S.color.x, S.color.y, S.color.z, S.att));
 		qw.ctl[id] = (S.head & 0xffu) | ((S.count & 0xffu) << 8) | ((unsigned)ph << 16) | ((unsigned)st << 24);
 	};
-	auto finish = [&]() { S.att = 0.f; save(QW_DONE, 0); };       // qw.acc IS wf.out.col
+	auto finish = [&]() { save(QW_DONE, 0); };       // qw.acc IS wf.out.col (.w is not read by the splat)
 	auto request_closest = [&](const Ray& r) {
 		float t0; unsigned best0;
 		analytic_prefix_closest(sc, r.o, r.d, t0, best0);
@@ -216,13 +228,23 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	// the contribution in flight (valid from QW_A1 on)
 	f3 pathWeight = mk3(0, 0, 0); Ray currentRay; currentRay.o = mk3(0, 0, 0); currentRay.d = mk3(0, 0, 1);
 	int nbrebonds = 0; bool show_lights = false, show_envmap = false, hadSS = false;
-	auto load_cur = [&]() {
-		const float4 w = QW_LD(&qw.cur_w[id]), o = QW_LD(&qw.cur_o[id]), d = QW_LD(&qw.cur_d[id]);
+	// weight and flags live in cur_w; the ray itself is read from the closest-hit request (wf.ray_o / ray_d hold it from POP
+	// until the next request of the sample): only the subsurface probe replaces the request while the ray is still needed,
+	// so its yield parks the ray in cur_o / cur_d and its answer puts it back.  F1 / TAIL / A3 never read the ray.
+	if (phase != QW_POP) {
+		const float4 w = QW_LD(&qw.cur_w[id]);
 		const unsigned bits = __float_as_uint(w.w);
-		pathWeight = mk3(w.x, w.y, w.z); currentRay.o = mk3(o.x, o.y, o.z); currentRay.d = mk3(d.x, d.y, d.z);
+		pathWeight = mk3(w.x, w.y, w.z);
 		nbrebonds = (int)(bits & 0xffffu); show_lights = (bits & 0x10000u) != 0; show_envmap = (bits & 0x20000u) != 0; hadSS = (bits & 0x40000u) != 0;
-	};
-	if (phase != QW_POP) load_cur();
+		if (phase == QW_A1 || (phase == QW_A2 && has_fog)) {
+			const float4 o = QW_LD(&wf.ray_o[id]), d = QW_LD(&wf.ray_d[id]);
+			currentRay.o = mk3(o.x, o.y, o.z); currentRay.d = mk3(d.x, d.y, d.z);
+		} else if (phase == QW_PROBE) {
+			const float4 o = QW_LD(&qw.cur_o[id]), d = QW_LD(&qw.cur_d[id]);
+			currentRay.o = mk3(o.x, o.y, o.z); currentRay.d = mk3(d.x, d.y, d.z);
+			QW_ST(&wf.ray_o[id], o); QW_ST(&wf.ray_d[id], d);
+		}
+	}
 
 	// vertex locals that cross segment boundaries (frame)
 	f3 P = mk3(0, 0, 0), Nn = mk3(0, 1, 0), rayDirection = mk3(0, 0, 1), Ksub = mk3(0, 0, 0), subsW = mk3(1, 1, 1), dir_l = mk3(0, 0, 1), wi = mk3(0, 0, 1), contrib = mk3(0, 0, 0);
@@ -231,19 +253,21 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	int objid = 0; bool sub_interaction = false, isShadowed = false;
 	int pending_add = 0;                  // 8: this call left an any-hit request whose term the traversal stage adds
 	bool deferred = false;                // fog: the any-hit request of the vertex is in flight, its answer (qw.vis) is read where the direct term is added
-	auto save_vertex = [&]() {
+	// with_light: the light sample (dir_l, wi) too — only A2 entered from an any-hit answer needs it; SUBS-less builds have subsW = 1
+	auto save_vertex = [&](bool with_light) {
 		FRS(0, make_float4(P.x, P.y, P.z, t_main));
 		FRS(1, make_float4(Nn.x, Nn.y, Nn.z, __uint_as_float((unsigned)objid | (sub_interaction ? 0x100u : 0u) | (isShadowed ? 0x200u : 0u) | (deferred ? 0x400u : 0u))));
 		FRS(2, make_float4(rayDirection.x, rayDirection.y, rayDirection.z, d_light2));
 		FRS(3, make_float4(m.Kd.x, m.Kd.y, m.Kd.z, m.Ks.x));
 		FRS(4, make_float4(m.Ks.y, m.Ks.z, m.Ne.x, m.Ne.y));
 		FRS(5, make_float4(m.Ne.z, Ksub.x, Ksub.y, Ksub.z));
-		FRS(6, make_float4(subsW.x, subsW.y, subsW.z, 0.f));
-		FRS(7, make_float4(dir_l.x, dir_l.y, dir_l.z, 0.f));
-		FRS(8, make_float4(wi.x, wi.y, wi.z, 0.f));
+		if (SUBS) FRS(6, make_float4(subsW.x, subsW.y, subsW.z, 0.f));
+		if (with_light) { FRS(7, make_float4(dir_l.x, dir_l.y, dir_l.z, 0.f)); FRS(8, make_float4(wi.x, wi.y, wi.z, 0.f)); }
 	};
-	auto load_vertex = [&]() {
-		const float4 a = FRL(0), b = FRL(1), c = FRL(2), d = FRL(3), e = FRL(4), f = FRL(5), g = FRL(6), h = FRL(7), i2 = FRL(8);
+	auto load_vertex = [&](bool with_light) {
+		const float4 a = FRL(0), b = FRL(1), c = FRL(2), d = FRL(3), e = FRL(4), f = FRL(5);
+		const float4 g = SUBS ? FRL(6) : make_float4(1.f, 1.f, 1.f, 0.f);
+		const float4 h = with_light ? FRL(7) : make_float4(0.f, 0.f, 1.f, 0.f), i2 = with_light ? FRL(8) : make_float4(0.f, 0.f, 1.f, 0.f);
 		P = mk3(a.x, a.y, a.z); t_main = a.w;
 		Nn = mk3(b.x, b.y, b.z); { const unsigned fl = __float_as_uint(b.w); objid = (int)(fl & 0xffu); sub_interaction = (fl & 0x100u) != 0; isShadowed = (fl & 0x200u) != 0; deferred = (fl & 0x400u) != 0; }
 		rayDirection = mk3(c.x, c.y, c.z); d_light2 = c.w;
@@ -337,7 +361,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				qw.aov_kd[id] = make_float4(m.Kd.x, m.Kd.y, m.Kd.z, 0.f);
 			}
 			if (nbrebonds == R.nb_bounces && has_bg && (!hit || h.obj == 1)) {  // :260-268
-				S.color = S.color + pathWeight * background_pixel(R, pi, pj);
+				add_color(pathWeight * background_pixel(R, pi, pj));
 				st = ST_POP; break;
 			}
 			if (!hit) { if (R.fog_density == 0) { st = ST_POP; break; } else { finish(); return 0; } }   // :654-657 (break ends the sample)
@@ -350,7 +374,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					site = show_envmap ? 1 : 0;
 					st = ST_FOG; break;              // no event: straight to what follows the fog call
 				}
-				if (show_envmap) S.color = S.color + (pathWeight * R.envmap_intensity) * m.Ke;
+				if (show_envmap) add_color((pathWeight * R.envmap_intensity) * m.Ke);
 				st = ST_POP; break;
 			}
 			if (h.obj == 0) {                                                   // :303-316
@@ -360,7 +384,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					st = ST_FOG; break;
 				}
 				const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f);
-				S.color = S.color + pathWeight * cc;
+				add_color(pathWeight * cc);
 				st = ST_POP; break;
 			}
 			const DObject& obj = sc->obj[h.obj];
@@ -412,6 +436,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 						FRS(12, hr);
 						FRS(6, make_float4(gauss0, gauss1, gauss2, r1s));
 						FRS(7, make_float4(r2_low ? 1.f : 0.f, 0.f, 0.f, 0.f));
+						QW_ST(&qw.cur_o[id], make_float4(currentRay.o.x, currentRay.o.y, currentRay.o.z, 0.f));
+						QW_ST(&qw.cur_d[id], make_float4(currentRay.d.x, currentRay.d.y, currentRay.d.z, 0.f));
 						QW_ST(&wf.ray_o[id], make_float4(po.x, po.y, po.z, tmax));
 						QW_ST(&wf.ray_d[id], make_float4(pd.x, pd.y, pd.z, __uint_as_float((unsigned)h.obj)));
 						save(QW_PROBE, 0);
@@ -442,7 +468,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					}
 				}
 			}
-			S.color = S.color + (pathWeight * m.Ke) * R.envmap_intensity;       // :411
+			add_color((pathWeight * m.Ke) * R.envmap_intensity);                // :411
 			if (obj.miroir) {                                                   // :413-436
 				Ray rm; rm.o = P + 0.001f * Nn; rm.d = reflect(rayDirection, Nn);
 				if (has_fog) {
@@ -502,14 +528,14 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					yield_shadow = true;
 				}
 			}
-			if (yield_shadow && obj.ghost) { save_vertex(); save(QW_A2, 0); return 2; }   // a ghost queues the path going straight on only if the light is visible
+			if (yield_shadow && obj.ghost) { save_vertex(true); save(QW_A2, 0); return 2; }   // a ghost queues the path going straight on only if the light is visible
 			if (yield_shadow && has_fog) deferred = true;
 			else if (yield_shadow) pending_add = 8;
-			if (has_fog) save_vertex();                                         // the fog event of site 5 comes back through the frame
+			if (has_fog) save_vertex(false);                                         // the fog event of site 5 comes back through the frame
 			st = ST_A2;
 	} while (0);
 	if (st == ST_A2) do {
-			if (a2_from_query) { load_vertex(); isShadowed = qw.vis[id] == 0.f; }
+			if (a2_from_query) { load_vertex(true); isShadowed = qw.vis[id] == 0.f; }
 			const DObject& obj = sc->obj[objid];
 			const double* const merl = obj.merl;
 			const f3 axeOP = fast_normalize(P - cl);
@@ -521,8 +547,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					currentRay.o = (P + rayDirection * 0.001f) + offset * 0.001f;
 					currentRay.d = rayDirection;
 					push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap, hadSS);
-					QW_ST(&qw.cur_o[id], make_float4(currentRay.o.x, currentRay.o.y, currentRay.o.z, 0.f));      // currentRay itself is replaced (the fog event below uses it)
-					QW_ST(&qw.cur_d[id], make_float4(currentRay.d.x, currentRay.d.y, currentRay.d.z, 0.f));
+					// (currentRay itself is replaced: the fog event below, in this call, uses it)
 				} else {                                                        // :538-553
 					const f3 brdf = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, wi, -rayDirection, Nn) : phong_eval(m, wi, -rayDirection, Nn));
 					const float J = dot(dir_l, -wi) / d_light2;
@@ -537,7 +562,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				st = ST_FOG; break;
 			}
 			if (pending_add) { const f3 pc = pathWeight * contrib; QW_ST(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f)); }
-			else S.color = S.color + pathWeight * contrib;                     // :566
+			else add_color(pathWeight * contrib);                              // :566
 			st = ST_A3;
 	} while (0);
 	// ---- the fog call of the site (one instance for the six sites: fogContribution up to its visibility query is ~2500
@@ -566,7 +591,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					const float dl2 = norm2(point_aleatoire - random_P);
 					if (interinter && (double)(ih.t * ih.t) < (double)dl2 * 0.99) visible = false;
 				}
-				S.att = T;
+				S.att = T; color_dirty = true;
 				if (visible) {
 					const f3 axeOP = normalize(random_P - cl);
 					const float p_uniform = 0.5f;
@@ -592,8 +617,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	if (st == ST_TAIL) do {
 			// the statements after the fog call of the site
 			if (site == 0) { st = ST_POP; break; }
-			if (site == 1) { const float4 ke = FRL(9); S.color = S.color + ((S.att * pathWeight) * R.envmap_intensity) * mk3(ke.x, ke.y, ke.z); st = ST_POP; break; }
-			if (site == 2) { const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f); S.color = S.color + (S.att * pathWeight) * cc; st = ST_POP; break; }
+			if (site == 1) { const float4 ke = FRL(9); add_color(((S.att * pathWeight) * R.envmap_intensity) * mk3(ke.x, ke.y, ke.z)); st = ST_POP; break; }
+			if (site == 2) { const f3 cc = show_lights ? mk3(R.lightPower, R.lightPower, R.lightPower) : mk3(0.f, 0.f, 0.f); add_color((S.att * pathWeight) * cc); st = ST_POP; break; }
 			if (site == 3 || site == 4) {
 				const float4 ro = FRL(7), rd = FRL(8);
 				Ray nr; nr.o = mk3(ro.x, ro.y, ro.z); nr.d = mk3(rd.x, rd.y, rd.z);
@@ -602,11 +627,11 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			}
 			// site 5: the diffuse vertex goes on (:565)
 			if (phase == QW_F1 || phase == QW_T5) {                             // entered from a query: the vertex is in the frame
-				load_vertex();
+				load_vertex(false);
 				const float4 c9 = FRL(9); contrib = mk3(c9.x, c9.y, c9.z);
 				if (deferred && qw.vis[id] == 0.f) { isShadowed = true; contrib = mk3(0, 0, 0); }   // :538 was assumed visible
 			}
-			S.color = S.color + (S.att * pathWeight) * contrib;
+			add_color((S.att * pathWeight) * contrib);
 			st = ST_A3;
 	} while (0);
 	// ---- A3: the continuation of the diffuse vertex (:570-632)
@@ -648,7 +673,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			const unsigned bits = __float_as_uint(c.w.w);
 			if ((int)(bits & 0xffffu) == 0) continue;                            // :240
 			if (norm2(mk3(c.w.x, c.w.y, c.w.z)) < sqr(0.01f)) continue;          // :241
-			QW_ST(&qw.cur_w[id], c.w); QW_ST(&qw.cur_o[id], c.o); QW_ST(&qw.cur_d[id], c.d);
+			QW_ST(&qw.cur_w[id], c.w);
 			Ray r; r.o = mk3(c.o.x, c.o.y, c.o.z); r.d = mk3(c.d.x, c.d.y, c.d.z);
 			request_closest(r);
 			save(QW_A1, 0);
