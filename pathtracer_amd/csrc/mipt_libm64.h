@@ -306,14 +306,18 @@ MIPT_L64 double mipt_acos64(double x) {
 		return r + cor;
 	}
 	const bool pos = m > 0;
-	if (k <= 0x3fdfffff) {                                                  // < 0.5
-		if (k <= 0x3fcfffff) return l64_acos_piece(x, pos, 11 * ((k >> 15) & 0x1f), 11);
-		return l64_acos_piece(x, pos, 11 * ((k >> 14) & 0x3f) + 352, 11);
+	if (k <= 0x3feeffff) {                                                  // [0.125, 0.96875): one piece of one of five ranges
+		// (row and row length picked with selects, ONE evaluation: lanes of a wave that fall into different ranges do not
+		// run five copies of the chain one after the other)
+		int n, stride;
+		if (k <= 0x3fcfffff) { n = 11 * ((k >> 15) & 0x1f); stride = 11; }              // < 0.25
+		else if (k <= 0x3fdfffff) { n = 11 * ((k >> 14) & 0x3f) + 352; stride = 11; }   // < 0.5
+		else if (k <= 0x3fe7ffff) { n = 12 * ((k >> 13) & 0x7f) + 1056; stride = 12; }  // < 0.75
+		else if (k <= 0x3fed7fff) { n = 13 * ((k >> 13) & 0x7f) + 992; stride = 13; }   // < 0.921875
+		else if (k <= 0x3fee7fff) { n = 14 * ((k >> 13) & 0x7f) + 884; stride = 14; }   // < 0.953125
+		else { n = 15 * ((k >> 13) & 0x7f) + 768; stride = 15; }                        // < 0.96875
+		return l64_acos_piece(x, pos, n, stride);
 	}
-	if (k <= 0x3fe7ffff) return l64_acos_piece(x, pos, 12 * ((k >> 13) & 0x7f) + 1056, 12);   // < 0.75
-	if (k <= 0x3fed7fff) return l64_acos_piece(x, pos, 13 * ((k >> 13) & 0x7f) + 992, 13);    // < 0.921875
-	if (k <= 0x3fee7fff) return l64_acos_piece(x, pos, 14 * ((k >> 13) & 0x7f) + 884, 14);    // < 0.953125
-	if (k <= 0x3feeffff) return l64_acos_piece(x, pos, 15 * ((k >> 13) & 0x7f) + 768, 15);    // < 0.96875
 	if (k <= 0x3fefffff) {                                                  // < 1
 		const double z = (pos ? 1.0 - x : x + 1.0) * 0.5;
 		const uint64_t zb = l64_bits(z);
@@ -391,76 +395,47 @@ MIPT_L64 double mipt_atan264(double y, double x) {
 	}
 	if (ax < 0x1.0p-500 || ay < 0x1.0p-500) { ax *= 0x1.0p+500; ay *= 0x1.0p+500; }
 	if (ax > 0x1.0p+500 || ay > 0x1.0p+500) { ax *= 0x1.0p-500; ay *= 0x1.0p-500; }
-	double u, du, z;
-	if (ax > ay) {
-		u = ay / ax;
-		const double v = ax * u, vv = l64_fma(ax, u, -v);
-		du = ((ay - v) - vv) / ax;
-		if (x > 0.0) {                                                      // (i) atan(ay / ax)
-			if (0.0625 > u) {
-				const double v2 = u * u;
-				z = u + l64_fma(u * v2, l64_at_poly(v2), du);
-			} else {
-				const uint64_t* row = l64_at_row(u);
-				const double t3 = u - l64_dbl(row[0]);
-				const double w = du + t3;
-				const double dw = (l64_abs(t3) > l64_abs(du)) ? (t3 - w) + du : (du - w) + t3;
-				const double t2 = l64_dbl(row[2]);
-				double p = l64_fma(w, l64_dbl(row[6]), l64_dbl(row[5]));
-				p = l64_fma(w, p, l64_dbl(row[4])); p = l64_fma(w, p, l64_dbl(row[3]));
-				p = (w * w) * p;
-				p = l64_fma(dw, t2, p);
-				z = l64_fma(w, t2, p) + l64_dbl(row[1]);
-			}
-			return l64_copysign(z, y);
-		}
-	} else {
-		u = ax / ay;
-		const double v = ay * u, vv = l64_fma(ay, u, -v);
-		du = ((ax - v) - vv) / ay;
-		if (x > 0.0) {                                                      // (ii) pi/2 - atan(ax / ay)
-			if (0.0625 > u) {
-				const double v2 = u * u;
-				const double zz = (u * v2) * l64_at_poly(v2);
-				const double t2 = L64_HP0 - u;
-				const double cor = (L64_HP0 > l64_abs(u)) ? (L64_HP0 - t2) - u : L64_HP0 - (u + t2);
-				z = ((((cor + L64_HP1) - du) - zz)) + t2;
-			} else {
-				const uint64_t* row = l64_at_row(u);
-				const double w = (u - l64_dbl(row[0])) + du;
-				const double zz = l64_fma(-w, l64_at_tail(row, w), L64_HP1);
-				z = (L64_HP0 - l64_dbl(row[1])) + zz;
-			}
-			return l64_copysign(z, y);
-		}
-	}
-	if (ay > ax) {                                                          // (iii) x < 0: pi/2 + atan(ax / ay)
-		if (0.0625 > u) {
-			const double v2 = u * u;
-			const double p = l64_at_poly(v2);
-			const double t2 = u + L64_HP0;
-			const double zz = (v2 * u) * p;
-			const double cor = (L64_HP0 > l64_abs(u)) ? (L64_HP0 - t2) + u : (u - t2) + L64_HP0;
-			z = (((cor + L64_HP1) + du) + zz) + t2;
-		} else {
+	// u = smaller / larger magnitude, du = its rounding error
+	const bool y_smaller = ax > ay;
+	const double num = y_smaller ? ay : ax, den = y_smaller ? ax : ay;
+	const double u = num / den;
+	const double v = den * u, vv = l64_fma(den, u, -v);
+	const double du = ((num - v) - vv) / den;
+	const bool small = 0.0625 > u;
+	const double v2 = u * u;
+	double z;
+	if (y_smaller && x > 0.0) {                                             // (i) atan(ay / ax)
+		if (small) z = u + l64_fma(u * v2, l64_at_poly(v2), du);
+		else {
 			const uint64_t* row = l64_at_row(u);
-			const double w = (u - l64_dbl(row[0])) + du;
-			const double zz = l64_fma(w, l64_at_tail(row, w), L64_HP1);
-			z = (L64_HP0 + l64_dbl(row[1])) + zz;
+			const double t3 = u - l64_dbl(row[0]);
+			const double w = du + t3;
+			const double dw = (l64_abs(t3) > l64_abs(du)) ? (t3 - w) + du : (du - w) + t3;
+			const double t2 = l64_dbl(row[2]);
+			double p = l64_fma(w, l64_dbl(row[6]), l64_dbl(row[5]));
+			p = l64_fma(w, p, l64_dbl(row[4])); p = l64_fma(w, p, l64_dbl(row[3]));
+			p = (w * w) * p;
+			p = l64_fma(dw, t2, p);
+			z = l64_fma(w, t2, p) + l64_dbl(row[1]);
 		}
 		return l64_copysign(z, y);
 	}
-	if (0.0625 > u) {                                                       // (iv) x < 0: pi - atan(ay / ax)
-		const double v2 = u * u;
-		const double zz = (v2 * u) * l64_at_poly(v2);
-		const double t2 = L64_PI - u;
-		const double cor = (L64_PI > l64_abs(u)) ? (L64_PI - t2) - u : L64_PI - (t2 + u);
-		z = (((cor + L64_PI_LO) - du) - zz) + t2;
+	// (ii) x > 0: pi/2 - atan(ax / ay)   (iii) x < 0, |y| > |x|: pi/2 + atan(ax / ay)   (iv) x < 0: pi - atan(ay / ax).
+	// One evaluation for the three: C -+ atan(u) with a - b written as a + (-b) (the same operation), so that lanes of a wave
+	// in different quadrants share the chain.
+	const bool third = !(x > 0.0) && ay > ax;
+	const double C = (x > 0.0 || third) ? L64_HP0 : L64_PI, C_lo = (x > 0.0 || third) ? L64_HP1 : L64_PI_LO;
+	if (small) {
+		const double zz = (u * v2) * l64_at_poly(v2);
+		const double q = third ? u : -u;
+		const double t2 = C + q;
+		const double cor = (C > l64_abs(u)) ? (C - t2) + q : (q - t2) + C;
+		z = (((cor + C_lo) + (third ? du : -du)) + (third ? zz : -zz)) + t2;
 	} else {
 		const uint64_t* row = l64_at_row(u);
 		const double w = (u - l64_dbl(row[0])) + du;
-		const double zz = l64_fma(-w, l64_at_tail(row, w), L64_PI_LO);
-		z = (L64_PI - l64_dbl(row[1])) + zz;
+		const double zz = l64_fma(third ? w : -w, l64_at_tail(row, w), C_lo);
+		z = (C + (third ? l64_dbl(row[1]) : -l64_dbl(row[1]))) + zz;
 	}
 	return l64_copysign(z, y);
 }
