@@ -207,17 +207,26 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 #ifndef MIPT_RESOLVE_UNROLL
 #define MIPT_RESOLVE_UNROLL 8           // sample loads in flight per thread: the kernel runs ~2 waves per SIMD and lives on memory-level parallelism
 #endif
+//
+// A rank of a multi-GPU partition owns one tile row in `tile_nranks`: its pass has as many samples as a whole-frame pass
+// (more samples per pixel) but only that fraction of the bands has work, so the grid above would leave most of the chip idle
+// (measured at 8 ranks: 29 ms against 10.7 ms for twice the samples).  There the samples of the pass are cut into `zs`
+// slices along the sample index (gridDim.z): every slice sums its samples from zero into its own full-size partial image and
+// k_resolve_sum adds the partial images to the accumulators in slice order — deterministic, and no longer the reference's
+// serial order, which a partial frame that is summed with other ranks' frames cannot keep anyway.
 template <int FS>
-__global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSamples in, float denom2, int rows, float* __restrict__ accum) {
+__global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSamples in, float denom2, int rows, float* __restrict__ accum_out, int zs, float* __restrict__ partial) {
 	const int W = R.W, H = R.H, ftw = 2 * FS + 1;
 	const int j2 = blockIdx.x * blockDim.x + threadIdx.x;
 	const int r0 = blockIdx.y * rows, r1 = min(H, r0 + rows);          // destination rows [r0, r1)
 	if (j2 >= W) return;
-	const int nk = ps.k1 - ps.k0;
+	const int nk_all = ps.k1 - ps.k0;
+	const int ka = zs > 1 ? (int)((long long)nk_all * blockIdx.z / zs) : 0, kb = zs > 1 ? (int)((long long)nk_all * (blockIdx.z + 1) / zs) : nk_all;
 	const size_t npx = (size_t)W * H;
+	float* __restrict__ accum = zs > 1 ? partial + (size_t)blockIdx.z * 4 * npx : accum_out;
 	float acc[ftw][4];                                                  // acc[di + FS] = destination row i + di while source row i is scanned
 	auto load_acc = [&](int i2, float* a) {
-		if (i2 >= r0 && i2 < r1) { const size_t d = (size_t)(H - i2 - 1) * W + j2; a[0] = accum[3 * d]; a[1] = accum[3 * d + 1]; a[2] = accum[3 * d + 2]; a[3] = accum[3 * npx + d]; }
+		if (zs <= 1 && i2 >= r0 && i2 < r1) { const size_t d = (size_t)(H - i2 - 1) * W + j2; a[0] = accum[3 * d]; a[1] = accum[3 * d + 1]; a[2] = accum[3 * d + 2]; a[3] = accum[3 * npx + d]; }
 		else { a[0] = a[1] = a[2] = a[3] = 0.f; }
 	};
 	const int i_first = max(0, r0 - FS), i_last = min(H - 1, r1 - 1 + FS);
@@ -240,7 +249,7 @@ __global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSampl
 			const float4* __restrict__ pc = in.col + slot;
 			const size_t stride = (size_t)ps.npix_slots;
 #pragma unroll MIPT_RESOLVE_UNROLL
-			for (int kk = 0; kk < nk; kk++) {
+			for (int kk = ka; kk < kb; kk++) {
 				const float2 jit = pj[(size_t)kk * stride];
 				const float4 c = pc[(size_t)kk * stride];
 				const float sb = sqr(fdj - jit.x);
@@ -269,6 +278,14 @@ __global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSampl
 	}
 }
 
+
+__global__ void __launch_bounds__(256) k_resolve_sum(float* __restrict__ accum, const float* __restrict__ partial, int zs, size_t n) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float a = accum[i];
+	for (int z = 0; z < zs; z++) a += partial[(size_t)z * n + i];
+	accum[i] = a;
+}
 
 // ---- denoiser inputs (has_denoiser branch of render_image_nopreviz, Raytracer.cpp:1631-1645) ---------------------------
 // getColor hands back the shading normal and Kd of the first hit (Raytracer.cpp:255-258).  They are read off the hit
@@ -337,6 +354,7 @@ struct mipt_ctx {
 	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
 	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
 	void* overflow_buf = nullptr; size_t overflow_buf_bytes = 0;     // 200-entry rings of the samples the wavefront queue abandoned
+	void* resolve_buf = nullptr; size_t resolve_buf_bytes = 0;       // partial images of the sliced splat (ranks of a partition)
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
 	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
@@ -373,6 +391,7 @@ struct mipt_ctx {
 	int64_t opt_inner_min = 16;
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
+	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
@@ -533,6 +552,7 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	hipSetDevice(c->device);
 	if (c->queue_buf) hipFree(c->queue_buf);
 	if (c->overflow_buf) hipFree(c->overflow_buf);
+	if (c->resolve_buf) hipFree(c->resolve_buf);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
 	if (c->tab_buf) hipFree(c->tab_buf);
@@ -567,6 +587,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
@@ -1354,10 +1375,19 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		else if (!dump) {
 			if (timed_begin(3)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const int rows = (int)c->opt_resolve_rows;
-			const dim3 sgrid((unsigned)((R.W + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)));
-			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum);
-			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum);
+			// a rank of a partition: the pass's samples in slices along the sample index (see k_resolve_scan)
+			const int share = (int)std::min<uint64_t>(64, (uint64_t)R.W * (uint64_t)R.H / std::max<uint64_t>(1, c->blk_valid_pixels));     // 1 / (owned fraction of the frame)
+			const int zs = (share > 1 && rows > 0 && (R.filter_size == 1 || R.filter_size == 2)) ? std::max(1, std::min((int)c->opt_resolve_slices > 0 ? (int)c->opt_resolve_slices : std::min(share, 8), P.k1 - P.k0)) : 1;
+			float* partial = nullptr;
+			if (zs > 1) {
+				if ((rc = ensure(c, &c->resolve_buf, &c->resolve_buf_bytes, (size_t)zs * 4 * (size_t)R.W * R.H * sizeof(float)))) return rc;
+				partial = (float*)c->resolve_buf;
+			}
+			const dim3 sgrid((unsigned)((R.W + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)), (unsigned)zs);
+			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum, zs, partial);
+			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum, zs, partial);
 			else hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+			if (zs > 1) { const size_t n4 = 4 * (size_t)R.W * R.H; hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d_accum, (const float*)partial, zs, n4); }
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 		}
 		HIPCHK(c, hipGetLastError());
