@@ -341,3 +341,25 @@ def test_pass_is_sized_for_the_free_memory():
     assert rt.stats()["passes"] == cfg.spp
     assert np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max() < 1e-5
     rt.set_option("pass_memory_limit", 0)
+
+
+def test_partition_rank_splat_slices_are_deterministic():
+    """A rank of a tile partition cuts the samples of a pass into slices along the sample index (the splat would leave most
+    of the chip idle otherwise) and adds the partial images in slice order: the same frame on every run, the frame of the
+    unsliced kernel up to the summation order, and the ranks still sum to the whole frame."""
+    g = load_golden("scene_blob32.npz")
+    ref = normalised(g["image"], g["count"])
+    frames = {}
+    for slices in (0, 0, 1, 5):
+        acc_i, acc_c = None, None
+        for rank in range(4):
+            r = capi.HostRaytracer(device=0)
+            r.set_partition(8, rank, 4)
+            setup_scene(r, "blob32")
+            r.set_option("resolve_slices", slices)
+            i2, c2 = r.render()
+            acc_i = i2 if acc_i is None else acc_i + i2
+            acc_c = c2 if acc_c is None else acc_c + c2
+        assert np.abs(normalised(acc_i, acc_c) - ref).max() < 1e-5
+        frames.setdefault(slices, []).append(acc_i.tobytes())
+    assert frames[0][0] == frames[0][1]
