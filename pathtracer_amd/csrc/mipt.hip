@@ -1854,9 +1854,9 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 }
 
 #ifdef MIPT_PROFILE_SIMD
-extern "C" int mipt_debug_simd_profile(unsigned long long* out16, int reset) {
-	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_simd_prof), 128) != hipSuccess) return MIPT_ERR_HIP;
-	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 128) != hipSuccess) return MIPT_ERR_HIP; }
+extern "C" int mipt_debug_simd_profile(unsigned long long* out32, int reset) {
+	if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_simd_prof), 256) != hipSuccess) return MIPT_ERR_HIP;
+	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 256) != hipSuccess) return MIPT_ERR_HIP; }
 	return MIPT_OK;
 }
 #endif

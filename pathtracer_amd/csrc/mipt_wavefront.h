@@ -359,6 +359,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			h.tri = has_inter ? (((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI)) : -1;
 			f3 P = mk3(0, 0, 0); Mat m;
 			m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
+			if (TIER == 1) {
+				MIPT_PROF_COUNT(16)
+				if (has_inter && h.obj == 1) MIPT_PROF_COUNT(20)
+				if (!has_inter || h.obj == 0) MIPT_PROF_COUNT(22)
+			}
 			if (has_inter) hit_material(sc, p.ray, h, P, m);
 			// pixel of this path (for the per-pixel Cranley-Patterson rotation) and its sample index
 			int kk = (int)(id / (unsigned)ps.npix_slots), slot = (int)(id % (unsigned)ps.npix_slots);
@@ -368,7 +373,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			bool c;
 			if (TIER == 1) {
 				int r = path_vertex_fast(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
-				if (r == VERTEX_DEFER) { slow_bits |= 1u << u; break; }
+				if (r == VERTEX_DEFER) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
+				if (sh.diffuse) MIPT_PROF_COUNT(18)
 				c = r == VERTEX_CONTINUE;
 			} else c = path_vertex<TIER != 2>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;

@@ -11,7 +11,7 @@ rt.apply_config(cfg); scenes.install(rt, mesh, mat); rt.prepare()
 rt.set_option("pipeline", 1)
 for kv in sys.argv[2:]:
     k, v = kv.split("="); rt.set_option(k, int(v))
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 rt.mipt.mipt_debug_simd_profile(out, 1)
 rt.render()
 rt.mipt.mipt_debug_simd_profile(out, 1)
@@ -22,5 +22,7 @@ print(text, sys.argv[2:], "extend ms %.2f shadow ms %.2f (instrumented build)" %
 names = {0: "inner step", 2: "leaf phase", 4: "leaf triangle iteration", 6: "object-loop pass", 8: "outer iteration (lanes alive)", 10: "refill"}
 for k, nm in names.items():
     print("  %-32s wave events %12d  mean active lanes %5.1f  lane events per ray %6.2f" % (nm, o[k], o[k + 1] / max(1, o[k]), o[k + 1] / rays))
+for k, nm in {16: "shade<1> sub-chunk", 18: "  diffuse vertex", 20: "  environment hit", 22: "  miss / light hit", 24: "  to the slow tier"}.items():
+    print("  %-32s wave events %12d  mean active lanes %5.1f  share of the vertices %5.1f%%" % (nm, o[k], o[k + 1] / max(1, o[k]), 100.0 * o[k + 1] / max(1, o[17])))
 tot = o[12] + o[13] + o[14]
 print("  wave cycles: refill+objects %.1f%%  inner %.1f%%  leaf %.1f%%" % (100 * o[12] / tot, 100 * o[13] / tot, 100 * o[14] / tot))
