@@ -15,7 +15,7 @@
 
 #define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
 #ifndef MIPT_EXTEND_WAVES
-#define MIPT_EXTEND_WAVES 6             // closest-hit kernel: 6 waves/SIMD with the derived triangle terms beats 7 waves with the fourth load (-1.7 % / -4 % stage time on C2 / C1)
+#define MIPT_EXTEND_WAVES 7             // closest-hit kernel: 7 waves/SIMD with the derived triangle terms, made possible by MIPT_HIT_WRITE_THROUGH (round 1: 6 waves with the derived terms beat 7 with the fourth load)
 #endif
 #ifndef MIPT_DERIVE_SHADOW
 #define MIPT_DERIVE_SHADOW 1           // the any-hit traversal loads 48 of the 64 bytes of a triangle record and derives N, m22 (-7 % stage time)
@@ -56,6 +56,14 @@ struct LaneState {
 };
 
 #define MIPT_NONE 0x7fffffffu
+// MIPT_HIT_WRITE_THROUGH: the closest-hit kernel does not carry (beta, gamma, best) of the best hit in registers: a ray's record
+// is written when the ray is fetched (what the analytic objects left) and rewritten at every accepted hit.  That frees the
+// registers that let the kernel run 7 waves per SIMD with the derived triangle terms (6 spilled values, all loop constants
+// reloaded outside the inner loop): extend -1.9 % on C1 / C2, +0.8 % on C3 (more accepted hits per ray inside the glass).
+// (Keeping `best` to skip the first write for rays that accept something: more spills, slower.)
+#ifndef MIPT_HIT_WRITE_THROUGH
+#define MIPT_HIT_WRITE_THROUGH 1
+#endif
 
 // One object of Scene::intersection / intersection_shadow for the lanes whose next object is `i`
 // (i is wave-uniform, so the object's description is fetched with scalar loads).  Returns true when
@@ -70,7 +78,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 		float t;
 		bool hit = (o.type == 1) ? sphere_test(o, org, d, t) : plane_test(o, org, d, t);
 		{
-			if (hit && t < st.t) { st.t = t; st.best = (int)(((unsigned)i << 27) | MIPT_HIT_NOTRI); st.beta = 0; st.gamma = 0; }
+			if (hit && t < st.t) { st.t = t; st.best = (int)(((unsigned)i << 27) | MIPT_HIT_NOTRI); st.beta = 0; st.gamma = 0; }     // (write-through: by the caller)
 		}
 		return false;
 	}
@@ -215,12 +223,18 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
 				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
-				if (!SHADOW && st.obj == first_mesh) { st.t = o4.w; st.best = (int)__float_as_uint(d4.w); }      // a fresh ray: what the analytic objects left
+				if (!SHADOW && st.obj == first_mesh) {                                                       // a fresh ray: what the analytic objects left
+					st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
+					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
+				}
 			}
 			if (need) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {
 				if (need && st.obj == i) {
-					if (visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts)) { need = false; alive = true; }
+					const float t_before = st.t;
+					const bool enter_mesh = visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
+					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI));
+					if (enter_mesh) { need = false; alive = true; }
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
 					else st.obj = i + 1;
 				}
@@ -232,7 +246,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						float4 c = wf.out.col[st.id], pc = wf.sh_c[st.id];
 						wf.out.col[st.id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
 					}
-				} else {
+				} else if (!MIPT_HIT_WRITE_THROUGH) {
 					wf.hit[st.id] = make_float4(st.t, st.beta, st.gamma, __uint_as_float((unsigned)st.best));
 				}
 				need = false;
@@ -370,7 +384,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 							if (!RESV) st.t = cur_t;
 							if (!SHADOW) {
 								const int local = first + win - (int)sc->obj[st.obj].tri_base;
-								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg;
+								if (MIPT_HIT_WRITE_THROUGH && !RESV) wf.hit[st.id] = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
+								else { st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg; }
 							}
 						}
 						if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
@@ -399,6 +414,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 							st.t = lt;
 							if (SHADOW) {
 								if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
+							} else if (MIPT_HIT_WRITE_THROUGH && !RESV) {
+								wf.hit[st.id] = make_float4(lt, lb, lg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
 							} else {
 								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg;
 							}
@@ -464,7 +481,7 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_EXTEND_WAVES))) k_q_probe(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_q_probe(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
 	traverse_queue<false, true>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
