@@ -275,14 +275,26 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #ifndef MIPT_SHADE_ROLLED
 #define MIPT_SHADE_ROLLED 1
 #endif
+// Round 1 requested the state of sub-chunk u+1 while sub-chunk u was shaded (a software pipeline over the first of the three
+// dependent round trips of a vertex).  That holds 18 registers across the whole vertex code: 143 instead of 126 in the fast
+// tier, i.e. 3 waves per SIMD instead of 4 — and a fourth wave without a single spilled value hides more latency than the
+// pipeline did (C2: generate + shade 482 -> 449 ms per step without the prefetch at 3 waves, -> 438 ms at 4; the measurement
+// of round 1 that "4 waves gain nothing" was taken with the prefetch in place and 28 spilled registers).  The general tiers
+// fall from 169 / 193 to 154 / 169 registers: 3 waves instead of 2 (C4, MERL tier: 1 096 -> 947 ms; glossy C1: 661 -> 596 ms).
 #ifndef MIPT_SHADE_WAVES
-#define MIPT_SHADE_WAVES 3
+#define MIPT_SHADE_WAVES 4
+#endif
+#ifndef MIPT_SHADE_PREFETCH
+#define MIPT_SHADE_PREFETCH 0
 #endif
 #ifndef MIPT_SHADE2_WAVES
-#define MIPT_SHADE2_WAVES 2
+#define MIPT_SHADE2_WAVES 3
+#endif
+#ifndef MIPT_SHADE3_WAVES
+#define MIPT_SHADE3_WAVES 3             // tiers 0 and 3 (general code with the measured BRDF)
 #endif
 template <int TIER>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : 2)))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : MIPT_SHADE3_WAVES)))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
 	const unsigned n = TIER >= 2 ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
 	unsigned* head = &wf.counters[MIPT_CNT((TIER >= 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
 	const unsigned* __restrict__ list = TIER >= 2 ? wf.list_slow : wf.list[b & 1];
@@ -315,12 +327,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		unsigned id_cur = load_id(0), id_nxt = load_id(1), id_nn = 0xffffffffu;
 		In cur, nxt;
 		cur.w = cur.o = cur.d = cur.hr = cur.col = make_float4(0.f, 0.f, 0.f, 0.f); cur.rs = make_uint2(0u, 0u); nxt = cur;
-		fetch(id_cur, id_cur != 0xffffffffu, cur);
+		if (MIPT_SHADE_PREFETCH) fetch(id_cur, id_cur != 0xffffffffu, cur);
 #pragma unroll 1
 		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
 			const unsigned id = id_cur;
 			id_nn = load_id(u + 2);
-			fetch(id_nxt, id_nxt != 0xffffffffu, nxt);       // in flight while this sub-chunk is shaded; moved into `cur` at the end of the body
+			if (MIPT_SHADE_PREFETCH) fetch(id_nxt, id_nxt != 0xffffffffu, nxt);       // in flight while this sub-chunk is shaded; moved into `cur` at the end of the body
+			else fetch(id_cur, id_cur != 0xffffffffu, cur);
 			const In sin = cur;
 			do {
 			if (id == 0xffffffffu) break;
@@ -425,7 +438,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			if (c) cont_bits |= 1u << u;
 			} while (0);
 #if MIPT_SHADE_ROLLED
-			cur = nxt; id_cur = id_nxt; id_nxt = id_nn;
+			if (MIPT_SHADE_PREFETCH) cur = nxt;
+			id_cur = id_nxt; id_nxt = id_nn;
 #endif
 		}
 		const unsigned* src = identity ? nullptr : list;
