@@ -7,7 +7,7 @@ from pathtracer_amd import capi, scenes
 mesh, cfg, mat, text = scenes.workload("c2", 1920, 1080, 1024, None)
 H = capi.HostRaytracer(device=0)
 H.apply_config(cfg); scenes.install(H, mesh, mat); H.prepare()
-for nr, zs in ((1, 0), (2, 0), (4, 0), (8, 0), (8, 1)):
+for nr, zs in [(1, 0), (2, 0), (4, 0), (8, 0), (8, 1)] if len(sys.argv) < 2 else [(1, int(v)) for v in sys.argv[1:]]:
     H.set_option('resolve_slices', zs)
     pr = H.params
     pr.tile_size, pr.tile_rank, pr.tile_nranks = 32, 0, nr
