@@ -359,6 +359,7 @@ struct mipt_ctx {
 	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
 	unsigned grid_qlogic[2] = {0, 0};
+	int qlogic_fog = -1;              // which build of the logic stage grid_qlogic was measured for
 	unsigned grid_qtrav[2] = {0, 0};  // resident blocks of k_q_traverse<false / true>
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
 	void* spill_buf = nullptr; size_t spill_buf_bytes = 0;
@@ -1250,9 +1251,13 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			hipLaunchKernelGGL(k_q_begin, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, c->d_cnt);
 			typedef void (*logic_fn)(const DScene*, DRender, DPass, DWave, DQueueWave, const unsigned*, const unsigned*, unsigned, unsigned*, int, int, DCounters*);
-			const logic_fn logic_k[2] = {c->scene_has_subsurface ? (logic_fn)k_q_logic<true, false> : (logic_fn)k_q_logic<false, false>,      // over a closest-hit list (or all samples)
-			                             c->scene_has_subsurface ? (logic_fn)k_q_logic<true, true> : (logic_fn)k_q_logic<false, true>};       // over an any-hit list
-			if (c->grid_qlogic[0] == 0) {                                 // resident blocks of the logic stage
+			const bool fog_on = R.fog_density > 1E-8;                       // the build without the fog code for scenes without fog
+			const logic_fn logic_tab[2][2][2] = {{{(logic_fn)k_q_logic<false, false, false>, (logic_fn)k_q_logic<false, true, false>}, {(logic_fn)k_q_logic<false, false, true>, (logic_fn)k_q_logic<false, true, true>}},
+			                                     {{(logic_fn)k_q_logic<true, false, false>, (logic_fn)k_q_logic<true, true, false>}, {(logic_fn)k_q_logic<true, false, true>, (logic_fn)k_q_logic<true, true, true>}}};
+			const logic_fn logic_k[2] = {logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][0],       // over a closest-hit list (or all samples)
+			                             logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][1]};      // over an any-hit list
+			if (c->grid_qlogic[0] == 0 || c->qlogic_fog != (fog_on ? 1 : 0)) {                                 // resident blocks of the logic stage (of the build in use)
+				c->qlogic_fog = fog_on ? 1 : 0;
 				for (int k = 0; k < 2; k++) {
 					int nb = 0;
 					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)logic_k[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;

@@ -33,7 +33,7 @@
 #define MIPT_QW_FIFO 32
 #endif
 #ifndef MIPT_QW_LOGIC_WAVES
-#define MIPT_QW_LOGIC_WAVES 2
+#define MIPT_QW_LOGIC_WAVES 2            // (+ 1 for the any-hit-list stage of the build without the fog code: 165 registers)
 #endif
 #define MIPT_QW_FRAME 13                  // float4 slots of the per-sample frame
 // The per-sample state (1.9 KB) is touched once per call: streaming cache policy, as the path state of pipeline 1
@@ -163,7 +163,7 @@ MIPT_DEV bool has_fog_early(const DRender& R) { return R.fog_density > 1E-8; }
 // call and its any-hit query runs in the same round as the closest-hit query of the next contribution; the term is added
 // to the colour by the any-hit stage, i.e. before the next vertex adds anything: the order of the additions is the
 // reference's.
-template <bool SUBS, bool SHADOW_LIST>
+template <bool SUBS, bool SHADOW_LIST, bool FOG>
 __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const DRender& R, const DPass& ps, const DWave& wf, const DQueueWave& qw, const unsigned id,
                                        unsigned& n_closest, unsigned& n_shadow) {
 	const unsigned N = qw.N;
@@ -185,13 +185,13 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 		load_color();
 		S.color = S.color + v; color_dirty = true;
 	};
-	if (has_fog_early(R)) load_color();
+	if (FOG && has_fog_early(R)) load_color();
 	S.head = ctl & 0xffu; S.count = (ctl >> 8) & 0xffu; S.overflow = false;
 	QContrib* const fifo = qw.fifo + (size_t)id * MIPT_QW_FIFO;
 	auto FRL = [&](int slot) -> float4 { return QW_LD(&qw.fr[(size_t)slot * N + id]); };
 	auto FRS = [&](int slot, float4 v) { QW_ST(&qw.fr[(size_t)slot * N + id], v); };
 	const bool has_bg = R.backgroundW > 0 && R.background != nullptr;       // :220
-	const bool has_fog = R.fog_density > 1E-8;                              // :207
+	const bool has_fog = FOG && R.fog_density > 1E-8;                       // :207 (FOG = false: the build for scenes without fog, no fog code in it)
 	const f3 cl = ld3(R.centerLight);
 	// pixel / sample index of this path id
 	const int kk = (int)(id / (unsigned)ps.npix_slots), slot_ = (int)(id % (unsigned)ps.npix_slots);
@@ -682,8 +682,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 }
 
 // One round of the logic stage over one id list of the previous round (or, round 0, over all path slots).
-template <bool SUBS, bool SHADOW_LIST>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_QW_LOGIC_WAVES))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
+template <bool SUBS, bool SHADOW_LIST, bool FOG>
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu((SHADOW_LIST && !FOG) ? MIPT_QW_LOGIC_WAVES + 1 : MIPT_QW_LOGIC_WAVES))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
                                                                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, unsigned n_imm,
                                                                                                 unsigned* __restrict__ head, int out_slot, int out_parity, DCounters* __restrict__ cnt) {
 	const unsigned n = n_ptr ? *n_ptr : n_imm;
@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			if (idx >= n) continue;
 			const unsigned id = list ? list[idx] : idx;
-			const int r = qw_advance<SUBS, SHADOW_LIST>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
+			const int r = qw_advance<SUBS, SHADOW_LIST, FOG>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
 			if (r < 0) over_bits |= 1u << u;
 			else {
 				if (r & 1) closest_bits |= 1u << u;
