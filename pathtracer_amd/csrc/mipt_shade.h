@@ -373,6 +373,9 @@ MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, P
 	}
 	ps.color = color;
 	ps.rng = rng;
+	// The last vertex of a path: getColor still samples a continuation and queues it with depth 0, and the loop head drops it
+	// (Raytracer.cpp:240) — nothing of it reaches the colour, so it is not computed.
+	if (ps.depth <= 1) return VERTEX_END;
 	float ip;
 	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
 	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
