@@ -269,7 +269,9 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 		sh.ray.d = wi;
 		sh.dist = sqrtf(d_light2) - 0.01f;
 	}
-	// indirect (:570-632): the same Cranley-Patterson-rotated lattice point at every depth
+	// indirect (:570-632): the same Cranley-Patterson-rotated lattice point at every depth.  Not for the last vertex of a path:
+	// its continuation would be queued with depth 0 and dropped by the loop head (:240) before anything of it reaches the colour.
+	if (ps.depth <= 1) return false;
 	float ip;
 	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
 	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
