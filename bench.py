@@ -152,8 +152,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # under torch.distributed.run: one process per GPU
+    in_process = [int(x) for x in args.in_process.split(",")] if args.in_process else []
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if in_process and world > 1:
+        raise SystemExit("--in-process drives its devices from one process: do not launch it under torch.distributed.run")
+    if launched and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks: they must agree")
+    if not launched and not in_process and args.gpus > 1:
+        # the plain command line: ONE process drives the N devices through the product's own multi-GPU entry,
+        # mipt_create(ids, N) -> worker thread + stream + partial framebuffer per device, one ncclReduce (RCCL) to device 0
+        in_process = list(range(args.gpus))
+    if in_process and len(in_process) != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but --in-process lists {len(in_process)} devices")
+        args.gpus = len(in_process)
+    # torch.cuda.device_count() does not initialise the GPU
+    n_dev = torch.cuda.device_count()
+    need = (max(in_process) + 1) if in_process else (local_rank + 1 if launched and not args.share_gpu else 1)
+    if n_dev < need:
+        raise SystemExit(f"bench.py --gpus {args.gpus} needs {need} visible device(s), this box has {n_dev}: refusing to measure fewer GPUs than asked for")
     if args.share_gpu:
         local_rank = 0
+    if in_process:
+        local_rank = in_process[0]                       # the caller's accumulator and stream live on the group's first device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -173,10 +196,8 @@ def main():
         dist.barrier()
     from pathtracer_amd import capi, scenes
 
-    in_process = [int(x) for x in args.in_process.split(",")] if args.in_process else []
-    if in_process and world > 1:
-        raise SystemExit("--in-process drives its devices from one process: do not launch it under torch.distributed.run")
     job_gpus = len(in_process) if in_process else world
+    assert job_gpus == args.gpus, (job_gpus, args.gpus)
     dims = {"c4": (3840, 2160)}.get(args.workload, (1920, 1080))
     npx = (args.width or dims[0]) * (args.height or dims[1])
     spp_pass = SPP_PER_PASS
@@ -298,7 +319,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
-                       "parallelism": f"tiles32x{job_gpus}" + (f", one process, mipt_create(n={job_gpus}): {rt.group_reduce_kind()}" if in_process else (", one process per GPU, RCCL all-reduce of the framebuffers" if world > 1 else "")),
+                       "parallelism": f"tiles32x{job_gpus}" + (f", one process, mipt_create(n={rt.group_size()}) on devices {in_process}: {rt.group_reduce_kind()}" if in_process else (f", one process per GPU, {world} ranks, {args.backend} all-reduce of the framebuffers" + (" (RCCL)" if args.backend == "nccl" else "") if world > 1 else "")),
+                       "ranks_in_reduce": (rt.group_size() if in_process else world), "reduce": (rt.group_reduce_kind() if in_process else (args.backend + " all_reduce" if world > 1 else "none")),
                        "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),
             "host_bvh_build_s": t_build,   # TriMesh::init as a whole (axis swap, BVH, triangle soup, tangents)

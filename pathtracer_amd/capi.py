@@ -528,6 +528,16 @@ class HostRaytracer:
         rc = self.mipt.mipt_render(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), CB(cb), None, C.byref(cancel))
         return rc, img, cnt, calls
 
+    def render_cancellable(self):
+        """mipt_render with a cancel flag that is never raised and NO progress callback: the library renders the range in
+        pass-sized chunks without a host synchronisation between them."""
+        self._need_device()
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        cancel = C.c_int(0)
+        self._check(self.mipt.mipt_render(self.ctx, self.render_params, _p(img, _f), _p(cnt, _f), None, None, C.byref(cancel)), "mipt_render")
+        return img, cnt
+
     def render_device(self, d_accum_ptr, stream=0):
         self._need_device()
         self._check(self.mipt.mipt_render_device(self.ctx, self.render_params, C.c_void_p(d_accum_ptr), C.c_void_p(stream)), "mipt_render_device")

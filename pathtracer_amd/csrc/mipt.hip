@@ -481,6 +481,7 @@ struct mipt_group {
 	std::vector<mipt_ctx*> member;            // member[0] = the context the caller holds
 	std::vector<hipStream_t> stream;          // one render stream per member
 	std::vector<hipEvent_t> done;             // "this member's partial framebuffer is complete"
+	std::vector<hipEvent_t> copied;           // copy reduce: "member 0's stream has read member i's partial framebuffer" (created on member 0's device)
 	std::vector<float*> acc; std::vector<size_t> acc_bytes;   // partial framebuffers, W*H*4 floats
 	float* tmp0 = nullptr; size_t tmp0_bytes = 0;             // staging on member 0's device for the copy reduce
 	std::vector<mipt_nccl_comm> comm;         // one communicator per member, or empty: copy reduce
@@ -510,11 +511,13 @@ extern "C" int mipt_create(const int* device_ids, int n, mipt_ctx** out) {
 			m->is_member = true;
 			g->member.push_back(m);
 		}
-		g->stream.assign(n, nullptr); g->done.assign(n, nullptr); g->acc.assign(n, nullptr); g->acc_bytes.assign(n, 0);
+		g->stream.assign(n, nullptr); g->done.assign(n, nullptr); g->copied.assign(n, nullptr); g->acc.assign(n, nullptr); g->acc_bytes.assign(n, 0);
 		for (int i = 0; i < n; i++) {
 			if (hipSetDevice(g->member[i]->device) != hipSuccess || hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking) != hipSuccess ||
 			    hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) { mipt_destroy(c); return MIPT_ERR_HIP; }
 		}
+		hipSetDevice(c->device);
+		for (int i = 1; i < n; i++) if (hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming) != hipSuccess) { mipt_destroy(c); return MIPT_ERR_HIP; }
 		// one RCCL communicator per member; a device listed twice (a single-GPU box exercising the group path) cannot have
 		// two ranks in one communicator: the framebuffers are then summed by device copies + adds
 		bool distinct = true;
@@ -545,6 +548,7 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 			if (i < g->acc.size() && g->acc[i]) hipFree(g->acc[i]);
 			if (i < g->stream.size() && g->stream[i]) hipStreamDestroy(g->stream[i]);
 			if (i < g->done.size() && g->done[i]) hipEventDestroy(g->done[i]);
+			if (i < g->copied.size() && g->copied[i]) hipEventDestroy(g->copied[i]);
 			if (i == 0 && g->tmp0) hipFree(g->tmp0);
 			if (i > 0) mipt_destroy(g->member[i]);
 		}
@@ -1512,6 +1516,11 @@ static int group_render_range(mipt_ctx* c, const mipt_render_params* p, int k0, 
 		for (int i = 1; i < n; i++) {
 			HIPCHK(c, hipStreamWaitEvent(g->stream[0], g->done[i], 0));
 			HIPCHK(c, hipMemcpyPeerAsync(g->tmp0, c->device, g->acc[i], g->member[i]->device, bytes, g->stream[0]));
+			// member i's partial framebuffer is cleared and refilled by the next range on ITS stream: that stream waits until
+			// this copy has read it (without it a second range could zero acc[i] under the copy: ranges are only separated by a
+			// host synchronisation when a progress callback is set)
+			HIPCHK(c, hipEventRecord(g->copied[i], g->stream[0]));
+			HIPCHK(c, hipStreamWaitEvent(g->stream[i], g->copied[i], 0));
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)c->n_cus * 4u), dim3(256), 0, g->stream[0], g->acc[0], (const float*)g->tmp0, count);
 		}
 	}

@@ -6,9 +6,14 @@
 * one process per GPU — world size 2 over gloo, each rank rendering its tiles with the real HIP path
   (mipt_render_device) and ONE all-reduce of the partial framebuffers, as bench.py does over RCCL.
 
-Both must reproduce the single-device frame up to the order of the float additions (1e-5 relative to white)."""
+Both must reproduce the single-device frame up to the order of the float additions (1e-5 relative to white).
+
+On a box with two or more devices the tests at the end enable themselves: the group [0, 1] must sum with RCCL's ncclReduce,
+and the one-process-per-GPU form runs over backend nccl (= RCCL) on two distinct devices."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -77,6 +82,25 @@ def test_group_progress_and_cancel():
         rt.set_option("reduce", 1)                                   # a device listed twice has no communicator
 
 
+def test_group_chunks_without_a_callback_do_not_race():
+    """A cancel flag without a progress callback cuts the range into chunks that are NOT separated by a host
+    synchronisation: member i's stream must not clear its partial framebuffer for chunk k + 1 while member 0's stream still
+    copies chunk k out of it (copy reduce).  Same chunks with the callback (host-synchronised) = the same bits."""
+    rt = capi.HostRaytracer(device=[0, 0, 0])
+    mesh, cfg, oid = setup_scene(rt, "blob32")
+    slots = cfg.W * cfg.H // 3
+    rt.set_option("paths_per_pass", max(64, slots))                  # one sample per chunk and device: cfg.spp chunks
+    assert cfg.spp >= 3
+    rc, img_cb, cnt_cb, calls = rt.render_progressive()
+    assert rc == capi.MIPT_OK and len(calls) >= 3
+    for _ in range(3):
+        img, cnt = rt.render_cancellable()
+        assert (img.view(np.uint32) == img_cb.view(np.uint32)).all() and (cnt.view(np.uint32) == cnt_cb.view(np.uint32)).all()
+    img1, cnt1 = rt.render()                                         # the whole range at once: other addition order
+    np.testing.assert_allclose(cnt, cnt1, rtol=1e-6)
+    assert np.abs(normalised(img, cnt) - normalised(img1, cnt1)).max() < 1e-6
+
+
 def test_rccl_is_loadable_and_callable():
     """dlopen(librccl.so.1), ncclCommInitAll, ncclGroupStart / ncclReduce / ncclGroupEnd, ncclCommDestroy with the
     signatures the group path uses, on one rank."""
@@ -118,3 +142,88 @@ def test_two_processes_reduce_real_partial_frames(tmp_path):
     img, cnt = acc[: 3 * npx].reshape(cfg.H, cfg.W, 3), acc[3 * npx:].reshape(cfg.H, cfg.W)
     np.testing.assert_allclose(cnt, cnt1, rtol=1e-5)
     assert np.abs(normalised(img, cnt) - normalised(img1, cnt1)).max() < 1e-5
+
+
+# ---- two or more devices: skipped on a one-GPU box, enabled by themselves elsewhere ---------------------------------------
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()          # does not initialise the GPU
+
+
+needs_two = pytest.mark.skipif(_n_devices() < 2, reason="needs two devices")
+
+
+@needs_two
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_group_of_distinct_devices_reduces_with_rccl(n):
+    if _n_devices() < n:
+        pytest.skip(f"needs {n} devices")
+    g = load_golden("scene_blob32.npz")
+    one = capi.HostRaytracer(device=0)
+    mesh, cfg, oid = setup_scene(one, "blob32")
+    img1, cnt1 = one.render()
+    grp = capi.HostRaytracer(device=list(range(n)))
+    setup_scene(grp, "blob32")
+    assert grp.group_size() == n
+    assert grp.group_reduce_kind() == "RCCL ncclReduce(sum, fp32, root 0)"
+    grp.set_option("reduce", 1)                                      # RCCL or fail
+    for _ in range(2):                                               # the second render reuses buffers and communicators
+        img, cnt = grp.render()
+        st, st1 = grp.stats(), one.stats()
+        assert st["rays_closest"] == st1["rays_closest"] and st["rays_shadow"] == st1["rays_shadow"]
+        np.testing.assert_allclose(cnt, cnt1, rtol=1e-5)
+        assert np.abs(normalised(img, cnt) - normalised(img1, cnt1)).max() < 1e-5
+        assert np.abs(normalised(img, cnt) - normalised(g["image"], g["count"])).max() < 1e-5
+    img_c, cnt_c = grp.render_cancellable()                          # chunked, a reduce per chunk, no host synchronisation
+    assert np.abs(normalised(img_c, cnt_c) - normalised(img1, cnt1)).max() < 1e-5
+    grp.set_option("reduce", 2)                                      # peer copies + adds between distinct devices
+    img2, cnt2 = grp.render()
+    assert np.abs(normalised(img2, cnt2) - normalised(img1, cnt1)).max() < 1e-5
+
+
+def _rank_nccl(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    rt = capi.HostRaytracer(device=rank)
+    rt.set_partition(16, rank, world)
+    setup_scene(rt, "blob32")
+    accum = torch.zeros(rt.W * rt.H * 4, dtype=torch.float32, device=f"cuda:{rank}")
+    rt.render_device(accum.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    dist.all_reduce(accum, op=dist.ReduceOp.SUM)                     # RCCL, on the device buffers, as bench.py does
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(out, accum.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@needs_two
+def test_two_processes_on_two_devices_reduce_over_rccl(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_rank_nccl, args=(2, port, out), nprocs=2, join=True)
+    one = capi.HostRaytracer(device=0)
+    mesh, cfg, oid = setup_scene(one, "blob32")
+    img1, cnt1 = one.render()
+    acc = np.load(out)
+    npx = cfg.W * cfg.H
+    img, cnt = acc[: 3 * npx].reshape(cfg.H, cfg.W, 3), acc[3 * npx:].reshape(cfg.H, cfg.W)
+    np.testing.assert_allclose(cnt, cnt1, rtol=1e-5)
+    assert np.abs(normalised(img, cnt) - normalised(img1, cnt1)).max() < 1e-5
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus N` without the launcher must use N devices (the in-library group) or exit non-zero."""
+    n = _n_devices()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to measure fewer GPUs" in (r.stderr + r.stdout)

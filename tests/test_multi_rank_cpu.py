@@ -74,3 +74,20 @@ def test_two_rank_reduce_matches_single_rank(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     full = splat(owners(1), None, make_samples())
     np.testing.assert_allclose(np.load(out), full, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus N` without the launcher must drive N devices (the in-library group, mipt_create(ids, N)) or
+    exit non-zero: it never falls back to fewer GPUs than asked for."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to measure fewer GPUs" in (r.stderr + r.stdout)
+    # under a launcher whose world size disagrees with --gpus the run is refused as well
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
