@@ -69,6 +69,10 @@ int ref_load_image(const char* file, unsigned char* out, int capacity, int* W, i
 	return 0;
 }
 
+// the reference's image writer, save_image (utils.cpp:177-234), for 8-bit and for float pixels (maxval as given)
+void ref_save_image_u8(const char* file, const unsigned char* rgb, int W, int H) { save_image(file, rgb, W, H); }
+void ref_save_image_f32(const char* file, const float* rgb, int W, int H, float maxval) { save_image(file, rgb, W, H, maxval); }
+
 // .scn scene files through the reference's own Raytracer::save_scene / load_scene (Raytracer.cpp:1096-1236)
 void ref_save_scene(RefCtx* c, const char* file) { c->rt->save_scene(file); }
 void ref_load_scene(RefCtx* c, const char* file) {

@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 
 #include "mipt_wavefront.h"
 #include "mipt_persistent.h"
+#include "mipt_unified.h"
 #include "mipt_build.h"
 #include "mipt_compositing.h"
 #include "mipt_queue_wave.h"
@@ -390,6 +391,11 @@ struct mipt_ctx {
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
+	int64_t opt_unified = 0;          // traversal stages: 1 = one fetch per lane and round (mipt_unified.h: measured 35-47 % slower, kept as the statement of that experiment), 0 = the phased kernels of mipt_persistent.h
+	int64_t opt_u_setup_min = 8;      // unified traversal: the object loop runs once this many fetched rays wait for it ...
+	int64_t opt_u_alive_low = 32;     // ... or at once while fewer than this many lanes traverse
+	unsigned grid_u[2] = {0, 0};      // resident blocks of k_wf_traverse_u<0 / 1>
+	unsigned grid_qu[2] = {0, 0};     // resident blocks of k_q_traverse_u<false / true>
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
@@ -590,6 +596,9 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
+	if (!strcmp(name, "unified")) { c->opt_unified = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "u_setup_min")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "u_setup_min must be in [1,64]"); c->opt_u_setup_min = value; return MIPT_OK; }
+	if (!strcmp(name, "u_alive_low")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "u_alive_low must be in [0,64]"); c->opt_u_alive_low = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
@@ -1237,6 +1246,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			c->grid_stage[k] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
 		}
 	}
+	if (c->grid_u[0] == 0) {
+		const void* kern[4] = {(const void*)k_wf_traverse_u<0>, (const void*)k_wf_traverse_u<1>, (const void*)k_q_traverse_u<false>, (const void*)k_q_traverse_u<true>};
+		for (int k = 0; k < 4; k++) {
+			int nb = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+			(k < 2 ? c->grid_u[k] : c->grid_qu[k - 2]) = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
+		}
+	}
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
@@ -1276,6 +1293,20 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
+			const bool unified = c->opt_unified != 0;
+			const int u_setup = (int)c->opt_u_setup_min, u_flags = (int)(c->opt_u_alive_low & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0);
+			auto q_traverse = [&](bool shadow, const TravQueue& tq, unsigned nq) {
+				const unsigned want = (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK;
+				if (unified) {
+					const dim3 g(std::max(1u, std::min(c->grid_qu[shadow ? 1 : 0], want)));
+					if (shadow) hipLaunchKernelGGL(k_q_traverse_u<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, u_setup, u_flags);
+					else hipLaunchKernelGGL(k_q_traverse_u<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, u_setup, u_flags);
+				} else {
+					const dim3 g(std::max(1u, std::min(c->grid_qtrav[shadow ? 1 : 0], want)));
+					if (shadow) hipLaunchKernelGGL(k_q_traverse<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					else hipLaunchKernelGGL(k_q_traverse<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+				}
+			};
 			for (int r = 0;; r++) {
 				if (r > 100000) return fail(c, MIPT_ERR_HIP, "the contribution queue did not drain");
 				const int slot = r & 3, par = r & 1;
@@ -1299,19 +1330,19 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (pair[1]) {
 					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = first ? nullptr : pair_dev + 1; tq.n_imm = pair[1]; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = first; tq.vis = nullptr; tq.skip_ghosts = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					hipLaunchKernelGGL(k_q_traverse<false>, dim3(std::max(1u, std::min(c->grid_qtrav[0], (pair[1] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					q_traverse(false, tq, pair[1]);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[0]) {
 					TravQueue tq; tq.list = qw.shl[par]; tq.n_ptr = pair_dev; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW(slot)]; tq.identity = false; tq.vis = qw.vis; tq.skip_ghosts = true;
 					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					hipLaunchKernelGGL(k_q_traverse<true>, dim3(std::max(1u, std::min(c->grid_qtrav[1], (pair[0] + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					q_traverse(true, tq, pair[0]);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (n_add) {
 					TravQueue tq; tq.list = qw.sha[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_SHADOW_ADD(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW_ADD(slot)]; tq.identity = false; tq.vis = (R.fog_density > 1E-8) ? qw.vis : nullptr; tq.skip_ghosts = true;   // fog: the logic stage reads the answer later
 					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					hipLaunchKernelGGL(k_q_traverse<true>, dim3(std::max(1u, std::min(c->grid_qtrav[1], (n_add + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					q_traverse(true, tq, n_add);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				// the logic stage of the next round, over the lists of this one; its counters (used four rounds ago) are cleared first
@@ -1342,7 +1373,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], k < 3 ? (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK) : grid_all)); };
+			const bool unified = c->opt_refill && c->opt_unified && !c->opt_merge_traverse;
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
+			const int u_setup = (int)c->opt_u_setup_min, u_flags = (int)(c->opt_u_alive_low & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0);
+			auto GU = [&](int k) { return dim3(std::min(c->grid_u[k], (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))); };
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			unsigned* const list_mem[2] = {wf.list[0], wf.list[1]};
@@ -1359,7 +1393,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				}
 				if (!merge || b == 0) {                                  // closest hits of depth b (merged mode: done by the launch of depth b-1)
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+					if (unified) hipLaunchKernelGGL(k_wf_traverse_u<0>, GU(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, u_setup, u_flags);
+					else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 					else hipLaunchKernelGGL(k_wf_extend, G(6), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
@@ -1373,6 +1408,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+				else if (unified) hipLaunchKernelGGL(k_wf_traverse_u<1>, GU(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, u_setup, u_flags);
 				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
 				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");

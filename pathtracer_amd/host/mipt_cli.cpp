@@ -2,8 +2,8 @@
 // (`pathtracer scene.scn out.png`, mainApp.cpp:38-49): the default loadScene() scene (light, environment sphere, ground
 // plane, camera) plus one OBJ/MTL mesh placed like a file dropped on the GUI (scale 30, bottom on the plane,
 // mainApp.cpp:2402-2410), rendered with Raytracer::render_image_nopreviz() on the GPU and written by save_image's rule:
-// the container follows the extension of the output name (utils.cpp:178-234; .png / .bmp / .tga / .ppm are written, any
-// other extension is an error, never another format under that name).
+// the container follows the extension of the output name (utils.cpp:178-234; .png / .bmp / .tga / .jpg / .ppm / .hdr are written,
+// any other extension is an error, never another format under that name).
 //
 //   mipt_render scene.scn out.png [nameSubst] [-s WxH] [-n spp] [-b bounces] [-f frame] [-d device[,device...]] [-g gpus]
 //        -f: Scene::current_frame, the time the scene's key-framed transforms are evaluated at (default 0)
@@ -15,13 +15,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <vector>
 
 #include "mipt_host.h"
 
 using namespace mipt_host;
 
 int main(int argc, char** argv) {
-	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.ppm [nameSubst] [-s WxH] [-n spp] [-b bounces] [-f frame] [-d device,...] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
+	if (argc < 3) { fprintf(stderr, "usage: %s scene.scn|mesh.obj out.png|.bmp|.tga|.jpg|.ppm|.hdr [nameSubst] [-s WxH] [-n spp] [-b bounces] [-f frame] [-d device,...] [-g gpus] [--merl file.binary] [--mirror]\n", argv[0]); return 2; }
 	int W = 1000, H = 800, spp = 100, bounces = 3, frame = 0;
 	int devices[64] = {0}, ndev = 1;
 	const char* merl = nullptr;
@@ -29,12 +30,9 @@ int main(int argc, char** argv) {
 	const char* name_subst = nullptr;                    // argv[3] of the reference's command line, when it is not an option
 	int first_opt = 3;
 	if (argc > 3 && argv[3][0] != '-') { name_subst = argv[3]; first_opt = 4; }
-	{   // an output name no writer exists for is refused before anything is rendered
-		char why[256];
-		const unsigned char px[3] = {0, 0, 0};
-		if (mh_save_image(argv[2], px, 1, 1, why, sizeof why) != 0) { fprintf(stderr, "%s: %s\n", argv[2], why); return 2; }
-		remove(argv[2]);
-	}
+	// an output name no writer exists for is refused before anything is rendered (by its name: an existing file of that
+	// name is not touched until the final write)
+	if (!mh_image_format_supported(argv[2], 1)) { fprintf(stderr, "%s: no writer for this extension (.png, .bmp, .tga, .jpg, .ppm, .hdr)\n", argv[2]); return 2; }
 	for (int i = first_opt; i < argc; i++) {
 		if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { fprintf(stderr, "bad size\n"); return 2; } }
 		else if (!strcmp(argv[i], "-n") && i + 1 < argc) spp = atoi(argv[++i]);
@@ -78,7 +76,17 @@ int main(int argc, char** argv) {
 	if (rc != MIPT_OK) { fprintf(stderr, "render failed (status %d): %s\n", rc, mh_last_error(h)); return 1; }
 	{
 		char why[256];
-		if (mh_save_image(argv[2], mh_image(h), W, H, why, sizeof why) != 0) { fprintf(stderr, "%s: %s\n", argv[2], why); return 1; }   // save_image(argv[2], &raytracer.image[0], W, H)
+		int bad;
+		if (mh_image_format_supported(argv[2], 0)) bad = mh_save_image(argv[2], mh_image(h), W, H, why, sizeof why);   // save_image(argv[2], &raytracer.image[0], W, H)
+		else {
+			// .hdr: the reference hands its 8-bit buffer to the float encoder (utils.cpp:184-190 instantiated for unsigned char reads
+			// W*H*3 floats out of W*H*3 bytes); here the file holds the linear radiance image, imagedouble / sample_count, white = 1
+			std::vector<float> lin((size_t)W * H * 3);
+			const float* acc = mh_imagedouble(h); const float* cnt = mh_sample_count(h);
+			for (size_t i = 0; i < (size_t)W * H; i++) for (int k = 0; k < 3; k++) lin[3 * i + k] = cnt[i] > 0.f ? acc[3 * i + k] / cnt[i] / 196964.7f : 0.f;
+			bad = mh_save_image_f32(argv[2], lin.data(), W, H, 1.f, why, sizeof why);
+		}
+		if (bad) { fprintf(stderr, "%s: %s\n", argv[2], why); return 1; }
 	}
 	auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
 	fprintf(stderr, "%s: load + BVH %.2f s, render %dx%d x %d spp %.2f s -> %s\n", argv[1], secs(t0, t1), W, H, spp, secs(t1, t2), argv[2]);

@@ -4,6 +4,7 @@
 // float arithmetic exactly because the device path consumes them.
 #include "mipt_host.h"
 #include "mipt_jpeg.h"
+#include "mipt_imgwrite.h"
 
 #include <algorithm>
 #include <cmath>
@@ -505,22 +506,36 @@ bool read_image_rgb8(const std::string& file, std::vector<unsigned char>& rgb, i
 
 // save_image for 8-bit RGB (utils.cpp:178-234): the container is chosen by the file name's extension, found anywhere in
 // the lower-cased name like the reference's `ls.find(".png")`, in its order of tests (.hdr, .bmp, .tga, .jpg, .png).
-// PNG (8-bit RGB, zlib deflate, per-row choice among the five scanline filters), 24-bit BMP, uncompressed TGA and binary
-// PPM are written here; what the reference writes through a lossy or float codec (.jpg, .hdr) or through CImg (anything
-// else) is refused loudly instead of being written in another format under that name.
-bool write_image_rgb8(const std::string& file, const unsigned char* rgb, int W, int H, std::string& why) {
-	if (W <= 0 || H <= 0 || !rgb) { why = "empty image"; return false; }
+// PNG (8-bit RGB, zlib deflate, per-row choice among the five scanline filters), 24-bit BMP, uncompressed TGA, baseline JPEG
+// at quality 100 (mipt_imgwrite.h: the bytes of the reference's encoder) and binary PPM are written here.  `.hdr` takes float
+// pixels (write_image_f32 below; the reference's 8-bit instantiation reinterprets its bytes as floats and reads out of
+// bounds, utils.cpp:184-190); what the reference writes through CImg (anything else) is refused loudly instead of being
+// written in another format under that name.
+enum ImageFormat { F_NONE, F_HDR, F_BMP, F_TGA, F_JPG, F_PNG, F_PPM };
+static ImageFormat image_format_of(const std::string& file) {
 	std::string ls(file);
 	for (char& ch : ls) ch = (char)tolower((unsigned char)ch);
 	auto has = [&](const char* ext) { return ls.find(ext) != std::string::npos; };
-	enum { F_PNG, F_BMP, F_TGA, F_PPM } fmt;
-	if (has(".hdr")) { why = "Radiance .hdr output is not written here (float codec of the reference)"; return false; }
-	else if (has(".bmp")) fmt = F_BMP;
-	else if (has(".tga")) fmt = F_TGA;
-	else if (has(".jpg")) { why = "JPEG output is not written here (lossy codec of the reference)"; return false; }
-	else if (has(".png")) fmt = F_PNG;
-	else if (has(".ppm")) fmt = F_PPM;
-	else { why = "unknown image extension (written here: .png, .bmp, .tga, .ppm)"; return false; }
+	return has(".hdr") ? F_HDR : has(".bmp") ? F_BMP : has(".tga") ? F_TGA : has(".jpg") ? F_JPG : has(".png") ? F_PNG : has(".ppm") ? F_PPM : F_NONE;
+}
+static bool write_file(const std::string& file, const std::vector<unsigned char>& out, std::string& why) {
+	FILE* f = fopen(file.c_str(), "wb");
+	if (!f) { why = "cannot create"; return false; }
+	const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+	if (fclose(f) != 0 || !ok) { why = "write failed"; return false; }
+	return true;
+}
+bool write_image_rgb8(const std::string& file, const unsigned char* rgb, int W, int H, std::string& why) {
+	if (W <= 0 || H <= 0 || !rgb) { why = "empty image"; return false; }
+	const ImageFormat fmt = image_format_of(file);
+	if (fmt == F_HDR) { why = "Radiance .hdr stores float pixels: hand the float image to save_image (mh_save_image_f32)"; return false; }
+	if (fmt == F_NONE) { why = "unknown image extension (written here: .png, .bmp, .tga, .jpg, .ppm, and .hdr from float pixels)"; return false; }
+	if (fmt == F_JPG) {
+		if (W > 65535 || H > 65535) { why = "JPEG dimensions are 16-bit"; return false; }
+		std::vector<unsigned char> jpg;
+		mipt_imgwrite::encode_jpeg_q100(rgb, W, H, jpg);
+		return write_file(file, jpg, why);
+	}
 	std::vector<unsigned char> out;
 	auto put = [&](const void* p, size_t n) { out.insert(out.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
 	auto le16 = [&](unsigned v) { unsigned char b[2] = {(unsigned char)v, (unsigned char)(v >> 8)}; put(b, 2); };
@@ -1684,6 +1699,30 @@ int mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char
 	if (write_image_rgb8(file, rgb, W, H, why)) return 0;
 	if (err && errlen > 0) { strncpy(err, why.c_str(), errlen - 1); err[errlen - 1] = 0; }
 	return -1;
+}
+// save_image<float> (utils.cpp:177-211): `.hdr` stores the floats as they are (EncodeRadianceHDR); every other container
+// gets min(255, max(0, val * (255. / maxval))) truncated to a byte, then the 8-bit writer of that container.
+int mh_save_image_f32(const char* file, const float* rgb, int W, int H, float maxval, char* err, int errlen) {
+	std::string why;
+	bool ok = false;
+	if (W <= 0 || H <= 0 || !rgb) why = "empty image";
+	else if (image_format_of(file) == F_HDR) {
+		std::vector<unsigned char> out;
+		mipt_imgwrite::encode_radiance_hdr(rgb, W, H, 3, out);
+		ok = write_file(file, out, why);
+	} else {
+		std::vector<unsigned char> scaled((size_t)W * H * 3);
+		for (size_t i = 0; i < scaled.size(); i++) scaled[i] = (unsigned char)std::min(255., std::max(0., rgb[i] * (255. / maxval)));
+		ok = write_image_rgb8(file, scaled.data(), W, H, why);
+	}
+	if (ok) return 0;
+	if (err && errlen > 0) { strncpy(err, why.c_str(), errlen - 1); err[errlen - 1] = 0; }
+	return -1;
+}
+// Is there a writer for this output name (8-bit pixels; for_float: float pixels)?  Looks at the name only: nothing is created.
+int mh_image_format_supported(const char* file, int for_float) {
+	const ImageFormat f = image_format_of(file ? file : "");
+	return f != F_NONE && (for_float || f != F_HDR);
 }
 int mh_save_scene(mh_raytracer* h, const char* scn) { return h->rt.save_scene(scn) ? 0 : -1; }
 int mh_num_objects(mh_raytracer* h) { return (int)h->rt.s.objects.size(); }

@@ -271,6 +271,8 @@ void mh_add_keyframe(mh_raytracer*, int obj, int frame);      // Object::add_key
 void mh_set_object_transform(mh_raytracer*, int obj, const float* translation3, const float* rotation9, float scale);   // max_translation, mat_rotation, scale
 int  mh_load_scene_subst(mh_raytracer*, const char* scn_file, const char* replacedNames);   // Raytracer::load_scene(filename, replacedNames): the '#' of mesh names
 int  mh_save_image(const char* file, const unsigned char* rgb, int W, int H, char* err, int errlen);   // save_image (utils.cpp:178-234) for 8-bit RGB: .png / .bmp / .tga / .ppm by extension; -1 + text otherwise
+int mh_save_image_f32(const char* file, const float* rgb, int W, int H, float maxval, char* err, int errlen);   // save_image<float>: .hdr (Radiance RGBE) keeps the floats
+int mh_image_format_supported(const char* file, int for_float);   // a writer exists for this output name (name only: nothing is created)
 int  mh_save_scene(mh_raytracer*, const char* scn_file);   // Raytracer::save_scene
 int  mh_num_objects(mh_raytracer*);
 void mh_get_scene_header(mh_raytracer*, float* out32);     // W,H,nrays,bounces, cam pos/dir/up, fov, focus, aperture, sigma, gamma, intensite_lum, intensite_envmap, frustum t

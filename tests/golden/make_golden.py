@@ -199,7 +199,7 @@ def main():
     print("c0 mean", float((img / np.maximum(cnt, 1)[..., None]).mean() / 196964.7))
 
 
-if __name__ == "__main__" and "--spheres" not in sys.argv and "--keyframes" not in sys.argv and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv:
+if __name__ == "__main__" and "--spheres" not in sys.argv and "--keyframes" not in sys.argv and "--denoiser-inputs" not in sys.argv and "--compositing" not in sys.argv and "--fog" not in sys.argv and "--subsurface" not in sys.argv and "--jpeg" not in sys.argv and "--lenticular" not in sys.argv and "--image-writers" not in sys.argv:
     main()
 
 
@@ -556,3 +556,60 @@ def main_spheres():
 
 if __name__ == "__main__" and "--spheres" in sys.argv:
     main_spheres()
+
+
+
+def main_image_writers():
+    """tests/golden/image_writers.npz: the FILES the reference's save_image (utils.cpp:177-234) writes — `.jpg` through its
+    vendored encoder at quality 100 for 8-bit pixels, `.hdr` through EncodeRadianceHDR for float pixels — for a few small
+    synthetic images (sizes that are not multiples of 8, a single pixel, rows longer than one 127-byte literal chunk,
+    zero / tiny / huge float values), plus the `.jpg` the float instantiation writes (its scaling to bytes)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    R = Ref()
+    g = {}
+    tmpdir = os.path.join(OUT, "_tmp_writers")
+    os.makedirs(tmpdir, exist_ok=True)
+
+    def pattern(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 7.) * np.cos(y / 5.), 127 + 100 * np.cos(x / 3. + y / 11.), (x * 3 + y * 5) % 256], -1)
+        return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+    sizes = [(37, 53), (8, 8), (1, 1), (16, 24), (9, 130), (64, 3)]
+    for n, (h, w) in enumerate(sizes):
+        img = np.ascontiguousarray(pattern(h, w))
+        if n == 3:
+            img[:] = rng.integers(0, 256, img.shape, dtype=np.uint8)           # noise: every coefficient alive, long codes, 0xFF stuffing
+        f = os.path.join(tmpdir, f"u8_{n}.jpg")
+        R.lib.ref_save_image_u8(f.encode(), img.ctypes.data_as(C.c_void_p), w, h)
+        g[f"u8_{n}"] = img
+        g[f"jpg_{n}"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+    for n, (h, w) in enumerate([(5, 7), (3, 130), (1, 1), (4, 300)]):
+        fl = np.exp(rng.normal(0, 4, (h, w, 3))).astype(np.float32)
+        fl[rng.random((h, w)) < 0.15] = 0.0
+        fl[rng.random((h, w)) < 0.1] *= np.float32(1e-18)
+        fl[rng.random((h, w)) < 0.05] *= np.float32(1e12)
+        if n == 0:
+            fl[0, 0] = (-1.0, 0.5, 0.25)                                        # a negative channel beside positive ones
+            fl[0, 1] = (1.0, 1.0, 1.0)
+        fl = np.ascontiguousarray(fl)
+        f = os.path.join(tmpdir, f"f32_{n}.hdr")
+        R.lib.ref_save_image_f32.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        R.lib.ref_save_image_f32(f.encode(), fl.ctypes.data_as(C.c_void_p), w, h, C.c_float(255.0))
+        g[f"f32_{n}"] = fl
+        g[f"hdr_{n}"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+    # save_image<float> into an 8-bit container: val * (255. / maxval), clamped, truncated
+    fl = np.ascontiguousarray((rng.random((11, 13, 3)) * 1.3 - 0.1).astype(np.float32))
+    f = os.path.join(tmpdir, "f32_scaled.jpg")
+    R.lib.ref_save_image_f32(f.encode(), fl.ctypes.data_as(C.c_void_p), 13, 11, C.c_float(1.0))
+    g["f32_scaled"] = fl
+    g["jpg_f32_scaled"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+    import shutil
+    shutil.rmtree(tmpdir)
+    g["n_u8"] = np.int32(len(sizes)); g["n_f32"] = np.int32(4)
+    np.savez_compressed(os.path.join(OUT, "image_writers.npz"), **g)
+    print("image writers:", {k: v.size for k, v in g.items() if k.startswith(("jpg", "hdr"))})
+
+
+if __name__ == "__main__" and "--image-writers" in sys.argv:
+    main_image_writers()

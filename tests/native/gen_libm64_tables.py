@@ -7,6 +7,22 @@ known independently (first entries, constants next to the table) before anything
 """
 import math, os, struct, sys
 
+LICENCE = """//
+// PROVENANCE AND LICENCE.  These arrays are numeric constant tables of the GNU C Library (glibc 2.35, Ubuntu 22.04's
+// libm.so.6), read out of the shipped binary's .rodata — the same values as sysdeps/ieee754/dbl-64/{e_exp_data.c,
+// e_pow_log_data.c, sincostab.c, asincos.tbl, uatan.tbl, root.tbl} of the glibc source tree.  glibc is
+//   Copyright (C) Free Software Foundation, Inc.,
+// distributed under the GNU Lesser General Public License, version 2.1 or (at your option) any later version
+// (https://www.gnu.org/licenses/old-licenses/lgpl-2.1.html); the exp / pow tables originate from ARM's optimized-routines
+// (Copyright (C) Arm Limited, MIT licence) and the sin / cos / asin / atan tables from the IBM Accurate Mathematical Library
+// (Copyright (C) IBM / Free Software Foundation, LGPL-2.1-or-later).  This file and csrc/mipt_libm64.h (the routines
+// restated from the same library so that the device computes what the reference's libm calls return) are therefore
+// LGPL-2.1-or-later material embedded in this library: redistribute the library under terms compatible with it (the
+// relinking requirement of LGPL section 6 is met by shipping this source; the generator, tests/native/gen_libm64_tables.py,
+// regenerates the file from any installed glibc 2.35 libm.so.6).  Nothing here comes from the reference repository.
+"""
+
+
 LIBM = sys.argv[1] if len(sys.argv) > 1 else "/lib/x86_64-linux-gnu/libm.so.6"
 EXP_DATA = 0xaf960       # struct exp_data: invln2N, shift, negln2hiN, negln2loN, poly[4], exp2_shift, exp2_poly[5], tab[2*128]
 POW_LOG_DATA = 0xb1b20   # struct pow_log_data: ln2hi, ln2lo, poly[7], tab[128] of {invc, pad, logc, logctail}
@@ -53,7 +69,7 @@ for i in (0, 100, 240):
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "pathtracer_amd", "csrc", "mipt_libm64_tables.h")
 with open(out, "w") as f:
     f.write("// mipt_libm64_tables.h — GENERATED by tests/native/gen_libm64_tables.py from the installed libm.so.6 (glibc 2.35): the tables of\n"
-            "// the double-precision exp / pow (exp_data.tab, pow_log_data.tab), sin / cos (__sincostab), acos (asncs, inroot) and atan2 (cij).  Bit patterns, not decimal.\n#pragma once\n#include <stdint.h>\n")
+            "// the double-precision exp / pow (exp_data.tab, pow_log_data.tab), sin / cos (__sincostab), acos (asncs, inroot) and atan2 (cij).  Bit patterns, not decimal.\n" + LICENCE + "#pragma once\n#include <stdint.h>\n")
     def arr(name, vals, per):
         f.write("MIPT_L64_TABLE uint64_t %s[%d] = {\n" % (name, len(vals)))
         for i in range(0, len(vals), per):

@@ -92,8 +92,8 @@ def test_light_linearity_and_weights(c1):
 
 def test_c2_workload_oracle_subset():
     """configs[2] at reduced tessellation (80 000 triangles so the oracle builds in seconds), full-size
-    textures, env map and frame: oracle on a random subset of (pixel, sample) pairs; L-inf tolerance of the
-    north star (acosf / atan2f of the env-map lookup are the device library's)."""
+    textures, env map and frame: oracle on a random subset of (pixel, sample) pairs, bit for bit (acosf / atan2f of the
+    env-map lookup are glibc's algorithms, csrc/mipt_invtrig.h) — the every-pixel test below asserts the same at full size."""
     from oracle.binding import Oracle
     mesh, cfg, mat, _ = scenes.workload("c2", spp=SPP, grid=200)
     rng = np.random.default_rng(12)
@@ -111,7 +111,7 @@ def test_c2_workload_oracle_subset():
     assert_bits(got_j, want_j, "jitter")
     err = np.abs(got.astype(np.float64) - want).max() / WHITE
     assert err < 1e-4, err                                   # north-star tolerance: per-pixel L-inf < 1e-4 on radiance / 196964.7
-    assert bits_equal(got, want).mean() > 0.95
+    assert_bits(got, want, "per-sample radiance")
 
 
 @pytest.mark.parametrize("wl,grid", [("c3", 200), ("c4", 160)])
@@ -199,7 +199,7 @@ def test_c4_real_geometry_oracle_subset():
     """configs[4] with its REAL geometry: 23 697 288 triangles (15 M nodes: the one config whose BVH exceeds the Infinity
     Cache), the tree built on the GPU (mipt_build_bvh), MERL table, thin-lens depth of field, 3840x2160.  The oracle builds
     its own tree with the reference's serial recursion and evaluates 2 000 random (pixel, sample) pairs; both schedulers
-    must return the same radiance bit for bit.  (About two minutes, nearly all of it the oracle's serial BVH build.)"""
+    must return the same radiance bit for bit.  (The oracle's threaded host build of the 23.7 M-triangle tree is most of its ~10 s.)"""
     from oracle.binding import Oracle
     mesh, cfg, mat, text = scenes.workload("c4", spp=SPP)
     assert mesh.ntri > 23_000_000, text

@@ -5,11 +5,10 @@ golden vectors generated from the compiled reference, and the oracle on fresh ra
 Bars: ray-level results (hit / object / triangle / t / P / normal / occlusion) are pure IEEE
 +,-,*,/,sqrt arithmetic and must be BIT-EXACT.  Per-sample radiance and the single-pass splatted
 image must be BIT-EXACT on every golden scene: sinf / cosf / powf / acosf / atan2f / expf / logf and the
-fp64 exp / pow / sincos (random_Phong, the MERL transform, the subsurface weight) are the host libm's
-algorithms (csrc/mipt_sincos.h, mipt_powf.h, mipt_invtrig.h, mipt_explog.h, mipt_libm64.h).  What still
-comes from the device library is the fp64 acos / atan2 of the MERL transform, which only select table
-cells.  The north-star tolerance, per-pixel L_inf < 1e-4 on radiance / 196964.7, is asserted beside the
-bit checks.
+fp64 exp / pow / sincos / acos / atan2 (random_Phong, the MERL transform, the subsurface weight) are the host
+libm's algorithms (csrc/mipt_sincos.h, mipt_powf.h, mipt_invtrig.h, mipt_explog.h, mipt_libm64.h): no
+transcendental of the path comes from the device library.  The north-star tolerance, per-pixel
+L_inf < 1e-4 on radiance / 196964.7, is asserted beside the bit checks.
 """
 import numpy as np
 import pytest
