@@ -43,6 +43,15 @@
 #ifndef MIPT_PREFETCH_IDS
 #define MIPT_PREFETCH_IDS 0
 #endif
+#ifndef MIPT_TRAV_STATE_NT
+#define MIPT_TRAV_STATE_NT 0            // the traversal reads rays and writes hit records with the streaming cache policy (as generate / shade do)
+#endif
+#ifndef MIPT_LEAF_PER_LANE
+#define MIPT_LEAF_PER_LANE 0            // probe: every leaf through the per-lane loop (no dense packing over the wave)
+#endif
+#ifndef MIPT_INNER_V2
+#define MIPT_INNER_V2 1                 // the inner step re-written against the measured issue costs (round 3)
+#endif
 #ifndef MIPT_PULL_DIV
 #define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
 #endif
@@ -75,7 +84,7 @@ struct LaneState {
 // One object of Scene::intersection / intersection_shadow for the lanes whose next object is `i`
 // (i is wave-uniform, so the object's description is fetched with scalar loads).  Returns true when
 // the lane has to start traversing mesh i (its traversal state is then set up).
-template <bool SHADOW>
+template <bool SHADOW, bool QUAD = false>
 __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 rd, LaneState& st, bool skip_ghosts) {
 	if (SHADOW && skip_ghosts && o.ghost) return false;          // getColor's shadow rays pass through ghost objects (Geometry.cpp:722, Raytracer.cpp:513)
 	f3 d = xf_dir(o.inv, rd);
@@ -100,7 +109,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 	if (!enter) return false;
 	st.o_xy = (mipt_f2){org.x, org.y}; st.i_xy = (mipt_f2){invd.x, invd.y}; st.oz_iz = (mipt_f2){org.z, invd.z}; st.d = d;
 	if (SHADOW) st.t = cur_best_t;
-	st.cur = o.root_ref; st.sp = 0;
+	st.cur = QUAD ? o.root_qref : o.root_ref; st.sp = 0;
 	return true;
 }
 
@@ -126,7 +135,7 @@ struct TravQueue {
 // frame of ONE mesh (wf.ray_o.w = max_t, wf.ray_d.w = the object), the traversal is the closest-hit one with the far bound
 // fixed at max_t, and every triangle hit in [0, max_t) draws one number from the sample's engine (wf.rng) in visiting order and
 // replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
-template <bool SHADOW, bool RESV = false>
+template <bool SHADOW, bool RESV = false, bool QUAD = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
                                                const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
 	const int inner_min = inner_min_flags & 0xffff;
@@ -237,19 +246,19 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		} else if (__ballot(need)) {
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
 			if (need) {
-				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
-				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
+				float4 o4 = MIPT_TRAV_STATE_NT ? wf_ld(SHADOW ? &wf.sh_o[st.id] : &wf.ray_o[st.id]) : (SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id]);
+				float4 d4 = MIPT_TRAV_STATE_NT ? wf_ld(SHADOW ? &wf.sh_d[st.id] : &wf.ray_d[st.id]) : (SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id]);
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
 				if (!SHADOW && st.obj == first_mesh) {                                                       // a fresh ray: what the analytic objects left
 					st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
-					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
+					if (MIPT_HIT_WRITE_THROUGH) { if (MIPT_TRAV_STATE_NT) wf_st(&wf.hit[st.id], make_float4(o4.w, 0.f, 0.f, d4.w)); else wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w); }
 				}
 			}
 			if (need) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {
 				if (need && st.obj == i) {
 					const float t_before = st.t;
-					const bool enter_mesh = visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
+					const bool enter_mesh = visit_object<SHADOW, QUAD>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
 					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI));
 					if (enter_mesh) { need = false; alive = true; }
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
@@ -280,6 +289,142 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		// ---- inner-node phase: every live lane descends until it holds a leaf or runs out of nodes
 		//      (the phase also ends when fewer than inner_min lanes are still descending while others
 		//      already wait with a leaf: the stragglers simply resume in the next round)
+		if (QUAD) {
+			// Two tree levels per step on 128-byte quad nodes (mipt_scene.h): the visit of an even-depth node N and of the child
+			// the ray enters first, from ONE fetch; a popped far child (MIPT_QHALF) fetches its parent's record again and tests
+			// its own two children only.  Slab distances of N's children = min / max of their children's (monotone in the
+			// plane: the same bits), everything else is the two-box step twice, in the reference's order.
+			const float s_ox = st.o_xy.x, s_oy = st.o_xy.y, s_oz = st.oz_iz.x, s_ix = st.i_xy.x, s_iy = st.i_xy.y, s_iz = st.oz_iz.y;
+			const bool sx = s_ix >= 0, sy = s_iy >= 0, sz = s_iz >= 0;
+			const float inf = __int_as_float(0x7f800000);
+			const bool literal = alive && (force_literal || fabsf(s_ix) == inf || fabsf(s_iy) == inf || fabsf(s_iz) == inf);
+			const bool any_literal = __ballot(literal) != 0;
+			const float t_shadow = SHADOW ? fminf(st.t, st.dist) : 0.f;
+			const uint32_t xflip = sx ? 0u : 0x80000000u;
+			const float4* __restrict__ quads = nodes;                       // (the kernel was handed the quad buffer)
+			for (;;) {
+				const bool inner = st.cur < MIPT_NONE;
+				const unsigned long long mi = __ballot(inner);
+				if (mi == 0) break;
+				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
+				if (inner) {
+					MIPT_PROF_COUNT(0)
+					const uint32_t qi = st.cur & MIPT_QIDX_MASK;
+					const bool half = (st.cur & MIPT_QHALF) != 0;
+					const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(quads) + ((size_t)qi << 7));
+					const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+					const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
+					const float t_lim = SHADOW ? t_shadow : st.t;
+					// per grandchild: entry distance clamped at 0 and whether the ray enters it below t_lim; per child the same from the unions
+					float tg0, tg1, tg2, tg3, tc0, tc1;
+					bool gg0, gg1, gg2, gg3, gc0, gc1;
+					if (any_literal) {
+						const f3 s_org = mk3(s_ox, s_oy, s_oz), s_invd = mk3(s_ix, s_iy, s_iz);
+						const f3 b0n = mk3(q0.x, q0.z, q1.x), b0x = mk3(q0.y, q0.w, q1.y), b1n = mk3(q1.z, q2.x, q2.z), b1x = mk3(q1.w, q2.y, q2.w);
+						const f3 b2n = mk3(q3.x, q3.z, q4.x), b2x = mk3(q3.y, q3.w, q4.y), b3n = mk3(q4.z, q5.x, q5.z), b3x = mk3(q4.w, q5.y, q5.w);
+						auto un = [](f3 a, f3 b) { return mk3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); };
+						auto ux = [](f3 a, f3 b) { return mk3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); };
+						auto lit = [&](f3 bn, f3 bx, float& tt) { bool g = box_test<!SHADOW>(bn, bx, s_org, s_invd, sx, sy, sz, tt); g = g && (tt < st.t); if (SHADOW) g = g && (tt < st.dist); return g; };
+						gg0 = lit(b0n, b0x, tg0); gg1 = lit(b1n, b1x, tg1); gg2 = lit(b2n, b2x, tg2); gg3 = lit(b3n, b3x, tg3);
+						gc0 = lit(un(b0n, b1n), ux(b0x, b1x), tc0); gc1 = lit(un(b2n, b3n), ux(b2x, b3x), tc1);
+					} else {
+						QuadSlab a0, a1, a2, a3;
+						quad_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a0);
+						quad_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a1);
+						quad_slab(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a2);
+						quad_slab(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a3);
+						gg0 = quad_accept<!SHADOW>(a0, t_lim, tg0); gg1 = quad_accept<!SHADOW>(a1, t_lim, tg1);
+						gg2 = quad_accept<!SHADOW>(a2, t_lim, tg2); gg3 = quad_accept<!SHADOW>(a3, t_lim, tg3);
+						gc0 = quad_accept<!SHADOW>(quad_union(a0, a1), t_lim, tc0); gc1 = quad_accept<!SHADOW>(quad_union(a2, a3), t_lim, tc1);
+					}
+					// level 1: N's children (TriangleMesh.cpp:1172-1190); a popped far child skips it
+					int side;                                                 // the child whose children are tested now: 0 / 1, 2 = none
+					bool need_pop = false;
+					if (half) side = (st.cur & MIPT_QSIDE) ? 1 : 0;
+					else {
+						const bool leaf0 = r1 == MIPT_QUAD_LEAF_CHILD, leaf1 = r3 == MIPT_QUAD_LEAF_CHILD;
+						const bool left_first = gc0 && (!gc1 || tc0 < tc1);
+						if (gc0 && gc1) {
+							const bool far_leaf = left_first ? leaf1 : leaf0;
+							const uint32_t far_ref = far_leaf ? (left_first ? r2 : r0) : (MIPT_QHALF | (left_first ? MIPT_QSIDE : 0u) | qi);
+							stk.push(st.sp, far_ref, left_first ? tc1 : tc0); st.sp++;
+						}
+						side = 2;
+						if (gc0 || gc1) {
+							const bool near_leaf = left_first ? leaf0 : leaf1;
+							if (near_leaf) st.cur = left_first ? r0 : r2;
+							else side = left_first ? 0 : 1;
+						} else need_pop = true;
+					}
+					// level 2: the children of that child, nothing between the two visits changes t (the reference pushes the near
+					// child and pops it at once)
+					if (side < 2) {
+						const bool ga = side ? gg2 : gg0, gb = side ? gg3 : gg1;
+						const float ta = side ? tg2 : tg0, tb = side ? tg3 : tg1;
+						const uint32_t ra = side ? r2 : r0, rb = side ? r3 : r1;
+						const bool left_first = ga && (!gb || ta < tb);
+						if (ga && gb) { stk.push(st.sp, left_first ? rb : ra, left_first ? tb : ta); st.sp++; }
+						if (ga || gb) st.cur = left_first ? ra : rb;
+						else need_pop = true;
+					}
+					if (need_pop) st.cur = pop_next();
+				}
+			}
+		} else
+#if MIPT_INNER_V2
+		// Round 3: the step priced in issue cycles (profiles/r3_b_instruction_issue_rates.txt: on this chip add / mul / fma / mov /
+		// logic issue at 2 cycles per wave, but min / max / compare / select / anything packed, DPP or with three sources at 4, an
+		// LDS operation at ~11-16).  What that changes: (i) scalar sub + mul instead of the packed pairs (same cycles, six
+		// registers fewer); (ii) one closed form per box with three compares instead of six: with max(t_enter, 0) <= t_exit
+		// standing for !(t_enter > t_exit) & !(t_exit < 0) (box_test_closed, mipt_trace.h); (iii) wave-uniform facts hoisted out
+		// of the loop (does any lane take the literal chain; lanes that are not traversing hold cur == NONE, so "inner" is one
+		// compare on cur instead of a mask product that the compiler materialises through two vector instructions per ballot);
+		// (iv) one push site (the far child chosen by selects) instead of one per order; (v) node addresses as a 32-bit byte
+		// offset on a scalar base.
+		{
+			const float s_ox = st.o_xy.x, s_oy = st.o_xy.y, s_oz = st.oz_iz.x, s_ix = st.i_xy.x, s_iy = st.i_xy.y, s_iz = st.oz_iz.y;
+			const bool sx = s_ix >= 0, sy = s_iy >= 0, sz = s_iz >= 0;     // signs[k] (TriangleMesh.cpp:1145)
+			const float inf = __int_as_float(0x7f800000);
+			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
+			// together with them) use the literal early-out chain
+			const bool literal = alive && (force_literal || fabsf(s_ix) == inf || fabsf(s_iy) == inf || fabsf(s_iz) == inf);
+			const bool any_literal = __ballot(literal) != 0;
+			const float t_lim = SHADOW ? fminf(st.t, st.dist) : 0.f;         // shadow: a child is entered when its t is below both (st.t only shrinks at leaves)
+			for (;;) {
+				const bool inner = st.cur < MIPT_NONE;                       // an inner-node reference (leaves have bit 31, idle lanes hold NONE)
+				const unsigned long long mi = __ballot(inner);
+				if (mi == 0) break;
+				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
+				if (inner) {
+					MIPT_PROF_COUNT(0)
+					const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (size_t)(st.cur << 6));     // (< 2^26 nodes: mipt_upload_scene)
+					const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+					const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+					float tl, tr;
+					bool goleft, goright;
+					if (any_literal) {
+						const f3 s_org = mk3(s_ox, s_oy, s_oz), s_invd = mk3(s_ix, s_iy, s_iz);
+						const f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
+						const f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
+						goleft = box_test<!SHADOW>(lmin, lmax, s_org, s_invd, sx, sy, sz, tl);
+						goright = box_test<!SHADOW>(rmin, rmax, s_org, s_invd, sx, sy, sz, tr);
+						goleft = goleft && (tl < st.t); goright = goright && (tr < st.t);
+						if (SHADOW) { goleft = goleft && (tl < st.dist); goright = goright && (tr < st.dist); }
+					} else {
+						goleft = box_test_closed<!SHADOW>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, tl);
+						goright = box_test_closed<!SHADOW>(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, tr);
+						if (SHADOW) { goleft = goleft && (tl < t_lim); goright = goright && (tr < t_lim); }
+						else { goleft = goleft && (tl < st.t); goright = goright && (tr < st.t); }
+					}
+					// near child first, ties -> right child; the far child is pushed with its tnear (TriangleMesh.cpp:1180-1187)
+					const bool left_first = goleft && (!goright || tl < tr);
+					if (goleft && goright) { stk.push(st.sp, left_first ? rref : lref, left_first ? tr : tl); st.sp++; }
+					if (goleft || goright) st.cur = left_first ? lref : rref;
+					else st.cur = pop_next();
+				}
+			}
+		}
+#else
 		{
 			const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
 			const bool sx = s_invd.x >= 0, sy = s_invd.y >= 0, sz = s_invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
@@ -328,6 +473,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				else st.cur = pop_next();
 			}
 		}
+#endif
 		MIPT_PROF_CLOCK(c2);
 		MIPT_PROF_CYCLES(13, c1, c2)
 		// ---- leaf phase.  The (ray, triangle) tests of all lanes that hold a leaf are packed densely over the
@@ -343,7 +489,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			const int count = leaf ? (int)((st.cur >> 26) & 31u) + 1 : 0;
 			bool per_lane = leaf;
 			if (leaf) MIPT_PROF_COUNT(2)
-			if (!any_alpha) {
+			if (!any_alpha && !MIPT_LEAF_PER_LANE) {
 				const int cnt = count <= 4 ? count : 0;
 				const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
 				if (b1 != 0) {
@@ -370,7 +516,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						if (j < total) {
 							MIPT_PROF_COUNT(4)
 							float a, bb, gg;
-							if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
+							if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0), MIPT_TRI_NT != 0>(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
 						}
 						int wj = 0;
 						bool upd = false;
@@ -401,7 +547,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 							if (!RESV) st.t = cur_t;
 							if (!SHADOW) {
 								const int local = first + win - (int)sc->obj[st.obj].tri_base;
-								if (MIPT_HIT_WRITE_THROUGH && !RESV) wf.hit[st.id] = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
+								if (MIPT_HIT_WRITE_THROUGH && !RESV) { const float4 h4 = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local)); if (MIPT_TRAV_STATE_NT) wf_st(&wf.hit[st.id], h4); else wf.hit[st.id] = h4; }
 								else { st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg; }
 							}
 						}
@@ -415,7 +561,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				for (int i = first; i < first + count; i++) {
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
-					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
+					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0), MIPT_TRI_NT != 0>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
 						bool accept = lt < st.t && (!RESV || lt >= 0.f);
 						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 						if (accept) {
@@ -465,8 +611,11 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // closest-hit queue of depth b + 1 — both were filled by shade(b) and are independent of each other, so one launch serves
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
-template <int MODE>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
+#ifndef MIPT_QUAD_WAVES
+#define MIPT_QUAD_WAVES 6               // waves per SIMD of the quad-node kernels (the step holds a 112-byte record)
+#endif
+template <int MODE, bool QUAD = false>
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD ? MIPT_QUAD_WAVES : (MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES)))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
 	uint32_t ntop = 0;
@@ -483,18 +632,18 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 #endif
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 1 || MODE == 2) traverse_queue<true, false, QUAD>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 0) traverse_queue<false, false, QUAD>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 2) traverse_queue<false, false, QUAD>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
 }
 
 // The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
 // (SHADOW = false: wf.ray_o / ray_d -> wf.hit) or any hits (SHADOW = true: wf.sh_o / sh_d -> tq.vis).
-template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+template <bool SHADOW, bool QUAD = false>
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD ? MIPT_QUAD_WAVES : (SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES)))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
+	traverse_queue<SHADOW, false, QUAD>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).
