@@ -352,6 +352,120 @@ def main():
             except Exception:
                 stream = None
             n_cus = 256
+            clock_ghz = 2.4
+            try:
+                props = torch.cuda.get_device_properties(dev)
+                n_cus = props.multi_processor_count
+                clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6 or 2.4
+            except Exception:
+                pass
+            # ---- what binds the traversal kernel.  Measured live: the launch duration (HIP events on the render
+            # stream) and the capacity of the memory system behind L2 for dependent random fetches (mipt_measure_dependent_gather on a
+            # table of the size of this scene's nodes + triangle records).  Derived from the committed PMC run of the same workload
+            # (profiles/r3_pmc_counters.json, per ray of that run x the rays of this one): L2 misses, L1 lookups, HBM bytes,
+            # instructions, mean vector-memory latency.
+            scene_bytes = int(mesh.ntri) * 64 + int(mesh.ntri) * 64          # ~ one fat node per triangle pair + one record per triangle
+            try:
+                cap_g = rt.measure_dependent_gather(max(64 << 20, scene_bytes), 2000, 2)      # 10^9 line fetches per second
+            except Exception:
+                cap_g = None
+            peak_l1 = n_cus * 64 * clock_ghz                            # GB/s: one 64-byte line lookup per CU and cycle
+            rf = {"bound": "hbm", "achieved": None, "peak": (cap_g * 128.0 if cap_g else None), "unit": "GB/s", "frac": None, "traffic": None,
+                  "bound_note": "the memory system behind L2 (Infinity Cache + HBM) serves DEPENDENT random fetches at a fixed rate of 128-byte lines "
+                                "(peak: measured in this run on a table of the scene's size, mipt_measure_dependent_gather; tools/valu_rate.hip: independent of waves and lanes); "
+                                "achieved = the kernel's L2 misses x 128 B / launch time.  The algorithmic-HBM fraction of SURVEY 8d is > 1 (most node fetches hit L1 / L2)",
+                  "kernel": kernel, "ms_per_launch": ms_per_launch, "launches": int(launches), "rays_per_launch": rays_per_launch,
+                  "frac_algorithmic_hbm": alg_hbm / 8000.0, "algorithmic_hbm_gb_per_s": alg_hbm, "hbm_peak_gb_per_s": 8000.0,
+                  "peak_measured_stream_read": stream, "dependent_gather_glines_per_s": cap_g,
+                  "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
+                  "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"]}
+            pmc_file = os.path.join(ROOT, "profiles", "r3_pmc_counters.json")
+            try:   # per-ray counter values of the dominant kernel from the committed PMC run of the same workload
+                pall = json.load(open(pmc_file))
+                pj = pall[args.workload]
+                pk = pj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
+                secs = ms_per_launch * 1e-3
+                rf["achieved"] = pk["l2_misses_per_ray"] * rays_per_launch * 128.0 / secs / 1e9
+                rf["frac"] = rf["achieved"] / rf["peak"] if rf["peak"] else None
+                rf["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
+                rf["traffic"] = pk["hbm_bytes_per_ray"] * rays_per_launch
+                rf["frac_hbm_measured"] = rf["traffic"] / secs / 8e12
+                lookups = pk["tcp_accesses_per_ray"] * rays_per_launch
+                rf["frac_l1_lookups"] = lookups * 64 / secs / 1e9 / peak_l1
+                rf["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
+                # latency model: rays in flight at FULL lane occupancy / (dependent steps per ray x mean vector-memory latency)
+                waves_per_cu = pk["waves"] / n_cus
+                steps_per_ray = ob["lines_closest"]                    # one dependent fetch per inner node visited and per triangle record tested
+                lat_s = pk["mean_vmem_latency_cycles"] / (clock_ghz * 1e9)
+                attainable = waves_per_cu * 64 * n_cus / (steps_per_ray * lat_s)
+                rf["frac_latency_model"] = (rays_per_launch / secs) / attainable
+                rf["latency_model"] = {"resident_waves_per_cu": waves_per_cu, "dependent_fetches_per_ray": steps_per_ray, "mean_vmem_latency_cycles": pk["mean_vmem_latency_cycles"],
+                                       "attainable_grays_per_s_at_full_lane_occupancy": attainable / 1e9, "wait_share_of_wave_cycles": pk["wait_share_of_wave_cycles"]}
+                # instruction issue: a vector instruction holds its SIMD 2 (add / mul / fma / mov / logic) or 4 cycles (min / max / compare / select /
+                # packed / DPP), a scalar one 4 cycles of the SIMD's scalar slot (profiles/r3_b_instruction_issue_rates.txt)
+                simd_cycles = 4 * n_cus * clock_ghz * 1e9 * secs
+                rf["valu_issue_busy_2_to_4_cycles"] = [2 * pk["valu_per_ray"] * rays_per_launch / simd_cycles, 4 * pk["valu_per_ray"] * rays_per_launch / simd_cycles]
+                rf["salu_issue_busy"] = 4 * pk["salu_per_ray"] * rays_per_launch / simd_cycles
+                rf["pmc_source"] = pj["source"]
+                import hashlib
+                lib_sha = hashlib.sha256(open(os.path.join(ROOT, "pathtracer_amd", os.path.basename(os.environ.get("MIPT_LIB_OVERRIDE", "libmipt.so"))), "rb").read()).hexdigest()[:16]
+                rf["derived_from_pmc_run"] = {"git_commit": pall.get("_build", {}).get("git_commit"), "same_library_build": pall.get("_build", {}).get("libmipt_sha256_16") == lib_sha}
+            except Exception as e:
+                rf["pmc_note"] = "profiles/r3_pmc_counters.json has no entry for this workload / kernel (%s: %s)" % (type(e).__name__, e)
+            out["roofline"] = rf
+            if pipeline == 1 and sh_launches:
+                sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
+                rs = {"kernel": "k_wf_traverse<1> (any-hit / shadow stage)", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
+                      "launches": int(sh_launches), "rays_per_launch": rays_s / sh_launches, "l1_lookups_per_ray_algorithmic": ob["lines_shadow"]}
+                try:
+                    pk = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_traverse<1>"]
+                    secs = sh_ms / sh_launches * 1e-3
+                    rs["frac"] = (pk["l2_misses_per_ray"] * rays_s / sh_launches * 128.0 / secs / 1e9) / rf["peak"] if rf["peak"] else None
+                    rs["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
+                    rs["frac_l1_lookups"] = pk["tcp_accesses_per_ray"] * rays_s / sh_launches * 64 / secs / 1e9 / peak_l1
+                    rs["frac_hbm_measured"] = pk["hbm_bytes_per_ray"] * rays_s / sh_launches / secs / 8e12
+                except Exception:
+                    pass
+                out["roofline_shadow_kernel"] = rs
+            if pipeline == 1 and shade_ms > 0:
+                # the shade stage: algorithmic path-state bytes per vertex (what a vertex must read and write: ray 32, weight 16, engine 8, hit 16,
+                # colour 16 in; ray 32, weight 16, engine 8, shadow request 48, colour 16, queue entries 8 out = 88 + 128, plus one 64-byte
+                # shading record) x vertices / stage time, against the HBM peak
+                verts = rays_c                                            # one shade vertex per closest-hit ray
+                state_bytes = 88 + 128 + 64
+                shade_secs = (shade_ms - 0.0) * 1e-3
+                rsh = {"kernel": "k_wf_generate + k_wf_shade<1,2> (per step)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_vertex": state_bytes,
+                       "vertices_per_step": verts / args.steps, "ms_per_step": shade_ms / args.steps,
+                       "achieved": verts * state_bytes / shade_secs / 1e9, "frac": verts * state_bytes / shade_secs / 8e12}
+                try:
+                    pks = json.load(open(pmc_file))[args.workload]["kernels"]
+                    tr = sum(pks[k]["hbm_bytes_per_launch"] for k in pks if k.startswith("k_wf_shade")) * max(1, launches) + pks["k_wf_generate"]["hbm_bytes_per_launch"] * (launches / max(1, cfg.nb_bounces))
+                    rsh["traffic"] = tr / args.steps
+                    rsh["frac_hbm_measured"] = tr / shade_secs / 8e12
+                except Exception:
+                    pass
+                out["roofline_shade_kernel"] = rsh
+            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
+        if world == 1 and not in_process and not args.pmc:
+            ob = oracle_bytes_per_ray(mesh, mat, cfg)
+            my_launches = max(1, launches)
+            ms_per_launch = kern_ms / my_launches
+            if pipeline == 0:     # one kernel casts both kinds of rays
+                kernel = "k_render_paths"
+                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
+            elif merged:          # dominant kernel = the traversal kernel, whose launches serve closest-hit and any-hit queues
+                kernel = "k_wf_traverse (closest-hit and any-hit queues; shadow(b) + extend(b+1) share a launch)"
+                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
+            else:                 # dominant kernel = closest-hit traversal
+                kernel = "k_wf_traverse<0> (closest-hit / extend stage)"
+                bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
+            alg_hbm = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            rays_per_launch = (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches
+            try:
+                stream = rt.measure_stream_read(8 << 30, 5)      # achievable read bandwidth of this device
+            except Exception:
+                stream = None
+            n_cus = 256
             try:
                 n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
             except Exception:

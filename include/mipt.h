@@ -286,6 +286,11 @@ int mipt_measure_stream_read(mipt_ctx* ctx, uint64_t bytes, int repeats, double*
  * node) gathered at pseudo-random 64-byte-aligned offsets of a `buffer_bytes` buffer; gb_per_s counts 64 bytes per record.
  * Under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter for gathers (tools/fetch_calibration.py). */
 int mipt_measure_gather_read(mipt_ctx* ctx, uint64_t buffer_bytes, uint64_t records, int repeats, double* gb_per_s);
+/* Rate, in 10^9 fetches per second, of DEPENDENT random 64-byte fetches from a table of `table_bytes` (rounded down to a power
+   of two of records): every lane of the chip walks a random cycle, four 16-byte loads per step.  The ceiling of the memory
+   system behind L2 for the access pattern of a BVH traversal step; bench.py prices the traversal kernel's L2 misses against it.
+   (Measurement aid like the two above: no counterpart in the reference.) */
+int mipt_measure_dependent_gather(mipt_ctx* ctx, uint64_t table_bytes, int steps, int repeats, double* gfetches_per_s);
 
 /* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
  * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes

@@ -27,7 +27,7 @@ MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
                 "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs"]
 
 _f = C.c_float
@@ -561,6 +561,12 @@ class HostRaytracer:
         """GB/s of 64-byte records gathered at random 64-byte-aligned offsets (mipt_measure_gather_read)."""
         out = C.c_double(0.0)
         self._check(self.mipt.mipt_measure_gather_read(self.ctx, C.c_uint64(buffer_bytes), C.c_uint64(records), int(repeats), C.byref(out)), "mipt_measure_gather_read")
+        return out.value
+
+    def measure_dependent_gather(self, table_bytes=256 << 20, steps=2000, repeats=2):
+        """10^9 dependent random 64-byte fetches per second from a table of that size (mipt_measure_dependent_gather)."""
+        out = C.c_double(0.0)
+        self._check(self.mipt.mipt_measure_dependent_gather(self.ctx, C.c_uint64(table_bytes), int(steps), int(repeats), C.byref(out)), "mipt_measure_dependent_gather")
         return out.value
 
     def stats(self):

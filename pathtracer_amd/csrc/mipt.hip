@@ -891,6 +891,28 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			int rc = upload_tex_list(c, lists[sl], counts[sl], &d.tex[sl]);
 			if (rc) return rc;
 		}
+		{   // the flattened group table (DGroupMat, mipt_scene.h)
+			const int mslots[5] = {MT_KD, MT_KS, MT_NE, MT_TRANSP, MT_REFR};
+			int ng = 0;
+			for (int sl : mslots) ng = std::max(ng, counts[sl]);
+			std::vector<DGroupMat> gm((size_t)ng + 1);
+			for (int g = 0; g <= ng; g++) {
+				DGroupMat& r = gm[g];
+				memset(&r, 0, sizeof r);
+				const float dKd[3] = {1, 1, 1}, dKs[3] = {0, 0, 0}, dNe[3] = {1, 1, 1};
+				memcpy(r.Kd, dKd, 12); memcpy(r.Ks, dKs, 12); memcpy(r.Ne, dNe, 12); r.transp_val = 1.f; r.refr = 1.3f;
+				if (g == ng) continue;                                   // the record of every group index outside the lists
+				auto entry = [&](int sl) -> const mipt_texture* { return g < counts[sl] ? &lists[sl][g] : nullptr; };
+				if (const mipt_texture* t = entry(MT_KD)) { if (t->W > 0) r.image_mask |= 1u << MT_KD; else memcpy(r.Kd, t->multiplier, 12); }
+				if (const mipt_texture* t = entry(MT_KS)) { if (t->W > 0) r.image_mask |= 1u << MT_KS; else memcpy(r.Ks, t->multiplier, 12); }
+				if (const mipt_texture* t = entry(MT_NE)) { if (t->W > 0) r.image_mask |= 1u << MT_NE; else memcpy(r.Ne, t->multiplier, 12); }
+				if (const mipt_texture* t = entry(MT_TRANSP)) { if (t->W > 0) r.image_mask |= 1u << MT_TRANSP; else r.transp_val = t->multiplier[0]; }
+				if (const mipt_texture* t = entry(MT_REFR)) { if (t->W > 0) r.image_mask |= 1u << MT_REFR; else r.refr = t->multiplier[0]; }
+			}
+			d.ngroups = ng;
+			int rc = upload(c, gm.data(), gm.size(), &d.gmat);
+			if (rc) return rc;
+		}
 		if (o.type == MIPT_OBJ_SPHERE) {
 			// material lists on a sphere are looked up at the spherical coordinates of its normal (Geometry.h:975-981); normal and
 			// alpha maps are read by TriMesh only (a sphere ignores them), a subsurface colour on a sphere was refused above
@@ -1828,6 +1850,54 @@ extern "C" int mipt_measure_gather_read(mipt_ctx* c, uint64_t buffer_bytes, uint
 	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(buf); hipFree(sink);
 	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
 	*gb_per_s = (double)grid * 256.0 * iters * 64.0 * repeats / (ms * 1e-3) / 1e9;
+	return MIPT_OK;
+}
+
+// Dependent random fetches: every lane walks one random cycle through a table of 64-byte records, four 16-byte loads per
+// step, the next index out of the record: the access pattern of a traversal step that misses the caches.  Its rate is the
+// ceiling of the memory system BEHIND L2 for this pattern (tools/valu_rate.hip: the same whatever the number of waves or
+// active lanes, the same for 128-byte records: a fixed rate of 128-byte line fetches); bench.py prices the traversal's L2
+// misses against it.  The table is a random cyclic permutation built on the device (Sattolo's walk per block is not needed:
+// next = (i * odd + c) mod n with an odd multiplier of a power-of-two n is one cycle covering every record).
+__global__ void __launch_bounds__(256) k_chase_init(float4* __restrict__ tab, unsigned nrec_pow2) {
+	const unsigned mask = nrec_pow2 - 1u;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec_pow2; i += gridDim.x * blockDim.x) {
+		const unsigned nxt = (i * 2654435761u + 0x9e3779b1u) & mask;                 // odd multiplier: a bijection of [0, 2^k)
+		tab[4 * (size_t)i] = make_float4(__uint_as_float(nxt), 0.f, 0.f, 0.f);
+		tab[4 * (size_t)i + 1] = tab[4 * (size_t)i + 2] = tab[4 * (size_t)i + 3] = make_float4(1.f, 2.f, 3.f, 4.f);
+	}
+}
+__global__ void __launch_bounds__(256) k_chase(const float4* __restrict__ tab, unsigned nrec_pow2, int steps, unsigned* __restrict__ sink) {
+	unsigned cur = ((blockIdx.x * 256u + threadIdx.x) * 2246822519u) & (nrec_pow2 - 1u);
+	unsigned acc = 0;
+	for (int i = 0; i < steps; i++) {
+		const float4* q = tab + 4 * (size_t)cur;
+		const float4 a = q[0], b = q[1], c2 = q[2], d = q[3];
+		acc += __float_as_uint(a.y) ^ __float_as_uint(b.x) ^ __float_as_uint(c2.x) ^ __float_as_uint(d.x);
+		cur = __float_as_uint(a.x);
+	}
+	if (acc == 0x12345678u) sink[0] = cur;
+}
+extern "C" int mipt_measure_dependent_gather(mipt_ctx* c, uint64_t table_bytes, int steps, int repeats, double* glines_per_s) {
+	if (!c || !glines_per_s || table_bytes < (1u << 20) || steps < 1 || repeats < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	unsigned nrec = 1u;
+	while ((uint64_t)nrec * 2u * 64u <= table_bytes && nrec < (1u << 30)) nrec *= 2u;    // the largest power of two of 64-byte records that fits
+	float4* tab = nullptr; unsigned* sink = nullptr;
+	HIPCHK(c, hipMalloc(&tab, (size_t)nrec * 64));
+	if (hipMalloc(&sink, 4) != hipSuccess) { hipFree(tab); return fail(c, MIPT_ERR_HIP, "hipMalloc failed"); }
+	hipLaunchKernelGGL(k_chase_init, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, 0, tab, nrec);
+	const unsigned grid = (unsigned)c->n_cus * 4u;                 // 4 waves per SIMD: the rate does not depend on it (2 .. 8 measured)
+	hipLaunchKernelGGL(k_chase, dim3(grid), dim3(256), 0, 0, tab, nrec, std::min(steps, 64), sink);   // warm-up
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0, 0);
+	for (int r = 0; r < repeats; r++) hipLaunchKernelGGL(k_chase, dim3(grid), dim3(256), 0, 0, tab, nrec, steps, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(tab); hipFree(sink);
+	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
+	*glines_per_s = (double)grid * 256.0 * steps * repeats / (ms * 1e-3) / 1e9;
 	return MIPT_OK;
 }
 

@@ -49,8 +49,11 @@
 #ifndef MIPT_LEAF_PER_LANE
 #define MIPT_LEAF_PER_LANE 0            // probe: every leaf through the per-lane loop (no dense packing over the wave)
 #endif
+#ifndef MIPT_NODE_REFS_X2
+#define MIPT_NODE_REFS_X2 0
+#endif
 #ifndef MIPT_INNER_V2
-#define MIPT_INNER_V2 1                 // the inner step re-written against the measured issue costs (round 3)
+#define MIPT_INNER_V2 0                 // 1 = the inner step re-written against the measured issue costs (round 3: -9 % vector instructions, bit-identical, 2 % SLOWER on every config: profiles/r3_c_traversal_experiments.txt)
 #endif
 #ifndef MIPT_PULL_DIV
 #define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
@@ -448,7 +451,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					q0 = lds_ld4(l + (r & 3)); q1 = lds_ld4(l + ((r + 1) & 3)); q2 = lds_ld4(l + ((r + 2) & 3)); q3 = lds_ld4(l + ((r + 3) & 3));
 				} else {
 					const float4* q = nodes + 4 * (size_t)st.cur;
-					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+					q0 = q[0]; q1 = q[1]; q2 = q[2];
+					if (MIPT_NODE_REFS_X2) { const float2 r2 = *reinterpret_cast<const float2*>(q + 3); q3 = make_float4(r2.x, r2.y, 0.f, 0.f); }      // the two references: 8 bytes (a dwordx2: half the address-unit cycles of a dwordx4)
+					else q3 = q[3];
 				}
 				uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 				float tl, tr;

@@ -66,6 +66,20 @@ struct DTriIsect { float A[3], u[3], v[3]; float invdetm, m11, m12, m22; float N
 #define MIPT_GROUP_MASK 0x3fffffff
 struct DTriShade { float normals[9]; float uvs[6]; int group; };                    // 64 B (group: material group | MIPT_GROUP_UV_OK)
 
+// What Object::queryMaterial (Geometry.h:399-445) returns for ONE material group of one object, flattened at upload: per
+// slot the constant colour of its list entry (Texture::multiplier when the entry has no image) or the reference's default
+// when the list is shorter than the group index.  Slots whose entry is an image (bit s of image_mask) still go through the
+// entry's descriptor.  Round 3: a vertex read its five slots through 25 dependent little loads (list length, list pointer,
+// three fields of the entry, per slot) and the CU issues one vector-memory instruction per ~10 ns whatever its width
+// (profiles/r3_b_instruction_issue_rates.txt): three 16-byte loads of this record replace them.
+struct DGroupMat {
+	float Kd[3], Ks[3], Ne[3];
+	float transp_val;          // mat.transp = transp_val < 0.5f (default list: 1.0 -> false)
+	float refr;                // default 1.3
+	uint32_t image_mask;
+	uint32_t _pad[4];
+};
+
 struct DObject {
 	int type, miroir, flip_normals, interp_normals;
 	float inv[12], trans[12], rot[9];
@@ -73,6 +87,8 @@ struct DObject {
 	const double* merl;
 	int ntex[MIPT_TEX_SLOTS];
 	const DTex* tex[MIPT_TEX_SLOTS];
+	const DGroupMat* gmat;     // [ngroups + 1]: groups 0 .. ngroups-1 (ngroups = the longest of the Kd / Ks / Ne / transp / refr lists), then the all-defaults record
+	int ngroups;
 	// Sphere
 	float O[3], R, R2;
 	int has_envmap, envW, envH;

@@ -242,15 +242,38 @@ MIPT_DEV f3 tex_getNormal(const DTex& tg, float u, float v) {  // BRDF.h:347-357
 }
 // Object::queryMaterial (Geometry.h:399-445).  idx is compared as size_t in the reference, so a
 // negative group selects the defaults.
+#ifndef MIPT_GROUP_TABLE
+#define MIPT_GROUP_TABLE 1
+#endif
 MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& mat) {
 	u = tex_wrap(u);
 	v = tex_wrap(v);
+#if MIPT_GROUP_TABLE
+	// the group's record (three 16-byte loads); only the slots whose entry is an image go through the entry's descriptor
+	typedef float v4f_ __attribute__((ext_vector_type(4)));
+	const unsigned ng = (unsigned)o.ngroups;
+	const unsigned gi = (unsigned)idx < ng ? (unsigned)idx : ng;
+	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(o.gmat + gi);
+	const v4f_ r0 = q[0], r1 = q[1], r2 = q[2];
+	mat.Kd = mk3(r0.x, r0.y, r0.z); mat.Ks = mk3(r0.w, r1.x, r1.y); mat.Ne = mk3(r1.z, r1.w, r2.x);
+	mat.transp = r2.y < 0.5f;                                                                                        // getBool, BRDF.h:335-346
+	mat.refr_index = r2.z;
+	const unsigned images = __float_as_uint(r2.w);
+	if (images != 0) {
+		if (images & (1u << MT_KD)) mat.Kd = tex_getVec(o.tex[MT_KD][idx], u, v);
+		if (images & (1u << MT_KS)) mat.Ks = tex_getVec(o.tex[MT_KS][idx], u, v);
+		if (images & (1u << MT_NE)) mat.Ne = tex_getVec(o.tex[MT_NE][idx], u, v);
+		if (images & (1u << MT_TRANSP)) mat.transp = tex_getValRed(o.tex[MT_TRANSP][idx], u, v) < 0.5f;
+		if (images & (1u << MT_REFR)) mat.refr_index = tex_getValRed(o.tex[MT_REFR][idx], u, v);
+	}
+#else
 	unsigned ui = (unsigned)idx;
 	mat.Kd = (ui >= (unsigned)o.ntex[MT_KD]) ? mk3(1, 1, 1) : tex_getVec(o.tex[MT_KD][idx], u, v);
 	mat.Ks = (ui >= (unsigned)o.ntex[MT_KS]) ? mk3(0, 0, 0) : tex_getVec(o.tex[MT_KS][idx], u, v);
 	mat.Ne = (ui >= (unsigned)o.ntex[MT_NE]) ? mk3(1, 1, 1) : tex_getVec(o.tex[MT_NE][idx], u, v);
 	mat.transp = (ui >= (unsigned)o.ntex[MT_TRANSP]) ? false : (tex_getValRed(o.tex[MT_TRANSP][idx], u, v) < 0.5f);   // getBool, BRDF.h:335-346
 	mat.refr_index = (ui >= (unsigned)o.ntex[MT_REFR]) ? 1.3f : tex_getValRed(o.tex[MT_REFR][idx], u, v);
+#endif
 	mat.Ke = mk3(0, 0, 0);
 	// Ksub is only read by the subsurface branch (out of scope); upload rejects non-zero Ksub.
 }

@@ -198,6 +198,59 @@ static void chase_bench() {
 	}
 }
 
+
+// ---- vector-memory issue: loads that hit L1 (every lane re-reads its own 64 bytes), 8 independent loads then a wait.
+//      Wall nanoseconds per wave-instruction and CU: what the address unit / L1 charge per instruction, by width and by
+//      the number of active lanes.
+template <int WIDTH>
+__global__ void __launch_bounds__(256) k_vmem(const float4* __restrict__ tab, int iters, unsigned active, float* sink) {
+	const unsigned lane = threadIdx.x & 63u;
+	const float4* p = tab + 4 * (size_t)((blockIdx.x * 256u + threadIdx.x) & 4095u);
+	float acc = 0.f;
+	if (lane < active) {
+		for (int i = 0; i < iters; i++) {
+			if (WIDTH == 4) { float4 a, b, c, d;
+				asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n global_load_dwordx4 %3, %4, off offset:48\n"
+				             "global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n global_load_dwordx4 %3, %4, off offset:48\n s_waitcnt vmcnt(0)"
+				             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+				acc += a.x + b.x + c.x + d.x; }
+			else if (WIDTH == 2) { float2 a, b, c, d;
+				asm volatile("global_load_dwordx2 %0, %4, off\n global_load_dwordx2 %1, %4, off offset:16\n global_load_dwordx2 %2, %4, off offset:32\n global_load_dwordx2 %3, %4, off offset:48\n"
+				             "global_load_dwordx2 %0, %4, off\n global_load_dwordx2 %1, %4, off offset:16\n global_load_dwordx2 %2, %4, off offset:32\n global_load_dwordx2 %3, %4, off offset:48\n s_waitcnt vmcnt(0)"
+				             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+				acc += a.x + b.x + c.x + d.x; }
+			else { float a, b, c, d;
+				asm volatile("global_load_dword %0, %4, off\n global_load_dword %1, %4, off offset:16\n global_load_dword %2, %4, off offset:32\n global_load_dword %3, %4, off offset:48\n"
+				             "global_load_dword %0, %4, off\n global_load_dword %1, %4, off offset:16\n global_load_dword %2, %4, off offset:32\n global_load_dword %3, %4, off offset:48\n s_waitcnt vmcnt(0)"
+				             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+				acc += a + b + c + d; }
+		}
+	}
+	if (acc == 12345.f) sink[0] = acc;
+}
+template <int WIDTH>
+static void vmem_bench(const char* name) {
+	float4* tab; float* sink;
+	hipMalloc((void**)&tab, 4096 * 64 + 4096); hipMalloc((void**)&sink, 64);
+	hipMemset(tab, 0, 4096 * 64 + 4096);
+	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+	const int cus = prop.multiProcessorCount;
+	printf("%-24s", name);
+	for (int wps : {2, 7}) for (unsigned active : {16u, 32u, 64u}) {
+		const int blocks = cus * wps, iters = 4000;
+		hipLaunchKernelGGL(k_vmem<WIDTH>, dim3(blocks), dim3(256), 0, 0, tab, 10, active, sink);
+		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+		hipEventRecord(e0, 0);
+		hipLaunchKernelGGL(k_vmem<WIDTH>, dim3(blocks), dim3(256), 0, 0, tab, iters, active, sink);
+		hipEventRecord(e1, 0); hipEventSynchronize(e1);
+		float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+		// instructions per CU: wps blocks x 4 waves x iters x 8
+		printf("  %dw/%2u lanes %6.2f", wps, active, ms * 1e6 / ((double)wps * 4 * iters * 8));
+	}
+	printf("   (ns per wave-instruction and CU)\n");
+	hipFree(tab); hipFree(sink);
+}
+
 typedef void (*kern_t)(unsigned long long*, int, float);
 
 int main() {
@@ -245,6 +298,8 @@ int main() {
 		}
 		printf("   | wall ns per instruction and SIMD: %6.3f %6.3f %6.3f %6.3f\n", wall[0], wall[1], wall[2], wall[3]);
 	}
+	printf("\nvector-memory loads that hit L1, by width, waves per SIMD and active lanes\n");
+	vmem_bench<4>("global_load_dwordx4"); vmem_bench<2>("global_load_dwordx2"); vmem_bench<1>("global_load_dword");
 	chase_bench();
 	return 0;
 }
