@@ -887,6 +887,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		}
 		for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) {
 			d.ntex[sl] = counts[sl];
+			if (sl == MT_NORMAL) d.ntex_normal = counts[sl];
 			if (counts[sl] < 0 || (counts[sl] > 0 && !lists[sl])) return fail(c, MIPT_ERR_INVALID, "object %d: bad texture list %d", i, sl);
 			int rc = upload_tex_list(c, lists[sl], counts[sl], &d.tex[sl]);
 			if (rc) return rc;
@@ -908,6 +909,12 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 				if (const mipt_texture* t = entry(MT_NE)) { if (t->W > 0) r.image_mask |= 1u << MT_NE; else memcpy(r.Ne, t->multiplier, 12); }
 				if (const mipt_texture* t = entry(MT_TRANSP)) { if (t->W > 0) r.image_mask |= 1u << MT_TRANSP; else r.transp_val = t->multiplier[0]; }
 				if (const mipt_texture* t = entry(MT_REFR)) { if (t->W > 0) r.image_mask |= 1u << MT_REFR; else r.refr = t->multiplier[0]; }
+			}
+			// (the Kd images were uploaded with the Kd list just above: their device addresses come back from that list)
+			if (ng > 0 && counts[MT_KD] > 0) {
+				std::vector<DTex> kd((size_t)counts[MT_KD]);
+				if (hipMemcpy(kd.data(), d.tex[MT_KD], kd.size() * sizeof(DTex), hipMemcpyDeviceToHost) != hipSuccess) return fail(c, MIPT_ERR_HIP, "reading back the Kd list failed");
+				for (int g = 0; g < ng && g < counts[MT_KD]; g++) if (gm[g].image_mask & (1u << MT_KD)) { gm[g].kd_values = kd[g].values; gm[g].kdW = kd[g].W; gm[g].kdH = kd[g].H; memcpy(gm[g].Kd, kd[g].mult, 12); }
 			}
 			d.ngroups = ng;
 			int rc = upload(c, gm.data(), gm.size(), &d.gmat);

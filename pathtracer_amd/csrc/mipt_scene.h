@@ -77,18 +77,23 @@ struct DGroupMat {
 	float transp_val;          // mat.transp = transp_val < 0.5f (default list: 1.0 -> false)
 	float refr;                // default 1.3
 	uint32_t image_mask;
-	uint32_t _pad[4];
+	const float* kd_values;    // the Kd entry's image when bit MT_KD of image_mask is set (texel * Kd[] = Texture::getVec): no trip through the entry's descriptor
+	int kdW, kdH;
 };
 
+// The first 64 bytes are what the shade stage needs of an object before it can fetch anything else (four 16-byte loads issued
+// together with the three matrices, one dependent round trip instead of six: the stage runs 4 waves per SIMD and waits on its
+// chain of dependent loads).
 struct DObject {
 	int type, miroir, flip_normals, interp_normals;
+	int nuvs, ngroups, ntex_normal, alpha_test;   // ntex_normal = ntex[MT_NORMAL]; alpha_test: an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
+	const DTriShade* shade; const DGroupMat* gmat; // gmat[ngroups + 1]: groups 0 .. ngroups-1 (ngroups = the longest of the Kd / Ks / Ne / transp / refr lists), then the all-defaults record
+	const float* tangent_soup;                     // Vector[3*ntri] or null
+	const double* merl;
 	float inv[12], trans[12], rot[9];
 	int brdf_kind;
-	const double* merl;
 	int ntex[MIPT_TEX_SLOTS];
 	const DTex* tex[MIPT_TEX_SLOTS];
-	const DGroupMat* gmat;     // [ngroups + 1]: groups 0 .. ngroups-1 (ngroups = the longest of the Kd / Ks / Ne / transp / refr lists), then the all-defaults record
-	int ngroups;
 	// Sphere
 	float O[3], R, R2;
 	int has_envmap, envW, envH;
@@ -98,17 +103,14 @@ struct DObject {
 	// TriMesh
 	const DFatNode* nodes;     // = DScene::all_nodes (child references are scene-wide)
 	const DTriIsect* tris;     // = DScene::all_tris (leaf references are scene-wide; mesh-local index = i - tri_base)
-	const DTriShade* shade;
 	uint32_t node_base, tri_base;
 	float root_min[3], root_max[3];
 	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
 	uint32_t root_qref;        // the same for the quad-node traversal (quad index of node 0, or the leaf ref)
-	int ntri, nuvs;
-	int alpha_test;            // an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
+	int ntri;
 	int ghost;                 // Object::ghost (Geometry.h:721): only the queue kernel (mipt_compositing.h) renders such scenes
 	const float* uvs;          // Vector[nuvs]
 	const int* uvidx;          // 3 ints per triangle (uvi,uvj,uvk), only when alpha_test
-	const float* tangent_soup; // Vector[3*ntri] or null
 };
 
 struct DScene {

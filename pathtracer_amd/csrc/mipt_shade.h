@@ -218,10 +218,9 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 		ps.color = ps.color + ps.weight * cc;
 		return false;
 	}
-	const DObject& obj = sc->obj[h.obj];
-	const double* const merl = MERL ? obj.merl : nullptr;
+	const double* const merl = MERL ? mat.merl : nullptr;               // (the object's flags came with the material: hit_material_obj)
 	ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
-	if (obj.miroir) {                                                    // :413-436
+	if (mat.miroir) {                                                    // :413-436
 		ps.ray.o = P + 0.001f * N;
 		ps.ray.d = reflect(rayDirection, N);
 		ps.depth--;
@@ -317,10 +316,9 @@ MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, P
 		ps.color = ps.color + ps.weight * cc;
 		return VERTEX_END;
 	}
-	const DObject& obj = sc->obj[h.obj];
-	if (obj.miroir || mat.transp) {                                      // mirror (:413-436) / Fresnel dielectric (:438-489): no NEE, no shadow ray
+	if (mat.miroir || mat.transp) {                                      // mirror (:413-436) / Fresnel dielectric (:438-489): no NEE, no shadow ray
 		ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;  // :411
-		if (obj.miroir) {
+		if (mat.miroir) {
 			ps.ray.o = P + 0.001f * N;
 			ps.ray.d = reflect(rayDirection, N);
 			ps.depth--;
@@ -347,7 +345,7 @@ MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, P
 		ps.depth--;
 		return VERTEX_CONTINUE;
 	}
-	const bool plain = obj.merl == nullptr &&
+	const bool plain = mat.merl == nullptr &&
 	                   mat.Ks.x == 0.f && mat.Ks.y == 0.f && mat.Ks.z == 0.f && mat.Ne.x >= 0.f && mat.Ne.y >= 0.f && mat.Ne.z >= 0.f;
 	if (!plain) return VERTEX_DEFER;
 	uint64_t rng = ps.rng;

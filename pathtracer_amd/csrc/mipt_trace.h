@@ -15,7 +15,28 @@ struct Mat {                       // MaterialValues (BRDF.h:7-20)
 	f3 shadingN, Kd, Ks, Ne, Ke;
 	bool transp;
 	float refr_index;
+	// of the object that was hit (not MaterialValues: read with the object's first 64 bytes by hit_material_obj, so that the
+	// vertex logic does not go back to the descriptor for them)
+	int miroir;
+	const double* merl;
 };
+
+// The first 64 bytes of a DObject (mipt_scene.h) in registers: four 16-byte loads issued together.
+struct ObjHot {
+	int type, miroir, flip_normals, interp_normals, nuvs, ngroups, ntex_normal, alpha_test;
+	const DTriShade* shade; const DGroupMat* gmat; const float* tangent_soup; const double* merl;
+};
+MIPT_DEV ObjHot load_obj_hot(const DObject& o) {
+	typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+	const __attribute__((address_space(1))) v4u_* q = (const __attribute__((address_space(1))) v4u_*)(&o);
+	const v4u_ a = q[0], b = q[1], c = q[2], d = q[3];
+	ObjHot h;
+	h.type = (int)a.x; h.miroir = (int)a.y; h.flip_normals = (int)a.z; h.interp_normals = (int)a.w;
+	h.nuvs = (int)b.x; h.ngroups = (int)b.y; h.ntex_normal = (int)b.z; h.alpha_test = (int)b.w;
+	h.shade = (const DTriShade*)(((uint64_t)c.y << 32) | c.x); h.gmat = (const DGroupMat*)(((uint64_t)c.w << 32) | c.z);
+	h.tangent_soup = (const float*)(((uint64_t)d.y << 32) | d.x); h.merl = (const double*)(((uint64_t)d.w << 32) | d.z);
+	return h;
+}
 
 // Closest-hit record carried through Scene::intersection; the material is evaluated once, for
 // the winning object (see scene_intersect).
@@ -245,22 +266,27 @@ MIPT_DEV f3 tex_getNormal(const DTex& tg, float u, float v) {  // BRDF.h:347-357
 #ifndef MIPT_GROUP_TABLE
 #define MIPT_GROUP_TABLE 1
 #endif
-MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& mat) {
+MIPT_DEV void query_material(const DObject& o, const DGroupMat* gmat, int ngroups, int idx, float u, float v, Mat& mat) {
 	u = tex_wrap(u);
 	v = tex_wrap(v);
 #if MIPT_GROUP_TABLE
-	// the group's record (three 16-byte loads); only the slots whose entry is an image go through the entry's descriptor
+	// the group's record (four 16-byte loads); only the slots whose entry is an image other than Kd's go through the entry's descriptor
 	typedef float v4f_ __attribute__((ext_vector_type(4)));
-	const unsigned ng = (unsigned)o.ngroups;
+	const unsigned ng = (unsigned)ngroups;
 	const unsigned gi = (unsigned)idx < ng ? (unsigned)idx : ng;
-	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(o.gmat + gi);
-	const v4f_ r0 = q[0], r1 = q[1], r2 = q[2];
+	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(gmat + gi);
+	const v4f_ r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
 	mat.Kd = mk3(r0.x, r0.y, r0.z); mat.Ks = mk3(r0.w, r1.x, r1.y); mat.Ne = mk3(r1.z, r1.w, r2.x);
 	mat.transp = r2.y < 0.5f;                                                                                        // getBool, BRDF.h:335-346
 	mat.refr_index = r2.z;
 	const unsigned images = __float_as_uint(r2.w);
 	if (images != 0) {
-		if (images & (1u << MT_KD)) mat.Kd = tex_getVec(o.tex[MT_KD][idx], u, v);
+		if (images & (1u << MT_KD)) {                                                                                // Texture::getVec (BRDF.h:293-308): texel * multiplier
+			DTex d; d.W = __float_as_int(r3.z); d.H = __float_as_int(r3.w);
+			glb_cfloat* val = (glb_cfloat*)(((uint64_t)__float_as_uint(r3.y) << 32) | __float_as_uint(r3.x));
+			const int ti = tex_index(d, u, v);
+			mat.Kd = mk3(val[ti] * r0.x, val[ti + 1] * r0.y, val[ti + 2] * r0.z);
+		}
 		if (images & (1u << MT_KS)) mat.Ks = tex_getVec(o.tex[MT_KS][idx], u, v);
 		if (images & (1u << MT_NE)) mat.Ne = tex_getVec(o.tex[MT_NE][idx], u, v);
 		if (images & (1u << MT_TRANSP)) mat.transp = tex_getValRed(o.tex[MT_TRANSP][idx], u, v) < 0.5f;
@@ -277,6 +303,7 @@ MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& m
 	mat.Ke = mk3(0, 0, 0);
 	// Ksub is only read by the subsurface branch (out of scope); upload rejects non-zero Ksub.
 }
+MIPT_DEV void query_material(const DObject& o, int idx, float u, float v, Mat& mat) { query_material(o, o.gmat, o.ngroups, idx, u, v, mat); }
 
 // alpha-map test of the leaf loop (TriangleMesh.cpp:1198-1205 / 1300-1307)
 // (not inlined: a rare path, and keeping its control flow out of the traversal loops avoids the hipcc
@@ -468,9 +495,9 @@ MIPT_DEV bool plane_test(const DObject& p, f3 o, f3 d, float& t) {
 }
 
 // ---------------------------------------------------------------- TriMesh::getMaterial (TriangleMesh.cpp:919-970)
-MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, float gamma, Mat& mat) {
+MIPT_DEV void mesh_material(const DObject& o, const ObjHot& hot, int tri, float alpha, float beta, float gamma, Mat& mat) {
 	typedef float v4f_ __attribute__((ext_vector_type(4)));
-	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(o.shade + tri);
+	const __attribute__((address_space(1))) v4f_* q = (const __attribute__((address_space(1))) v4f_*)(hot.shade + tri);
 	const v4f_ r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
 	const float4 q0 = make_float4(r0.x, r0.y, r0.z, r0.w), q1 = make_float4(r1.x, r1.y, r1.z, r1.w), q2 = make_float4(r2.x, r2.y, r2.z, r2.w), q3 = make_float4(r3.x, r3.y, r3.z, r3.w);
 	f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
@@ -481,22 +508,22 @@ MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, 
 	const int group = graw >= 0 ? (graw & MIPT_GROUP_MASK) : graw;
 	float u = 0, v = 0;
 	bool has_uv = false;
-	if (o.nuvs != 0 && graw >= 0 && (graw & MIPT_GROUP_UV_OK)) {
+	if (hot.nuvs != 0 && graw >= 0 && (graw & MIPT_GROUP_UV_OK)) {
 		u = (uv00 * alpha + uv10 * beta + uv20 * gamma);
 		v = (uv01 * alpha + uv11 * beta + uv21 * gamma);
 		has_uv = true;
 	}
-	query_material(o, group, u, v, mat);
+	query_material(o, hot.gmat, hot.ngroups, group, u, v, mat);
 	f3 N;
-	if (!o.interp_normals) {
+	if (!hot.interp_normals) {
 		const DTriIsect& T = o.tris[o.tri_base + tri];
 		N = ld3(T.N);
 	} else {
 		N = n0 * alpha + n1 * beta + n2 * gamma;
 	}
 	N = normalize(N);
-	if (o.ntex[MT_NORMAL] != 0 && has_uv && (unsigned)group < (unsigned)o.ntex[MT_NORMAL] && o.tangent_soup != nullptr) {
-		const float* ts = o.tangent_soup + 9 * (size_t)tri;
+	if (hot.ntex_normal != 0 && has_uv && (unsigned)group < (unsigned)hot.ntex_normal && hot.tangent_soup != nullptr) {
+		const float* ts = hot.tangent_soup + 9 * (size_t)tri;
 		f3 tangent = ld3(ts) * alpha + ld3(ts + 3) * beta + ld3(ts + 6) * gamma;
 		tangent = normalize(tangent);
 		f3 bitangent = cross(N, tangent);
@@ -505,9 +532,10 @@ MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, 
 		if (Ns.x == 0.f && Ns.y == 0.f && Ns.z == 0.f) Ns = N;
 		N = normalize(Ns);
 	}
-	if (o.flip_normals) N = -N;
+	if (hot.flip_normals) N = -N;
 	mat.shadingN = N;
 }
+MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, float gamma, Mat& mat) { const ObjHot hot = load_obj_hot(o); mesh_material(o, hot, tri, alpha, beta, gamma, mat); }
 
 // Sphere material (Geometry.h:948-991)
 MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
@@ -567,11 +595,13 @@ MIPT_DEV bool scene_closest(const DScene* __restrict__ sc, Ray r, Hit& h, STK& s
 // World-space hit point and MaterialValues of the winning object (tail of Scene::intersection,
 // Geometry.cpp:668-684, plus the winner's own material code).
 MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat) {
+	const ObjHot hot = load_obj_hot(o);                  // (issued together with the matrix loads below)
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
 	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
-	if (o.type == 1) sphere_material(o, Pl, mat);
-	else if (o.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
+	mat.miroir = hot.miroir; mat.merl = hot.merl;
+	if (hot.type == 1) sphere_material(o, Pl, mat);
+	else if (hot.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, hot.gmat, hot.ngroups, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
 	else {
 		float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
 		// NaN / Inf clean-up of the winner's barycentrics (TriangleMesh.cpp:1219-1226)
@@ -582,7 +612,7 @@ MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat
 		if (isinf(alpha)) alpha = 1;
 		if (isinf(beta)) beta = 1;
 		if (isinf(gamma)) gamma = 1;
-		mesh_material(o, h.tri, alpha, beta, gamma, mat);
+		mesh_material(o, hot, h.tri, alpha, beta, gamma, mat);
 	}
 	P = xf_point(o.trans, Pl);
 	mat.shadingN = fast_normalize(xf_rot(o.rot, mat.shadingN));
