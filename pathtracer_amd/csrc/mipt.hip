@@ -190,7 +190,6 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 
 #include "mipt_wavefront.h"
 #include "mipt_persistent.h"
-#include "mipt_unified.h"
 #include "mipt_build.h"
 #include "mipt_compositing.h"
 #include "mipt_queue_wave.h"
@@ -349,9 +348,6 @@ struct mipt_ctx {
 	std::vector<void*> scene_allocs;
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
-	const DQuadNode* d_all_quads = nullptr;     // null: the scene's boxes do not allow quad nodes (quad_note says why)
-	std::string quad_note;
-	int64_t opt_quad_nodes = 0;       // persistent traversal on quad nodes (measured slower: DESIGN.md 4d; the kernels stay as the statement of the experiment) (two tree levels per 128-byte fetch) when the scene has them
 	const DTriIsect* d_all_tris = nullptr;
 	bool scene_has_ghost = false;     // a ghost object, a background photo or fog: rendered by the queue kernel (mipt_compositing.h)
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
@@ -394,13 +390,8 @@ struct mipt_ctx {
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
-	int64_t opt_unified = 0;          // traversal stages: 1 = one fetch per lane and round (mipt_unified.h: measured 35-47 % slower, kept as the statement of that experiment), 0 = the phased kernels of mipt_persistent.h
-	int64_t opt_u_setup_min = 8;      // unified traversal: the object loop runs once this many fetched rays wait for it ...
-	int64_t opt_u_alive_low = 32;     // ... or at once while fewer than this many lanes traverse
-	unsigned grid_quad[3] = {0, 0, 0};   // resident blocks of k_wf_traverse<0 / 1 / 2, quad nodes>
-	unsigned grid_qquad[2] = {0, 0};     // resident blocks of k_q_traverse<false / true, quad nodes>
-	unsigned grid_u[2] = {0, 0};      // resident blocks of k_wf_traverse_u<0 / 1>
-	unsigned grid_qu[2] = {0, 0};     // resident blocks of k_q_traverse_u<false / true>
+	int64_t opt_leaf_max = 0;             // traversal: the inner phase ends once this many lanes wait with a leaf (0 = never for that reason)
+	int64_t opt_standby_threshold = 16;   // traversal: lanes without a standby ray before the wave fetches some (mipt_persistent.h, MIPT_STANDBY)
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
@@ -601,10 +592,8 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
-	if (!strcmp(name, "quad_nodes")) { c->opt_quad_nodes = value != 0; return MIPT_OK; }
-	if (!strcmp(name, "unified")) { c->opt_unified = value != 0; return MIPT_OK; }
-	if (!strcmp(name, "u_setup_min")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "u_setup_min must be in [1,64]"); c->opt_u_setup_min = value; return MIPT_OK; }
-	if (!strcmp(name, "u_alive_low")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "u_alive_low must be in [0,64]"); c->opt_u_alive_low = value; return MIPT_OK; }
+	if (!strcmp(name, "leaf_max")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "leaf_max must be in [0,64]"); c->opt_leaf_max = value; return MIPT_OK; }
+	if (!strcmp(name, "standby_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "standby_threshold must be in [1,64]"); c->opt_standby_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
@@ -644,8 +633,8 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 
 // staging of all meshes' traversal records (one device buffer each)
 // (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
-struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; std::unique_ptr<DQuadNode[]> quad; size_t nquad = 0; };
-struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0, nquad_total = 0; int top_nodes = 0; bool quad_ok = true; std::string quad_why; };
+struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; };
+struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; int top_nodes = 0; };
 #define MIPT_TOP_RESERVE 255             // inner nodes stored breadth-first in front of a mesh's node range (>= MIPT_TOP_NODES of any build)
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
@@ -689,8 +678,8 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	// the traversal stack holds at most one pending far child per inner node on the current root-to-leaf path: refuse
 	// trees deeper than the stack instead of overrunning it (the reference's own fixed 50-entry stack is UB there,
 	// TriangleMesh.cpp:1153).  Children follow their parent in the node array, so one forward pass gives the depths.
-	std::vector<unsigned char> depth(nn, 0);
 	{
+		std::vector<unsigned char> depth(nn, 0);
 		depth[0] = 1;
 		int deepest = 1;
 		for (int i = 0; i < nn; i++) {
@@ -734,53 +723,6 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	int rc;
 	if ((rc = child_ref(0, d.root_ref))) return rc;
 	memcpy(d.root_min, m->bvh_bbox_min, 12); memcpy(d.root_max, m->bvh_bbox_max, 12);
-	// quad nodes (mipt_scene.h): one 128-byte record per inner node at even depth (the root is at depth 0), in node order
-	d.root_qref = d.root_ref;
-	if (stg.quad_ok) {
-		const uint32_t quad_base = (uint32_t)stg.nquad_total;
-		std::vector<int> quad_index(nn, -1);
-		int nquad = 0;
-		for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf && (depth[i] & 1)) quad_index[i] = nquad++;       // depth[] counts from 1
-		if ((size_t)quad_base + (size_t)nquad > MIPT_QIDX_MASK) { stg.quad_ok = false; stg.quad_why = "more than 2^29 quad nodes"; }
-		// a box must be the union of its children's boxes, coordinate by coordinate (== on floats: +0 / -0 are the same plane)
-		for (int i = 0; i < nn && stg.quad_ok; i++) {
-			if (m->nodes[i].isleaf) continue;
-			const mipt_bvh_node &a = m->nodes[m->nodes[i].fg], &b = m->nodes[m->nodes[i].fd], &n = m->nodes[i];
-			for (int k = 0; k < 3; k++)
-				if (!(std::min(a.bbox_min[k], b.bbox_min[k]) == n.bbox_min[k]) || !(std::max(a.bbox_max[k], b.bbox_max[k]) == n.bbox_max[k])) { stg.quad_ok = false; stg.quad_why = "a node's box is not the union of its children's boxes"; }
-		}
-		if (stg.quad_ok) {
-			chunk.nquad = (size_t)std::max(nquad, 1);
-			chunk.quad.reset(new DQuadNode[chunk.nquad]);
-			memset(chunk.quad.get(), 0, chunk.nquad * sizeof(DQuadNode));
-			auto qref = [&](int node, uint32_t& ref) -> int {
-				if (!m->nodes[node].isleaf) { ref = quad_base + (uint32_t)quad_index[node]; return MIPT_OK; }
-				return child_ref(node, ref);
-			};
-			auto put_box = [&](float* dst, const mipt_bvh_node& n) { for (int k = 0; k < 3; k++) { dst[2 * k] = n.bbox_min[k]; dst[2 * k + 1] = n.bbox_max[k]; } };
-			for (int i = 0; i < nn; i++) {
-				if (quad_index[i] < 0) continue;
-				DQuadNode& qn = chunk.quad[quad_index[i]];
-				const int kid[2] = {m->nodes[i].fg, m->nodes[i].fd};
-				for (int cidx = 0; cidx < 2; cidx++) {
-					const mipt_bvh_node& ch = m->nodes[kid[cidx]];
-					if (ch.isleaf) {
-						put_box(qn.box[2 * cidx], ch); put_box(qn.box[2 * cidx + 1], ch);
-						if ((rc = child_ref(kid[cidx], qn.ref[2 * cidx]))) return rc;
-						qn.ref[2 * cidx + 1] = MIPT_QUAD_LEAF_CHILD;
-					} else {
-						const int gk[2] = {ch.fg, ch.fd};
-						for (int g = 0; g < 2; g++) {
-							put_box(qn.box[2 * cidx + g], m->nodes[gk[g]]);
-							if ((rc = qref(gk[g], qn.ref[2 * cidx + g]))) return rc;
-						}
-					}
-				}
-			}
-			if (!m->nodes[0].isleaf) d.root_qref = quad_base + (uint32_t)quad_index[0];
-			stg.nquad_total += chunk.nquad;
-		}
-	}
 	std::vector<int> uvidx;
 	const bool has_uv = m->n_uvs > 0 && m->uvs;
 	if (has_uv) uvidx.resize((size_t)nt * 3);
@@ -960,13 +902,6 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		HIPCHK(c, hipMalloc(&dn, stg.nfat_total * sizeof(DFatNode))); c->scene_allocs.push_back(dn);
 		HIPCHK(c, hipMalloc(&dt, stg.nt_total * sizeof(DTriIsect))); c->scene_allocs.push_back(dt);
 		HIPCHK(c, hipMalloc(&dsh, stg.nt_total * sizeof(DTriShade))); c->scene_allocs.push_back(dsh);
-		void* dq = nullptr;
-		if (stg.quad_ok && stg.nquad_total > 0) {
-			HIPCHK(c, hipMalloc(&dq, stg.nquad_total * sizeof(DQuadNode))); c->scene_allocs.push_back(dq);
-			size_t oq = 0;
-			for (const MeshChunk& ch : stg.chunks) { HIPCHK(c, hipMemcpy((DQuadNode*)dq + oq, ch.quad.get(), ch.nquad * sizeof(DQuadNode), hipMemcpyHostToDevice)); oq += ch.nquad; }
-		}
-		H.all_quads = (const DQuadNode*)dq;
 		size_t on = 0, ot = 0;
 		for (const MeshChunk& ch : stg.chunks) {
 			HIPCHK(c, hipMemcpy((DFatNode*)dn + on, ch.fat.get(), ch.nfat * sizeof(DFatNode), hipMemcpyHostToDevice));
@@ -986,8 +921,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	rc = upload(c, hs.data(), 1, &dsc);
 	if (rc) return rc;
 	c->d_scene = const_cast<DScene*>(dsc);
-	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris; c->d_all_quads = H.all_quads;
-	c->quad_note = stg.quad_ok ? "" : stg.quad_why;
+	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
 	c->scene_has_subsurface = scene_subs;
@@ -1336,22 +1270,6 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			c->grid_stage[k] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
 		}
 	}
-	if (c->grid_quad[0] == 0) {
-		const void* kern[5] = {(const void*)k_wf_traverse<0, true>, (const void*)k_wf_traverse<1, true>, (const void*)k_wf_traverse<2, true>, (const void*)k_q_traverse<false, true>, (const void*)k_q_traverse<true, true>};
-		for (int k = 0; k < 5; k++) {
-			int nb = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
-			(k < 3 ? c->grid_quad[k] : c->grid_qquad[k - 3]) = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
-		}
-	}
-	if (c->grid_u[0] == 0) {
-		const void* kern[4] = {(const void*)k_wf_traverse_u<0>, (const void*)k_wf_traverse_u<1>, (const void*)k_q_traverse_u<false>, (const void*)k_q_traverse_u<true>};
-		for (int k = 0; k < 4; k++) {
-			int nb = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
-			(k < 2 ? c->grid_u[k] : c->grid_qu[k - 2]) = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
-		}
-	}
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
@@ -1390,25 +1308,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			};
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
-			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
-			const bool unified = c->opt_unified != 0;
-			const int u_setup = (int)c->opt_u_setup_min, u_flags = (int)(c->opt_u_alive_low & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0);
+			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xff) | ((int)(c->opt_leaf_max & 0xff) << 8) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17) | ((int)(c->opt_standby_threshold & 127) << 24);
 			auto q_traverse = [&](bool shadow, const TravQueue& tq, unsigned nq) {
-				const unsigned want = (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK;
-				if (unified) {
-					const dim3 g(std::max(1u, std::min(c->grid_qu[shadow ? 1 : 0], want)));
-					if (shadow) hipLaunchKernelGGL(k_q_traverse_u<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, u_setup, u_flags);
-					else hipLaunchKernelGGL(k_q_traverse_u<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, u_setup, u_flags);
-				} else if (c->opt_quad_nodes && c->d_all_quads) {
-					const dim3 g(std::max(1u, std::min(c->grid_qquad[shadow ? 1 : 0], want)));
-					const float4* d_quads = (const float4*)c->d_all_quads;
-					if (shadow) hipLaunchKernelGGL((k_q_traverse<true, true>), g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_quads, c->d_all_tris, wf, tq, thr, imin);
-					else hipLaunchKernelGGL((k_q_traverse<false, true>), g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_quads, c->d_all_tris, wf, tq, thr, imin);
-				} else {
-					const dim3 g(std::max(1u, std::min(c->grid_qtrav[shadow ? 1 : 0], want)));
-					if (shadow) hipLaunchKernelGGL(k_q_traverse<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
-					else hipLaunchKernelGGL(k_q_traverse<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
-				}
+				const dim3 g(std::max(1u, std::min(c->grid_qtrav[shadow ? 1 : 0], (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
+				if (shadow) hipLaunchKernelGGL(k_q_traverse<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+				else hipLaunchKernelGGL(k_q_traverse<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 			};
 			for (int r = 0;; r++) {
 				if (r > 100000) return fail(c, MIPT_ERR_HIP, "the contribution queue did not drain");
@@ -1476,15 +1380,9 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt);
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], k < 3 ? (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK) : grid_all)); };
-			const bool unified = c->opt_refill && c->opt_unified && !c->opt_merge_traverse;
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
-			const int u_setup = (int)c->opt_u_setup_min, u_flags = (int)(c->opt_u_alive_low & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0);
-			const bool quad = c->opt_quad_nodes && c->d_all_quads != nullptr;
-			const float4* d_quads = (const float4*)c->d_all_quads;
-			auto GQ = [&](int k) { return dim3(std::min(c->grid_quad[k], (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))); };
-			auto GU = [&](int k) { return dim3(std::min(c->grid_u[k], (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))); };
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
-			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
+			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xff) | ((int)(c->opt_leaf_max & 0xff) << 8) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17) | ((int)(c->opt_standby_threshold & 127) << 24);
 			unsigned* const list_mem[2] = {wf.list[0], wf.list[1]};
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (c->opt_sort_rays && !merge && b > 0) {                // reorder the closest-hit queue of this depth (written by shade(b-1))
@@ -1499,9 +1397,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				}
 				if (!merge || b == 0) {                                  // closest hits of depth b (merged mode: done by the launch of depth b-1)
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					if (unified) hipLaunchKernelGGL(k_wf_traverse_u<0>, GU(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, u_setup, u_flags);
-					else if (c->opt_refill && quad) hipLaunchKernelGGL((k_wf_traverse<0, true>), GQ(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_quads, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
-					else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+					if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<0>, G(0), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 					else hipLaunchKernelGGL(k_wf_extend, G(6), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b, (unsigned)total);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
@@ -1514,10 +1410,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (merge && b + 1 < p->nb_bounces && quad) hipLaunchKernelGGL((k_wf_traverse<2, true>), GQ(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_quads, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
-				else if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
-				else if (unified) hipLaunchKernelGGL(k_wf_traverse_u<1>, GU(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, u_setup, u_flags);
-				else if (c->opt_refill && quad) hipLaunchKernelGGL((k_wf_traverse<1, true>), GQ(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_quads, c->d_all_tris, wf, b, 0u, thr, imin);
+				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
 				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");

@@ -43,17 +43,27 @@
 #ifndef MIPT_PREFETCH_IDS
 #define MIPT_PREFETCH_IDS 0
 #endif
-#ifndef MIPT_TRAV_STATE_NT
-#define MIPT_TRAV_STATE_NT 0            // the traversal reads rays and writes hit records with the streaming cache policy (as generate / shade do)
+// MIPT_STANDBY (round 3): every lane keeps a second, fully set-up ray beside the one it traverses and takes it the moment the
+// first is finished — inside the inner loop, without waiting for the wave's next refill.  Why: a CU issues ONE vector-memory
+// instruction per ~10 ns whatever its width and almost whatever the number of its active lanes (tools/valu_rate.hip,
+// profiles/r3_b_instruction_issue_rates.txt), the traversal kernels spend ~90 % of their time at that rate (1.03 G such
+// instructions per launch of the closest-hit kernel = 4.0 M per CU x 10 ns = 40 of its 45.5 ms), and 85 % of them are the four
+// loads of a node at 32.5 of 64 lanes.  What a launch costs is therefore node-load INSTRUCTIONS, and a lane that sits empty
+// between the end of its ray and the next refill (a refill waits until 36 lanes are empty, because it costs the object loop
+// for few lanes) pays them for nothing.  The standby ray costs 13 registers (the kernels then run 5 waves per SIMD instead of
+// 7) and no LDS: it has not entered the tree yet, its stack is empty.  Scenes whose first mesh is their last object only
+// (every BASELINE config): a ray that leaves the mesh is decided, nothing else has to be visited for it.
+#ifndef MIPT_STANDBY
+#define MIPT_STANDBY 1
 #endif
-#ifndef MIPT_LEAF_PER_LANE
-#define MIPT_LEAF_PER_LANE 0            // probe: every leaf through the per-lane loop (no dense packing over the wave)
+#ifndef MIPT_STANDBY_INLOOP
+#define MIPT_STANDBY_INLOOP 1
 #endif
-#ifndef MIPT_NODE_REFS_X2
-#define MIPT_NODE_REFS_X2 0
+#ifndef MIPT_STANDBY_AFTER_LEAF
+#define MIPT_STANDBY_AFTER_LEAF 1
 #endif
-#ifndef MIPT_INNER_V2
-#define MIPT_INNER_V2 0                 // 1 = the inner step re-written against the measured issue costs (round 3: -9 % vector instructions, bit-identical, 2 % SLOWER on every config: profiles/r3_c_traversal_experiments.txt)
+#ifndef MIPT_STANDBY_WAVES
+#define MIPT_STANDBY_WAVES 5
 #endif
 #ifndef MIPT_PULL_DIV
 #define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
@@ -87,7 +97,7 @@ struct LaneState {
 // One object of Scene::intersection / intersection_shadow for the lanes whose next object is `i`
 // (i is wave-uniform, so the object's description is fetched with scalar loads).  Returns true when
 // the lane has to start traversing mesh i (its traversal state is then set up).
-template <bool SHADOW, bool QUAD = false>
+template <bool SHADOW>
 __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 rd, LaneState& st, bool skip_ghosts) {
 	if (SHADOW && skip_ghosts && o.ghost) return false;          // getColor's shadow rays pass through ghost objects (Geometry.cpp:722, Raytracer.cpp:513)
 	f3 d = xf_dir(o.inv, rd);
@@ -112,7 +122,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 	if (!enter) return false;
 	st.o_xy = (mipt_f2){org.x, org.y}; st.i_xy = (mipt_f2){invd.x, invd.y}; st.oz_iz = (mipt_f2){org.z, invd.z}; st.d = d;
 	if (SHADOW) st.t = cur_best_t;
-	st.cur = QUAD ? o.root_qref : o.root_ref; st.sp = 0;
+	st.cur = o.root_ref; st.sp = 0;
 	return true;
 }
 
@@ -138,10 +148,11 @@ struct TravQueue {
 // frame of ONE mesh (wf.ray_o.w = max_t, wf.ray_d.w = the object), the traversal is the closest-hit one with the far bound
 // fixed at max_t, and every triangle hit in [0, max_t) draws one number from the sample's engine (wf.rng) in visiting order and
 // replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
-template <bool SHADOW, bool RESV = false, bool QUAD = false>
+template <bool SHADOW, bool RESV = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
                                                const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
-	const int inner_min = inner_min_flags & 0xffff;
+	const int inner_min = inner_min_flags & 0xff;
+	const int leaf_max = ((inner_min_flags >> 8) & 0xff) ? ((inner_min_flags >> 8) & 0xff) : 65;      // the inner phase also ends once this many lanes wait with a leaf (standby rays keep the phase fed: without it the leaves starve)
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
 	const unsigned n = tq.n_ptr ? *tq.n_ptr : tq.n_imm;
@@ -167,6 +178,32 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	bool drained = false;
 	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
 	const bool any_alpha = sc->any_alpha != 0;
+	// ---- the standby ray (MIPT_STANDBY): in the frame of the scene's only mesh, root box passed, not yet in the tree
+	const bool sb_ok = MIPT_STANDBY && !RESV && lane_limit == 64u && first_mesh + 1 == nobj;
+	const int sb_threshold = ((inner_min_flags >> 24) & 127) ? ((inner_min_flags >> 24) & 127) : 16;      // lanes without a standby ray before the wave fetches some
+	const uint32_t sb_root = sb_ok ? sc->obj[first_mesh].root_ref : MIPT_NONE;
+	int sb_state = 0;                    // 0 none, 1 id requested, 2 ray requested, 3 ready (see the pipeline in front of the object loop)
+	mipt_f2 sb_o_xy = {0.f, 0.f}, sb_i_xy = {0.f, 0.f}, sb_oz_iz = {0.f, 0.f};
+	f3 sb_d = mk3(0, 0, 0);
+	float sb_t = 0.f, sb_dist = 0.f;
+	unsigned sb_id = 0;
+	bool fin = false;                    // shadow rays: the light sample of path fin_id is visible, its term is still to be added
+	unsigned fin_id = 0;
+	// the lane's finished ray is settled and its standby ray becomes the lane's ray; false when that cannot be done here (no
+	// standby ray, or a second visible light sample while the first still waits for its addition: the wave's next round
+	// settles the ray the ordinary way)
+	auto take_standby = [&]() -> bool {
+		if (sb_state != 3) return false;
+		if (SHADOW) {
+			if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
+			else if (!st.best) { if (fin) return false; fin = true; fin_id = st.id; }
+		}
+		st.o_xy = sb_o_xy; st.i_xy = sb_i_xy; st.oz_iz = sb_oz_iz; st.d = sb_d;
+		st.t = sb_t; st.dist = sb_dist; st.id = sb_id; st.cur = sb_root; st.sp = 0; st.obj = first_mesh;
+		if (SHADOW) st.best = 0;
+		sb_state = 0;
+		return true;
+	};
 
 	auto pop_next = [&]() -> uint32_t {
 		while (st.sp > 0) {
@@ -181,6 +218,21 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	for (;;) {
 		MIPT_PROF_CLOCK(c0);
 		if (alive) MIPT_PROF_COUNT(8)
+		if (MIPT_STANDBY && sb_ok) {
+			if (SHADOW && __ballot(fin) != 0) {
+				if (fin) {
+					const float4 c = wf.out.col[fin_id], pc = wf.sh_c[fin_id];
+					wf.out.col[fin_id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);        // Raytracer.cpp:566
+					fin = false;
+				}
+			}
+			if (!alive && !need && sb_state == 3) {           // (its previous ray was settled by the object loop of the last round)
+				st.o_xy = sb_o_xy; st.i_xy = sb_i_xy; st.oz_iz = sb_oz_iz; st.d = sb_d;
+				st.t = sb_t; st.dist = sb_dist; st.id = sb_id; st.cur = sb_root; st.sp = 0; st.obj = first_mesh;
+				if (SHADOW) st.best = 0;
+				sb_state = 0; alive = true;
+			}
+		}
 		// ---- refill idle lanes from the queue
 		unsigned long long idle = __ballot(!alive && !need && lane < lane_limit);
 		int nidle = __popcll(idle);
@@ -226,6 +278,74 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				ahead_at = chunk_next;
 			}
 		}
+		// ---- standby rays for the lanes that traverse and have none, as a pipeline of three rounds so that nothing waits for a
+		//      load it has just issued: (A) a queue entry is reserved and its id requested; (B) next round the id is there and the
+		//      ray is requested; (C) the round after, the ray is there: into the mesh's frame, root box (TriangleMesh.cpp:1133-1157).
+		//      The loads of A and B land during the traversal phases in between (they sit in the standby registers meanwhile).
+		if (MIPT_STANDBY && sb_ok) {
+			if (sb_state == 2) {                                                   // (C)
+				const float4 o4 = make_float4(sb_o_xy.x, sb_o_xy.y, sb_oz_iz.x, sb_t), d4 = make_float4(sb_d.x, sb_d.y, sb_d.z, sb_dist);
+				const unsigned id = sb_id;
+				if (!SHADOW && MIPT_HIT_WRITE_THROUGH) wf.hit[id] = make_float4(o4.w, 0.f, 0.f, d4.w);        // what the analytic objects left
+				const DObject& o = sc->obj[first_mesh];
+				bool enter = !(SHADOW && tq.skip_ghosts && o.ghost);
+				const f3 d = xf_dir(o.inv, mk3(d4.x, d4.y, d4.z));
+				const f3 org = xf_point(o.inv, mk3(o4.x, o4.y, o4.z));
+				const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+				float t_root;
+				const float cur_best_t = SHADOW ? __int_as_float(0x7f800000) : o4.w;
+				enter = enter && box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
+				if (enter && t_root > cur_best_t) enter = false;
+				if (SHADOW && enter && t_root > o4.w) enter = false;
+				sb_state = 0;
+				if (enter) {
+					sb_o_xy = (mipt_f2){org.x, org.y}; sb_i_xy = (mipt_f2){invd.x, invd.y}; sb_oz_iz = (mipt_f2){org.z, invd.z}; sb_d = d;
+					sb_t = cur_best_t; sb_dist = o4.w;
+					sb_state = 3;
+				} else if (SHADOW) {                                  // no mesh in the way: the light sample is visible (closest hits: the record above stands)
+					if (tq.vis) tq.vis[id] = 1.f;
+					else {
+						const float4 c = wf.out.col[id], pc = wf.sh_c[id];
+						wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);                  // Raytracer.cpp:566
+					}
+				}
+			}
+			if (sb_state == 1) {                                                   // (B)
+				const unsigned raw = __float_as_uint(sb_dist);
+				const unsigned id = identity ? sb_id : raw;
+				const bool valid = identity ? (raw & MIPT_WF_VALID) != 0 : true;
+				sb_state = 0;
+				if (valid) {
+					const float4 o4 = SHADOW ? wf.sh_o[id] : wf.ray_o[id];
+					const float4 d4 = SHADOW ? wf.sh_d[id] : wf.ray_d[id];
+					sb_o_xy = (mipt_f2){o4.x, o4.y}; sb_oz_iz = (mipt_f2){o4.z, 0.f}; sb_t = o4.w; sb_d = mk3(d4.x, d4.y, d4.z); sb_dist = d4.w;
+					sb_id = id; sb_state = 2;
+				}
+			}
+			if (!drained) {                                                        // (A)
+				const unsigned long long want = __ballot(alive && sb_state == 0);
+				const int nwant = __popcll(want);
+				if (nwant >= sb_threshold) {
+					if (chunk_next >= chunk_end) {
+						unsigned base = 0;
+						if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
+						else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
+						base = __builtin_amdgcn_readfirstlane(base);
+						if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
+						else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
+					}
+					const unsigned take = min((unsigned)nwant, chunk_end - chunk_next);
+					const unsigned prefix = (unsigned)__popcll(want & below);
+					if (alive && sb_state == 0 && prefix < take) {
+						const unsigned idx = chunk_next + prefix;
+						sb_id = idx;
+						sb_dist = identity ? wf.wgt[idx].w : __uint_as_float(list[idx]);
+						sb_state = 1;
+					}
+					chunk_next += take;
+				}
+			}
+		}
 		// ---- object loop (wave-uniform index): new rays start at object 0, rays that just left a mesh
 		//      continue behind it; a ray stops at the first mesh it has to traverse
 		if (RESV) {
@@ -249,19 +369,19 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		} else if (__ballot(need)) {
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
 			if (need) {
-				float4 o4 = MIPT_TRAV_STATE_NT ? wf_ld(SHADOW ? &wf.sh_o[st.id] : &wf.ray_o[st.id]) : (SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id]);
-				float4 d4 = MIPT_TRAV_STATE_NT ? wf_ld(SHADOW ? &wf.sh_d[st.id] : &wf.ray_d[st.id]) : (SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id]);
+				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
+				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
 				if (!SHADOW && st.obj == first_mesh) {                                                       // a fresh ray: what the analytic objects left
 					st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
-					if (MIPT_HIT_WRITE_THROUGH) { if (MIPT_TRAV_STATE_NT) wf_st(&wf.hit[st.id], make_float4(o4.w, 0.f, 0.f, d4.w)); else wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w); }
+					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
 				}
 			}
 			if (need) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {
 				if (need && st.obj == i) {
 					const float t_before = st.t;
-					const bool enter_mesh = visit_object<SHADOW, QUAD>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
+					const bool enter_mesh = visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
 					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI));
 					if (enter_mesh) { need = false; alive = true; }
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
@@ -283,7 +403,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		}
 		{
 			const int nalive = __popcll(__ballot(alive));
-			if (nalive == 0) { if (drained) break; else continue; }
+			if (nalive == 0) { if (drained && !(MIPT_STANDBY && sb_ok && __ballot(sb_state != 0) != 0)) break; else continue; }
 			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
 		}
 		MIPT_PROF_CLOCK(c1);
@@ -292,154 +412,18 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		// ---- inner-node phase: every live lane descends until it holds a leaf or runs out of nodes
 		//      (the phase also ends when fewer than inner_min lanes are still descending while others
 		//      already wait with a leaf: the stragglers simply resume in the next round)
-		if (QUAD) {
-			// Two tree levels per step on 128-byte quad nodes (mipt_scene.h): the visit of an even-depth node N and of the child
-			// the ray enters first, from ONE fetch; a popped far child (MIPT_QHALF) fetches its parent's record again and tests
-			// its own two children only.  Slab distances of N's children = min / max of their children's (monotone in the
-			// plane: the same bits), everything else is the two-box step twice, in the reference's order.
-			const float s_ox = st.o_xy.x, s_oy = st.o_xy.y, s_oz = st.oz_iz.x, s_ix = st.i_xy.x, s_iy = st.i_xy.y, s_iz = st.oz_iz.y;
-			const bool sx = s_ix >= 0, sy = s_iy >= 0, sz = s_iz >= 0;
-			const float inf = __int_as_float(0x7f800000);
-			const bool literal = alive && (force_literal || fabsf(s_ix) == inf || fabsf(s_iy) == inf || fabsf(s_iz) == inf);
-			const bool any_literal = __ballot(literal) != 0;
-			const float t_shadow = SHADOW ? fminf(st.t, st.dist) : 0.f;
-			const uint32_t xflip = sx ? 0u : 0x80000000u;
-			const float4* __restrict__ quads = nodes;                       // (the kernel was handed the quad buffer)
-			for (;;) {
-				const bool inner = st.cur < MIPT_NONE;
-				const unsigned long long mi = __ballot(inner);
-				if (mi == 0) break;
-				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
-				if (inner) {
-					MIPT_PROF_COUNT(0)
-					const uint32_t qi = st.cur & MIPT_QIDX_MASK;
-					const bool half = (st.cur & MIPT_QHALF) != 0;
-					const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(quads) + ((size_t)qi << 7));
-					const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
-					const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
-					const float t_lim = SHADOW ? t_shadow : st.t;
-					// per grandchild: entry distance clamped at 0 and whether the ray enters it below t_lim; per child the same from the unions
-					float tg0, tg1, tg2, tg3, tc0, tc1;
-					bool gg0, gg1, gg2, gg3, gc0, gc1;
-					if (any_literal) {
-						const f3 s_org = mk3(s_ox, s_oy, s_oz), s_invd = mk3(s_ix, s_iy, s_iz);
-						const f3 b0n = mk3(q0.x, q0.z, q1.x), b0x = mk3(q0.y, q0.w, q1.y), b1n = mk3(q1.z, q2.x, q2.z), b1x = mk3(q1.w, q2.y, q2.w);
-						const f3 b2n = mk3(q3.x, q3.z, q4.x), b2x = mk3(q3.y, q3.w, q4.y), b3n = mk3(q4.z, q5.x, q5.z), b3x = mk3(q4.w, q5.y, q5.w);
-						auto un = [](f3 a, f3 b) { return mk3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); };
-						auto ux = [](f3 a, f3 b) { return mk3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); };
-						auto lit = [&](f3 bn, f3 bx, float& tt) { bool g = box_test<!SHADOW>(bn, bx, s_org, s_invd, sx, sy, sz, tt); g = g && (tt < st.t); if (SHADOW) g = g && (tt < st.dist); return g; };
-						gg0 = lit(b0n, b0x, tg0); gg1 = lit(b1n, b1x, tg1); gg2 = lit(b2n, b2x, tg2); gg3 = lit(b3n, b3x, tg3);
-						gc0 = lit(un(b0n, b1n), ux(b0x, b1x), tc0); gc1 = lit(un(b2n, b3n), ux(b2x, b3x), tc1);
-					} else {
-						QuadSlab a0, a1, a2, a3;
-						quad_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a0);
-						quad_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a1);
-						quad_slab(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a2);
-						quad_slab(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, xflip, a3);
-						gg0 = quad_accept<!SHADOW>(a0, t_lim, tg0); gg1 = quad_accept<!SHADOW>(a1, t_lim, tg1);
-						gg2 = quad_accept<!SHADOW>(a2, t_lim, tg2); gg3 = quad_accept<!SHADOW>(a3, t_lim, tg3);
-						gc0 = quad_accept<!SHADOW>(quad_union(a0, a1), t_lim, tc0); gc1 = quad_accept<!SHADOW>(quad_union(a2, a3), t_lim, tc1);
-					}
-					// level 1: N's children (TriangleMesh.cpp:1172-1190); a popped far child skips it
-					int side;                                                 // the child whose children are tested now: 0 / 1, 2 = none
-					bool need_pop = false;
-					if (half) side = (st.cur & MIPT_QSIDE) ? 1 : 0;
-					else {
-						const bool leaf0 = r1 == MIPT_QUAD_LEAF_CHILD, leaf1 = r3 == MIPT_QUAD_LEAF_CHILD;
-						const bool left_first = gc0 && (!gc1 || tc0 < tc1);
-						if (gc0 && gc1) {
-							const bool far_leaf = left_first ? leaf1 : leaf0;
-							const uint32_t far_ref = far_leaf ? (left_first ? r2 : r0) : (MIPT_QHALF | (left_first ? MIPT_QSIDE : 0u) | qi);
-							stk.push(st.sp, far_ref, left_first ? tc1 : tc0); st.sp++;
-						}
-						side = 2;
-						if (gc0 || gc1) {
-							const bool near_leaf = left_first ? leaf0 : leaf1;
-							if (near_leaf) st.cur = left_first ? r0 : r2;
-							else side = left_first ? 0 : 1;
-						} else need_pop = true;
-					}
-					// level 2: the children of that child, nothing between the two visits changes t (the reference pushes the near
-					// child and pops it at once)
-					if (side < 2) {
-						const bool ga = side ? gg2 : gg0, gb = side ? gg3 : gg1;
-						const float ta = side ? tg2 : tg0, tb = side ? tg3 : tg1;
-						const uint32_t ra = side ? r2 : r0, rb = side ? r3 : r1;
-						const bool left_first = ga && (!gb || ta < tb);
-						if (ga && gb) { stk.push(st.sp, left_first ? rb : ra, left_first ? tb : ta); st.sp++; }
-						if (ga || gb) st.cur = left_first ? ra : rb;
-						else need_pop = true;
-					}
-					if (need_pop) st.cur = pop_next();
-				}
-			}
-		} else
-#if MIPT_INNER_V2
-		// Round 3: the step priced in issue cycles (profiles/r3_b_instruction_issue_rates.txt: on this chip add / mul / fma / mov /
-		// logic issue at 2 cycles per wave, but min / max / compare / select / anything packed, DPP or with three sources at 4, an
-		// LDS operation at ~11-16).  What that changes: (i) scalar sub + mul instead of the packed pairs (same cycles, six
-		// registers fewer); (ii) one closed form per box with three compares instead of six: with max(t_enter, 0) <= t_exit
-		// standing for !(t_enter > t_exit) & !(t_exit < 0) (box_test_closed, mipt_trace.h); (iii) wave-uniform facts hoisted out
-		// of the loop (does any lane take the literal chain; lanes that are not traversing hold cur == NONE, so "inner" is one
-		// compare on cur instead of a mask product that the compiler materialises through two vector instructions per ballot);
-		// (iv) one push site (the far child chosen by selects) instead of one per order; (v) node addresses as a 32-bit byte
-		// offset on a scalar base.
 		{
-			const float s_ox = st.o_xy.x, s_oy = st.o_xy.y, s_oz = st.oz_iz.x, s_ix = st.i_xy.x, s_iy = st.i_xy.y, s_iz = st.oz_iz.y;
-			const bool sx = s_ix >= 0, sy = s_iy >= 0, sz = s_iz >= 0;     // signs[k] (TriangleMesh.cpp:1145)
-			const float inf = __int_as_float(0x7f800000);
-			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
-			// together with them) use the literal early-out chain
-			const bool literal = alive && (force_literal || fabsf(s_ix) == inf || fabsf(s_iy) == inf || fabsf(s_iz) == inf);
-			const bool any_literal = __ballot(literal) != 0;
-			const float t_lim = SHADOW ? fminf(st.t, st.dist) : 0.f;         // shadow: a child is entered when its t is below both (st.t only shrinks at leaves)
-			for (;;) {
-				const bool inner = st.cur < MIPT_NONE;                       // an inner-node reference (leaves have bit 31, idle lanes hold NONE)
-				const unsigned long long mi = __ballot(inner);
-				if (mi == 0) break;
-				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
-				if (inner) {
-					MIPT_PROF_COUNT(0)
-					const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (size_t)(st.cur << 6));     // (< 2^26 nodes: mipt_upload_scene)
-					const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-					const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-					float tl, tr;
-					bool goleft, goright;
-					if (any_literal) {
-						const f3 s_org = mk3(s_ox, s_oy, s_oz), s_invd = mk3(s_ix, s_iy, s_iz);
-						const f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
-						const f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
-						goleft = box_test<!SHADOW>(lmin, lmax, s_org, s_invd, sx, sy, sz, tl);
-						goright = box_test<!SHADOW>(rmin, rmax, s_org, s_invd, sx, sy, sz, tr);
-						goleft = goleft && (tl < st.t); goright = goright && (tr < st.t);
-						if (SHADOW) { goleft = goleft && (tl < st.dist); goright = goright && (tr < st.dist); }
-					} else {
-						goleft = box_test_closed<!SHADOW>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, tl);
-						goright = box_test_closed<!SHADOW>(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, s_ox, s_oy, s_oz, s_ix, s_iy, s_iz, sx, sy, sz, tr);
-						if (SHADOW) { goleft = goleft && (tl < t_lim); goright = goright && (tr < t_lim); }
-						else { goleft = goleft && (tl < st.t); goright = goright && (tr < st.t); }
-					}
-					// near child first, ties -> right child; the far child is pushed with its tnear (TriangleMesh.cpp:1180-1187)
-					const bool left_first = goleft && (!goright || tl < tr);
-					if (goleft && goright) { stk.push(st.sp, left_first ? rref : lref, left_first ? tr : tl); st.sp++; }
-					if (goleft || goright) st.cur = left_first ? lref : rref;
-					else st.cur = pop_next();
-				}
-			}
-		}
-#else
-		{
-			const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
-			const bool sx = s_invd.x >= 0, sy = s_invd.y >= 0, sz = s_invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
+			bool sx = st.i_xy.x >= 0, sy = st.i_xy.y >= 0, sz = st.oz_iz.y >= 0;     // signs[k] (TriangleMesh.cpp:1145)
 			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
 			// together with them) use the literal early-out chain
 			const float inf = __int_as_float(0x7f800000);
-			const bool literal = alive && (force_literal || fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
+			bool literal = alive && (force_literal || fabsf(st.i_xy.x) == inf || fabsf(st.i_xy.y) == inf || fabsf(st.oz_iz.y) == inf);
 			for (;;) {
 				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
 				const unsigned long long mi = __ballot(inner);
 				if (mi == 0) break;
 				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
+				if (MIPT_STANDBY && __popcll(__ballot((int)st.cur < 0 && alive)) >= leaf_max) break;
 				if (!inner) continue;
 				MIPT_PROF_COUNT(0)
 				float4 q0, q1, q2, q3;
@@ -451,14 +435,13 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					q0 = lds_ld4(l + (r & 3)); q1 = lds_ld4(l + ((r + 1) & 3)); q2 = lds_ld4(l + ((r + 2) & 3)); q3 = lds_ld4(l + ((r + 3) & 3));
 				} else {
 					const float4* q = nodes + 4 * (size_t)st.cur;
-					q0 = q[0]; q1 = q[1]; q2 = q[2];
-					if (MIPT_NODE_REFS_X2) { const float2 r2 = *reinterpret_cast<const float2*>(q + 3); q3 = make_float4(r2.x, r2.y, 0.f, 0.f); }      // the two references: 8 bytes (a dwordx2: half the address-unit cycles of a dwordx4)
-					else q3 = q[3];
+					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
 				}
 				uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 				float tl, tr;
 				bool goleft, goright;
 				if (__ballot(literal) != 0) {
+					const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
 					f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
 					f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
 					goleft = box_test<!SHADOW>(lmin, lmax, s_org, s_invd, sx, sy, sz, tl);
@@ -476,9 +459,13 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				} else if (goleft) st.cur = lref;
 				else if (goright) st.cur = rref;
 				else st.cur = pop_next();
+				// the ray has left the tree and a standby ray waits: it starts at the root in the wave's next step
+				if (MIPT_STANDBY && MIPT_STANDBY_INLOOP && sb_ok && st.cur == MIPT_NONE && take_standby()) {
+					sx = st.i_xy.x >= 0; sy = st.i_xy.y >= 0; sz = st.oz_iz.y >= 0;
+					literal = force_literal || fabsf(st.i_xy.x) == inf || fabsf(st.i_xy.y) == inf || fabsf(st.oz_iz.y) == inf;
+				}
 			}
 		}
-#endif
 		MIPT_PROF_CLOCK(c2);
 		MIPT_PROF_CYCLES(13, c1, c2)
 		// ---- leaf phase.  The (ray, triangle) tests of all lanes that hold a leaf are packed densely over the
@@ -494,7 +481,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			const int count = leaf ? (int)((st.cur >> 26) & 31u) + 1 : 0;
 			bool per_lane = leaf;
 			if (leaf) MIPT_PROF_COUNT(2)
-			if (!any_alpha && !MIPT_LEAF_PER_LANE) {
+			if (!any_alpha) {
 				const int cnt = count <= 4 ? count : 0;
 				const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
 				if (b1 != 0) {
@@ -521,7 +508,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						if (j < total) {
 							MIPT_PROF_COUNT(4)
 							float a, bb, gg;
-							if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0), MIPT_TRI_NT != 0>(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
+							if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + f + slot, ro, rd, a, bb, gg)) { lt = a; lb = bb; lg = gg; }
 						}
 						int wj = 0;
 						bool upd = false;
@@ -552,7 +539,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 							if (!RESV) st.t = cur_t;
 							if (!SHADOW) {
 								const int local = first + win - (int)sc->obj[st.obj].tri_base;
-								if (MIPT_HIT_WRITE_THROUGH && !RESV) { const float4 h4 = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local)); if (MIPT_TRAV_STATE_NT) wf_st(&wf.hit[st.id], h4); else wf.hit[st.id] = h4; }
+								if (MIPT_HIT_WRITE_THROUGH && !RESV) wf.hit[st.id] = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
 								else { st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg; }
 							}
 						}
@@ -566,7 +553,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				for (int i = first; i < first + count; i++) {
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
-					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0), MIPT_TRI_NT != 0>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
+					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
 						bool accept = lt < st.t && (!RESV || lt >= 0.f);
 						int local = 0;                                   // mesh-local triangle index, only needed for accepted hits
 						if (accept) {
@@ -596,6 +583,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		}
 		MIPT_PROF_CLOCK(c3);
 		MIPT_PROF_CYCLES(14, c2, c3)
+		// ---- a ray that ended in the leaf phase hands its lane to the standby ray at once
+		if (MIPT_STANDBY && MIPT_STANDBY_AFTER_LEAF && sb_ok && alive && st.cur == MIPT_NONE) take_standby();
 		// ---- mesh finished: the ray goes on with the objects behind it (next iteration's object loop)
 		if (RESV) {
 			if (alive && st.cur == MIPT_NONE) {
@@ -616,11 +605,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // closest-hit queue of depth b + 1 — both were filled by shade(b) and are independent of each other, so one launch serves
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
-#ifndef MIPT_QUAD_WAVES
-#define MIPT_QUAD_WAVES 6               // waves per SIMD of the quad-node kernels (the step holds a 112-byte record)
-#endif
-template <int MODE, bool QUAD = false>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD ? MIPT_QUAD_WAVES : (MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES)))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
+template <int MODE>
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_STANDBY ? MIPT_STANDBY_WAVES : (MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES)))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
 	uint32_t ntop = 0;
@@ -637,18 +623,18 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 #endif
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	if (MODE == 1 || MODE == 2) traverse_queue<true, false, QUAD>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 0) traverse_queue<false, false, QUAD>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 2) traverse_queue<false, false, QUAD>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
 }
 
 // The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
 // (SHADOW = false: wf.ray_o / ray_d -> wf.hit) or any hits (SHADOW = true: wf.sh_o / sh_d -> tq.vis).
-template <bool SHADOW, bool QUAD = false>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD ? MIPT_QUAD_WAVES : (SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES)))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+template <bool SHADOW>
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_STANDBY ? MIPT_STANDBY_WAVES : (SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES)))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	traverse_queue<SHADOW, false, QUAD>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
+	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).

@@ -37,28 +37,6 @@ struct DFatNode {          // 64 B, 64-B aligned.  Slabs are stored per axis as 
 	uint32_t _pad[2];
 };
 
-// Two tree levels per record (round 3).  Beyond L2 the chip fetches 128-byte lines at a fixed rate (tools/valu_rate.hip: a
-// dependent random fetch of 64 and of 128 bytes cost the same), so a 64-byte fat node wastes half of every line it misses on and
-// a ray pays one dependent round trip per level.  A quad node is the 128-byte record of an inner node N at EVEN depth: the
-// boxes of N's four grandchildren and their references.  The boxes of N's children are the unions of their children's boxes
-// (mipt_upload_scene verifies it node by node: build_bbox bounds the same vertices), and a slab distance is a monotone function
-// of its plane, so the children's slab distances are the min / max of the grandchildren's — bit for bit: the record serves
-// the visit of N (test both children) AND the visit of the child the ray enters first (test its two children), in the
-// reference's order, with one fetch.  A child that is a leaf stores its own box twice (box[2c] = box[2c+1]), its leaf
-// reference in ref[2c] and MIPT_QUAD_LEAF_CHILD in ref[2c+1].
-//   reference values in the traversal:  quad index (< 2^29)                        visit N: both levels
-//                                       MIPT_QHALF | side << 29 | quad index       visit child `side` of N: its two children only (a popped far child)
-//                                       MIPT_LEAF_BIT | ...                        a leaf (as in a fat node)
-#define MIPT_QHALF 0x40000000u
-#define MIPT_QSIDE 0x20000000u
-#define MIPT_QIDX_MASK 0x1fffffffu
-#define MIPT_QUAD_LEAF_CHILD 0x7fffffffu
-struct DQuadNode {         // 128 B, 128-B aligned (112 used: seven 16-byte loads)
-	float box[4][6];       // grandchild g = 2 * child + side: xmin, xmax, ymin, ymax, zmin, zmax
-	uint32_t ref[4];
-	uint32_t _pad[4];
-};
-
 // Intersection record, 64 B.  A test that loads only the first 48 bytes derives N = cross(u, v) and m22 = |v|^2 with the
 // operations Triangle's constructor used (TriangleMesh.h:70-78: same bits) and saves one vector-memory instruction.
 struct DTriIsect { float A[3], u[3], v[3]; float invdetm, m11, m12, m22; float N[3]; };
@@ -106,7 +84,6 @@ struct DObject {
 	uint32_t node_base, tri_base;
 	float root_min[3], root_max[3];
 	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
-	uint32_t root_qref;        // the same for the quad-node traversal (quad index of node 0, or the leaf ref)
 	int ntri;
 	int ghost;                 // Object::ghost (Geometry.h:721): only the queue kernel (mipt_compositing.h) renders such scenes
 	const float* uvs;          // Vector[nuvs]
@@ -118,7 +95,6 @@ struct DScene {
 	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)
 	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
 	int top_nodes;               // all_nodes[0 .. top_nodes) are the first inner nodes of the first mesh in breadth-first order (LDS copy, mipt_persistent.h)
-	const DQuadNode* all_quads;  // quad nodes of every mesh (null: some mesh's boxes are not the unions of their children's: fat nodes only)
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

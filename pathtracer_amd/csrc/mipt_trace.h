@@ -129,90 +129,11 @@ MIPT_DEV bool box_test_pairs(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mipt
 	return ok;
 }
 
-// box_test_pairs with every operand in a register of its own and the accept test reduced to what costs least on this chip
-// (profiles/r3_b_instruction_issue_rates.txt: min / max / compare / select issue at half the rate of add / mul): the same
-// fp32 subtractions and multiplications on the same operands (a packed fp32 instruction issues at half rate too, so the
-// pairs saved instruction slots, not cycles, and cost six duplicated ray registers), then
-//     t_out = max(t_enter, 0)                                   (the reference's `if (t < 0) t = 0`; -0 becomes +0, which no later
-//                                                                comparison can tell apart)
-//     ok    = t_out <= t_exit  [& the x-split sign test]
-// which equals box_test_pairs' ok for every ray without an infinite 1/d component (those take box_test):
-//   * generic variant:  !(t_enter > t_exit) & !(t_exit < 0)  <=>  max(t_enter, 0) <= t_exit   (no NaN among the operands);
-//   * x-split variants: !(t_enter > t_exit) & !rejx & !(min(fy, fz) < 0).  When rejx is false the far-x product fx is >= 0
-//     (far_x - o.x and 1/d.x then have the same sign, or the difference is 0), so min(fy, fz) < 0 <=> t_exit < 0 and the
-//     same identity applies; when rejx is true both forms reject.
-template <bool XSPLIT>
-MIPT_DEV bool box_test_closed(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax, float ox, float oy, float oz, float ix, float iy, float iz,
-                              bool sx, bool sy, bool sz, float& t_out) {
-	const float rx0 = xmin - ox, rx1 = xmax - ox;
-	const float tx0 = rx0 * ix, tx1 = rx1 * ix, ty0 = (ymin - oy) * iy, ty1 = (ymax - oy) * iy, tz0 = (zmin - oz) * iz, tz1 = (zmax - oz) * iz;
-	const float nx = sx ? tx0 : tx1, fx = sx ? tx1 : tx0;
-	const float ny = sy ? ty0 : ty1, fy = sy ? ty1 : ty0;
-	const float nz = sz ? tz0 : tz1, fz = sz ? tz1 : tz0;
-	const float t_enter = fmaxf(fmaxf(nx, ny), nz);
-	const float t_exit = fminf(fminf(fx, fy), fz);
-	const float t0 = fmaxf(t_enter, 0.f);
-	bool ok = t0 <= t_exit;
-	if (XSPLIT) {
-		// sx: reject when (far plane - o.x) < 0, !sx: when it is > 0 (Geometry.h:146-204): one comparison after flipping the sign for !sx
-		const float rfar = __uint_as_float(__float_as_uint(sx ? rx1 : rx0) ^ (sx ? 0u : 0x80000000u));
-		ok = ok & !(rfar < 0);
-	}
-	t_out = t0;
-	return ok;
-}
-
-// Slab distances of one box for the quad-node step (mipt_persistent.h): near / far distance per axis and the x-split operand
-// (far plane - o.x, sign-flipped for rays going down x: rejected when negative).  The distances of the union of two boxes are
-// the min of the near and the max of the far ones: (plane - o) * invd is monotone in the plane, so the min / max commutes
-// with it bit for bit (no NaN: rays with an infinite 1/d component take the literal chain on explicit union boxes).
-struct QuadSlab { float nx, ny, nz, fx, fy, fz, rf; };
-MIPT_DEV void quad_slab(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax, float ox, float oy, float oz, float ix, float iy, float iz,
-                        bool sx, bool sy, bool sz, uint32_t xflip, QuadSlab& s) {
-	const float rx0 = xmin - ox, rx1 = xmax - ox;
-	const float tx0 = rx0 * ix, tx1 = rx1 * ix, ty0 = (ymin - oy) * iy, ty1 = (ymax - oy) * iy, tz0 = (zmin - oz) * iz, tz1 = (zmax - oz) * iz;
-	s.nx = sx ? tx0 : tx1; s.fx = sx ? tx1 : tx0;
-	s.ny = sy ? ty0 : ty1; s.fy = sy ? ty1 : ty0;
-	s.nz = sz ? tz0 : tz1; s.fz = sz ? tz1 : tz0;
-	s.rf = __uint_as_float(__float_as_uint(sx ? rx1 : rx0) ^ xflip);
-}
-MIPT_DEV QuadSlab quad_union(const QuadSlab& a, const QuadSlab& b) {
-	QuadSlab u;
-	u.nx = fminf(a.nx, b.nx); u.ny = fminf(a.ny, b.ny); u.nz = fminf(a.nz, b.nz);
-	u.fx = fmaxf(a.fx, b.fx); u.fy = fmaxf(a.fy, b.fy); u.fz = fmaxf(a.fz, b.fz);
-	u.rf = fmaxf(a.rf, b.rf);
-	return u;
-}
-// box_test_closed's accept test on slab distances, with the caller's bound folded in: entered && t_out < t_lim
-template <bool XSPLIT>
-MIPT_DEV bool quad_accept(const QuadSlab& s, float t_lim, float& t_out) {
-	const float t_enter = fmaxf(fmaxf(s.nx, s.ny), s.nz);
-	const float t_exit = fminf(fminf(s.fx, s.fy), s.fz);
-	const float t0 = fmaxf(t_enter, 0.f);
-	bool ok = (t0 <= t_exit) & (t0 < t_lim);
-	if (XSPLIT) ok = ok & !(s.rf < 0);
-	t_out = t0;
-	return ok;
-}
-
 // ---------------------------------------------------------------- Triangle::intersection (TriangleMesh.h:82-104)
-// MIPT_TRI_NT: the persistent traversal reads triangle records with the non-temporal (streaming) cache policy.  Beyond L2 the
-// memory system serves a fixed RATE of random 64-byte fetches (tools/valu_rate.hip: ~56 G/s from a 212 MB table whatever
-// the number of waves or lanes), and the traversal runs at ~2/3 of it: what it can still win is L2 misses per ray.  A triangle
-// record is tested by few rays before 160 MB of other records have passed; marking it streaming leaves the 4 MB of each
-// XCD's L2 to the upper levels of the tree.
-#ifndef MIPT_TRI_NT
-#define MIPT_TRI_NT 0
-#endif
-template <bool DERIVE = false, bool NT = false>
+template <bool DERIVE = false>
 MIPT_DEV bool tri_test(const DTriIsect* __restrict__ T, f3 o, f3 d, float& t, float& beta, float& gamma) {
 	const float4* q = reinterpret_cast<const float4*>(T);
-	typedef float v4f_ __attribute__((ext_vector_type(4)));
-	float4 q0, q1, q2;
-	if (NT) {
-		const v4f_ r0 = __builtin_nontemporal_load((const v4f_*)q), r1 = __builtin_nontemporal_load((const v4f_*)q + 1), r2 = __builtin_nontemporal_load((const v4f_*)q + 2);
-		q0 = make_float4(r0.x, r0.y, r0.z, r0.w); q1 = make_float4(r1.x, r1.y, r1.z, r1.w); q2 = make_float4(r2.x, r2.y, r2.z, r2.w);
-	} else { q0 = q[0]; q1 = q[1]; q2 = q[2]; }
+	const float4 q0 = q[0], q1 = q[1], q2 = q[2];
 	const f3 A = mk3(q0.x, q0.y, q0.z), u = mk3(q0.w, q1.x, q1.y), v = mk3(q1.z, q1.w, q2.x);
 	const float invdetm = q2.y, m11 = q2.z, m12 = q2.w;
 	f3 N; float m22;
