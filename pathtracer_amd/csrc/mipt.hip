@@ -390,8 +390,6 @@ struct mipt_ctx {
 	int64_t opt_pipeline = 1;
 	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
 	int64_t opt_inner_min = 16;
-	int64_t opt_leaf_max = 0;             // traversal: the inner phase ends once this many lanes wait with a leaf (0 = never for that reason)
-	int64_t opt_standby_threshold = 16;   // traversal: lanes without a standby ray before the wave fetches some (mipt_persistent.h, MIPT_STANDBY)
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
@@ -592,8 +590,6 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
-	if (!strcmp(name, "leaf_max")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "leaf_max must be in [0,64]"); c->opt_leaf_max = value; return MIPT_OK; }
-	if (!strcmp(name, "standby_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "standby_threshold must be in [1,64]"); c->opt_standby_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "lane_limit")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "lane_limit must be in [0,64]"); c->opt_lane_limit = value; return MIPT_OK; }
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
@@ -634,8 +630,7 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 // staging of all meshes' traversal records (one device buffer each)
 // (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
 struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; };
-struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; int top_nodes = 0; };
-#define MIPT_TOP_RESERVE 255             // inner nodes stored breadth-first in front of a mesh's node range (>= MIPT_TOP_NODES of any build)
+struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; };
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
@@ -650,20 +645,11 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 	std::vector<int> fat_index(nn, -1);
 	int nfat = 0;
 	for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) nfat++;
-	// Position of the inner nodes in the buffer: the first MIPT_TOP_RESERVE of them in BREADTH-first order (the levels every
-	// ray crosses: the traversal kernels keep a copy of that prefix in LDS), the others behind them in the reference's
-	// depth-first order.  Child references are indices, so the order in memory is free.
+	// inner nodes keep the reference's depth-first order (child references are indices: breadth-first and hybrid orders were
+	// measured in round 1 / 2 and changed nothing)
 	{
-		std::vector<int> bfs;
-		if (nn > 0 && !m->nodes[0].isleaf) bfs.push_back(0);
-		for (size_t h = 0; h < bfs.size() && bfs.size() < MIPT_TOP_RESERVE; h++) {
-			const int kids[2] = {m->nodes[bfs[h]].fg, m->nodes[bfs[h]].fd};
-			for (int kid : kids) if (kid > bfs[h] && kid < nn && !m->nodes[kid].isleaf && bfs.size() < MIPT_TOP_RESERVE) bfs.push_back(kid);
-		}
 		int next = 0;
-		for (int i : bfs) fat_index[i] = next++;
-		for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf && fat_index[i] < 0) fat_index[i] = next++;
-		if (stg.chunks.empty()) stg.top_nodes = (int)bfs.size();
+		for (int i = 0; i < nn; i++) if (!m->nodes[i].isleaf) fat_index[i] = next++;
 	}
 	auto child_ref = [&](int node, uint32_t& ref) -> int {
 		if (node < 0 || node >= nn) return fail(c, MIPT_ERR_INVALID, "BVH child index out of range");
@@ -910,7 +896,6 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			on += ch.nfat; ot += ch.nt;
 		}
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
-		H.top_nodes = stg.top_nodes;
 	}
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
@@ -1209,7 +1194,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
 		if (c->opt_sort_rays) { sort_list = (unsigned*)carve(N * sizeof(unsigned)); sort_hist = (unsigned*)carve(MIPT_SORT_BINS * 2048 * sizeof(unsigned)); }
 		wf.out = S;
-		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
+		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * (MIPT_BLOCK > MIPT_TRAV_BLOCK ? MIPT_BLOCK : MIPT_TRAV_BLOCK) * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
 	}
 	float4 *aov_n = nullptr, *aov_kd = nullptr;
@@ -1235,7 +1220,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
 		qw.ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
-		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * MIPT_BLOCK * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
+		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * (MIPT_BLOCK > MIPT_TRAV_BLOCK ? MIPT_BLOCK : MIPT_TRAV_BLOCK) * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
 		if (c->grid_qtrav[0] == 0) {
 			const void* kern[2] = {(const void*)k_q_traverse<false>, (const void*)k_q_traverse<true>};
@@ -1308,7 +1293,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			};
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
-			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xff) | ((int)(c->opt_leaf_max & 0xff) << 8) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17) | ((int)(c->opt_standby_threshold & 127) << 24);
+			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			auto q_traverse = [&](bool shadow, const TravQueue& tq, unsigned nq) {
 				const dim3 g(std::max(1u, std::min(c->grid_qtrav[shadow ? 1 : 0], (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
 				if (shadow) hipLaunchKernelGGL(k_q_traverse<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
@@ -1382,7 +1367,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], k < 3 ? (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK) : grid_all)); };
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
-			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xff) | ((int)(c->opt_leaf_max & 0xff) << 8) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17) | ((int)(c->opt_standby_threshold & 127) << 24);
+			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			unsigned* const list_mem[2] = {wf.list[0], wf.list[1]};
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (c->opt_sort_rays && !merge && b > 0) {                // reorder the closest-hit queue of this depth (written by shade(b-1))

@@ -23,15 +23,8 @@
 #ifndef MIPT_DERIVE_EXTEND
 #define MIPT_DERIVE_EXTEND 1           // the closest-hit traversal too, at 6 waves per SIMD (84 registers; at 7 waves / 72 registers deriving spills: +15 %)
 #endif
-// Top of the tree in LDS: the first MIPT_TOP_NODES inner nodes of the scene's first mesh in breadth-first order (mipt_upload_scene
-// stores them in front of the node buffer) are copied into LDS by every block; a lane whose current node is one of them reads
-// its 64 bytes with four ds_read_b128 instead of four global_load_dwordx4.  0 = off.  The blocks are then MIPT_TRAV_BLOCK threads
-// so that the copy is shared by more waves (LDS per block: stack 80 B + leaf map 4 B per thread + 64 B per cached node).
-#ifndef MIPT_TOP_NODES
-#define MIPT_TOP_NODES 0
-#endif
 #ifndef MIPT_TRAV_BLOCK
-#define MIPT_TRAV_BLOCK (MIPT_TOP_NODES ? 512 : 256)
+#define MIPT_TRAV_BLOCK 256
 #endif
 #ifndef MIPT_PULL_CHUNK
 #define MIPT_PULL_CHUNK 512u            // ids reserved per global atomic (sub-allocated wave-locally); swept 128 .. 4096 on C2: 512 and 256 best, 1024 +0.5 %, 4096 +3.7 % (tails), 128 +2 %
@@ -42,28 +35,6 @@
 // latency is covered by the other six waves of the SIMD.  Off.
 #ifndef MIPT_PREFETCH_IDS
 #define MIPT_PREFETCH_IDS 0
-#endif
-// MIPT_STANDBY (round 3): every lane keeps a second, fully set-up ray beside the one it traverses and takes it the moment the
-// first is finished — inside the inner loop, without waiting for the wave's next refill.  Why: a CU issues ONE vector-memory
-// instruction per ~10 ns whatever its width and almost whatever the number of its active lanes (tools/valu_rate.hip,
-// profiles/r3_b_instruction_issue_rates.txt), the traversal kernels spend ~90 % of their time at that rate (1.03 G such
-// instructions per launch of the closest-hit kernel = 4.0 M per CU x 10 ns = 40 of its 45.5 ms), and 85 % of them are the four
-// loads of a node at 32.5 of 64 lanes.  What a launch costs is therefore node-load INSTRUCTIONS, and a lane that sits empty
-// between the end of its ray and the next refill (a refill waits until 36 lanes are empty, because it costs the object loop
-// for few lanes) pays them for nothing.  The standby ray costs 13 registers (the kernels then run 5 waves per SIMD instead of
-// 7) and no LDS: it has not entered the tree yet, its stack is empty.  Scenes whose first mesh is their last object only
-// (every BASELINE config): a ray that leaves the mesh is decided, nothing else has to be visited for it.
-#ifndef MIPT_STANDBY
-#define MIPT_STANDBY 1
-#endif
-#ifndef MIPT_STANDBY_INLOOP
-#define MIPT_STANDBY_INLOOP 1
-#endif
-#ifndef MIPT_STANDBY_AFTER_LEAF
-#define MIPT_STANDBY_AFTER_LEAF 1
-#endif
-#ifndef MIPT_STANDBY_WAVES
-#define MIPT_STANDBY_WAVES 5
 #endif
 #ifndef MIPT_PULL_DIV
 #define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
@@ -150,9 +121,8 @@ struct TravQueue {
 // replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
 template <bool SHADOW, bool RESV = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, const lds_float4* __restrict__ top, const uint32_t ntop) {
-	const int inner_min = inner_min_flags & 0xff;
-	const int leaf_max = ((inner_min_flags >> 8) & 0xff) ? ((inner_min_flags >> 8) & 0xff) : 65;      // the inner phase also ends once this many lanes wait with a leaf (standby rays keep the phase fed: without it the leaves starve)
+                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
+	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
 	const unsigned n = tq.n_ptr ? *tq.n_ptr : tq.n_imm;
@@ -178,33 +148,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	bool drained = false;
 	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
 	const bool any_alpha = sc->any_alpha != 0;
-	// ---- the standby ray (MIPT_STANDBY): in the frame of the scene's only mesh, root box passed, not yet in the tree
-	const bool sb_ok = MIPT_STANDBY && !RESV && lane_limit == 64u && first_mesh + 1 == nobj;
-	const int sb_threshold = ((inner_min_flags >> 24) & 127) ? ((inner_min_flags >> 24) & 127) : 16;      // lanes without a standby ray before the wave fetches some
-	const uint32_t sb_root = sb_ok ? sc->obj[first_mesh].root_ref : MIPT_NONE;
-	int sb_state = 0;                    // 0 none, 1 id requested, 2 ray requested, 3 ready (see the pipeline in front of the object loop)
-	mipt_f2 sb_o_xy = {0.f, 0.f}, sb_i_xy = {0.f, 0.f}, sb_oz_iz = {0.f, 0.f};
-	f3 sb_d = mk3(0, 0, 0);
-	float sb_t = 0.f, sb_dist = 0.f;
-	unsigned sb_id = 0;
-	bool fin = false;                    // shadow rays: the light sample of path fin_id is visible, its term is still to be added
-	unsigned fin_id = 0;
-	// the lane's finished ray is settled and its standby ray becomes the lane's ray; false when that cannot be done here (no
-	// standby ray, or a second visible light sample while the first still waits for its addition: the wave's next round
-	// settles the ray the ordinary way)
-	auto take_standby = [&]() -> bool {
-		if (sb_state != 3) return false;
-		if (SHADOW) {
-			if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
-			else if (!st.best) { if (fin) return false; fin = true; fin_id = st.id; }
-		}
-		st.o_xy = sb_o_xy; st.i_xy = sb_i_xy; st.oz_iz = sb_oz_iz; st.d = sb_d;
-		st.t = sb_t; st.dist = sb_dist; st.id = sb_id; st.cur = sb_root; st.sp = 0; st.obj = first_mesh;
-		if (SHADOW) st.best = 0;
-		sb_state = 0;
-		return true;
-	};
-
 	auto pop_next = [&]() -> uint32_t {
 		while (st.sp > 0) {
 			--st.sp;
@@ -218,21 +161,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	for (;;) {
 		MIPT_PROF_CLOCK(c0);
 		if (alive) MIPT_PROF_COUNT(8)
-		if (MIPT_STANDBY && sb_ok) {
-			if (SHADOW && __ballot(fin) != 0) {
-				if (fin) {
-					const float4 c = wf.out.col[fin_id], pc = wf.sh_c[fin_id];
-					wf.out.col[fin_id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);        // Raytracer.cpp:566
-					fin = false;
-				}
-			}
-			if (!alive && !need && sb_state == 3) {           // (its previous ray was settled by the object loop of the last round)
-				st.o_xy = sb_o_xy; st.i_xy = sb_i_xy; st.oz_iz = sb_oz_iz; st.d = sb_d;
-				st.t = sb_t; st.dist = sb_dist; st.id = sb_id; st.cur = sb_root; st.sp = 0; st.obj = first_mesh;
-				if (SHADOW) st.best = 0;
-				sb_state = 0; alive = true;
-			}
-		}
 		// ---- refill idle lanes from the queue
 		unsigned long long idle = __ballot(!alive && !need && lane < lane_limit);
 		int nidle = __popcll(idle);
@@ -276,74 +204,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				const unsigned e = chunk_next + lane;
 				ahead = e < chunk_end ? list[e] : 0u;
 				ahead_at = chunk_next;
-			}
-		}
-		// ---- standby rays for the lanes that traverse and have none, as a pipeline of three rounds so that nothing waits for a
-		//      load it has just issued: (A) a queue entry is reserved and its id requested; (B) next round the id is there and the
-		//      ray is requested; (C) the round after, the ray is there: into the mesh's frame, root box (TriangleMesh.cpp:1133-1157).
-		//      The loads of A and B land during the traversal phases in between (they sit in the standby registers meanwhile).
-		if (MIPT_STANDBY && sb_ok) {
-			if (sb_state == 2) {                                                   // (C)
-				const float4 o4 = make_float4(sb_o_xy.x, sb_o_xy.y, sb_oz_iz.x, sb_t), d4 = make_float4(sb_d.x, sb_d.y, sb_d.z, sb_dist);
-				const unsigned id = sb_id;
-				if (!SHADOW && MIPT_HIT_WRITE_THROUGH) wf.hit[id] = make_float4(o4.w, 0.f, 0.f, d4.w);        // what the analytic objects left
-				const DObject& o = sc->obj[first_mesh];
-				bool enter = !(SHADOW && tq.skip_ghosts && o.ghost);
-				const f3 d = xf_dir(o.inv, mk3(d4.x, d4.y, d4.z));
-				const f3 org = xf_point(o.inv, mk3(o4.x, o4.y, o4.z));
-				const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-				float t_root;
-				const float cur_best_t = SHADOW ? __int_as_float(0x7f800000) : o4.w;
-				enter = enter && box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
-				if (enter && t_root > cur_best_t) enter = false;
-				if (SHADOW && enter && t_root > o4.w) enter = false;
-				sb_state = 0;
-				if (enter) {
-					sb_o_xy = (mipt_f2){org.x, org.y}; sb_i_xy = (mipt_f2){invd.x, invd.y}; sb_oz_iz = (mipt_f2){org.z, invd.z}; sb_d = d;
-					sb_t = cur_best_t; sb_dist = o4.w;
-					sb_state = 3;
-				} else if (SHADOW) {                                  // no mesh in the way: the light sample is visible (closest hits: the record above stands)
-					if (tq.vis) tq.vis[id] = 1.f;
-					else {
-						const float4 c = wf.out.col[id], pc = wf.sh_c[id];
-						wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);                  // Raytracer.cpp:566
-					}
-				}
-			}
-			if (sb_state == 1) {                                                   // (B)
-				const unsigned raw = __float_as_uint(sb_dist);
-				const unsigned id = identity ? sb_id : raw;
-				const bool valid = identity ? (raw & MIPT_WF_VALID) != 0 : true;
-				sb_state = 0;
-				if (valid) {
-					const float4 o4 = SHADOW ? wf.sh_o[id] : wf.ray_o[id];
-					const float4 d4 = SHADOW ? wf.sh_d[id] : wf.ray_d[id];
-					sb_o_xy = (mipt_f2){o4.x, o4.y}; sb_oz_iz = (mipt_f2){o4.z, 0.f}; sb_t = o4.w; sb_d = mk3(d4.x, d4.y, d4.z); sb_dist = d4.w;
-					sb_id = id; sb_state = 2;
-				}
-			}
-			if (!drained) {                                                        // (A)
-				const unsigned long long want = __ballot(alive && sb_state == 0);
-				const int nwant = __popcll(want);
-				if (nwant >= sb_threshold) {
-					if (chunk_next >= chunk_end) {
-						unsigned base = 0;
-						if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
-						else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
-						base = __builtin_amdgcn_readfirstlane(base);
-						if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
-						else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
-					}
-					const unsigned take = min((unsigned)nwant, chunk_end - chunk_next);
-					const unsigned prefix = (unsigned)__popcll(want & below);
-					if (alive && sb_state == 0 && prefix < take) {
-						const unsigned idx = chunk_next + prefix;
-						sb_id = idx;
-						sb_dist = identity ? wf.wgt[idx].w : __uint_as_float(list[idx]);
-						sb_state = 1;
-					}
-					chunk_next += take;
-				}
 			}
 		}
 		// ---- object loop (wave-uniform index): new rays start at object 0, rays that just left a mesh
@@ -403,7 +263,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		}
 		{
 			const int nalive = __popcll(__ballot(alive));
-			if (nalive == 0) { if (drained && !(MIPT_STANDBY && sb_ok && __ballot(sb_state != 0) != 0)) break; else continue; }
+			if (nalive == 0) { if (drained) break; else continue; }
 			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
 		}
 		MIPT_PROF_CLOCK(c1);
@@ -413,27 +273,21 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		//      (the phase also ends when fewer than inner_min lanes are still descending while others
 		//      already wait with a leaf: the stragglers simply resume in the next round)
 		{
-			bool sx = st.i_xy.x >= 0, sy = st.i_xy.y >= 0, sz = st.oz_iz.y >= 0;     // signs[k] (TriangleMesh.cpp:1145)
+			const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
+			const bool sx = s_invd.x >= 0, sy = s_invd.y >= 0, sz = s_invd.z >= 0;     // signs[k] (TriangleMesh.cpp:1145)
 			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
 			// together with them) use the literal early-out chain
 			const float inf = __int_as_float(0x7f800000);
-			bool literal = alive && (force_literal || fabsf(st.i_xy.x) == inf || fabsf(st.i_xy.y) == inf || fabsf(st.oz_iz.y) == inf);
+			const bool literal = alive && (force_literal || fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
 			for (;;) {
 				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
 				const unsigned long long mi = __ballot(inner);
 				if (mi == 0) break;
 				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
-				if (MIPT_STANDBY && __popcll(__ballot((int)st.cur < 0 && alive)) >= leaf_max) break;
 				if (!inner) continue;
 				MIPT_PROF_COUNT(0)
 				float4 q0, q1, q2, q3;
-				if (MIPT_TOP_NODES && st.cur < ntop) {
-					// piece p of node n sits at slot (p + (n >> 2)) & 3 of its 64 bytes: the 16 lanes one LDS cycle serves then
-					// spread over all 16 bank quads instead of the 4 that "piece p of any node" maps to
-					const lds_float4* l = top + 4 * st.cur;
-					const unsigned r = st.cur >> 2;
-					q0 = lds_ld4(l + (r & 3)); q1 = lds_ld4(l + ((r + 1) & 3)); q2 = lds_ld4(l + ((r + 2) & 3)); q3 = lds_ld4(l + ((r + 3) & 3));
-				} else {
+				{
 					const float4* q = nodes + 4 * (size_t)st.cur;
 					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
 				}
@@ -441,7 +295,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				float tl, tr;
 				bool goleft, goright;
 				if (__ballot(literal) != 0) {
-					const f3 s_org = mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), s_invd = mk3(st.i_xy.x, st.i_xy.y, st.oz_iz.y);
 					f3 lmin = mk3(q0.x, q0.z, q1.x), lmax = mk3(q0.y, q0.w, q1.y);
 					f3 rmin = mk3(q1.z, q2.x, q2.z), rmax = mk3(q1.w, q2.y, q2.w);
 					goleft = box_test<!SHADOW>(lmin, lmax, s_org, s_invd, sx, sy, sz, tl);
@@ -459,11 +312,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				} else if (goleft) st.cur = lref;
 				else if (goright) st.cur = rref;
 				else st.cur = pop_next();
-				// the ray has left the tree and a standby ray waits: it starts at the root in the wave's next step
-				if (MIPT_STANDBY && MIPT_STANDBY_INLOOP && sb_ok && st.cur == MIPT_NONE && take_standby()) {
-					sx = st.i_xy.x >= 0; sy = st.i_xy.y >= 0; sz = st.oz_iz.y >= 0;
-					literal = force_literal || fabsf(st.i_xy.x) == inf || fabsf(st.i_xy.y) == inf || fabsf(st.oz_iz.y) == inf;
-				}
 			}
 		}
 		MIPT_PROF_CLOCK(c2);
@@ -583,8 +431,6 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		}
 		MIPT_PROF_CLOCK(c3);
 		MIPT_PROF_CYCLES(14, c2, c3)
-		// ---- a ray that ended in the leaf phase hands its lane to the standby ray at once
-		if (MIPT_STANDBY && MIPT_STANDBY_AFTER_LEAF && sb_ok && alive && st.cur == MIPT_NONE) take_standby();
 		// ---- mesh finished: the ray goes on with the objects behind it (next iteration's object loop)
 		if (RESV) {
 			if (alive && st.cur == MIPT_NONE) {
@@ -606,40 +452,28 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 // both and the drain phase of the first queue (few rays left, most lanes idle) is covered by waves already working on the
 // second: a pass has nb_bounces + 1 traversal launches instead of 2 nb_bounces.
 template <int MODE>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_STANDBY ? MIPT_STANDBY_WAVES : (MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES)))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	uint32_t ntop = 0;
-	const lds_float4* top = nullptr;
-#if MIPT_TOP_NODES
-	__shared__ float4 lds_top_[4 * MIPT_TOP_NODES];
-	ntop = min((uint32_t)sc->top_nodes, (uint32_t)MIPT_TOP_NODES);
-	for (uint32_t k = threadIdx.x; k < 4 * ntop; k += MIPT_TRAV_BLOCK) {
-		const uint32_t n = k >> 2, piece = k & 3;
-		lds_top_[4 * n + ((piece + (n >> 2)) & 3)] = nodes[k];
-	}
-	__syncthreads();
-	top = (const lds_float4*)lds_top_;
-#endif
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, top, ntop);
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap);
 }
 
 // The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
 // (SHADOW = false: wf.ray_o / ray_d -> wf.hit) or any hits (SHADOW = true: wf.sh_o / sh_d -> tq.vis).
 template <bool SHADOW>
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_STANDBY ? MIPT_STANDBY_WAVES : (SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES)))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
+	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_q_probe(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
-	traverse_queue<false, true>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, nullptr, 0u);
+	traverse_queue<false, true>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
 }

@@ -94,7 +94,7 @@ struct DScene {
 	int nobj;
 	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)
 	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
-	int top_nodes;               // all_nodes[0 .. top_nodes) are the first inner nodes of the first mesh in breadth-first order (LDS copy, mipt_persistent.h)
+	int _pad0;
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

@@ -278,15 +278,11 @@ struct ScratchStack {            // private (scratch) memory: any occupancy, slo
 // global scratch buffer that is normally never touched.  Both pointers carry their address space in
 // the type so that pushes and pops compile to ds_* / global_* instructions, not flat ones.
 #ifndef MIPT_LDS_STACK
-#ifndef MIPT_LDS_STACK
 #define MIPT_LDS_STACK 10
-#endif
 #endif
 #define MIPT_SPILL_STACK (MIPT_STACK_DEPTH - MIPT_LDS_STACK)
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
 typedef __attribute__((address_space(1))) uint2 glb_uint2;
-typedef __attribute__((address_space(3))) float4 lds_float4;
-MIPT_DEV float4 lds_ld4(const lds_float4* p) { return make_float4(p->x, p->y, p->z, p->w); }
 struct LdsStack {
 	lds_uint2* base;              // &lds[threadIdx.x]
 	glb_uint2* spill;             // &spill[global thread id]
