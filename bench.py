@@ -27,19 +27,27 @@ of the K timed steps (+ the final reduce), inputs resident in HBM, barrier + syn
 sides, max over ranks.
 
 roofline (dominant kernel = the closest-hit traversal, k_wf_traverse<0>; its mean launch duration is measured here with
-HIP events on the render stream).  Three fractions, none of which can exceed 1 by construction except the first:
+HIP events on the render stream).  Measured live in this run: the duration, the capacity of the memory system behind L2 for
+dependent random fetches (mipt_measure_dependent_gather) and the cost of a vector-memory instruction (mipt_measure_vmem_issue).
+Per-ray counter values (L2 misses, L1 lookups, HBM bytes, instructions, vector-memory latency) come from the committed PMC run of
+the same workload, profiles/r3_pmc_counters.json, which records the commit and the hash of the library it profiled
+(derived_from_pmc_run.same_library_build says whether this run uses that build).  None of the fractions except the first can
+exceed 1 by construction:
   frac_algorithmic_hbm  ALGORITHMIC bytes per launch / duration / 8 TB/s.  Bytes per ray come from the CPU
                         oracle's counters of the reference's ordered traversal on a bounded sample of the same scene and
                         camera (B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.  It exceeds 1:
-                        the BVH is served by L2 and the Infinity Cache, those bytes never cross HBM.
-  frac_hbm_measured     HBM bytes the kernel really moved (rocprofv3 PMC, profiles/r2_pmc_counters.json, per ray of the
-                        profiled run x the rays of this run; FETCH_SIZE corrected with the gather factor measured by
-                        tools/fetch_calibration.py) / duration / 8 TB/s
-  frac                  the most utilised hardware resource the counters show for this kernel: vector-L1 (TCP) line
-                        lookups, one 64-byte line per CU and cycle at most.  achieved = TCP_TOTAL_CACHE_ACCESSES per ray
-                        (same PMC file) x rays per launch x 64 B / duration; peak = CUs x 64 B x 2.4 GHz.  Beside it:
-                        the lookups per ray the kernel makes and the algorithmic minimum (one per inner node visited, one
-                        per triangle record tested, oracle counters).
+                        most node fetches are served by L1 / L2, those bytes never cross HBM.
+  frac (bound "hbm")    the memory system behind L2: achieved = the kernel's L2 misses x 128 B (the line the fabric moves per miss)
+                        / duration; peak = the measured rate of dependent random fetches from a table of the scene's size x 128 B
+  frac_hbm_measured     HBM bytes the kernel really moved (FETCH_SIZE corrected with the gather factor of
+                        tools/fetch_calibration.py, + WRITE_SIZE) / duration / 8 TB/s
+  frac_vmem_issue       the CU's vector-memory instruction rate: instructions per CU x measured ns per instruction / duration
+                        (~0.9: what the kernel runs against)
+  frac_l1_lookups       TCP line lookups x 64 B / duration against one line per CU and cycle
+  frac_latency_model    achieved rays/s / (resident waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency)):
+                        what the same waves would deliver with every lane busy at the measured latency
+  valu / salu issue     instruction counts x the measured issue cost (2-4 cycles per vector, 4 per scalar instruction and SIMD)
+roofline_shade_kernel: algorithmic path-state bytes per vertex x vertices / stage time against the HBM peak, and its measured traffic.
 
 cpu_baseline (rank 0, N=1 only): the compiled reference's own render_image_nopreviz() on all host
 cores when oracle/_ref/libptref.so is present (kind "reference"), otherwise the oracle's threaded
@@ -406,6 +414,15 @@ def main():
                 simd_cycles = 4 * n_cus * clock_ghz * 1e9 * secs
                 rf["valu_issue_busy_2_to_4_cycles"] = [2 * pk["valu_per_ray"] * rays_per_launch / simd_cycles, 4 * pk["valu_per_ray"] * rays_per_launch / simd_cycles]
                 rf["salu_issue_busy"] = 4 * pk["salu_per_ray"] * rays_per_launch / simd_cycles
+                # vector-memory issue: the CU serves one vector-memory wave-instruction per ~10 ns (measured in this run at the mean number of
+                # active lanes of the kernel's loads: mipt_measure_vmem_issue); the kernel's instruction count per CU x that figure / its time
+                try:
+                    lanes_per_instr = 32            # mean active lanes of the node loads (tools/simd_prof.py: 31.8 - 32.5 on this workload)
+                    ns_instr = rt.measure_vmem_issue(lanes_per_instr, 3000)
+                    rf["frac_vmem_issue"] = pk["vmem_per_ray"] * rays_per_launch / n_cus * ns_instr * 1e-9 / secs
+                    rf["vmem_issue"] = {"instructions_per_ray": pk["vmem_per_ray"], "ns_per_instruction_and_cu": ns_instr, "at_active_lanes": lanes_per_instr}
+                except Exception as e:
+                    rf["vmem_issue_note"] = "%s: %s" % (type(e).__name__, e)
                 rf["pmc_source"] = pj["source"]
                 import hashlib
                 lib_sha = hashlib.sha256(open(os.path.join(ROOT, "pathtracer_amd", os.path.basename(os.environ.get("MIPT_LIB_OVERRIDE", "libmipt.so"))), "rb").read()).hexdigest()[:16]
@@ -445,66 +462,6 @@ def main():
                 except Exception:
                     pass
                 out["roofline_shade_kernel"] = rsh
-            out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
-        if world == 1 and not in_process and not args.pmc:
-            ob = oracle_bytes_per_ray(mesh, mat, cfg)
-            my_launches = max(1, launches)
-            ms_per_launch = kern_ms / my_launches
-            if pipeline == 0:     # one kernel casts both kinds of rays
-                kernel = "k_render_paths"
-                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
-            elif merged:          # dominant kernel = the traversal kernel, whose launches serve closest-hit and any-hit queues
-                kernel = "k_wf_traverse (closest-hit and any-hit queues; shadow(b) + extend(b+1) share a launch)"
-                bytes_per_launch = (rays_c * ob["bytes_closest"] + rays_s * ob["bytes_shadow"]) / my_launches
-            else:                 # dominant kernel = closest-hit traversal
-                kernel = "k_wf_traverse<0> (closest-hit / extend stage)"
-                bytes_per_launch = rays_c * ob["bytes_closest"] / my_launches
-            alg_hbm = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
-            rays_per_launch = (rays_c if (pipeline and not merged) else rays_c + rays_s) / my_launches
-            try:
-                stream = rt.measure_stream_read(8 << 30, 5)      # achievable read bandwidth of this device
-            except Exception:
-                stream = None
-            n_cus = 256
-            try:
-                n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            except Exception:
-                pass
-            peak_l1 = n_cus * 64 * 2.4                            # GB/s: one 64-byte line lookup per CU and cycle at 2.4 GHz
-            rf = {"bound": "l1", "achieved": None, "peak": peak_l1, "unit": "GB/s", "frac": None, "traffic": None,
-                  "bound_note": "vector-L1 (TCP) line lookups, 64 B per CU-cycle: the most utilised resource the PMC counters show for this kernel; "
-                                "the algorithmic-HBM fraction of SURVEY 8d is > 1 (BVH served by L2 / Infinity Cache) and measured HBM traffic is far from its peak",
-                  "kernel": kernel, "ms_per_launch": ms_per_launch, "launches": int(launches), "rays_per_launch": rays_per_launch,
-                  "frac_algorithmic_hbm": alg_hbm / 8000.0, "algorithmic_hbm_gb_per_s": alg_hbm, "hbm_peak_gb_per_s": 8000.0,
-                  "peak_measured_stream_read": stream, "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
-                  "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"]}
-            try:   # per-ray counter values of the dominant kernel from the committed PMC run of the same workload
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_counters.json")))[args.workload]
-                pk = pj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
-                lookups = pk["tcp_accesses_per_ray"] * rays_per_launch
-                rf["achieved"] = lookups * 64 / (ms_per_launch * 1e-3) / 1e9
-                rf["frac"] = rf["achieved"] / peak_l1
-                rf["l1_lookups_per_cu_cycle_at_2.4GHz"] = lookups / (n_cus * 2.4e9 * ms_per_launch * 1e-3)
-                rf["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
-                rf["traffic"] = pk["hbm_bytes_per_ray"] * rays_per_launch
-                rf["frac_hbm_measured"] = rf["traffic"] / (ms_per_launch * 1e-3) / 8e12
-                rf["pmc_source"] = pj["source"]
-            except Exception as e:
-                rf["pmc_note"] = "profiles/r2_pmc_counters.json has no entry for this workload / kernel (%s)" % type(e).__name__
-            out["roofline"] = rf
-            if pipeline == 1 and sh_launches:
-                sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
-                rs = {"kernel": "k_wf_traverse<1> (any-hit / shadow stage)", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
-                      "launches": int(sh_launches), "rays_per_launch": rays_s / sh_launches, "l1_lookups_per_ray_algorithmic": ob["lines_shadow"]}
-                try:
-                    pk = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_counters.json")))[args.workload]["kernels"]["k_wf_traverse<1>"]
-                    lk = pk["tcp_accesses_per_ray"] * rays_s / sh_launches
-                    rs["frac"] = lk * 64 / (sh_ms / sh_launches * 1e-3) / 1e9 / peak_l1
-                    rs["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
-                    rs["frac_hbm_measured"] = pk["hbm_bytes_per_ray"] * rays_s / sh_launches / (sh_ms / sh_launches * 1e-3) / 8e12
-                except Exception:
-                    pass
-                out["roofline_shadow_kernel"] = rs
             out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(mesh, mat, cfg, ob["rays_per_path"])

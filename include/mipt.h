@@ -291,6 +291,11 @@ int mipt_measure_gather_read(mipt_ctx* ctx, uint64_t buffer_bytes, uint64_t reco
    system behind L2 for the access pattern of a BVH traversal step; bench.py prices the traversal kernel's L2 misses against it.
    (Measurement aid like the two above: no counterpart in the reference.) */
 int mipt_measure_dependent_gather(mipt_ctx* ctx, uint64_t table_bytes, int steps, int repeats, double* gfetches_per_s);
+/* Nanoseconds a compute unit spends per vector-memory wave-instruction (16-byte loads that hit L1, `active_lanes` of 64 lanes
+   active, 7 waves per SIMD issuing).  On this chip the figure barely depends on the load width or on the number of lanes: it
+   is an instruction rate, and the persistent traversal kernels run at ~90 % of it; bench.py prices their instruction count
+   against it.  (Measurement aid: no counterpart in the reference.) */
+int mipt_measure_vmem_issue(mipt_ctx* ctx, int active_lanes, int iters, double* ns_per_instruction_and_cu);
 
 /* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
  * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes

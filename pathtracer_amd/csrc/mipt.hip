@@ -1786,6 +1786,48 @@ extern "C" int mipt_measure_dependent_gather(mipt_ctx* c, uint64_t table_bytes, 
 	return MIPT_OK;
 }
 
+// What a CU charges per vector-memory wave-instruction: loads that hit L1 (every lane re-reads its own 64-byte record of a
+// 256 KB table, four global_load_dwordx4 per step, eight in flight), `active` of 64 lanes, 7 waves per SIMD.  On MI355X this is
+// ~10 ns per instruction and CU at 32 active lanes and ~13 ns at 64, the same for 8- and 16-byte loads and for 2 or 7 waves per
+// SIMD (tools/valu_rate.hip): a rate of INSTRUCTIONS, not of bytes or lanes.  The traversal kernels issue 1.0 G of them per
+// launch; bench.py prices that count against this figure (roofline.frac_vmem_issue).
+__global__ void __launch_bounds__(256) k_vmem_issue(const float4* __restrict__ tab, int iters, unsigned active, float* __restrict__ sink) {
+	const unsigned lane = threadIdx.x & 63u;
+	const float4* p = tab + 4 * (size_t)((blockIdx.x * 256u + threadIdx.x) & 4095u);
+	float acc = 0.f;
+	if (lane < active) {
+		for (int i = 0; i < iters; i++) {
+			float4 a, b, c, d;
+			asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n global_load_dwordx4 %3, %4, off offset:48\n"
+			             "global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n global_load_dwordx4 %3, %4, off offset:48\n s_waitcnt vmcnt(0)"
+			             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+			acc += a.x + b.x + c.x + d.x;
+		}
+	}
+	if (acc == 12345.f) sink[0] = acc;
+}
+extern "C" int mipt_measure_vmem_issue(mipt_ctx* c, int active_lanes, int iters, double* ns_per_instruction_and_cu) {
+	if (!c || !ns_per_instruction_and_cu || active_lanes < 1 || active_lanes > 64 || iters < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	float4* tab = nullptr; float* sink = nullptr;
+	HIPCHK(c, hipMalloc(&tab, 4096 * 64 + 4096));
+	if (hipMalloc(&sink, 4) != hipSuccess) { hipFree(tab); return fail(c, MIPT_ERR_HIP, "hipMalloc failed"); }
+	hipMemset(tab, 0, 4096 * 64 + 4096);
+	const int wps = 7;
+	const unsigned grid = (unsigned)c->n_cus * wps;
+	hipLaunchKernelGGL(k_vmem_issue, dim3(grid), dim3(256), 0, 0, tab, 16, (unsigned)active_lanes, sink);      // warm-up
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(k_vmem_issue, dim3(grid), dim3(256), 0, 0, tab, iters, (unsigned)active_lanes, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1); hipFree(tab); hipFree(sink);
+	if (!(ms > 0.f)) return fail(c, MIPT_ERR_HIP, "timing failed");
+	*ns_per_instruction_and_cu = (double)ms * 1e6 / ((double)wps * 4 * iters * 8);      // per CU: wps blocks x 4 waves x iters x 8 instructions
+	return MIPT_OK;
+}
+
 // =====================================================================================
 // BVH construction on the device (mipt_build.h): same nodes, same positions, same triangle order as
 // TriMesh::build_bvh (TriangleMesh.cpp:878-885, 1029-1130)
