@@ -230,8 +230,9 @@ def main():
     rt.apply_config(cfg)
     rt.set_partition(32, rank, world)
     t0 = time.time()
-    mesh_obj = scenes.install(rt, mesh, mat)
+    mesh_obj = rt.add_mesh(mesh)                 # TriMesh::init: axis swap, BVH (on the GPU), triangle soup, tangents
     t_build = time.time() - t0
+    scenes.install_material(rt, mesh_obj, mat)   # material lists, textures, environment map
     bvh_who, bvh_s, bvh_dev_s = rt.mesh_bvh_builder(mesh_obj)
     t0 = time.time()
     rt.prepare()

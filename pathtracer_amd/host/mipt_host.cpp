@@ -252,6 +252,14 @@ void TriMesh::add_default_group_materials(int ngroups) {
 // TriMesh::init after the file has been read (TriangleMesh.cpp:742-841), scaling = 1, offset = 0, preserve_input = false
 void TriMesh::finish_init(bool center) {
 	g_content_epoch++;
+	const bool trace = getenv("MIPT_BUILD_TRACE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char* what) {
+		if (!trace) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[TriMesh::init] %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
 	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
 	const int nvtx = (int)vertices.size();
@@ -276,6 +284,7 @@ void TriMesh::finish_init(bool center) {
 	}
 	permuted_triangle_index.resize(nf);
 	parallel_for(nf, [&](int a, int b) { for (int i = a; i < b; i++) permuted_triangle_index[i] = i; });
+	phase("axis swap, bounds, centring");
 	// build_bvh (:878-885): on the GPU (mipt_build_bvh, same tree and triangle order) or with the host recursion below
 	build_bbox(0, nf, bvh.bbox);
 	const auto t_build = std::chrono::steady_clock::now();
@@ -289,6 +298,7 @@ void TriMesh::finish_init(bool center) {
 		build_bvh_recur(bvh.nodes, 0, nf, 0);
 	}
 	bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
+	phase("build_bvh");
 	build_bbox(0, nf, bbox);
 	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
 	triangleSoup.resize(nf);
@@ -312,7 +322,9 @@ void TriMesh::finish_init(bool center) {
 	}
 	});
 	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
+	phase("triangle soup");
 	if (nt != 0) setup_tangents();
+	phase("tangents");
 }
 
 // ---------------------------------------------------------------- OBJ / MTL ingestion
@@ -981,28 +993,72 @@ void TriMesh::build_bvh_recur(PodVec<BVHNodes>& out, int i0, int i1, int depth) 
 
 // setup_tangents (TriangleMesh.cpp:601-711): only tangentSoup is read by the path (normal maps).
 void TriMesh::setup_tangents() {
+	// TriangleMesh.cpp:572-640.  The reference walks the faces once and adds every face's (sdir, tdir) into its three
+	// vertices: per vertex the sum runs in ascending face order, which fixes its rounding.  Here the per-face vectors are
+	// computed on all threads, a vertex -> incident corners table (ascending face order) is filled in one serial pass, and the
+	// vertices then sum their own lists concurrently — the same additions in the same order.
 	const int nv = (int)vertices.size(), nf = (int)indices.size();
-	std::vector<Vector> tan1(nv), tan2(nv);
-	for (int i = 0; i < nf; i++) {
-		const auto& t = indices[i];
-		if (t.uvi == -1 || t.uvj == -1 || t.uvk == -1) continue;
-		Vector vA = sub(vertices[t.vtxj], vertices[t.vtxi]), vB = sub(vertices[t.vtxk], vertices[t.vtxi]);
-		Vector sA = sub(uvs[t.uvj], uvs[t.uvi]), sB = sub(uvs[t.uvk], uvs[t.uvi]);
-		float det = (sA[0] * sB[1] - sB[0] * sA[1]);
-		Vector sdir, tdir;
-		if (det != 0) { sdir = divs(sub(mul(sB[1], vA), mul(sA[1], vB)), det); tdir = divs(sub(mul(sA[0], vB), mul(sB[0], vA)), det); }
-		else { sdir = mul(0.00001f, vA); tdir = mul(0.00001f, vB); }
-		for (int a : {t.vtxi, t.vtxj, t.vtxk}) { tan1[a] = add(tan1[a], sdir); tan2[a] = add(tan2[a], tdir); }
-	}
-	std::vector<int> v2n(nv, 0);
-	for (int i = 0; i < nf; i++) { v2n[indices[i].vtxi] = indices[i].ni; v2n[indices[i].vtxj] = indices[i].nj; v2n[indices[i].vtxk] = indices[i].nk; }
-	std::vector<Vector> tangents(nv);
-	for (int i = 0; i < nv; i++) {
-		Vector N = normalized(normals[v2n[i]]);
-		tangents[i] = normalized(sub(tan1[i], mul(dot(tan1[i], N), N)));
-	}
+	const bool trace = getenv("MIPT_BUILD_TRACE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char* what) {
+		if (!trace) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[setup_tangents] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
+	PodVec<Vector> sdir(nf), tdir(nf);                       // (PodVec: no serial zero fill of 30 MB each; every used entry is written below)
+	PodVec<unsigned char> has(nf);
+	parallel_for(nf, [&](int a, int b) {
+		for (int i = a; i < b; i++) {
+			const auto& t = indices[i];
+			has[i] = !(t.uvi == -1 || t.uvj == -1 || t.uvk == -1);
+			if (!has[i]) continue;
+			Vector vA = sub(vertices[t.vtxj], vertices[t.vtxi]), vB = sub(vertices[t.vtxk], vertices[t.vtxi]);
+			Vector sA = sub(uvs[t.uvj], uvs[t.uvi]), sB = sub(uvs[t.uvk], uvs[t.uvi]);
+			float det = (sA[0] * sB[1] - sB[0] * sA[1]);
+			if (det != 0) { sdir[i] = divs(sub(mul(sB[1], vA), mul(sA[1], vB)), det); tdir[i] = divs(sub(mul(sA[0], vB), mul(sB[0], vA)), det); }
+			else { sdir[i] = mul(0.00001f, vA); tdir[i] = mul(0.00001f, vB); }
+		}
+	});
+	phase("per-face vectors");
+	// vertex -> incident corners (3 * face + k): counted and filled on all threads with atomic cursors, so a vertex's list comes
+	// out in arbitrary order; every vertex sorts its own short list before it sums (ascending face order = the reference's)
+	std::vector<int> first((size_t)nv + 1, 0);
+	parallel_for(nf, [&](int a, int b) {
+		for (int i = a; i < b; i++) { __atomic_fetch_add(&first[indices[i].vtxi + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&first[indices[i].vtxj + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&first[indices[i].vtxk + 1], 1, __ATOMIC_RELAXED); }
+	});
+	phase("count");
+	for (int v = 0; v < nv; v++) first[v + 1] += first[v];
+	std::vector<int> fill(first.begin(), first.end() - 1);
+	PodVec<int> corner((size_t)nf * 3);
+	parallel_for(nf, [&](int a, int b) {
+		for (int i = a; i < b; i++) {
+			corner[__atomic_fetch_add(&fill[indices[i].vtxi], 1, __ATOMIC_RELAXED)] = 3 * i;
+			corner[__atomic_fetch_add(&fill[indices[i].vtxj], 1, __ATOMIC_RELAXED)] = 3 * i + 1;
+			corner[__atomic_fetch_add(&fill[indices[i].vtxk], 1, __ATOMIC_RELAXED)] = 3 * i + 2;
+		}
+	});
+	phase("prefix + fill");
+	PodVec<Vector> tangents(nv);
+	parallel_for(nv, [&](int a, int b) {
+		for (int v = a; v < b; v++) {
+			Vector t1, t2;
+			int nidx = 0;                                           // v2n: the normal index of the last corner that names the vertex (vertices no face names keep 0)
+			std::sort(corner.begin() + first[v], corner.begin() + first[v + 1]);
+			for (int e = first[v]; e < first[v + 1]; e++) {
+				const int f = corner[e] / 3, k = corner[e] % 3;
+				if (has[f]) { t1 = add(t1, sdir[f]); t2 = add(t2, tdir[f]); }
+				nidx = k == 0 ? indices[f].ni : (k == 1 ? indices[f].nj : indices[f].nk);
+			}
+			(void)t2;
+			Vector N = normalized(normals[nidx]);
+			tangents[v] = normalized(sub(t1, mul(dot(t1, N), N)));
+		}
+	});
+	phase("per-vertex sums");
 	tangentSoup.resize((size_t)nf * 3);
-	for (int i = 0; i < nf; i++) { tangentSoup[3 * i] = tangents[indices[i].vtxi]; tangentSoup[3 * i + 1] = tangents[indices[i].vtxj]; tangentSoup[3 * i + 2] = tangents[indices[i].vtxk]; }
+	parallel_for(nf, [&](int a, int b) { for (int i = a; i < b; i++) { tangentSoup[3 * (size_t)i] = tangents[indices[i].vtxi]; tangentSoup[3 * (size_t)i + 1] = tangents[indices[i].vtxj]; tangentSoup[3 * (size_t)i + 2] = tangents[indices[i].vtxk]; } });
+	phase("tangent soup");
 }
 
 // ---------------------------------------------------------------- Scene

@@ -274,6 +274,12 @@ def install(X, mesh, mat):
     """Adds the workload's mesh and material to X: a capi.HostRaytracer, an oracle.binding.Oracle or a
     binding.Ref (they share these method names).  Returns the object id."""
     oid = X.add_mesh(mesh)
+    install_material(X, oid, mat)
+    return oid
+
+
+def install_material(X, oid, mat):
+    """The workload's material, textures, BRDF table and environment map on object `oid` of X."""
     if mat is not None:
         X.set_group_material(oid, 0, mat["Kd"], mat["Ks"], mat["Ne"], mat.get("transp", 1.0), mat.get("refr", 1.3))
         for slot, img in mat.get("tex", {}).items():
@@ -282,7 +288,6 @@ def install(X, mesh, mat):
             X.set_brdf_merl(oid, mat["merl"])
         if "envmap" in mat:
             X.set_envmap(mat["envmap"])
-    return oid
 
 
 # ---------------------------------------------------------------- an OBJ / MTL / PPM scene on disk
