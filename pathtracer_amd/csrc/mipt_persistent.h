@@ -194,7 +194,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						// closest-hit rays arrive with the (t, object) found in front of the first mesh, shadow rays
 						// arrive only if no sphere / plane occludes them
 						st.id = id; st.obj = first_mesh; need = true;
-						if (SHADOW) { st.dist = wf.sh_o[id].w; st.best = 0; }
+						if (SHADOW) st.best = 0;                                         // (dist_light arrives with the ray: object loop below)
 						else if (!RESV) { st.beta = 0; st.gamma = 0; }               // st.t / st.best arrive with the ray (object loop below)
 					}
 				}
@@ -228,10 +228,13 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			}
 		} else if (__ballot(need)) {
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
-			if (need) {
+			// (a ray that has left its last object only has to be settled below: it is not fetched again — 6 % of the kernel's
+			// vector-memory instructions on a one-mesh scene, and the kernel runs at the CU's rate of those: DESIGN.md 4d)
+			if (need && (st.obj < nobj || (!SHADOW && st.obj == first_mesh))) {     // (a scene without a mesh: a fresh closest-hit ray still brings its record)
 				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
 				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+				if (SHADOW) st.dist = o4.w;
 				if (!SHADOW && st.obj == first_mesh) {                                                       // a fresh ray: what the analytic objects left
 					st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
 					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);

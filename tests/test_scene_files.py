@@ -141,5 +141,17 @@ def test_scene_file_radiance_and_cli(tmp_path):
     assert r.returncode == 0, r.stderr
     assert png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
     assert np.array_equal(host_read(png), u8)
-    r = subprocess.run([exe, scn, str(tmp_path / "out.jpg")], capture_output=True, text=True)
-    assert r.returncode != 0 and "JPEG" in r.stderr and not (tmp_path / "out.jpg").exists()
+    # .jpg (baseline, quality 100: the reference's encoder byte for byte, tests/test_image_writers.py) and .hdr are written too
+    jpg = tmp_path / "out.jpg"
+    r = subprocess.run([exe, scn, str(jpg)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dec = host_read(jpg)
+    assert dec.shape == u8.shape and np.abs(dec.astype(int) - u8.astype(int)).max() <= 6
+    hdr = tmp_path / "out.hdr"
+    r = subprocess.run([exe, scn, str(hdr)], capture_output=True, text=True)
+    assert r.returncode == 0 and hdr.read_bytes().startswith(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (H.H, H.W)), r.stderr
+    # a name no writer exists for is refused before anything is rendered, and an existing file of that name is left alone
+    gif = tmp_path / "out.gif"
+    gif.write_bytes(b"keep me")
+    r = subprocess.run([exe, scn, str(gif)], capture_output=True, text=True)
+    assert r.returncode != 0 and "no writer" in r.stderr and gif.read_bytes() == b"keep me"
