@@ -358,7 +358,8 @@ struct mipt_ctx {
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
 	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
-	unsigned grid_qlogic[2] = {0, 0};
+	unsigned grid_qlogic[3] = {0, 0, 0};  // closest-hit list, any-hit list, fast tier of the closest-hit list
+	int64_t opt_queue_fast_tier = 1;  // 0: the general build of the logic stage for every sample (measurement / test hook)
 	int qlogic_fog = -1;              // which build of the logic stage grid_qlogic was measured for
 	unsigned grid_qtrav[2] = {0, 0};  // resident blocks of k_q_traverse<false / true>
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
@@ -590,6 +591,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_ring")) { if (value < 1) return fail(c, MIPT_ERR_INVALID, "queue_ring must be >= 1"); c->opt_queue_ring = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_wavefront")) { c->opt_queue_wavefront = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "queue_fast_tier")) { c->opt_queue_fast_tier = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
 	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
@@ -797,7 +799,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (o.brdf_kind != MIPT_BRDF_PHONG && o.brdf_kind != MIPT_BRDF_MERL) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: unknown BRDF kind %d", i, o.brdf_kind);
 		if (o.brdf_kind == MIPT_BRDF_MERL && !o.merl_data) return fail(c, MIPT_ERR_INVALID, "object %d: MERL BRDF without a table", i);
 		if (i < 2 && o.type != MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_INVALID, "objects 0 and 1 must be the light and environment spheres");
-		d.type = o.type; d.miroir = o.miroir; d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
+		d.type = o.type; d.miroir = (o.miroir ? 1 : 0) | (o.ghost ? 2 : 0); d.flip_normals = o.flip_normals; d.interp_normals = o.interp_normals;
 		d.ghost = o.ghost ? 1 : 0;
 		if (o.ghost) scene_ghost = true;
 		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
@@ -1156,7 +1158,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES + (c->opt_sort_rays ? sizeof(unsigned) : 0); fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned) + MIPT_SORT_BINS * 2048 * sizeof(unsigned) + 64; }
 	if (want_aov) per_path += 2 * sizeof(float4);
 	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
-		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 9 * sizeof(unsigned);
+		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 10 * sizeof(unsigned);
 		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
 	}
 	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? MIPT_QW_FIFO : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
@@ -1223,6 +1225,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		qw.prl[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.prl[1] = (unsigned*)carve(N * sizeof(unsigned));
 		qw.sha[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.sha[1] = (unsigned*)carve(N * sizeof(unsigned));
 		qw.overflow = (unsigned*)carve(N * sizeof(unsigned));
+		qw.slow = (unsigned*)carve(N * sizeof(unsigned));
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
 		qw.ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
@@ -1284,11 +1287,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			                                     {{(logic_fn)k_q_logic<true, false, false>, (logic_fn)k_q_logic<true, true, false>}, {(logic_fn)k_q_logic<true, false, true>, (logic_fn)k_q_logic<true, true, true>}}};
 			const logic_fn logic_k[2] = {logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][0],       // over a closest-hit list (or all samples)
 			                             logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][1]};      // over an any-hit list
+			// the fast tier of the closest-hit-list stage (scenes without fog and subsurface groups): what it leaves goes to logic_k[0] in the same round
+			const bool fast_tier = MIPT_QW_FAST && !fog_on && !c->scene_has_subsurface && c->opt_queue_fast_tier;
+			const logic_fn logic_fast = (logic_fn)k_q_logic<false, false, false, true>;
 			if (c->grid_qlogic[0] == 0 || c->qlogic_fog != (fog_on ? 1 : 0)) {                                 // resident blocks of the logic stage (of the build in use)
 				c->qlogic_fog = fog_on ? 1 : 0;
-				for (int k = 0; k < 2; k++) {
+				for (int k = 0; k < 3; k++) {
 					int nb = 0;
-					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)logic_k[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k == 2 ? (const void*)logic_fast : (const void*)logic_k[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
 					c->grid_qlogic[k] = (unsigned)c->n_cus * (unsigned)nb;
 				}
 			}
@@ -1296,6 +1302,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (n_host == 0) return;
 				const dim3 g(std::max(1u, std::min(c->grid_qlogic[shadow_list], (n_host + MIPT_BLOCK - 1) / MIPT_BLOCK)));
 				hipLaunchKernelGGL(logic_k[shadow_list], g, dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, list, n_ptr, n_imm, head, out_slot, out_parity, c->d_cnt);
+			};
+			// the closest-hit list: the fast tier, then the general build over what it left (at most n_host samples; the count is on the device)
+			auto launch_logic_closest = [&](const unsigned* list, const unsigned* n_ptr, unsigned n_imm, unsigned n_host, int out_slot, int out_parity) {
+				if (n_host == 0) return;
+				if (!fast_tier) { launch_logic(0, list, n_ptr, n_imm, n_host, &qw.counters[MIPT_QW_HEAD_LOGIC_A(out_slot)], out_slot, out_parity); return; }
+				const dim3 g(std::max(1u, std::min(c->grid_qlogic[2], (n_host + MIPT_BLOCK - 1) / MIPT_BLOCK)));
+				hipLaunchKernelGGL(logic_fast, g, dim3(MIPT_BLOCK), 0, st, (const DScene*)c->d_scene, R, P, wf, qw, list, n_ptr, n_imm, &qw.counters[MIPT_QW_HEAD_LOGIC_A(out_slot)], out_slot, out_parity, c->d_cnt);
+				launch_logic(0, qw.slow, &qw.counters[MIPT_QW_N_SLOW(out_slot)], 0, n_host, &qw.counters[MIPT_QW_HEAD_LOGIC_SLOW(out_slot)], out_slot, out_parity);
 			};
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
@@ -1347,8 +1361,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				const int nslot = (r + 1) & 3, npar = (r + 1) & 1;
 				HIPCHK(c, hipMemsetAsync(&qw.counters[MIPT_QW_PAIR(nslot)], 0, MIPT_QW_SLOT_WORDS * sizeof(unsigned), st));
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (first) launch_logic(0, nullptr, nullptr, pair[1], pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
-				else launch_logic(0, qw.live[par], pair_dev + 1, 0, pair[1], &qw.counters[MIPT_QW_HEAD_LOGIC_A(nslot)], nslot, npar);
+				if (first) launch_logic_closest(nullptr, nullptr, pair[1], pair[1], nslot, npar);
+				else launch_logic_closest(qw.live[par], pair_dev + 1, 0, pair[1], nslot, npar);
 				launch_logic(1, qw.shl[par], pair_dev, 0, pair[0], &qw.counters[MIPT_QW_HEAD_LOGIC_B(nslot)], nslot, npar);
 				launch_logic(0, qw.prl[par], &qw.counters[MIPT_QW_N_PROBE(slot)], 0, n_probe, &qw.counters[MIPT_QW_HEAD_LOGIC_C(nslot)], nslot, npar);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");

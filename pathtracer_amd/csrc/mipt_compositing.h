@@ -352,7 +352,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 			}
 		}
 		color = color + (pathWeight * m.Ke) * R.envmap_intensity;           // :411
-		if (obj.miroir) {                                                   // :413-436
+		if (obj.miroir & 1) {                                               // :413-436
 			Ray rm; rm.o = P + 0.001f * N; rm.d = reflect(rayDirection, N);
 			if (has_fog) { fog(currentRay, cl); push(attenuationFactor * pathWeight, rm, nbrebonds - 1, show_lights, true, hadSS); }
 			else push(pathWeight, rm, nbrebonds - 1, show_lights, true, hadSS);

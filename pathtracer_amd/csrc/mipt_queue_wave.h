@@ -35,6 +35,12 @@
 #ifndef MIPT_QW_LOGIC_WAVES
 #define MIPT_QW_LOGIC_WAVES 2            // (+ 1 for the any-hit-list stage of the build without the fog code: 165 registers)
 #endif
+#ifndef MIPT_QW_FAST_WAVES
+#define MIPT_QW_FAST_WAVES 4             // the fast tier of the closest-hit-list stage (scenes without fog / subsurface groups)
+#endif
+#ifndef MIPT_QW_FAST
+#define MIPT_QW_FAST 1
+#endif
 #define MIPT_QW_FRAME 13                  // float4 slots of the per-sample frame
 // The per-sample state (1.9 KB) is touched once per call: streaming cache policy, as the path state of pipeline 1
 #ifndef MIPT_QW_STREAM
@@ -60,6 +66,8 @@ enum { QW_POP = 0, QW_A1 = 1, QW_A2 = 2, QW_F1 = 3, QW_DONE = 4, QW_PROBE = 5, Q
 #define MIPT_QW_HEAD_SHADOW_ADD(s) ((s) * MIPT_QW_SLOT_WORDS + 224)
 #define MIPT_QW_HEAD_PROBE(s) ((s) * MIPT_QW_SLOT_WORDS + 256)
 #define MIPT_QW_HEAD_LOGIC_C(s) ((s) * MIPT_QW_SLOT_WORDS + 192)  // logic stage over the previous round's probe list
+#define MIPT_QW_N_SLOW(s) ((s) * MIPT_QW_SLOT_WORDS + 162)        // samples the fast tier of the round's logic stage left to the general build
+#define MIPT_QW_HEAD_LOGIC_SLOW(s) ((s) * MIPT_QW_SLOT_WORDS + 288)
 #define MIPT_QW_N_OVERFLOW (4 * MIPT_QW_SLOT_WORDS)
 #define MIPT_QW_COUNTERS (4 * MIPT_QW_SLOT_WORDS + 32)
 
@@ -75,6 +83,7 @@ struct DQueueWave {
 	unsigned* shl[2];                // ids with an any-hit request
 	unsigned* prl[2];                // ids with a subsurface probe request
 	unsigned* sha[2];                // ids with an any-hit request whose answer only decides whether wf.sh_c is added to the colour
+	unsigned* slow;                  // ids the fast tier of the logic stage left to the general build (consumed in the same round)
 	unsigned* overflow;              // ids whose ring overflowed
 	unsigned* counters;
 	float4 *aov_n, *aov_kd;          // denoiser inputs or null
@@ -163,7 +172,16 @@ MIPT_DEV bool has_fog_early(const DRender& R) { return R.fog_density > 1E-8; }
 // call and its any-hit query runs in the same round as the closest-hit query of the next contribution; the term is added
 // to the colour by the any-hit stage, i.e. before the next vertex adds anything: the order of the additions is the
 // reference's.
-template <bool SUBS, bool SHADOW_LIST, bool FOG>
+//
+// FAST (round 3): the tier of pipeline 1's k_wf_shade<1> for this pipeline — a build for the closest-hit list of scenes without fog
+// and without subsurface groups that knows only what most vertices are: a miss, the light, the environment sphere, a mirror,
+// a dielectric, or a Lambert vertex (Ks = 0, Ne >= 0, no measured BRDF; of a ghost: up to its any-hit request).  Everything else
+// returns 16 BEFORE anything of the sample has been modified (nothing is stored, no counter is touched, the engine is advanced
+// on a copy) and the general build takes the sample in the same round (list_slow).  The Lambert vertex is path_vertex_fast's
+// (mipt_shade.h: eval = Kd / pi, the diffuse lobe picked, pdf = dot / pi): the arithmetic of the general code with the terms
+// that are exactly zero left out.  Without the Phong lobe (fp64 pow), the measured BRDF, the ghost / fog / subsurface segments
+// and the frame the build needs 128 registers instead of 206: 4 waves per SIMD instead of 2.
+template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false>
 __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const DRender& R, const DPass& ps, const DWave& wf, const DQueueWave& qw, const unsigned id,
                                        unsigned& n_closest, unsigned& n_shadow) {
 	const unsigned N = qw.N;
@@ -171,6 +189,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	int phase = (int)((ctl >> 16) & 0xffu);
 	int site = (int)(ctl >> 24);
 	if (phase == QW_DONE) return 0;
+	static_assert(!FAST || (!SUBS && !SHADOW_LIST && !FOG), "the fast tier serves the closest-hit list of scenes without fog and subsurface groups");
+	if (FAST && phase != QW_A1) return 16;
 	QwSample S;
 	{ const uint2 rs = QW_LD(&wf.rng[id]); S.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
 	// The colour is read when something is added to it and written back when it has changed.  Adding a zero vector never
@@ -388,6 +408,17 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				st = ST_POP; break;
 			}
 			const DObject& obj = sc->obj[h.obj];
+			uint64_t rng_fast = S.rng, rng_light = S.rng; float l1_fast = 0.f, l2_fast = 0.f;
+			if (FAST) {
+				if (m.merl != nullptr) return 16;
+				if (!m.miroir && !m.transp) {
+					if (!(m.Ks.x == 0.f && m.Ks.y == 0.f && m.Ks.z == 0.f && m.Ne.x >= 0.f && m.Ne.y >= 0.f && m.Ne.z >= 0.f)) return 16;
+					l1_fast = pcg_uniform(rng_fast); l2_fast = pcg_uniform(rng_fast);
+					rng_light = rng_fast;                                       // the engine behind the light sample
+					// lobe pick of PhongBRDF::sample (BRDF.h:73) with p = 1 - 0/3.f = 1: the diffuse lobe unless u == 1.0f (2^-25: the general build)
+					if (!((float)pcg_next(rng_fast) / 4294967296.f < 1.f)) return 16;
+				}
+			}
 			Ksub = mk3(0, 0, 0); subsW = mk3(1.f, 1.f, 1.f); sub_interaction = false;
 			if (SUBS) {
 				Ksub = hit_ksub(obj, h, xf_point(obj.inv, currentRay.o) + h.t * xf_dir(obj.inv, currentRay.d));
@@ -469,7 +500,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				}
 			}
 			add_color((pathWeight * m.Ke) * R.envmap_intensity);                // :411
-			if (obj.miroir) {                                                   // :413-436
+			if (FAST ? (m.miroir != 0) : ((obj.miroir & 1) != 0)) {             // :413-436
 				Ray rm; rm.o = P + 0.001f * Nn; rm.d = reflect(rayDirection, Nn);
 				if (has_fog) {
 					FRS(0, make_float4(P.x, P.y, P.z, t_main));
@@ -505,6 +536,64 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				push(pathWeight, nr, nbrebonds - 1, show_lights, true, hadSS);
 				st = ST_POP; break;
 			}
+			if (FAST) {
+				// ---- Lambert vertex, whole: light sample (:490-513), direct term (:538-566), continuation (:570-632)
+				S.rng = rng_fast;                                               // l1, l2 and the lobe pick of the continuation are drawn
+				const f3 axeOP = fast_normalize(P - cl);
+				dir_l = random_cos(axeOP, l1_fast, l2_fast);
+				const f3 pt_l = dir_l * R.radiusLight + cl;
+				wi = fast_normalize(pt_l - P);
+				d_light2 = norm2(pt_l - P);
+				const f3 brdf = m.Kd / (float)MIPT_PI;
+				bool yield_shadow = false;
+				if (dot(Nn, wi) < 0) isShadowed = true;
+				else {
+					Ray rl; rl.o = P + 0.01f * wi; rl.d = wi;
+					const float dist = sqrtf(d_light2) - 0.01f;
+					n_shadow++;
+					if (qw_analytic_occluded(sc, rl.o, rl.d, dist)) isShadowed = true;
+					else if (!qw_meshes_missed(sc, rl.o, rl.d, dist)) {
+						QW_ST(&wf.sh_o[id], make_float4(rl.o.x, rl.o.y, rl.o.z, dist));
+						QW_ST(&wf.sh_d[id], make_float4(rl.d.x, rl.d.y, rl.d.z, 0.f));
+						yield_shadow = true;
+					}
+				}
+				// a ghost queues the path going straight on only if the light is visible: its any-hit answer is waited for (A2 of the
+				// general build, over the any-hit list, goes on from the frame; the lobe pick is drawn there)
+				if (yield_shadow && m.ghost) { S.rng = rng_light; m.shadingN = Nn; save_vertex(true); save(QW_A2, 0); return 2; }
+				contrib = mk3(0, 0, 0);
+				if (m.ghost) {
+					if (!isShadowed) {                                          // :522-536
+						const f3 offset = dot(Nn, rayDirection) > 0 ? Nn : -Nn;
+						Ray through; through.o = (P + rayDirection * 0.001f) + offset * 0.001f; through.d = rayDirection;
+						push(pathWeight, through, nbrebonds, show_lights, show_envmap, hadSS);
+					}
+				} else if (!isShadowed) {
+					const float J = dot(dir_l, -wi) / d_light2;
+					const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+					if (proba > 0.f) contrib = contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(Nn, wi)) * J / proba)) * brdf;
+				}
+				if (yield_shadow) { const f3 pc = pathWeight * contrib; QW_ST(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f)); pending_add = 8; }
+				else add_color(pathWeight * contrib);                           // :566
+				// the continuation of a path's last vertex is queued with depth 0 and dropped by the loop head (:240): not computed
+				if (nbrebonds > 1) {
+					float ip;
+					const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * k], &ip);
+					const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * k + 1], &ip);
+					const f3 dir = random_cos(Nn, r1, r2);
+					const float pdf = (float)((double)(1.f * dot(Nn, dir)) / (MIPT_PI) + (double)(0.f));
+					if (!(dot(dir, Nn) < 0 || dot(dir, reflect(rayDirection, Nn)) < 0 || pdf <= 0)) {   // :593
+						f3 nw = ((pathWeight * mk3(1.f, 1.f, 1.f)) * brdf) * (dot(Nn, dir) / pdf);          // :611
+						if (m.ghost && has_bg) {                                // :614-621
+							const f3 bg = background_pixel(R, pi, pj);
+							nw = nw * mk3(bg.x / 196964.699f, bg.y / 196964.699f, bg.z / 196964.699f);
+						}
+						Ray next; next.o = P + 0.01f * dir; next.d = dir;
+						push(nw, next, nbrebonds - 1, false, (show_envmap && isShadowed) || !m.ghost, hadSS);   // :626-629 (the diffuse lobe was sampled)
+					}
+				}
+				st = ST_POP; break;
+			}
 			// ---- diffuse / glossy vertex: the light sample (:490-513)
 			const f3 axeOP = fast_normalize(P - cl);
 			const float l1 = pcg_uniform(S.rng);
@@ -534,7 +623,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			if (has_fog) save_vertex(false);                                         // the fog event of site 5 comes back through the frame
 			st = ST_A2;
 	} while (0);
-	if (st == ST_A2) do {
+	if (!FAST && st == ST_A2) do {
 			if (a2_from_query) { load_vertex(true); isShadowed = qw.vis[id] == 0.f; }
 			const DObject& obj = sc->obj[objid];
 			const double* const merl = obj.merl;
@@ -567,12 +656,12 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	} while (0);
 	// ---- the fog call of the site (one instance for the six sites: fogContribution up to its visibility query is ~2500
 	//      instructions of exact expf / logf / atan2f / tanf)
-	if (st == ST_FOG) {
+	if (!FAST && st == ST_FOG) {
 			if (fog_begin(site, currentRay, fog_light)) return 1 | (deferred ? 8 : 0);
 			if (deferred) { save(QW_T5, site); return 2; }                       // no event: the answer of the light-sample query is needed now
 			st = ST_TAIL;
 	}
-	if (!SHADOW_LIST && st == ST_F1Q) {
+	if (!FAST && !SHADOW_LIST && st == ST_F1Q) {
 			// the second half of fogContribution, once the closest hit along the in-scattering direction is known
 			{
 				const float4 lo = QW_LD(&wf.ray_o[id]), ld = QW_LD(&wf.ray_d[id]), hr = QW_LD(&wf.hit[id]), f10 = FRL(10), f11 = FRL(11);
@@ -614,7 +703,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			}
 			st = ST_TAIL;
 	}
-	if (st == ST_TAIL) do {
+	if (!FAST && st == ST_TAIL) do {
 			// the statements after the fog call of the site
 			if (site == 0) { st = ST_POP; break; }
 			if (site == 1) { const float4 ke = FRL(9); add_color(((S.att * pathWeight) * R.envmap_intensity) * mk3(ke.x, ke.y, ke.z)); st = ST_POP; break; }
@@ -635,7 +724,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			st = ST_A3;
 	} while (0);
 	// ---- A3: the continuation of the diffuse vertex (:570-632)
-	if (st == ST_A3) do {
+	if (!FAST && st == ST_A3) do {
 			const DObject& obj = sc->obj[objid];
 			const double* const merl = obj.merl;
 			float ip;
@@ -682,8 +771,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 }
 
 // One round of the logic stage over one id list of the previous round (or, round 0, over all path slots).
-template <bool SUBS, bool SHADOW_LIST, bool FOG>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu((SHADOW_LIST && !FOG) ? MIPT_QW_LOGIC_WAVES + 1 : MIPT_QW_LOGIC_WAVES))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
+template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false>
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? MIPT_QW_FAST_WAVES : ((SHADOW_LIST && !FOG) ? MIPT_QW_LOGIC_WAVES + 1 : MIPT_QW_LOGIC_WAVES)))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
                                                                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, unsigned n_imm,
                                                                                                 unsigned* __restrict__ head, int out_slot, int out_parity, DCounters* __restrict__ cnt) {
 	const unsigned n = n_ptr ? *n_ptr : n_imm;
@@ -691,14 +780,15 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	unsigned base;
 	QueuePuller q; q.init();
 	while (q.pull(head, n, base)) {
-		unsigned closest_bits = 0, shadow_bits = 0, over_bits = 0, probe_bits = 0, add_bits = 0;
+		unsigned closest_bits = 0, shadow_bits = 0, over_bits = 0, probe_bits = 0, add_bits = 0, slow_bits = 0;
 #pragma unroll 1
 		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			if (idx >= n) continue;
 			const unsigned id = list ? list[idx] : idx;
-			const int r = qw_advance<SUBS, SHADOW_LIST, FOG>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
+			const int r = qw_advance<SUBS, SHADOW_LIST, FOG, FAST>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
 			if (r < 0) over_bits |= 1u << u;
+			else if (FAST && r == 16) slow_bits |= 1u << u;
 			else {
 				if (r & 1) closest_bits |= 1u << u;
 				if (r & 2) shadow_bits |= 1u << u;
@@ -710,6 +800,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		queue_push(qw.overflow, &qw.counters[MIPT_QW_N_OVERFLOW], over_bits, list, base);
 		if (SUBS && !SHADOW_LIST) queue_push(qw.prl[out_parity], &qw.counters[MIPT_QW_N_PROBE(out_slot)], probe_bits, list, base);
 		if (!SHADOW_LIST) queue_push(qw.sha[out_parity], &qw.counters[MIPT_QW_N_SHADOW_ADD(out_slot)], add_bits, list, base);
+		if (FAST) queue_push(qw.slow, &qw.counters[MIPT_QW_N_SLOW(out_slot)], slow_bits, list, base);
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);

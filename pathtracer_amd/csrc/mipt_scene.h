@@ -63,7 +63,7 @@ struct DGroupMat {
 // together with the three matrices, one dependent round trip instead of six: the stage runs 4 waves per SIMD and waits on its
 // chain of dependent loads).
 struct DObject {
-	int type, miroir, flip_normals, interp_normals;
+	int type, miroir, flip_normals, interp_normals;   // miroir: bit 0 = Object::miroir, bit 1 = Object::ghost (both reach the shade stage with the first 16 bytes)
 	int nuvs, ngroups, ntex_normal, alpha_test;   // ntex_normal = ntex[MT_NORMAL]; alpha_test: an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
 	const DTriShade* shade; const DGroupMat* gmat; // gmat[ngroups + 1]: groups 0 .. ngroups-1 (ngroups = the longest of the Kd / Ks / Ne / transp / refr lists), then the all-defaults record
 	const float* tangent_soup;                     // Vector[3*ntri] or null
