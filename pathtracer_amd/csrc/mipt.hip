@@ -1539,6 +1539,7 @@ static int group_render_range(mipt_ctx* c, const mipt_render_params* p, int k0, 
 	}
 	for (int i = 0; i < n; i++) if (rcs[i]) { if (i) fail(c, rcs[i], "device %d: %s", g->member[i]->device, g->member[i]->err.c_str()); hipSetDevice(c->device); return rcs[i]; }
 	// the framebuffer reduce: the analogue of the per-thread buffer sum of Raytracer.cpp:1669-1685
+	bool reduced = false;
 	if (!g->comm.empty() && g->opt_reduce != 2) {
 		RcclApi& api = rccl_api();
 		int r = api.GroupStart();
@@ -1548,8 +1549,14 @@ static int group_render_range(mipt_ctx* c, const mipt_render_params* p, int k0, 
 		}
 		const int r2 = api.GroupEnd();
 		hipSetDevice(c->device);
-		if (r != 0 || r2 != 0) return fail(c, MIPT_ERR_HIP, "ncclReduce failed: %s", api.GetErrorString(r ? r : r2));
-	} else {
+		if (r == 0 && r2 == 0) reduced = true;
+		else if (g->opt_reduce == 1) return fail(c, MIPT_ERR_HIP, "ncclReduce failed: %s", api.GetErrorString(r ? r : r2));
+		else {   // a collective that cannot be enqueued (nothing of it has run): this range and the following ones are summed by copies; the note says why
+			g->reduce_note = std::string("copy reduce: ncclReduce failed: ") + api.GetErrorString(r ? r : r2);
+			g->opt_reduce = 2;
+		}
+	}
+	if (!reduced) {
 		HIPCHK(c, hipSetDevice(c->device));
 		if (g->tmp0_bytes < bytes) {
 			if (g->tmp0) { hipFree(g->tmp0); g->tmp0 = nullptr; g->tmp0_bytes = 0; }

@@ -411,7 +411,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			uint64_t rng_fast = S.rng, rng_light = S.rng; float l1_fast = 0.f, l2_fast = 0.f;
 			if (FAST) {
 				if (m.merl != nullptr) return 16;
-				if (!m.miroir && !m.transp) {
+				if (!(m.miroir & 1) && !m.transp) {
 					if (!(m.Ks.x == 0.f && m.Ks.y == 0.f && m.Ks.z == 0.f && m.Ne.x >= 0.f && m.Ne.y >= 0.f && m.Ne.z >= 0.f)) return 16;
 					l1_fast = pcg_uniform(rng_fast); l2_fast = pcg_uniform(rng_fast);
 					rng_light = rng_fast;                                       // the engine behind the light sample
@@ -500,7 +500,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				}
 			}
 			add_color((pathWeight * m.Ke) * R.envmap_intensity);                // :411
-			if (FAST ? (m.miroir != 0) : ((obj.miroir & 1) != 0)) {             // :413-436
+			if (FAST ? ((m.miroir & 1) != 0) : ((obj.miroir & 1) != 0)) {             // :413-436
 				Ray rm; rm.o = P + 0.001f * Nn; rm.d = reflect(rayDirection, Nn);
 				if (has_fog) {
 					FRS(0, make_float4(P.x, P.y, P.z, t_main));
@@ -560,9 +560,9 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				}
 				// a ghost queues the path going straight on only if the light is visible: its any-hit answer is waited for (A2 of the
 				// general build, over the any-hit list, goes on from the frame; the lobe pick is drawn there)
-				if (yield_shadow && m.ghost) { S.rng = rng_light; m.shadingN = Nn; save_vertex(true); save(QW_A2, 0); return 2; }
+				if (yield_shadow && ((m.miroir & 2) != 0)) { S.rng = rng_light; m.shadingN = Nn; save_vertex(true); save(QW_A2, 0); return 2; }
 				contrib = mk3(0, 0, 0);
-				if (m.ghost) {
+				if (((m.miroir & 2) != 0)) {
 					if (!isShadowed) {                                          // :522-536
 						const f3 offset = dot(Nn, rayDirection) > 0 ? Nn : -Nn;
 						Ray through; through.o = (P + rayDirection * 0.001f) + offset * 0.001f; through.d = rayDirection;
@@ -584,12 +584,12 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					const float pdf = (float)((double)(1.f * dot(Nn, dir)) / (MIPT_PI) + (double)(0.f));
 					if (!(dot(dir, Nn) < 0 || dot(dir, reflect(rayDirection, Nn)) < 0 || pdf <= 0)) {   // :593
 						f3 nw = ((pathWeight * mk3(1.f, 1.f, 1.f)) * brdf) * (dot(Nn, dir) / pdf);          // :611
-						if (m.ghost && has_bg) {                                // :614-621
+						if (((m.miroir & 2) != 0) && has_bg) {                                // :614-621
 							const f3 bg = background_pixel(R, pi, pj);
 							nw = nw * mk3(bg.x / 196964.699f, bg.y / 196964.699f, bg.z / 196964.699f);
 						}
 						Ray next; next.o = P + 0.01f * dir; next.d = dir;
-						push(nw, next, nbrebonds - 1, false, (show_envmap && isShadowed) || !m.ghost, hadSS);   // :626-629 (the diffuse lobe was sampled)
+						push(nw, next, nbrebonds - 1, false, (show_envmap && isShadowed) || !((m.miroir & 2) != 0), hadSS);   // :626-629 (the diffuse lobe was sampled)
 					}
 				}
 				st = ST_POP; break;

@@ -22,14 +22,18 @@ MIPT_HD float mipt_sincos_poly(double x, double x2, int n, bool neg) {
 		double s = x + x3 * s1;
 		return (float)(s + x7 * t1);
 	} else {
-		double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
-		if (neg) { c0 = -c0; c1 = -c1; c2 = -c2; c3 = -c3; c4 = -c4; }
+		// glibc's second table holds the five cosine coefficients negated.  Every operation below is odd in the coefficient set
+		// (round-to-nearest is symmetric: fl(-a) = -fl(a)), so the polynomial of the negated table is the negated polynomial, bit
+		// for bit, and so is its conversion to float (the value is never 0: |x| <= pi/4): one sign flip instead of five selected
+		// doubles — which cost the shade kernels ten registers and, at 128 registers, sixteen spilled values per vertex.
+		const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
 		double x4 = x2 * x2;
 		double t2 = c3 + x2 * c4;
 		double t1 = c0 + x2 * c1;
 		double x6 = x4 * x2;
 		double c = t1 + x4 * c2;
-		return (float)(c + x6 * t2);
+		const float r = (float)(c + x6 * t2);
+		return neg ? -r : r;
 	}
 }
 MIPT_HD uint32_t mipt_abstop12(float x) { return (__builtin_bit_cast(uint32_t, x) >> 20) & 0x7ff; }

@@ -17,7 +17,7 @@ struct Mat {                       // MaterialValues (BRDF.h:7-20)
 	float refr_index;
 	// of the object that was hit (not MaterialValues: read with the object's first 64 bytes by hit_material_obj, so that the
 	// vertex logic does not go back to the descriptor for them)
-	int miroir, ghost;
+	int miroir;                    // DObject::miroir: bit 0 mirror, bit 1 ghost (ghost scenes are the queue pipeline's: only it looks at the bit)
 	const double* merl;
 };
 
@@ -516,7 +516,7 @@ MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
 	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
-	mat.miroir = hot.miroir & 1; mat.ghost = (hot.miroir >> 1) & 1; mat.merl = hot.merl;   // DObject::miroir: bit 0 mirror, bit 1 ghost
+	mat.miroir = hot.miroir; mat.merl = hot.merl;
 	if (hot.type == 1) sphere_material(o, Pl, mat);
 	else if (hot.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, hot.gmat, hot.ngroups, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
 	else {
