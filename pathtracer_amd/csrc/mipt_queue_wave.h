@@ -33,7 +33,7 @@
 #define MIPT_QW_FIFO 32
 #endif
 #ifndef MIPT_QW_LOGIC_WAVES
-#define MIPT_QW_LOGIC_WAVES 2            // (+ 1 for the any-hit-list stage of the build without the fog code: 165 registers)
+#define MIPT_QW_LOGIC_WAVES 3            // general builds of the logic stage (188-237 registers unconstrained; round 3, after sinf / cosf lost their selected constants: 3 waves with 20-70 spilled values beat 2 without — subsurface logic 59.5 -> 51.8 ms, fog 110.7 -> 107.8, ghost +-0); + 1 for the any-hit-list stage of the build without the fog code
 #endif
 #ifndef MIPT_QW_FAST_WAVES
 #define MIPT_QW_FAST_WAVES 4             // the fast tier of the closest-hit-list stage (scenes without fog / subsurface groups)

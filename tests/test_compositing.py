@@ -142,3 +142,20 @@ def test_gpu_compositing_depth_zero_and_one(depth):
         outs.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
     assert_bits(outs[1], outs[0], f"per-sample radiance at depth {depth}")
     assert outs[1].any() == (depth > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", COMPOSITING_KINDS)
+def test_gpu_logic_stage_tiers_agree(kind):
+    """Round 3: the closest-hit-list logic stage runs as a fast tier (Lambert / mirror / dielectric / miss vertices, ghosts up to
+    their any-hit request) plus the general build over what it leaves (csrc/mipt_queue_wave.h, FAST).  Both orders of work —
+    tiers, general build alone, and the tiers with a two-entry ring (samples abandoned to the 200-entry fallback) — give
+    the golden radiance bit for bit."""
+    g = np.load(GOLD)
+    for opts in ({}, {"queue_fast_tier": 0}, {"queue_ring": 2}):
+        H = capi.HostRaytracer(device=0)
+        cfg = compositing_scene(H, kind)
+        for k, v in opts.items():
+            H.set_option(k, v)
+        rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+        assert_bits(rgb, g[kind + "_rgb"], f"per-sample radiance with {opts or 'the default tiers'}")
