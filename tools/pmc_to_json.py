@@ -5,7 +5,8 @@ tools/fetch_calibration.py measured it on this device: the traversal kernels rea
 other kernels mostly by wide streaming accesses (factor `stream`, the 1/2 of MI355X_MICROARCH.md).  The file records the git
 commit and the hash of the library that was profiled: bench.py flags fractions derived from it when it runs another build.
 
-usage: python tools/pmc_to_json.py profiles/r2_fetch_calibration.json c2=profiles/r3_f_c2_pmc_summary.txt:gpurun_out/pmc_r3_f_p1.log [c1=...]"""
+usage: python tools/pmc_to_json.py profiles/r2_fetch_calibration.json c2=<summary>:<log with the bench line>[:<path shown as source>] [c1=...]
+(on the GPU box there is no .git: MIPT_GIT_COMMIT names the commit of the snapshot)"""
 import hashlib, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,8 @@ def canon(k):          # "k_wf_traverse<0, false>" -> "k_wf_traverse<0>"
 out = {}
 for arg in sys.argv[2:]:
     wl, rest = arg.split("=")
-    path, benchlog = rest.split(":")
+    path, benchlog, *shown = rest.split(":")          # optional third field: the path the summary is committed under
+    shown = shown[0] if shown else path
     bench = None
     for line in open(benchlog):
         if line.startswith("{"):
@@ -59,10 +61,10 @@ for arg in sys.argv[2:]:
             e["vmem_per_ray"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / rays
             e["l1_lookups_per_cu_cycle"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * cyc)
         kernels[k] = e
-    out[wl] = {"source": path + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
+    out[wl] = {"source": shown + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
                                 "FETCH_SIZE factors from " + sys.argv[1], "kernels": kernels}
 lib = os.path.join(ROOT, "pathtracer_amd", "libmipt.so")
-out["_build"] = {"git_commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+out["_build"] = {"git_commit": os.environ.get("MIPT_GIT_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
                  "libmipt_sha256_16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
                  "flags": "__graft_entry__.HIPCC_FLAGS (default library)"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r3_pmc_counters.json"), "w"), indent=1)
