@@ -336,7 +336,10 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     wavefront stages (default), 0 = one thread per sample with the queue in HBM (the round-1 kernel; same results)
  *   "queue_ring"      test hook: pending contributions a sample may hold in the wavefront stages (default and maximum 32); samples that
  *                     need more are rendered by the one-thread-per-sample loop with the reference's 200-entry ring (same results)
- *   "reduce"          groups only: 0 = RCCL when its communicators exist (default), 1 = RCCL or fail, 2 = device copies + adds
+ *   "queue_fast_tier" wavefront stages of the contribution queue, scenes without fog and subsurface colours: 1 = the closest-hit list goes
+ *                     through a fast tier first and the general build takes what it leaves (default), 0 = general build only (same results)
+ *   "reduce"          groups only: 0 = RCCL when its communicators exist (default; a reduce that cannot be enqueued falls back to 2 and
+ *                     mipt_group_reduce_kind says why), 1 = RCCL or fail, 2 = device copies + adds
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
  *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
