@@ -355,6 +355,7 @@ struct mipt_ctx {
 	void* queue_buf = nullptr; size_t queue_buf_bytes = 0;
 	void* overflow_buf = nullptr; size_t overflow_buf_bytes = 0;     // 200-entry rings of the samples the wavefront queue abandoned
 	void* resolve_buf = nullptr; size_t resolve_buf_bytes = 0;       // partial images of the sliced splat (ranks of a partition)
+	bool scene_inherit = false;       // a sphere without material lists (DScene::inherit_material): no wavefront stages
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
 	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
@@ -790,7 +791,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false;
+	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false, scene_inherit = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -863,10 +864,10 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			// Scene::intersection keeps ONE MaterialValues for all objects of its loop (`localmat`, Geometry.cpp:596), and a sphere
 			// without material lists writes only the normal and Ke into it: such a sphere is shaded with whatever the object tested
 			// before it left there (the ground plane's colour if the ray also crosses the plane, a mesh's material at a hit further
-			// away ...).  That is an accident of the loop, not a material; the light and the environment never reach the BRDF, a
-			// mirror does not read the material, every other sphere needs lists of its own.
-			if (i >= 2 && !o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR]))
-				return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: a sphere without material lists (it would be shaded with the material of whichever object Scene::intersection tested before it)", i);
+			// away ...).  The light and the environment never reach the BRDF and a mirror does not read the material; for every other such
+			// sphere the scene is rendered the way the reference's loop runs (scene_intersect_inherit, mipt_trace.h: one thread per sample;
+			// round 3 — rounds 1 and 2 refused these scenes).
+			if (i >= 2 && !o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) scene_inherit = true;
 			if (i >= 2) sphere_extra = true;
 			memcpy(d.O, o.O, 12); d.R = o.R; d.R2 = o.R * o.R;
 			d.has_envmap = o.has_envmap; d.envW = o.envW; d.envH = o.envH; d.envtex = nullptr;
@@ -910,6 +911,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (d.type != MIPT_OBJ_TRIMESH) continue;
 		d.nodes = H.all_nodes; d.tris = H.all_tris; d.shade = all_shade + d.tri_base;
 	}
+	H.inherit_material = scene_inherit ? 1 : 0;
 	const DScene* dsc = nullptr;
 	rc = upload(c, hs.data(), 1, &dsc);
 	if (rc) return rc;
@@ -928,7 +930,8 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->fog.density = s->fog_density; c->fog.absorption = s->fog_absorption; c->fog.density_decay = s->fog_density_decay; c->fog.absorption_decay = s->fog_absorption_decay;
 	c->fog.phase_aniso = s->phase_aniso; c->fog.ground_level = s->fog_ground_level; c->fog.type = s->fog_type; c->fog.phase_type = s->fog_phase_type;
 	if (s->fog_density > 1E-8f && (s->n_objects < 3 || s->fog_type < 0 || s->fog_type > 1 || s->fog_phase_type < 0 || s->fog_phase_type > 2)) return fail(c, MIPT_ERR_INVALID, "bad fog description");
-	c->scene_has_ghost = scene_ghost || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
+	c->scene_has_ghost = scene_ghost || scene_inherit || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
+	c->scene_inherit = scene_inherit;  // a sphere without material lists: the one-thread-per-sample loop of the queue kernel (Scene::intersection with its one MaterialValues)
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	c->grid_qlogic[0] = 0;
 	return MIPT_OK;
@@ -1145,7 +1148,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (nblocks == 0 || kb == ke) return MIPT_OK;
 	const int npix_slots = nblocks * 64;
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
-	const bool queue_wave = c->scene_has_ghost && c->opt_queue_wavefront;
+	const bool queue_wave = c->scene_has_ghost && c->opt_queue_wavefront && !c->scene_inherit;
 	if (c->scene_has_ghost && !queue_wave) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
 	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass);
 	spp_pass = std::min(spp_pass, ke - kb);

@@ -94,7 +94,8 @@ struct DScene {
 	int nobj;
 	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)
 	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
-	int _pad0;
+	int inherit_material;        // some sphere beyond objects 0 / 1 has no material lists and is not a mirror: Scene::intersection's ONE MaterialValues for all objects
+	                             // of its loop decides what it is shaded with (Geometry.cpp:596); such scenes are rendered by the one-thread-per-sample kernel (mipt_trace.h)
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

@@ -455,10 +455,12 @@ MIPT_DEV void mesh_material(const DObject& o, const ObjHot& hot, int tri, float 
 MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, float gamma, Mat& mat) { const ObjHot hot = load_obj_hot(o); mesh_material(o, hot, tri, alpha, beta, gamma, mat); }
 
 // Sphere material (Geometry.h:948-991)
-MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat) {
+// inherit: `mat` is the ONE MaterialValues of Scene::intersection's loop (scene_intersect_inherit below) — a sphere without lists leaves
+// in it what the object tested before wrote; otherwise such a sphere (the light; upload lets no other one through) gets the defaults
+MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat, bool inherit = false) {
 	f3 N = Plocal - ld3(s.O);
 	// MaterialValues() defaults for the fields a texture-less sphere never writes (BRDF.h:9-16)
-	mat.Kd = mk3(0.5f, 0.5f, 0.5f); mat.Ks = mk3(0, 0, 0); mat.Ne = mk3(100, 100, 100); mat.transp = false; mat.refr_index = 0.f;
+	if (!inherit) { mat.Kd = mk3(0.5f, 0.5f, 0.5f); mat.Ks = mk3(0, 0, 0); mat.Ne = mk3(100, 100, 100); mat.transp = false; mat.refr_index = 0.f; }
 	if (s.has_envmap) {
 		N = fast_normalize(N);
 		float theta = 1.f - mipt_acosf(N.y) / (float)MIPT_PI;
@@ -511,13 +513,13 @@ MIPT_DEV bool scene_closest(const DScene* __restrict__ sc, Ray r, Hit& h, STK& s
 
 // World-space hit point and MaterialValues of the winning object (tail of Scene::intersection,
 // Geometry.cpp:668-684, plus the winner's own material code).
-MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat) {
+MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat, bool inherit = false) {
 	const ObjHot hot = load_obj_hot(o);                  // (issued together with the matrix loads below)
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
 	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
 	mat.miroir = hot.miroir; mat.merl = hot.merl;
-	if (hot.type == 1) sphere_material(o, Pl, mat);
+	if (hot.type == 1) sphere_material(o, Pl, mat, inherit);
 	else if (hot.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, hot.gmat, hot.ngroups, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
 	else {
 		float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
@@ -538,8 +540,43 @@ MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f
 // (A wave-uniform loop over the objects, with scalar loads of the description, was measured slower in the shade stage:
 // the material chains of the distinct objects in a wave then run one after the other.)
 
+// Scene::intersection as the reference runs it, for scenes with a sphere that has no material lists (DScene::inherit_material):
+// ONE MaterialValues serves all objects of the loop (`localmat`, Geometry.cpp:596), every object that reports a hit — closer than the
+// best so far or not — writes its material into it (a mesh reports only closer hits, TriangleMesh.cpp:1198), a sphere without lists
+// writes the normal and Ke only (Geometry.h:983-986), and the winner takes a copy at the moment it wins (:611-621).  So such a
+// sphere is shaded with the Kd / Ks / Ne / transparency / index of the last object before it in the list that the ray also hit,
+// at THAT object's hit point — or with MaterialValues()'s defaults when there was none (the light and, without an environment map,
+// object 1 write nothing either).
+template <class STK>
+__device__ __attribute__((noinline)) bool scene_intersect_inherit(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat, STK& stk) {
+	h.obj = -1; h.tri = -1; h.beta = 0; h.gamma = 0;
+	float min_t = __int_as_float(0x7f800000);
+	Mat localmat;                          // MaterialValues() (BRDF.h:9-16); transp and refr_index are not initialised there: false / 0 as in the oracle
+	localmat.shadingN = mk3(0, 1, 0); localmat.Kd = mk3(0.5f, 0.5f, 0.5f); localmat.Ks = mk3(0, 0, 0); localmat.Ne = mk3(100, 100, 100); localmat.Ke = mk3(0, 0, 0);
+	localmat.transp = false; localmat.refr_index = 0.f; localmat.miroir = 0; localmat.merl = nullptr;
+	const int nobj = sc->nobj;
+	for (int i = 0; i < nobj; i++) {
+		const DObject& o = sc->obj[i];
+		const f3 d = xf_dir(o.inv, r.d);
+		const f3 org = xf_point(o.inv, r.o);
+		float t; int tri = -1; float b = 0, g = 0;
+		bool hit;
+		if (o.type == 1) hit = sphere_test(o, org, d, t);
+		else if (o.type == 2) hit = plane_test(o, org, d, t);
+		else hit = mesh_traverse<false>(o, org, d, min_t, 0.f, t, tri, b, g, stk);
+		if (!hit) continue;
+		Hit hi; hi.obj = i; hi.tri = tri; hi.t = t; hi.beta = b; hi.gamma = g;
+		f3 Pi;
+		hit_material_obj(o, r, hi, Pi, localmat, true);
+		if (t < min_t) { min_t = t; h = hi; P = Pi; mat = localmat; }
+	}
+	h.t = min_t;
+	return h.obj >= 0;
+}
+
 template <class STK>
 MIPT_DEV bool scene_intersect(const DScene* __restrict__ sc, Ray r, Hit& h, f3& P, Mat& mat, STK& stk) {
+	if (sc->inherit_material) return scene_intersect_inherit(sc, r, h, P, mat, stk);
 	if (!scene_closest(sc, r, h, stk)) return false;
 	hit_material(sc, r, h, P, mat);
 	return true;

@@ -517,18 +517,31 @@ if __name__ == "__main__" and "--keyframes" in sys.argv:
 
 
 # ---- spheres beside the light (0) and the environment (1) (Geometry.h:849-992)
-SPHERE_KINDS = ("mixed", "glossy", "nomesh")
+SPHERE_KINDS = ("mixed", "glossy", "nomesh", "bare")
 
 
 def sphere_scene(X, kind):
     """Spheres as ordinary scene objects, in front of and behind the mesh in the object list: a constant diffuse one, a mirror,
     an image-textured glossy one (lists looked up at the spherical coordinates of the normal), glass; `nomesh`: no TriMesh
-    at all, flipped normals.  (A sphere WITHOUT material lists is not a case: Scene::intersection would shade it with the
-    material of whichever object it tested before, Geometry.cpp:596.)"""
+    at all, flipped normals.  `bare`: spheres WITHOUT material lists before and behind the mesh and behind a textured sphere —
+    Scene::intersection shades such a sphere with the material of the last object before it in the list that the ray also hit
+    (its one MaterialValues for all objects of the loop, Geometry.cpp:596), at that object's own hit point."""
     cfg = scenes.config_c1(48, 30, 3)
     cfg.nb_bounces = 5 if kind == "mixed" else 4
     X.apply_config(cfg)
     a = X.add_sphere((-12, -17, 8), 9.0)
+    if kind == "bare":
+        m = X.add_mesh(scenes.blob_mesh(16, with_uv=True), scale=20.0)
+        X.set_group_material(m, 0, (0.7, 0.8, 0.3), (0.2, 0.2, 0.2), (30., 30., 30.))
+        X.set_group_texture(m, 0, 0, scenes.checker_texture())
+        b = X.add_sphere((14, -14, 2), 8.0)
+        c = X.add_sphere((0, -20, 18), 6.0)
+        X.add_group_material(c, (0.9, 0.2, 0.1), (0.3, 0.3, 0.3), (20, 20, 20), 1.0, 1.3)
+        X.set_group_texture(c, 0, 0, scenes.checker_texture(32, 16, 5, 4))
+        X.add_sphere((-20, -18, -6), 7.0, flip_normals=True)
+        X.add_sphere((4, -22, 26), 3.0)
+        X.prepare()
+        return cfg
     X.add_group_material(a, (0.2, 0.6, 0.9), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
     if kind != "nomesh":
         X.add_mesh(scenes.blob_mesh(16), scale=20.0)

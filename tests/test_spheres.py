@@ -1,7 +1,9 @@
 """Spheres beside the light (object 0) and the environment (object 1) (Geometry.h:849-992): ordinary scene
 objects in front of or behind the meshes in the object list — constant colour, mirror, glossy, image-textured (material
 lists looked up at the spherical coordinates of the normalised normal), glass, flipped normals.  A sphere without
-material lists is refused: Scene::intersection shades it with the material of whichever object it tested before.
+material lists (kind `bare`) is shaded by Scene::intersection with the material of the last object before it in the list that the
+ray also hit (one MaterialValues for all objects of its loop, Geometry.cpp:596): such scenes run through the one-thread-per-sample
+kernel, which walks the objects the way the reference does (csrc/mipt_trace.h scene_intersect_inherit).
 tests/golden/spheres.npz comes from the compiled reference (tests/golden/make_golden.py --spheres)."""
 import os
 import sys
@@ -103,9 +105,25 @@ def test_gpu_random_sphere_scenes_against_oracle(seed):
 
 
 @pytest.mark.gpu
-def test_sphere_without_material_lists_is_refused():
-    H = capi.HostRaytracer(device=0)
-    H.apply_config(scenes.config_c1(16, 16, 1))
-    H.add_sphere((0, -20, 5), 4.0)
-    with pytest.raises(capi.MiptError, match="without material lists"):
-        H.prepare()
+def test_sphere_without_material_lists_takes_the_material_of_the_object_before_it():
+    """Rounds 1 and 2 refused such a scene.  The reference shades the sphere with what the ground plane (object 2, hit by every ray
+    that points down) or the environment sphere left in Scene::intersection's MaterialValues: image, splat and the ray API
+    (mipt_trace: the same loop) against the oracle, with and without fog; the scene runs on the queue kernel's one-thread form."""
+    from oracle.binding import Oracle
+    for fog in (False, True):
+        outs = []
+        for X in (Oracle(), capi.HostRaytracer(device=0)):
+            cfg = scenes.config_c1(40, 28, 2)
+            cfg.nb_bounces = 4
+            X.apply_config(cfg)
+            X.add_sphere((0, -20, 5), 9.0)
+            X.add_sphere((12, -10, 14), 5.0, flip_normals=True)
+            if fog:
+                X.set_fog(0.5, 0.4)
+            X.prepare()
+            px = np.stack(np.meshgrid(np.arange(cfg.H), np.arange(cfg.W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+            outs.append((X.getcolor_samples(px, 0, cfg.spp)[0], X.render_seeded()))
+            if isinstance(X, capi.HostRaytracer):
+                assert X.stats()["pipeline"] == 2
+        assert_bits(outs[1][0], outs[0][0], f"per-sample radiance (fog {fog})")
+        assert_bits(outs[1][1][0], outs[0][1][0], f"splatted image (fog {fog})")

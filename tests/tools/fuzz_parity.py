@@ -3,7 +3,8 @@ camera, light, aperture, depth, materials incl. glossy / mirror / dielectric / t
 compared bit for bit on both pipelines.  usage: python tests/tools/fuzz_parity.py [n_scenes] [seed] [--queue]   (test infrastructure: the oracle is the checker)
 --queue: every scene also draws from the features of the contribution-queue kernel (ghost objects, background photo, fog in
 both media with the three phase functions, subsurface colours), alone and combined.
---spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh."""
+--spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh.
+--bare-spheres: the same, and a sphere may have no material lists at all (such scenes run on the one-thread-per-sample kernel)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -12,7 +13,8 @@ from pathtracer_amd import capi, scenes
 from oracle.binding import Oracle
 
 QUEUE = "--queue" in sys.argv
-SPHERES = "--spheres" in sys.argv
+SPHERES = "--spheres" in sys.argv or "--bare-spheres" in sys.argv
+BARE = "--bare-spheres" in sys.argv      # spheres may also come WITHOUT material lists (kind 5: shaded with the material of the object tested before, Geometry.cpp:596)
 argv = [a for a in sys.argv if not a.startswith("--")]
 n_scenes = int(argv[1]) if len(argv) > 1 else 20
 rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
@@ -39,7 +41,7 @@ for it in range(n_scenes):
     sph = []
     if SPHERES:
         for k in range(int(rng.integers(1, 4))):
-            sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 5)),
+            sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 6 if BARE else 5)),
                             first=bool(rng.random() < 0.3), flip=bool(rng.random() < 0.15), Kd=rng.uniform(0.05, 1, 3), Ks=rng.uniform(0, 0.6, 3), Ne=rng.uniform(1, 200, 3)))
     def put_spheres(X, first):
         for q in sph:
@@ -95,7 +97,7 @@ for it in range(n_scenes):
     pix = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
     want = O.getcolor_samples(pix, 0, spp)[0]
     line = "%2d %-8s n=%-3d scale %-5g %3dx%-3d spp %d depth %d aperture %-4g" % (it, kind, n, scale, W, H, spp, cfg.nb_bounces, cfg.aperture)
-    line += " " + "+".join(feats) + (" spheres " + "".join("cmgtd"[q["kind"]] for q in sph) if sph else "")
+    line += " " + "+".join(feats) + (" spheres " + "".join("cmgtdb"[q["kind"]] for q in sph) if sph else "")
     for pipeline in ((1,) if feats else (1, 0)):
         G.set_option("pipeline", pipeline)
         got = G.getcolor_samples(pix, 0, spp)[0]
