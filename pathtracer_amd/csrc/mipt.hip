@@ -868,7 +868,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			// sphere the scene is rendered the way the reference's loop runs (scene_intersect_inherit, mipt_trace.h: one thread per sample;
 			// round 3 — rounds 1 and 2 refused these scenes).
 			if (i >= 2 && !o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) scene_inherit = true;
-			if (i >= 2) sphere_extra = true;
+			if (i >= 2 && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) sphere_extra = true;   // (a mirror too: getColor looks at Ksub before the mirror branch)
 			memcpy(d.O, o.O, 12); d.R = o.R; d.R2 = o.R * o.R;
 			d.has_envmap = o.has_envmap; d.envW = o.envW; d.envH = o.envH; d.envtex = nullptr;
 			if (o.has_envmap) {
@@ -920,7 +920,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
 	c->scene_has_subsurface = scene_subs;
-	if (scene_subs && sphere_extra) return fail(c, MIPT_ERR_UNSUPPORTED, "spheres beside the light and the environment in a scene with subsurface colours (a sphere leaves the Ksub of the object tested before it in place)");
+	if (scene_subs && sphere_extra) return fail(c, MIPT_ERR_UNSUPPORTED, "a sphere without material lists in a scene with subsurface colours (it leaves the Ksub of the object tested before it in place; a sphere with lists writes Ksub = 0 and is fine)");
 	c->d_background = nullptr; c->backgroundW = c->backgroundH = 0;
 	if (s->background && s->backgroundW > 0 && s->backgroundH > 0) {
 		int rc = upload(c, s->background, (size_t)s->backgroundW * s->backgroundH * 3, &c->d_background);

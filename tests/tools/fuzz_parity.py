@@ -43,6 +43,7 @@ for it in range(n_scenes):
         for k in range(int(rng.integers(1, 4))):
             sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 6 if BARE else 5)),
                             first=bool(rng.random() < 0.3), flip=bool(rng.random() < 0.15), Kd=rng.uniform(0.05, 1, 3), Ks=rng.uniform(0, 0.6, 3), Ne=rng.uniform(1, 200, 3)))
+    sph_lists = all(q["kind"] in (0, 2, 3, 4) for q in sph)      # subsurface colours go with spheres that have material lists (a sphere without — mirror or not — would inherit Ksub: refused)
     def put_spheres(X, first):
         for q in sph:
             if q["first"] != first: continue
@@ -89,8 +90,8 @@ for it in range(n_scenes):
             if pick[1] < 0.25: X.set_object_ghost(oid, True)
             if pick[2] < 0.6: X.set_background(photo)
             if pick[3] < 0.5: X.set_fog(*fog)
-            if pick[4] < 0.4 and kind not in ("two",) and not sph: X.set_group_subsurface(oid, 0, ksub)
-        feats = [n for n, on in (("ghostfloor", pick[0] < 0.45), ("ghostmesh", pick[1] < 0.25), ("photo", pick[2] < 0.6), ("fog%d/%d" % (fog[4], fog[5]), pick[3] < 0.5), ("sss", pick[4] < 0.4 and kind != "two" and not sph)) if on]
+            if pick[4] < 0.4 and kind not in ("two",) and sph_lists: X.set_group_subsurface(oid, 0, ksub)
+        feats = [n for n, on in (("ghostfloor", pick[0] < 0.45), ("ghostmesh", pick[1] < 0.25), ("photo", pick[2] < 0.6), ("fog%d/%d" % (fog[4], fog[5]), pick[3] < 0.5), ("sss", pick[4] < 0.4 and kind != "two" and sph_lists)) if on]
     for X, oid in out:
         X.prepare()
     O, G = out[0][0], out[1][0]
