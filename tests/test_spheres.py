@@ -127,3 +127,32 @@ def test_sphere_without_material_lists_takes_the_material_of_the_object_before_i
                 assert X.stats()["pipeline"] == 2
         assert_bits(outs[1][0], outs[0][0], f"per-sample radiance (fog {fog})")
         assert_bits(outs[1][1][0], outs[0][1][0], f"splatted image (fog {fog})")
+
+
+@pytest.mark.gpu
+def test_subsurface_colour_beside_spheres_with_material_lists():
+    """Rounds 1-2 refused every extra sphere in a scene with subsurface colours.  Only a sphere WITHOUT lists inherits Ksub (the shared
+    MaterialValues of Scene::intersection); a sphere with lists writes Ksub = 0 (Geometry.h:399-445).  HIP path (wavefront stages
+    with the subsurface probe) against the oracle; the list-less case stays refused."""
+    from oracle.binding import Oracle
+    outs = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        cfg = scenes.config_c1(40, 28, 3)
+        cfg.nb_bounces = 4
+        X.apply_config(cfg)
+        a = X.add_sphere((-14, -16, 6), 7.0)
+        X.add_group_material(a, (0.2, 0.6, 0.9), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
+        m = X.add_mesh(scenes.blob_mesh(14), scale=18.0)
+        X.set_group_subsurface(m, 0, (0.8, 0.5, 0.3))
+        b = X.add_sphere((15, -15, 3), 6.0)
+        X.add_group_material(b, (0.5, 0.5, 0.1), (0.4, 0.4, 0.4), (50, 50, 50), 1.0, 1.3)
+        X.prepare()
+        outs.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
+    assert_bits(outs[1], outs[0], "per-sample radiance, subsurface mesh between two spheres")
+    H = capi.HostRaytracer(device=0)
+    H.apply_config(scenes.config_c1(16, 16, 1))
+    m = H.add_mesh(scenes.blob_mesh(8))
+    H.set_group_subsurface(m, 0, (0.8, 0.5, 0.3))
+    H.add_sphere((0, -20, 5), 4.0, mirror=True)
+    with pytest.raises(capi.MiptError, match="without material lists in a scene with subsurface"):
+        H.prepare()
