@@ -113,9 +113,10 @@ typedef struct mipt_object {
 
 /* Scene (Geometry.h:1238-1400).  As in Raytracer::loadScene (Raytracer.cpp:1257-1269) object 0
  * is the light sphere (Scene::lumiere), object 1 the environment sphere, object 2.. the rest.  A sphere among
- * "the rest" needs material lists of its own or the mirror flag: without them the reference shades it with the
- * material of whichever object Scene::intersection tested before it (one `localmat` for the loop, Geometry.cpp:596);
- * mipt_upload_scene refuses that case with MIPT_ERR_UNSUPPORTED. */
+ * "the rest" without material lists of its own (and without the mirror flag) is shaded as the reference shades it: with the
+ * material of the last object before it in the list that the ray also hit, at that object's hit point (one `localmat` for
+ * the loop of Scene::intersection, Geometry.cpp:596).  Such a scene is rendered by the one-thread-per-sample kernel (about a
+ * fifth of the wavefront pipeline's rate); together with subsurface colours it is refused (MIPT_ERR_UNSUPPORTED). */
 typedef struct mipt_scene_desc {
 	int32_t n_objects;
 	const mipt_object* objects;
