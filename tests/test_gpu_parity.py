@@ -362,3 +362,45 @@ def test_partition_rank_splat_slices_are_deterministic():
         assert np.abs(normalised(acc_i, acc_c) - ref).max() < 1e-5
         frames.setdefault(slices, []).append(acc_i.tobytes())
     assert frames[0][0] == frames[0][1]
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_object_table_full_and_one_too_many(pipeline):
+    """The scene table holds MIPT_MAX_OBJECTS = 16 objects (include/mipt.h): light, environment, ground plane, two meshes and
+    eleven spheres of every kind fill it — bit for bit against the oracle, depth 0 (nothing traced) and depth 3 —; a seventeenth
+    object is refused with a message, not truncated."""
+    from oracle.binding import Oracle
+
+    def build(X, extra):
+        cfg = scenes.config_c1(44, 30, 2)
+        cfg.nb_bounces = 3
+        X.apply_config(cfg)
+        rng = np.random.default_rng(7)
+        X.add_mesh(scenes.blob_mesh(10), scale=12.0)
+        for k in range(11 + extra):
+            c = (float(rng.uniform(-30, 30)), float(rng.uniform(-26, 0)), float(rng.uniform(-15, 25)))
+            o = X.add_sphere(c, float(rng.uniform(2, 6)), mirror=(k % 4 == 1))
+            if k % 4 == 0: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
+            if k % 4 == 2: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0.3, 0.3, 0.3), (40, 40, 40), 1.0, 1.3)
+            if k % 4 == 3: X.add_group_material(o, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, 1.4)
+        X.add_mesh(scenes.blob_mesh(8), scale=6.0)
+        return cfg
+
+    O, G = Oracle(), capi.HostRaytracer(device=0)
+    for X in (O, G):
+        cfg = build(X, 0)
+        X.prepare()
+    assert G.num_objects() == 16                       # MIPT_MAX_OBJECTS
+    G.set_option("pipeline", pipeline)
+    pix = all_pixels(cfg)
+    assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], O.getcolor_samples(pix, 0, cfg.spp)[0], "16 objects, depth 3")
+    for X in (O, G):
+        X.set_render(cfg.W, cfg.H, cfg.spp, 0)
+        X.prepare()
+    black = G.getcolor_samples(pix, 0, cfg.spp)[0]
+    assert_bits(black, O.getcolor_samples(pix, 0, cfg.spp)[0], "depth 0")
+    assert not black.any()
+    G2 = capi.HostRaytracer(device=0)
+    build(G2, 1)
+    with pytest.raises(capi.MiptError, match="n_objects"):
+        G2.prepare()
