@@ -1,0 +1,55 @@
+"""The bench line's contract (one JSON line: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+scaling / vs_baseline / dtype / data / config.workload, + `roofline` and `cpu_baseline`), checked on the committed closing record
+of the round and on its internal consistency: fractions = achieved / peak, stage times sum to the step, the dominant kernel's
+launches fit inside the step, counters derived from the library the line was measured with, nothing above its ceiling except
+SURVEY 8(d)'s algorithmic-HBM figure (which counts bytes the caches serve).  BASELINE.json's metric string is the line's."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def closing_lines():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_h_c[1-4]_bench.json")))
+    assert files, "the closing record of round 3 is missing from profiles/"
+    return [(os.path.basename(f), json.loads(open(f).read().strip().splitlines()[-1])) for f in files]
+
+
+@pytest.mark.parametrize("name,line", closing_lines())
+def test_committed_bench_line_keeps_the_contract(name, line):
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["metric"] == base["metric"] and line["unit"] == "Mrays/s" and line["higher_is_better"] is True
+    assert line["vs_baseline"] is None                         # the reference publishes no number for this metric
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert line["n_gpus"] == 1 and line["finite"] is True
+    # value = rays / time; the stages account for the step
+    ls = line["launch_stats"]
+    rays = ls["rays_closest"] + ls["rays_shadow"]
+    assert rays / (line["ms_per_step"] * 1e-3 * line["steps"]) / 1e6 == pytest.approx(line["value"], rel=1e-6)
+    st = line["stage_ms_per_step"]
+    assert sum(st.values()) == pytest.approx(line["ms_per_step"], rel=0.02)
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    assert r["ms_per_launch"] * r["launches"] / line["steps"] == pytest.approx(st["extend"], rel=0.02)
+    assert r["derived_from_pmc_run"]["same_library_build"] is True
+    for k in ("frac", "frac_vmem_issue", "frac_latency_model", "frac_hbm_measured", "frac_l1_lookups", "salu_issue_busy"):
+        assert 0.0 < r[k] <= 1.0, (k, r[k])
+    assert r["frac_algorithmic_hbm"] > 1.0 or name != "r3_h_c2_bench.json"      # most node fetches never cross HBM
+    sh = line["roofline_shade_kernel"]
+    assert 0.0 < sh["frac"] <= 1.0 and 0.0 < sh["frac_hbm_measured"] <= 1.0
+
+
+def test_default_line_carries_the_cpu_baseline():
+    line = dict(closing_lines())["r3_h_c2_bench.json"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["unit"] == "Mrays/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert line["value"] / cb["value"] > 50              # context, not credit: the CPU path timed beside the GPU one
+    assert line["host_bvh_build_s"] <= 0.1               # TriMesh::init of the 2.5 M-triangle mesh
