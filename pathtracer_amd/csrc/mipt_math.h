@@ -87,15 +87,21 @@ MIPT_DEV double pt_atan264(double y, double x) { return mipt_atan264(y, x); }
 // powf: the host libm's algorithm, bit for bit (mipt_powf.h), for positive finite x and finite non-zero y; the exact
 // special values (pow(x,0) = 1, pow(1,y) = 1, zero / inf / NaN / negative bases) come from the device library.
 __device__ __attribute__((noinline)) float powf_special(float x, float y) { return powf(x, y); }
+// powf_general is a LEAF (it hands the arguments it does not cover back as NaN — its own results are never NaN: a positive finite
+// base and a finite exponent give a number, an infinity or zero — and the inlined caller takes them to powf_special): a function that
+// calls another one saves its return address through a vector register in scratch, two vector-memory instructions per call, six
+// calls per glossy vertex.
 __device__ __attribute__((noinline)) float powf_general(float x, float y) {
 	float r;
 	if (mipt_powf_main(x, y, r)) return r;
-	return powf_special(x, y);
+	return __int_as_float(0x7fc00000);
 }
 MIPT_DEV float pt_powf(float x, float y) {
 	if (y == 0.f) return 1.f;
 	if (x == 1.f) return 1.f;
-	return powf_general(x, y);
+	const float r = powf_general(x, y);
+	if (r == r) return r;
+	return powf_special(x, y);
 }
 
 // Raytracer.cpp:1294-1299 fast_exp (Schraudolph, on a double)

@@ -132,9 +132,12 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	// nodes / tris are kernel arguments (not read from *sc) so that the compiler knows they are global
 	// ids reserved per global atomic: large enough to keep the same-address atomic rate low (one costs ~11 ns
 	// chip-wide), small enough that every wave of the grid gets several chunks (tail balance)
-	const unsigned nwaves = gridDim.x * (MIPT_TRAV_BLOCK / 64), wave_id = blockIdx.x * (MIPT_TRAV_BLOCK / 64) + (threadIdx.x >> 6);
+	// (wave-uniform values are made scalar explicitly: derived from threadIdx or through min / max they would sit in vector registers,
+	//  and at 72 registers the compiler kept four of them — and the leaf map's address — in scratch, reloaded in the refill and in
+	//  every leaf round: scratch accesses are vector-memory instructions, the resource this kernel runs out of)
+	const unsigned nwaves = gridDim.x * (MIPT_TRAV_BLOCK / 64), wave_id = blockIdx.x * (MIPT_TRAV_BLOCK / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	bool first_pull = true;
-	const unsigned pull_chunk = max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_TRAV_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u));
+	const unsigned pull_chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_TRAV_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u)));
 	const unsigned lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -457,7 +460,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 template <int MODE>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
-	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap);
@@ -470,13 +473,13 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 template <bool SHADOW>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
-	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
 	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) k_q_probe(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
-	unsigned char* leafmap = lds_leafmap_ + (threadIdx.x >> 6) * 256;
+	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
 	traverse_queue<false, true>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
 }
