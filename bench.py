@@ -27,26 +27,23 @@ of the K timed steps (+ the final reduce), inputs resident in HBM, barrier + syn
 sides, max over ranks.
 
 roofline (dominant kernel = the closest-hit traversal, k_wf_traverse<0>; its mean launch duration is measured here with
-HIP events on the render stream).  Measured live in this run: the duration, the capacity of the memory system behind L2 for
-dependent random fetches (mipt_measure_dependent_gather) and the cost of a vector-memory instruction (mipt_measure_vmem_issue).
-Per-ray counter values (L2 misses, L1 lookups, HBM bytes, instructions, vector-memory latency) come from the committed PMC run of
-the same workload, profiles/r3_pmc_counters.json, which records the commit and the hash of the library it profiled
-(derived_from_pmc_run.same_library_build says whether this run uses that build).  None of the fractions except the first can
-exceed 1 by construction:
-  frac_algorithmic_hbm  ALGORITHMIC bytes per launch / duration / 8 TB/s.  Bytes per ray come from the CPU
-                        oracle's counters of the reference's ordered traversal on a bounded sample of the same scene and
-                        camera (B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.  It exceeds 1:
-                        most node fetches are served by L1 / L2, those bytes never cross HBM.
-  frac (bound "hbm")    the memory system behind L2: achieved = the kernel's L2 misses x 128 B (the line the fabric moves per miss)
-                        / duration; peak = the measured rate of dependent random fetches from a table of the scene's size x 128 B
-  frac_hbm_measured     HBM bytes the kernel really moved (FETCH_SIZE corrected with the gather factor of
-                        tools/fetch_calibration.py, + WRITE_SIZE) / duration / 8 TB/s
-  frac_vmem_issue       the CU's vector-memory instruction rate: instructions per CU x measured ns per instruction / duration
-                        (~0.9: what the kernel runs against)
-  frac_l1_lookups       TCP line lookups x 64 B / duration against one line per CU and cycle
-  frac_latency_model    achieved rays/s / (resident waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency)):
-                        what the same waves would deliver with every lane busy at the measured latency
-  valu / salu issue     instruction counts x the measured issue cost (2-4 cycles per vector, 4 per scalar instruction and SIMD)
+HIP events on the render stream).  Every fraction names its denominator:
+  frac  (bound "hbm")   SURVEY.md 8(d) / the task contract: achieved = ALGORITHMIC bytes per launch / duration, peak = HBM 8 TB/s.
+                        Bytes per ray come from the CPU oracle's counters of the reference's ordered traversal on a bounded sample of
+                        the same scene and camera (B_ray = 24*n_box + 8*n_node + 64*n_tri), times the rays one launch casts.  It
+                        EXCEEDS 1 (frac_note): most node fetches are served by L1 / L2 / the Infinity Cache and never cross HBM.
+  traffic, frac_hbm_measured   HBM bytes per launch from the PMC counters (FETCH_SIZE corrected with the gather factor of
+                        tools/fetch_calibration.py, + WRITE_SIZE), and those / duration / 8 TB/s
+  ceilings_measured_in_this_run   fractions against ceilings this run measured on the device itself, each with its "ceiling_source":
+      dependent_gather  the kernel's L2 misses x 128 B / duration against mipt_measure_dependent_gather (dependent random 128-byte
+                        fetches from a table of the scene's size: mostly Infinity Cache, NOT an HBM figure)
+      vmem_issue        vector-memory wave-instructions per CU x the cost of one (mipt_measure_vmem_issue at the kernel's mean
+                        active lanes) / duration: the figure the kernel runs against
+  frac_l1_lookups, latency_model, instruction_issue   TCP line lookups against one per CU and cycle; achieved rays/s against resident
+                        waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency); instruction counts x issue cost
+Per-ray counter values come from the committed PMC run of the same workload (profiles/r4_pmc_counters.json; separate --pmc passes).
+derived_from_pmc_run.same_library_build compares __graft_entry__.source_hash() (csrc/* + include/mipt.h + hipcc flags) with the hash
+that run recorded; when they differ everything derived from the counters is null and derived_from_pmc_run.stale is true.
 roofline_shade_kernel: algorithmic path-state bytes per vertex x vertices / stage time against the HBM peak, and its measured traffic.
 
 cpu_baseline (rank 0, N=1 only): the compiled reference's own render_image_nopreviz() on all host
@@ -227,6 +224,10 @@ def main():
     args.width, args.height = cfg.W, cfg.H
 
     rt = capi.HostRaytracer(device=in_process if in_process else local_rank)
+    if in_process and len(set(in_process)) == len(in_process) and len(in_process) > 1:
+        # distinct devices: the group's framebuffer reduce must be RCCL's ncclReduce or the run fails (option reduce = 1 keeps an RCCL
+        # failure instead of falling back to peer copies: a first multi-GPU lease cannot silently measure the copy reduce)
+        rt.set_option("reduce", 1)
     rt.apply_config(cfg)
     rt.set_partition(32, rank, world)
     t0 = time.time()
@@ -317,6 +318,8 @@ def main():
         elapsed = float(tmax[0]); rays_c, rays_s, paths = float(tsum[1]), float(tsum[2]), float(tsum[3])
     rays = rays_c + rays_s
 
+    if in_process and len(set(in_process)) == len(in_process) and len(in_process) > 1 and not rt.group_reduce_kind().startswith("RCCL"):
+        raise SystemExit("bench.py --gpus %d on distinct devices must reduce with RCCL, the library reports: %s" % (args.gpus, rt.group_reduce_kind()))
     if rank == 0:
         img = accum[: args.width * args.height * 3]
         finite = bool(torch.isfinite(img).all().item())
@@ -368,80 +371,99 @@ def main():
                 clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6 or 2.4
             except Exception:
                 pass
-            # ---- what binds the traversal kernel.  Measured live: the launch duration (HIP events on the render
-            # stream) and the capacity of the memory system behind L2 for dependent random fetches (mipt_measure_dependent_gather on a
-            # table of the size of this scene's nodes + triangle records).  Derived from the committed PMC run of the same workload
-            # (profiles/r3_pmc_counters.json, per ray of that run x the rays of this one): L2 misses, L1 lookups, HBM bytes,
-            # instructions, mean vector-memory latency.
+            # ---- the roofline object (task contract / SURVEY 8d): achieved = ALGORITHMIC bytes per launch / launch time, peak = HBM 8 TB/s,
+            # traffic = HBM bytes per launch from the PMC counters.  Everything else names its own denominator: fractions against ceilings
+            # this run measured itself (mipt_measure_*) sit under "ceilings_measured_in_this_run", what is scaled from the committed PMC run
+            # of the same workload (profiles/r4_pmc_counters.json: per ray of that run x the rays of this one) is dropped to null and
+            # flagged stale when this run's library is not the build that was profiled (hash of csrc/* + flags, __graft_entry__.source_hash).
             scene_bytes = int(mesh.ntri) * 64 + int(mesh.ntri) * 64          # ~ one fat node per triangle pair + one record per triangle
             try:
                 cap_g = rt.measure_dependent_gather(max(64 << 20, scene_bytes), 2000, 2)      # 10^9 line fetches per second
             except Exception:
                 cap_g = None
             peak_l1 = n_cus * 64 * clock_ghz                            # GB/s: one 64-byte line lookup per CU and cycle
-            rf = {"bound": "hbm", "achieved": None, "peak": (cap_g * 128.0 if cap_g else None), "unit": "GB/s", "frac": None, "traffic": None,
-                  "bound_note": "the memory system behind L2 (Infinity Cache + HBM) serves DEPENDENT random fetches at a fixed rate of 128-byte lines "
-                                "(peak: measured in this run on a table of the scene's size, mipt_measure_dependent_gather; tools/valu_rate.hip: independent of waves and lanes); "
-                                "achieved = the kernel's L2 misses x 128 B / launch time.  The algorithmic-HBM fraction of SURVEY 8d is > 1 (most node fetches hit L1 / L2)",
+            secs = ms_per_launch * 1e-3
+            rf = {"bound": "hbm", "achieved": alg_hbm, "peak": 8000.0, "unit": "GB/s", "frac": alg_hbm / 8000.0, "traffic": None,
+                  "frac_definition": "SURVEY 8(d): algorithmic bytes per launch (24 n_box + 8 n_node + 64 n_tri from the oracle's counters of the reference's ordered traversal, "
+                                     "x the rays of one launch) / mean launch time (HIP events on the render stream) / HBM peak 8 TB/s (MI355X_MICROARCH.md)",
+                  "frac_note": "a value > 1 means cache-served: most node fetches hit L1 / L2 / the Infinity Cache and never cross HBM; the bytes that do are `traffic` "
+                               "(frac_hbm_measured = traffic / launch time / 8 TB/s)",
                   "kernel": kernel, "ms_per_launch": ms_per_launch, "launches": int(launches), "rays_per_launch": rays_per_launch,
-                  "frac_algorithmic_hbm": alg_hbm / 8000.0, "algorithmic_hbm_gb_per_s": alg_hbm, "hbm_peak_gb_per_s": 8000.0,
-                  "peak_measured_stream_read": stream, "dependent_gather_glines_per_s": cap_g,
+                  "algorithmic_bytes_per_launch": bytes_per_launch, "frac_algorithmic_hbm": alg_hbm / 8000.0,
+                  "peak_measured_stream_read": stream,
                   "bytes_per_closest_ray": ob["bytes_closest"], "bytes_per_shadow_ray": ob["bytes_shadow"],
-                  "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"]}
-            pmc_file = os.path.join(ROOT, "profiles", "r3_pmc_counters.json")
+                  "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"],
+                  "frac_hbm_measured": None}
+            ceil = {}
+            pmc_file = os.path.join(ROOT, "profiles", "r4_pmc_counters.json")
+            pk = None
             try:   # per-ray counter values of the dominant kernel from the committed PMC run of the same workload
                 pall = json.load(open(pmc_file))
                 pj = pall[args.workload]
                 pk = pj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
-                secs = ms_per_launch * 1e-3
-                rf["achieved"] = pk["l2_misses_per_ray"] * rays_per_launch * 128.0 / secs / 1e9
-                rf["frac"] = rf["achieved"] / rf["peak"] if rf["peak"] else None
-                rf["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
+                same = pall.get("_build", {}).get("source_sha256_16") == ge.source_hash() and not os.environ.get("MIPT_LIB_OVERRIDE")
+                rf["derived_from_pmc_run"] = {"file": "profiles/r4_pmc_counters.json", "source": pj["source"], "git_commit": pall.get("_build", {}).get("git_commit"),
+                                              "same_library_build": same, "stale": not same,
+                                              "keyed_on": "sha256 of pathtracer_amd/csrc/*, include/mipt.h and the hipcc flags (the binary is not bit-reproducible)"}
+                if not same:
+                    pk = None
+            except Exception as e:
+                rf["pmc_note"] = "profiles/r4_pmc_counters.json has no entry for this workload / kernel (%s: %s)" % (type(e).__name__, e)
+            lanes_per_instr = 32
+            if pk:
                 rf["traffic"] = pk["hbm_bytes_per_ray"] * rays_per_launch
                 rf["frac_hbm_measured"] = rf["traffic"] / secs / 8e12
-                lookups = pk["tcp_accesses_per_ray"] * rays_per_launch
-                rf["frac_l1_lookups"] = lookups * 64 / secs / 1e9 / peak_l1
+                rf["hbm_traffic_over_algorithmic_bytes"] = rf["traffic"] / bytes_per_launch
+                rf["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
                 rf["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
+                rf["frac_l1_lookups"] = {"frac": pk["tcp_accesses_per_ray"] * rays_per_launch * 64 / secs / 1e9 / peak_l1,
+                                         "denominator": "one 64-byte L1 (TCP) line lookup per CU and cycle (%d CUs x %.2f GHz)" % (n_cus, clock_ghz)}
                 # latency model: rays in flight at FULL lane occupancy / (dependent steps per ray x mean vector-memory latency)
                 waves_per_cu = pk["waves"] / n_cus
                 steps_per_ray = ob["lines_closest"]                    # one dependent fetch per inner node visited and per triangle record tested
                 lat_s = pk["mean_vmem_latency_cycles"] / (clock_ghz * 1e9)
                 attainable = waves_per_cu * 64 * n_cus / (steps_per_ray * lat_s)
-                rf["frac_latency_model"] = (rays_per_launch / secs) / attainable
-                rf["latency_model"] = {"resident_waves_per_cu": waves_per_cu, "dependent_fetches_per_ray": steps_per_ray, "mean_vmem_latency_cycles": pk["mean_vmem_latency_cycles"],
+                rf["latency_model"] = {"frac": (rays_per_launch / secs) / attainable, "denominator": "resident waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency)",
+                                       "resident_waves_per_cu": waves_per_cu, "dependent_fetches_per_ray": steps_per_ray, "mean_vmem_latency_cycles": pk["mean_vmem_latency_cycles"],
                                        "attainable_grays_per_s_at_full_lane_occupancy": attainable / 1e9, "wait_share_of_wave_cycles": pk["wait_share_of_wave_cycles"]}
                 # instruction issue: a vector instruction holds its SIMD 2 (add / mul / fma / mov / logic) or 4 cycles (min / max / compare / select /
                 # packed / DPP), a scalar one 4 cycles of the SIMD's scalar slot (profiles/r3_b_instruction_issue_rates.txt)
                 simd_cycles = 4 * n_cus * clock_ghz * 1e9 * secs
-                rf["valu_issue_busy_2_to_4_cycles"] = [2 * pk["valu_per_ray"] * rays_per_launch / simd_cycles, 4 * pk["valu_per_ray"] * rays_per_launch / simd_cycles]
-                rf["salu_issue_busy"] = 4 * pk["salu_per_ray"] * rays_per_launch / simd_cycles
-                # vector-memory issue: the CU serves one vector-memory wave-instruction per ~10 ns (measured in this run at the mean number of
-                # active lanes of the kernel's loads: mipt_measure_vmem_issue); the kernel's instruction count per CU x that figure / its time
-                try:
-                    lanes_per_instr = 32            # mean active lanes of the node loads (tools/simd_prof.py: 31.8 - 32.5 on this workload)
+                rf["instruction_issue"] = {"valu_issue_busy_2_to_4_cycles": [2 * pk["valu_per_ray"] * rays_per_launch / simd_cycles, 4 * pk["valu_per_ray"] * rays_per_launch / simd_cycles],
+                                           "salu_issue_busy": 4 * pk["salu_per_ray"] * rays_per_launch / simd_cycles,
+                                           "denominator": "issue cycles of the 4 SIMDs x %d CUs (cost per instruction: profiles/r3_b_instruction_issue_rates.txt)" % n_cus,
+                                           "active_lanes_per_vector_instruction": pk.get("active_lanes_per_vector_instruction")}
+                if pk.get("active_lanes_per_vector_instruction"):
+                    lanes_per_instr = int(max(1, min(64, round(pk["active_lanes_per_vector_instruction"]))))
+                if cap_g:
+                    ach = pk["l2_misses_per_ray"] * rays_per_launch * 128.0 / secs / 1e9
+                    ceil["dependent_gather"] = {"frac": ach / (cap_g * 128.0), "achieved_gb_per_s": ach, "peak_gb_per_s": cap_g * 128.0, "glines_per_s": cap_g,
+                                                "ceiling_source": "measured in this run by mipt_measure_dependent_gather: dependent random fetches of 128-byte lines from a table of the scene's size (%d MB)" % (max(64 << 20, scene_bytes) >> 20),
+                                                "achieved_definition": "the kernel's L2 misses x 128 B / launch time (mostly served by the Infinity Cache: not an HBM figure)"}
+                try:   # the CU serves one vector-memory wave-instruction per ~10 ns (measured at the kernel's mean number of active lanes)
                     ns_instr = rt.measure_vmem_issue(lanes_per_instr, 3000)
-                    rf["frac_vmem_issue"] = pk["vmem_per_ray"] * rays_per_launch / n_cus * ns_instr * 1e-9 / secs
-                    rf["vmem_issue"] = {"instructions_per_ray": pk["vmem_per_ray"], "ns_per_instruction_and_cu": ns_instr, "at_active_lanes": lanes_per_instr}
+                    ceil["vmem_issue"] = {"frac": pk["vmem_per_ray"] * rays_per_launch / n_cus * ns_instr * 1e-9 / secs,
+                                          "instructions_per_ray": pk["vmem_per_ray"], "ns_per_instruction_and_cu": ns_instr, "at_active_lanes": lanes_per_instr,
+                                          "ceiling_source": "measured in this run by mipt_measure_vmem_issue: cost of a vector-memory wave-instruction per CU at that many active lanes"}
                 except Exception as e:
-                    rf["vmem_issue_note"] = "%s: %s" % (type(e).__name__, e)
-                rf["pmc_source"] = pj["source"]
-                import hashlib
-                lib_sha = hashlib.sha256(open(os.path.join(ROOT, "pathtracer_amd", os.path.basename(os.environ.get("MIPT_LIB_OVERRIDE", "libmipt.so"))), "rb").read()).hexdigest()[:16]
-                rf["derived_from_pmc_run"] = {"git_commit": pall.get("_build", {}).get("git_commit"), "same_library_build": pall.get("_build", {}).get("libmipt_sha256_16") == lib_sha}
-            except Exception as e:
-                rf["pmc_note"] = "profiles/r3_pmc_counters.json has no entry for this workload / kernel (%s: %s)" % (type(e).__name__, e)
+                    ceil["vmem_issue_note"] = "%s: %s" % (type(e).__name__, e)
+            elif cap_g:
+                ceil["dependent_gather"] = {"frac": None, "peak_gb_per_s": cap_g * 128.0, "glines_per_s": cap_g,
+                                            "ceiling_source": "measured in this run by mipt_measure_dependent_gather (no current PMC run to take the kernel's L2 misses from)"}
+            rf["ceilings_measured_in_this_run"] = ceil
             out["roofline"] = rf
             if pipeline == 1 and sh_launches:
                 sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
                 rs = {"kernel": "k_wf_traverse<1> (any-hit / shadow stage)", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
                       "launches": int(sh_launches), "rays_per_launch": rays_s / sh_launches, "l1_lookups_per_ray_algorithmic": ob["lines_shadow"]}
                 try:
-                    pk = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_traverse<1>"]
-                    secs = sh_ms / sh_launches * 1e-3
-                    rs["frac"] = (pk["l2_misses_per_ray"] * rays_s / sh_launches * 128.0 / secs / 1e9) / rf["peak"] if rf["peak"] else None
-                    rs["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
-                    rs["frac_l1_lookups"] = pk["tcp_accesses_per_ray"] * rays_s / sh_launches * 64 / secs / 1e9 / peak_l1
-                    rs["frac_hbm_measured"] = pk["hbm_bytes_per_ray"] * rays_s / sh_launches / secs / 8e12
+                    if not pk: raise KeyError("no current PMC run")
+                    pks = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_traverse<1>"]
+                    secs_s = sh_ms / sh_launches * 1e-3
+                    rs["frac_dependent_gather"] = (pks["l2_misses_per_ray"] * rays_s / sh_launches * 128.0 / secs_s / 1e9) / (cap_g * 128.0) if cap_g else None
+                    rs["l2_misses_per_ray"] = pks["l2_misses_per_ray"]
+                    rs["frac_l1_lookups"] = pks["tcp_accesses_per_ray"] * rays_s / sh_launches * 64 / secs_s / 1e9 / peak_l1
+                    rs["frac_hbm_measured"] = pks["hbm_bytes_per_ray"] * rays_s / sh_launches / secs_s / 8e12
                 except Exception:
                     pass
                 out["roofline_shadow_kernel"] = rs
@@ -453,9 +475,11 @@ def main():
                 state_bytes = 88 + 128 + 64
                 shade_secs = (shade_ms - 0.0) * 1e-3
                 rsh = {"kernel": "k_wf_generate + k_wf_shade<1,2> (per step)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_vertex": state_bytes,
+                       "frac_definition": "algorithmic path-state bytes per vertex x vertices / stage time / HBM peak 8 TB/s",
                        "vertices_per_step": verts / args.steps, "ms_per_step": shade_ms / args.steps,
                        "achieved": verts * state_bytes / shade_secs / 1e9, "frac": verts * state_bytes / shade_secs / 8e12}
                 try:
+                    if not pk: raise KeyError("no current PMC run")
                     pks = json.load(open(pmc_file))[args.workload]["kernels"]
                     tr = sum(pks[k]["hbm_bytes_per_launch"] for k in pks if k.startswith("k_wf_shade")) * max(1, launches) + pks["k_wf_generate"]["hbm_bytes_per_launch"] * (launches / max(1, cfg.nb_bounces))
                     rsh["traffic"] = tr / args.steps

@@ -154,6 +154,15 @@ static uint64_t g_cnt[8];
 static void cnt_flush(void) {
 	for (int k = 0; k < 8; k++) { if (tl_cnt[k]) { __atomic_fetch_add(&g_cnt[k], tl_cnt[k], __ATOMIC_RELAXED); tl_cnt[k] = 0; } }
 }
+/* Traversal event trace (diagnostic; tests/tools/sched_sim.py): when a buffer is installed, every TriMesh traversal of the
+   calling thread appends 0xFF kind(0 closest / 1 any-hit) [0xFE = the root box rejected the ray], then one byte per node
+   popped: an inner node = the number of stack entries that remain behind it (what a stack that only stores far children
+   holds), a leaf = 0x80 | its triangle count; o_trace_mark() appends 0xFD (a new camera path). */
+static _Thread_local uint8_t* tl_trace = NULL;
+static _Thread_local size_t tl_trace_len = 0, tl_trace_cap = 0;
+void o_trace_set(uint8_t* buf, size_t cap) { tl_trace = buf; tl_trace_cap = cap; tl_trace_len = 0; }
+size_t o_trace_len(void) { return tl_trace_len; }
+static inline void trace_byte(uint8_t b) { if (tl_trace) { if (tl_trace_len < tl_trace_cap) tl_trace[tl_trace_len] = b; tl_trace_len++; } }
 void o_counters_reset(void) { cnt_flush(); memset(g_cnt, 0, sizeof g_cnt); }
 void o_counters_get(uint64_t* out8) { cnt_flush(); memcpy(out8, g_cnt, sizeof g_cnt); }
 
@@ -422,8 +431,9 @@ static int mesh_intersection(const o_obj* o, const o_ray* d, v3* P, float* t, o_
 
 	tl_cnt[6]++;
 	c_box++;
-	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &t_box_left)) { tl_cnt[0] += c_box; return 0; }
-	if (t_box_left > cur_best_t) { tl_cnt[0] += c_box; return 0; }
+	trace_byte(0xFF); trace_byte(0);
+	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &t_box_left)) { tl_cnt[0] += c_box; trace_byte(0xFE); return 0; }
+	if (t_box_left > cur_best_t) { tl_cnt[0] += c_box; trace_byte(0xFE); return 0; }
 
 	int l[50];
 	float tnear[50];
@@ -437,6 +447,7 @@ static int mesh_intersection(const o_obj* o, const o_ray* d, v3* P, float* t, o_
 		c_node++;
 		const int fg = g->nodes[current].fg;
 		const int fd = g->nodes[current].fd;
+		if (tl_trace) trace_byte(g->nodes[current].isleaf ? (uint8_t)(0x80 | (fd - fg > 63 ? 63 : fd - fg)) : (uint8_t)(idx_back + 1));
 		if (!g->nodes[current].isleaf) {
 			c_box += 2;
 			if (signs[0] == 1) {
@@ -511,8 +522,9 @@ static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, fl
 
 	tl_cnt[7]++;
 	c_box++;
-	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &t_box_left)) { tl_cnt[3] += c_box; return 0; }
-	if (t_box_left > cur_best_t || t_box_left > dist_light) { tl_cnt[3] += c_box; return 0; }
+	trace_byte(0xFF); trace_byte(1);
+	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &t_box_left)) { tl_cnt[3] += c_box; trace_byte(0xFE); return 0; }
+	if (t_box_left > cur_best_t || t_box_left > dist_light) { tl_cnt[3] += c_box; trace_byte(0xFE); return 0; }
 
 	int l[50];
 	float tnear[50];
@@ -526,6 +538,7 @@ static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, fl
 		c_node++;
 		const int fg = g->nodes[current].fg;
 		const int fd = g->nodes[current].fd;
+		if (tl_trace) trace_byte(g->nodes[current].isleaf ? (uint8_t)(0x80 | (fd - fg > 63 ? 63 : fd - fg)) : (uint8_t)(idx_back + 1));
 		if (!g->nodes[current].isleaf) {
 			c_box += 2;
 			goleft = (box_invd(g->nodes[fg].bmin, g->nodes[fg].bmax, invd.origin, invd.direction, signs, &t_box_left) && (t_box_left < *t) && (t_box_left < dist_light));
@@ -1932,6 +1945,20 @@ void o_render_denoiser_inputs(o_ctx* c, float* imagedouble, float* sample_count,
 	}
 	#pragma omp parallel
 	cnt_flush();
+}
+
+/* diagnostic: the traversal events of the samples k0 .. k1-1 of the given pixels, one camera path after the other on the calling
+   thread (sample index outermost, as the device numbers its path slots).  Returns the bytes the trace needs (<= cap: complete). */
+unsigned long long o_trace_samples(o_ctx* c, int npix, const int* ij, int k0, int k1, uint8_t* buf, unsigned long long cap) {
+	o_trace_set(buf, cap);
+	for (int k = k0; k < k1; k++) for (int q = 0; q < npix; q++) {
+		float dx, dy;
+		trace_byte(0xFD);
+		(void)sample_radiance(c, ij[2 * q], ij[2 * q + 1], k, &dx, &dy, NULL);
+	}
+	size_t n = tl_trace_len;
+	o_trace_set(NULL, 0);
+	return n;
 }
 
 void o_getcolor_samples(o_ctx* c, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy) {

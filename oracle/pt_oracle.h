@@ -70,6 +70,8 @@ void   o_phong_eval(int n, const float* mat9, const float* wi3, const float* wo3
 
 /* radiance: per-(pixel,sample) stream pcg32(p*65536+k), p = i*W+j */
 void   o_getcolor_samples(o_ctx*, int npix, const int* ij, int k0, int k1, float* out_rgb, float* out_dxdy);
+/* diagnostic (tests/tools/sched_sim.py): traversal events of those samples, path after path; returns the bytes needed */
+unsigned long long o_trace_samples(o_ctx*, int npix, const int* ij, int k0, int k1, uint8_t* buf, unsigned long long cap);
 void   o_render_seeded(o_ctx*, float* imagedouble, float* sample_count);
 void   o_set_object_ghost(o_ctx*, int obj, int ghost);
 void   o_set_lenticular(o_ctx*, int on, int nb_images, float max_angle, int pixel_width);

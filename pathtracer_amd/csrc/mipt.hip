@@ -390,8 +390,8 @@ struct mipt_ctx {
 	int blk_nblocks = 0;
 	uint64_t blk_valid_pixels = 0;
 	int64_t opt_pipeline = 1;
-	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
-	int64_t opt_inner_min = 16;
+	int64_t opt_refill_threshold = MIPT_READY_LIST ? MIPT_RL_FILL_THRESHOLD : MIPT_REFILL_THRESHOLD;
+	int64_t opt_inner_min = MIPT_READY_LIST ? MIPT_RL_INNER_MIN : 16;
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
@@ -1339,7 +1339,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (n_probe) {
 					TravQueue tq; tq.list = qw.prl[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_PROBE(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_PROBE(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
+					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq,
+					                   MIPT_READY_LIST ? MIPT_REFILL_THRESHOLD : thr, MIPT_READY_LIST ? ((imin & ~0xffff) | 16) : imin);      // (the probes run the loop without the ready list)
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[1]) {
@@ -1546,15 +1547,20 @@ static int group_render_range(mipt_ctx* c, const mipt_render_params* p, int k0, 
 	if (!g->comm.empty() && g->opt_reduce != 2) {
 		RcclApi& api = rccl_api();
 		int r = api.GroupStart();
+		int enqueued = 0;                   // members whose ncclReduce was accepted into the group
 		for (int i = 0; i < n && r == 0; i++) {
 			hipSetDevice(g->member[i]->device);
 			r = api.Reduce(g->acc[i], g->acc[i], count, MIPT_NCCL_FLOAT32, MIPT_NCCL_SUM, 0, g->comm[i], g->stream[i]);
+			if (r == 0) enqueued++;
 		}
 		const int r2 = api.GroupEnd();
 		hipSetDevice(c->device);
 		if (r == 0 && r2 == 0) reduced = true;
-		else if (g->opt_reduce == 1) return fail(c, MIPT_ERR_HIP, "ncclReduce failed: %s", api.GetErrorString(r ? r : r2));
-		else {   // a collective that cannot be enqueued (nothing of it has run): this range and the following ones are summed by copies; the note says why
+		else if (g->opt_reduce == 1 || enqueued > 0)
+			// part of the group may have been launched: acc[0] may hold a partial sum and a stream may sit in a collective its peers never
+			// join — summing the same in-place buffers again by copies would double-count or hang, so the failure is the caller's
+			return fail(c, MIPT_ERR_HIP, "ncclReduce failed (%d of %d members enqueued): %s", enqueued, n, api.GetErrorString(r ? r : r2));
+		else {   // ncclGroupStart or the FIRST enqueue failed: nothing of the collective exists; this range and the following ones are summed by copies, the note says why
 			g->reduce_note = std::string("copy reduce: ncclReduce failed: ") + api.GetErrorString(r ? r : r2);
 			g->opt_reduce = 2;
 		}
@@ -1772,12 +1778,12 @@ extern "C" int mipt_measure_gather_read(mipt_ctx* c, uint64_t buffer_bytes, uint
 // step, the next index out of the record: the access pattern of a traversal step that misses the caches.  Its rate is the
 // ceiling of the memory system BEHIND L2 for this pattern (tools/valu_rate.hip: the same whatever the number of waves or
 // active lanes, the same for 128-byte records: a fixed rate of 128-byte line fetches); bench.py prices the traversal's L2
-// misses against it.  The table is a random cyclic permutation built on the device (Sattolo's walk per block is not needed:
-// next = (i * odd + c) mod n with an odd multiplier of a power-of-two n is one cycle covering every record).
+// misses against it.  The table is one cycle through every record, built on the device: next = (a i + c) mod 2^k has full period
+// exactly when c is odd and a = 1 (mod 4) (Hull-Dobell); both constants below satisfy it (0x9E3779B1 = 1 mod 4, and odd).
 __global__ void __launch_bounds__(256) k_chase_init(float4* __restrict__ tab, unsigned nrec_pow2) {
 	const unsigned mask = nrec_pow2 - 1u;
 	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec_pow2; i += gridDim.x * blockDim.x) {
-		const unsigned nxt = (i * 2654435761u + 0x9e3779b1u) & mask;                 // odd multiplier: a bijection of [0, 2^k)
+		const unsigned nxt = (i * 2654435761u + 0x9e3779b1u) & mask;                 // a = 1 mod 4, c odd: one cycle of length 2^k
 		tab[4 * (size_t)i] = make_float4(__uint_as_float(nxt), 0.f, 0.f, 0.f);
 		tab[4 * (size_t)i + 1] = tab[4 * (size_t)i + 2] = tab[4 * (size_t)i + 3] = make_float4(1.f, 2.f, 3.f, 4.f);
 	}

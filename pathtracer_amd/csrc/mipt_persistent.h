@@ -13,7 +13,9 @@
 // stack traversal per mesh, same pruning); only WHICH lane runs it and WHEN changes.
 #pragma once
 
-#define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
+#define MIPT_REFILL_THRESHOLD 36        // loop without the ready list (the subsurface probes): refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum), inner phase until < 16 lanes descend
+#define MIPT_RL_FILL_THRESHOLD 8        // with the ready list: fill when the list is empty and this many lanes are idle,
+#define MIPT_RL_INNER_MIN 32            // and end the inner phase when fewer than this many lanes descend (tests/tools/sched_sim.c)
 #ifndef MIPT_EXTEND_WAVES
 #define MIPT_EXTEND_WAVES 7             // closest-hit kernel: 7 waves/SIMD with the derived triangle terms, made possible by MIPT_HIT_WRITE_THROUGH (round 1: 6 waves with the derived terms beat 7 with the fourth load)
 #endif
@@ -55,7 +57,48 @@ struct LaneState {
 	int count;              // reservoir: intersections accepted so far
 };
 
-#define MIPT_NONE 0x7fffffffu
+// MIPT_READY_LIST (round 4; measured, NOT the default — DESIGN.md 4e): a per-wave list of rays that are already fetched,
+// transformed and root-tested, kept in LDS.  tests/tools/sched_sim.c replays the oracle's per-ray node sequences through this loop's
+// lane scheduling (it reproduces the instrumented kernel's counters to 1 %): with a refill at 36 idle lanes the inner steps of
+// configs[2] run at 38 of 64 lanes, and keeping the lanes full does not help by itself (32.5 lanes with a refill at 8: an inner phase
+// lasts until fewer than inner_min lanes descend, so more live lanes only make it longer).  What raises the lanes is both together:
+// lanes re-bound at every outer iteration AND the inner phase ended at 32 descending lanes (45 lanes per inner step, -17 % inner
+// steps at +3 % leaf phases) — affordable only if re-binding a lane costs no global round trip.  So: a FILL fetches and sets up rays
+// with every lane that is given one (idle lanes for themselves, in place; busy lanes for the list, beside the traversal state they
+// keep), when the list is empty and >= refill_threshold lanes are idle; a TAKE hands list entries to idle lanes at the one wave-level
+// point in front of the inner phase (one ballot, a prefix count, LDS reads; nothing inside the inner loop).  Every ray still performs
+// the reference's sequence of operations: the GPU parity suite is green with it (165 tests).
+// MEASURED (profiles/r4_b_*): 44.8 lanes per inner step, vector-memory instructions -15 %, vector -10 %, scalar -9.5 % per launch — and
+// the closest-hit stage of configs[2] 2.3 % SLOWER at 7 waves per SIMD (any-hit +5 %, configs[3] +6 %): L1->L2 requests +17 %, L2
+// misses +8 %, tag-conflict stalls +77 % (a sixth more rays in flight per CU thrash the 32 KB L1 and the L2 share).  At 6 waves it
+// beats the 6-wave loop without it by 4.3 % — which is 3.4 % behind 7 waves without it.  The kernel does not run at an instruction
+// rate (one more load instruction per inner step, +20 % of them, costs 6 %: profiles/r4_b_access_probes.txt).
+#ifndef MIPT_READY_LIST
+#define MIPT_READY_LIST 0
+#endif
+#ifndef MIPT_RL_CAP
+#define MIPT_RL_CAP 28                  // entries per wave (48 bytes each): stack of 8 + leaf map + list = 22 784 bytes per block, 7 blocks per CU
+#endif
+typedef float mipt_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) mipt_f4 lds_float4;      // (a plain vector type: HIP's float4 class has no constructors from LDS references)
+
+// the wave's slice of the block's ready list (nullptr without the feature)
+#if MIPT_READY_LIST
+#define MIPT_DECLARE_READY_LIST(rl) \
+	__shared__ mipt_f4 lds_ready_[(MIPT_TRAV_BLOCK / 64) * MIPT_RL_CAP * 3]; \
+	lds_float4* rl = (lds_float4*)lds_ready_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (MIPT_RL_CAP * 3)
+#else
+#define MIPT_DECLARE_READY_LIST(rl) lds_float4* rl = nullptr
+#endif
+
+// A lane's state is kept in st.cur beside the node reference (no separate flags: at 72 registers two flags cost two registers):
+// an inner node (< MIPT_ST_NEED), a leaf (bit 31), or one of
+#define MIPT_ST_NEED 0x7ffffffdu        // the lane's ray must visit its next object(s)
+#define MIPT_ST_IDLE 0x7ffffffeu        // the lane holds no ray
+#define MIPT_NONE 0x7fffffffu           // the ray has just left its mesh (it counts as alive until the end of the outer iteration)
+#define MIPT_L_ALIVE (st.cur - MIPT_ST_NEED >= 2u)
+#define MIPT_L_NEED (st.cur == MIPT_ST_NEED)
+#define MIPT_L_IDLE (st.cur == MIPT_ST_IDLE)
 // MIPT_HIT_WRITE_THROUGH: the closest-hit kernel does not carry (beta, gamma, best) of the best hit in registers: a ray's record
 // is written when the ray is fetched (what the analytic objects left) and rewritten at every accepted hit.  That frees the
 // registers that let the kernel run 7 waves per SIMD with the derived triangle terms (6 spilled values, all loop constants
@@ -119,9 +162,11 @@ struct TravQueue {
 // frame of ONE mesh (wf.ray_o.w = max_t, wf.ray_d.w = the object), the traversal is the closest-hit one with the far bound
 // fixed at max_t, and every triangle hit in [0, max_t) draws one number from the sample's engine (wf.rng) in visiting order and
 // replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
-template <bool SHADOW, bool RESV = false>
+template <bool SHADOW, bool RESV = false, bool RL = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
+                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, lds_float4* rl_base = nullptr) {
+	static_assert(!RL || !RESV, "the ready list serves the closest-hit and any-hit queues");
+	static_assert(!RL || MIPT_HIT_WRITE_THROUGH, "the ready list keeps no best-hit registers");
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
@@ -139,17 +184,18 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	bool first_pull = true;
 	const unsigned pull_chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_TRAV_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u)));
 	const unsigned lane = lane_id();
-	const unsigned long long below = (1ull << lane) - 1ull;
+	// set bits of a wave mask below the calling lane (v_mbcnt takes the mask from scalar registers: no per-lane `lanes below me` mask is kept)
+	auto below_count = [](unsigned long long m) -> unsigned { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
 
 	LaneState st;
-	st.cur = MIPT_NONE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0; st.rng = 0; st.count = 0;
+	st.cur = MIPT_ST_IDLE; st.sp = 0; st.obj = 0; st.best = 0; st.id = 0; st.t = 0; st.beta = 0; st.gamma = 0; st.dist = 0; st.rng = 0; st.count = 0;
 	st.o_xy = (mipt_f2){0.f, 0.f}; st.i_xy = (mipt_f2){0.f, 0.f}; st.oz_iz = (mipt_f2){0.f, 0.f}; st.d = mk3(0, 0, 0);
-	bool alive = false;                  // the lane holds a ray that is inside a mesh traversal
-	bool need = false;                   // the lane holds a ray that must visit its next object(s)
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
 	unsigned ahead = 0, ahead_at = 0xffffffffu;   // MIPT_PREFETCH_IDS: entry ahead_at + lane of the list (valid while ahead_at == chunk_next)
 	bool drained = false;
+	unsigned rl_head = 0, rl_count = 0;           // ready list: wave-uniform
 	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
+	const uint32_t root_first = (RL && first_mesh < nobj) ? sc->obj[first_mesh].root_ref : MIPT_NONE;
 	const bool any_alpha = sc->any_alpha != 0;
 	auto pop_next = [&]() -> uint32_t {
 		while (st.sp > 0) {
@@ -163,11 +209,11 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 
 	for (;;) {
 		MIPT_PROF_CLOCK(c0);
-		if (alive) MIPT_PROF_COUNT(8)
+		if (MIPT_L_ALIVE) MIPT_PROF_COUNT(8)
 		// ---- refill idle lanes from the queue
-		unsigned long long idle = __ballot(!alive && !need && lane < lane_limit);
+		unsigned long long idle = RL ? 0ull : __ballot(MIPT_L_IDLE && lane < lane_limit);
 		int nidle = __popcll(idle);
-		if (!drained && nidle >= refill_threshold) {
+		if (!RL && !drained && nidle >= refill_threshold) {
 			if (chunk_next >= chunk_end) {
 				// The first chunk of every wave is assigned statically (chunk number = wave number), later ones come
 				// from the shared counter: 8192 waves hitting one address at launch cost ~90 us (one same-address
@@ -180,11 +226,11 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
 			}
 			unsigned take = min((unsigned)nidle, chunk_end - chunk_next);
-			const unsigned my_prefix = (unsigned)__popcll(idle & below);
+			const unsigned my_prefix = below_count(idle);
 			unsigned id_ahead = 0;
 			const bool use_ahead = MIPT_PREFETCH_IDS && !identity && ahead_at == chunk_next;       // wave-uniform
 			if (use_ahead) id_ahead = (unsigned)__builtin_amdgcn_ds_bpermute((int)((my_prefix & 63u) << 2), (int)ahead);
-			if (!alive && !need && lane < lane_limit) {
+			if (MIPT_L_IDLE && lane < lane_limit) {
 				unsigned prefix = my_prefix;
 				if (prefix < take) {
 					unsigned idx = chunk_next + prefix;
@@ -196,7 +242,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						// the stage that created the ray has already visited the analytic objects (mipt_wavefront.h):
 						// closest-hit rays arrive with the (t, object) found in front of the first mesh, shadow rays
 						// arrive only if no sphere / plane occludes them
-						st.id = id; st.obj = first_mesh; need = true;
+						st.id = id; st.obj = first_mesh; st.cur = MIPT_ST_NEED;
 						if (SHADOW) st.best = 0;                                         // (dist_light arrives with the ray: object loop below)
 						else if (!RESV) { st.beta = 0; st.gamma = 0; }               // st.t / st.best arrive with the ray (object loop below)
 					}
@@ -212,7 +258,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		// ---- object loop (wave-uniform index): new rays start at object 0, rays that just left a mesh
 		//      continue behind it; a ray stops at the first mesh it has to traverse
 		if (RESV) {
-			if (need) {
+			if (MIPT_L_NEED) {
 				const float4 o4 = wf.ray_o[st.id], d4 = wf.ray_d[st.id];
 				const DObject& o = sc->obj[__float_as_uint(d4.w)];
 				const f3 org = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
@@ -220,20 +266,19 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				float t_root;
 				bool enter = box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
 				if (enter && t_root > o4.w) enter = false;
-				need = false;
+				st.cur = MIPT_ST_IDLE;
 				if (enter) {
 					st.o_xy = (mipt_f2){org.x, org.y}; st.i_xy = (mipt_f2){invd.x, invd.y}; st.oz_iz = (mipt_f2){org.z, invd.z}; st.d = d;
 					st.t = o4.w; st.cur = o.root_ref; st.sp = 0; st.obj = (int)__float_as_uint(d4.w);
 					st.count = 0; st.best = (int)MIPT_HIT_MISS; st.dist = 0.f; st.beta = 0.f; st.gamma = 0.f;
 					{ const uint2 rs = wf.rng[st.id]; st.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
-					alive = true;
 				} else wf.hit[st.id] = make_float4(0.f, 0.f, 0.f, __uint_as_float(MIPT_HIT_MISS));      // no draw: the engine stays as it is
 			}
-		} else if (__ballot(need)) {
+		} else if (RL ? __builtin_expect(__ballot(MIPT_L_NEED) != 0, 0) : (__ballot(MIPT_L_NEED) != 0)) {      // (with the ready list: only rays between two meshes of a scene with several)
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
 			// (a ray that has left its last object only has to be settled below: it is not fetched again — 6 % of the kernel's
 			// vector-memory instructions on a one-mesh scene, and the kernel runs at the CU's rate of those: DESIGN.md 4d)
-			if (need && (st.obj < nobj || (!SHADOW && st.obj == first_mesh))) {     // (a scene without a mesh: a fresh closest-hit ray still brings its record)
+			if (MIPT_L_NEED && (st.obj < nobj || (!SHADOW && st.obj == first_mesh))) {     // (a scene without a mesh: a fresh closest-hit ray still brings its record)
 				float4 o4 = SHADOW ? wf.sh_o[st.id] : wf.ray_o[st.id];
 				float4 d4 = SHADOW ? wf.sh_d[st.id] : wf.ray_d[st.id];
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
@@ -243,18 +288,18 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
 				}
 			}
-			if (need) MIPT_PROF_COUNT(6)
+			if (MIPT_L_NEED) MIPT_PROF_COUNT(6)
 			for (int i = first_mesh; i < nobj; i++) {
-				if (need && st.obj == i) {
+				if (MIPT_L_NEED && st.obj == i) {
 					const float t_before = st.t;
 					const bool enter_mesh = visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
 					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI));
-					if (enter_mesh) { need = false; alive = true; }
+					if (enter_mesh) {}                                   // (st.cur is the mesh's root now)
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
 					else st.obj = i + 1;
 				}
 			}
-			if (need) {                                               // object list exhausted: the ray is decided
+			if (MIPT_L_NEED) {                                        // object list exhausted: the ray is decided
 				if (SHADOW) {
 					if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
 					else if (!st.best) {
@@ -264,11 +309,124 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				} else if (!MIPT_HIT_WRITE_THROUGH) {
 					wf.hit[st.id] = make_float4(st.t, st.beta, st.gamma, __uint_as_float((unsigned)st.best));
 				}
-				need = false;
+				st.cur = MIPT_ST_IDLE;
 			}
 		}
-		{
-			const int nalive = __popcll(__ballot(alive));
+		if (RL) {
+			// ---- ready list.  No lane is between two objects here (the object loop above has placed or settled those), so a lane
+			//      is idle exactly when it is not alive.
+			// TAKE: idle lane number j takes entry head + j.  Record: (o.x o.y 1/d.x 1/d.y) (o.z 1/d.z d.x d.y) (d.z t|dist id object).
+			auto take = [&]() {
+				const unsigned long long idle_m = __ballot(MIPT_L_IDLE);
+				const unsigned ntake = min((unsigned)__popcll(idle_m), rl_count);                   // wave-uniform
+				if (ntake == 0) return;
+				const unsigned j = below_count(idle_m);
+				if (MIPT_L_IDLE && j < ntake) {
+					const lds_float4* e = rl_base + 3u * (rl_head + j);
+					const mipt_f4 a = e[0], b = e[1], c = e[2];
+					st.o_xy = (mipt_f2){a.x, a.y}; st.i_xy = (mipt_f2){a.z, a.w}; st.oz_iz = (mipt_f2){b.x, b.y}; st.d = mk3(b.z, b.w, c.x);
+					if (SHADOW) { st.t = __int_as_float(0x7f800000); st.dist = c.y; st.best = 0; } else st.t = c.y;
+					st.id = __float_as_uint(c.z); st.obj = (int)__float_as_uint(c.w);
+					st.cur = st.obj == first_mesh ? root_first : sc->obj[st.obj].root_ref; st.sp = 0;
+				}
+				rl_head += ntake; rl_count -= ntake;
+			};
+			take();
+			const unsigned long long idle_m = __ballot(MIPT_L_IDLE);
+			const unsigned n_idle = (unsigned)__popcll(idle_m);
+			if (__builtin_expect(!drained && rl_count == 0 && n_idle >= (unsigned)refill_threshold, 0)) {       // (a fill is rare next to inner steps: tell the register allocator)
+				// FILL: the idle lanes fetch a ray each for themselves, the first MIPT_RL_CAP busy lanes one each for the list
+				if (chunk_next >= chunk_end) {
+					unsigned base = 0;
+					if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
+					else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
+					base = __builtin_amdgcn_readfirstlane(base);
+					if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
+					else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
+				}
+				if (!drained) {
+					const unsigned avail = chunk_end - chunk_next;
+					const unsigned n_own = min(n_idle, avail);
+					const unsigned n_extra = min(min((unsigned)MIPT_RL_CAP, avail - n_own), 64u - n_idle);
+					const unsigned r_idle = below_count(idle_m), r_busy = lane - r_idle;       // rank among the idle / the busy lanes
+					const bool own = MIPT_L_IDLE;
+					const bool fetch = own ? r_idle < n_own : r_busy < n_extra;
+					const unsigned idx = chunk_next + (own ? r_idle : n_own + r_busy);
+					chunk_next += n_own + n_extra;
+					bool entered = false;
+					unsigned nid = 0; int nobject = 0; float ntv = 0.f;
+					mipt_f2 no_xy = {0.f, 0.f}, ni_xy = {0.f, 0.f}, noz_iz = {0.f, 0.f}; f3 nd = mk3(0, 0, 0);
+					if (fetch) {
+						nid = identity ? idx : list[idx];
+						bool valid = true;
+						if (identity) valid = (__float_as_uint(wf.wgt[nid].w) & MIPT_WF_VALID) != 0;
+						if (valid) {
+							MIPT_PROF_COUNT(10)
+							// (the stage that created the ray has already visited the analytic objects in front of the first mesh: closest-hit
+							//  rays arrive with the (t, object) found there, shadow rays arrive only if none of them occludes)
+							const float4 o4 = SHADOW ? wf.sh_o[nid] : wf.ray_o[nid];
+							const float4 d4 = SHADOW ? wf.sh_d[nid] : wf.ray_d[nid];
+							const f3 ro = mk3(o4.x, o4.y, o4.z), rd = mk3(d4.x, d4.y, d4.z);
+							float bt = SHADOW ? __int_as_float(0x7f800000) : o4.w;            // closest: best t so far
+							if (!SHADOW) wf.hit[nid] = make_float4(o4.w, 0.f, 0.f, d4.w);
+							bool pending = true;
+							for (int i = first_mesh; i < nobj; i++) {
+								if (pending) {
+									const DObject& o = sc->obj[i];
+									if (SHADOW && tq.skip_ghosts && o.ghost) continue;
+									const f3 d = xf_dir(o.inv, rd);
+									const f3 org = xf_point(o.inv, ro);
+									if (o.type != 0) {                         // spheres / planes behind the first mesh (shadow rays: tested when the request was made)
+										if (!SHADOW) {
+											float tt;
+											const bool hit = (o.type == 1) ? sphere_test(o, org, d, tt) : plane_test(o, org, d, tt);
+											if (hit && tt < bt) { bt = tt; wf.hit[nid] = make_float4(tt, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI)); }
+										}
+										continue;
+									}
+									const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+									float t_root;
+									bool enter = box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
+									if (enter && t_root > bt) enter = false;
+									if (SHADOW && enter && t_root > o4.w) enter = false;
+									if (enter) {
+										pending = false; entered = true; nobject = i;
+										no_xy = (mipt_f2){org.x, org.y}; ni_xy = (mipt_f2){invd.x, invd.y}; noz_iz = (mipt_f2){org.z, invd.z}; nd = d;
+										ntv = SHADOW ? o4.w : bt;
+									}
+								}
+							}
+							if (SHADOW && pending) {                       // no mesh in the way: visible
+								if (tq.vis) tq.vis[nid] = 1.f;
+								else {
+									const float4 c = wf.out.col[nid], pc = wf.sh_c[nid];
+									wf.out.col[nid] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+								}
+							}
+						}
+					}
+					const unsigned long long to_list = __ballot(entered && !own);
+					if (entered) {
+						if (own) {
+							st.o_xy = no_xy; st.i_xy = ni_xy; st.oz_iz = noz_iz; st.d = nd;
+							if (SHADOW) { st.t = __int_as_float(0x7f800000); st.dist = ntv; st.best = 0; } else st.t = ntv;
+							st.id = nid; st.obj = nobject;
+							st.cur = nobject == first_mesh ? root_first : sc->obj[nobject].root_ref; st.sp = 0;
+						} else {
+							lds_float4* e = rl_base + 3u * below_count(to_list);
+							e[0] = (mipt_f4){no_xy.x, no_xy.y, ni_xy.x, ni_xy.y};
+							e[1] = (mipt_f4){noz_iz.x, noz_iz.y, nd.x, nd.y};
+							e[2] = (mipt_f4){nd.z, ntv, __uint_as_float(nid), __uint_as_float((unsigned)nobject)};
+						}
+					}
+					rl_head = 0; rl_count = (unsigned)__popcll(to_list);
+					__builtin_amdgcn_wave_barrier();
+					take();                                        // idle lanes whose own ray missed every mesh
+				}
+			}
+			if (__ballot(MIPT_L_ALIVE) == 0) { if (drained && rl_count == 0) break; else continue; }
+		} else {
+			const int nalive = __popcll(__ballot(MIPT_L_ALIVE));
 			if (nalive == 0) { if (drained) break; else continue; }
 			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
 		}
@@ -284,18 +442,31 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			// a direction component that is exactly 0 can make a slab product NaN: such rays (and the lanes that step
 			// together with them) use the literal early-out chain
 			const float inf = __int_as_float(0x7f800000);
-			const bool literal = alive && (force_literal || fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
+			const bool literal = MIPT_L_ALIVE && (force_literal || fabsf(s_invd.x) == inf || fabsf(s_invd.y) == inf || fabsf(s_invd.z) == inf);
 			for (;;) {
-				const bool inner = alive && st.cur != MIPT_NONE && !(st.cur & MIPT_LEAF_BIT);
+				const bool inner = st.cur < MIPT_ST_NEED;
 				const unsigned long long mi = __ballot(inner);
 				if (mi == 0) break;
-				if (__popcll(mi) < inner_min && __ballot(alive && !inner) != 0) break;
+				if (__popcll(mi) < inner_min && __ballot(st.cur >= MIPT_NONE) != 0) break;      // (a leaf, or a ray that has run out of nodes)
 				if (!inner) continue;
 				MIPT_PROF_COUNT(0)
 				float4 q0, q1, q2, q3;
 				{
 					const float4* q = nodes + 4 * (size_t)st.cur;
 					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+#if defined(MIPT_PROBE_EXTRA_LOAD)
+					// measurement builds only (tools/build_variant.sh): what one more 16-byte access per lane and inner step costs — 1: from the node's
+					// own line (a fifth L1 lookup, no new line), 2: from the line behind it (a lookup AND a line the step does not need),
+					// 3: the node's line again as ONE more instruction of 4 bytes per lane (instruction cost without the data return)
+					{
+						float4 extra;
+						const float4* qe = q + (MIPT_PROBE_EXTRA_LOAD == 2 ? 4 : 2);
+						if (MIPT_PROBE_EXTRA_LOAD == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); extra = make_float4(0.f, 0.f, 0.f, 0.f); }      // the control: the wait alone
+						else if (MIPT_PROBE_EXTRA_LOAD == 3) { float e1; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e1) : "v"(qe) : "memory"); extra = make_float4(e1, 0.f, 0.f, 0.f); }
+						else asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(extra) : "v"(qe) : "memory");
+						if (__float_as_uint(extra.x) == 0x7fc12345u) q3.w = extra.y;          // never true: keeps the load alive
+					}
+#endif
 				}
 				uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
 				float tl, tr;
@@ -313,6 +484,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				goleft = goleft && (tl < st.t); goright = goright && (tr < st.t);
 				if (SHADOW) { goleft = goleft && (tl < st.dist); goright = goright && (tr < st.dist); }
 				if (goleft && goright) {
+					if (st.sp >= 6) MIPT_PROF_COUNT(26)
+					if (st.sp >= 8) MIPT_PROF_COUNT(28)
+					if (st.sp >= 10) MIPT_PROF_COUNT(30)
 					if (tl < tr) { stk.push(st.sp, rref, tr); st.sp++; st.cur = lref; }
 					else { stk.push(st.sp, lref, tl); st.sp++; st.cur = rref; }
 				} else if (goleft) st.cur = lref;
@@ -330,7 +504,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		//      the one the sequential loop accepts.  Leaves with more triangles (degenerate splits) and scenes with
 		//      alpha-tested meshes take the per-lane loop below.
 		{
-			const bool leaf = alive && st.cur != MIPT_NONE && (st.cur & MIPT_LEAF_BIT);
+			const bool leaf = (int)st.cur < 0;
 			const int first = (int)(st.cur & MIPT_LEAF_FIRST_MASK);
 			const int count = leaf ? (int)((st.cur >> 26) & 31u) + 1 : 0;
 			bool per_lane = leaf;
@@ -339,7 +513,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				const int cnt = count <= 4 ? count : 0;
 				const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
 				if (b1 != 0) {
-					const int prefix = __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below) + __popcll(b4 & below);
+					unsigned pfx = 0;                 // tests of the lanes below this one (v_mbcnt accumulates)
+					for (const unsigned long long m : {b1, b2, b3, b4}) pfx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, pfx));
+					const int prefix = (int)pfx;
 					const int total = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
 					for (int k = 0; k < 4; k++) if (k < cnt) leafmap[prefix + k] = (unsigned char)(lane | ((unsigned)k << 6));
 					__builtin_amdgcn_wave_barrier();
@@ -439,16 +615,28 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		MIPT_PROF_CYCLES(14, c2, c3)
 		// ---- mesh finished: the ray goes on with the objects behind it (next iteration's object loop)
 		if (RESV) {
-			if (alive && st.cur == MIPT_NONE) {
-				alive = false;
+			if (st.cur == MIPT_NONE) {
+				st.cur = MIPT_ST_IDLE;
 				const unsigned tri = (unsigned)st.best == MIPT_HIT_MISS ? MIPT_HIT_MISS : ((unsigned)st.best & MIPT_HIT_NOTRI);
 				wf.hit[st.id] = make_float4(st.dist, st.beta, st.gamma, __uint_as_float(tri));
 				wf.rng[st.id] = make_uint2((unsigned)st.rng, (unsigned)(st.rng >> 32));
 			}
-		} else if (alive && st.cur == MIPT_NONE) {
-			alive = false; need = true;
-			// shadow: a hit with t >= 0.999*dist is not an occluder (Geometry.cpp:736) -> next object
-			st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
+		} else if (st.cur == MIPT_NONE) {
+			st.cur = MIPT_ST_IDLE;
+			if (RL && ((SHADOW && st.best) || st.obj + 1 >= nobj)) {
+				// the ray's last object: settled here, from what the lane holds (a closest-hit ray's record is already written)
+				if (SHADOW) {
+					if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
+					else if (!st.best) {
+						const float4 c = wf.out.col[st.id], pc = wf.sh_c[st.id];
+						wf.out.col[st.id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+					}
+				}
+			} else {
+				st.cur = MIPT_ST_NEED;
+				// shadow: a hit with t >= 0.999*dist is not an occluder (Geometry.cpp:736) -> next object
+				st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
+			}
 		}
 	}
 }
@@ -461,11 +649,12 @@ template <int MODE>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
+	MIPT_DECLARE_READY_LIST(rl);
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap);
-	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap);
-	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 1 || MODE == 2) traverse_queue<true, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, rl);
+	if (MODE == 0) traverse_queue<false, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, rl);
+	if (MODE == 2) traverse_queue<false, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, rl);
 }
 
 // The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
@@ -474,7 +663,8 @@ template <bool SHADOW>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
-	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
+	MIPT_DECLARE_READY_LIST(rl);
+	traverse_queue<SHADOW, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, rl);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).

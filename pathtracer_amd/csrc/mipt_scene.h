@@ -90,6 +90,16 @@ struct DObject {
 	const int* uvidx;          // 3 ints per triangle (uvi,uvj,uvk), only when alpha_test
 };
 
+// load_obj_hot() and the group-table branch of query_material() (mipt_trace.h) read these records with raw 16-byte loads at fixed
+// offsets; the host fills them by field name.  A reordered field must fail here, not corrupt every material lookup.
+#include <stddef.h>
+static_assert(offsetof(DObject, type) == 0 && offsetof(DObject, nuvs) == 16 && offsetof(DObject, shade) == 32 && offsetof(DObject, gmat) == 40 &&
+              offsetof(DObject, tangent_soup) == 48 && offsetof(DObject, merl) == 56 && offsetof(DObject, inv) == 64, "DObject: the shade stage loads its first 64 bytes as four 16-byte words");
+static_assert(sizeof(DObject) % 8 == 0, "DObject holds pointers: DScene::obj[] must keep them aligned");
+static_assert(sizeof(DGroupMat) == 64 && offsetof(DGroupMat, transp_val) == 36 && offsetof(DGroupMat, image_mask) == 44 && offsetof(DGroupMat, kd_values) == 48 &&
+              offsetof(DGroupMat, kdW) == 56, "DGroupMat: one 64-byte record per material group, read as four 16-byte words (image_mask in r2.w)");
+static_assert(sizeof(DFatNode) == 64 && sizeof(DTriIsect) == 64 && sizeof(DTriShade) == 64, "64-byte records");
+
 struct DScene {
 	int nobj;
 	int any_alpha;               // some mesh rejects hits by an alpha map inside its leaf loop (TriangleMesh.cpp:1198-1205)

@@ -100,9 +100,12 @@ MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, dou
 	double cx = axis[1] * v[2] - axis[2] * v[1], cy = axis[2] * v[0] - axis[0] * v[2], cz = axis[0] * v[1] - axis[1] * v[0];
 	out[0] += cx * sa; out[1] += cy * sa; out[2] += cz * sa;
 }
-// (cold paths of the shade stage are kept out of line so that they do not inflate the register
-// allocation and the instruction footprint of the common diffuse path)
-__device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
+// merl_eval_inline: the body.  The wavefront shade stage of scenes with a measured BRDF runs BOTH evaluations of a vertex through one
+// inlined copy of it (path_vertex<true>: a two-trip loop).  As a function it saved 12 callee-saved registers through scratch — 24
+// scratch accesses per call, two calls per vertex, every one a vector-memory instruction.
+// merl_eval: the same out of line for the other callers (pipeline 0 and the contribution-queue kernels), where the cold path must
+// not inflate the register allocation of the common one.
+MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
 	f3 wil = mk3(dot(wi, t1), dot(wi, t2), dot(wi, N));
@@ -158,6 +161,7 @@ __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ dat
 	double b = data[ind + 90 * 90 * 360] * (1.66 / 1500.0);
 	return mk3((float)r, (float)g, (float)b);
 }
+__device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N); }
 
 // ---------------------------------------------------------------- path state
 struct PathState {
@@ -199,6 +203,13 @@ struct ShadowRequest {
 // be multiplied with once the shadow query is resolved (color += pathWeight*currentContrib).
 // MERL = false: the scene has no measured BRDF (the caller knows from the upload): the fp64 table evaluation is not
 // compiled into the kernel, which is what its register count is otherwise sized for.
+// MIPT_MERL_ONE_COPY (round 4, measured, off): both measured-BRDF evaluations of a vertex through one INLINED copy of merl_eval (a two-trip
+// loop) instead of two calls.  The calls save 12 callee-saved registers through scratch (24 accesses each); inlined, the kernel's own
+// allocation at 3 waves per SIMD spills 81 values (416 bytes of scratch per lane) around the fp64 code: generate + shade of configs[4]
+// 864 -> 1 095 ms per step (profiles/r4_c_c4_merl_one_inlined_copy_sweep.txt).
+#ifndef MIPT_MERL_ONE_COPY
+#define MIPT_MERL_ONE_COPY 0
+#endif
 template <bool MERL = true>
 MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathState& ps, bool has_inter, const Hit& h, f3 P, const Mat& mat,
                           int pix, int sampleID, ShadowRequest& sh, f3& weight_at_vertex) {
@@ -220,7 +231,7 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	}
 	const double* const merl = MERL ? mat.merl : nullptr;               // (the object's flags came with the material: hit_material_obj)
 	ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
-	if (mat.miroir) {                                                    // :413-436
+	if (mat.miroir & 1) {                                                // :413-436 (bit 1 of miroir is Object::ghost: mipt_scene.h)
 		ps.ray.o = P + 0.001f * N;
 		ps.ray.d = reflect(rayDirection, N);
 		ps.depth--;
@@ -258,6 +269,47 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	f3 pt_l = dir_l * R.radiusLight + cl;
 	f3 wi = fast_normalize(pt_l - P);
 	float d_light2 = norm2(pt_l - P);
+	if (MERL && MIPT_MERL_ONE_COPY && merl) {
+		// measured BRDF: the light sample's evaluation (:540-544) and the continuation's (:603-607) are independent of each other
+		// (IsoMERLBRDF::sample is the cosine lobe and draws nothing from the engine, BRDF.h:198-203), so both directions are
+		// prepared first and evaluated by the two trips of one loop around the inlined evaluation
+		const bool lit = !(dot(mat.shadingN, wi) < 0);
+		bool cont = ps.depth > 1;
+		f3 dir = mk3(0, 0, 0);
+		float pdf = 0.f;
+		if (cont) {
+			float ip;
+			const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
+			const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
+			dir = random_cos(N, r1, r2);
+			pdf = (float)((double)dot(N, dir) / (MIPT_PI));
+			if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) cont = false;   // :593
+		}
+		f3 brdf = mk3(0, 0, 0), brdf_i = mk3(0, 0, 0);
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			if (k ? cont : lit) {
+				const f3 e = merl_eval_inline(merl, k ? dir : wi, -rayDirection, N);
+				if (k) brdf_i = e; else brdf = e;
+			}
+		}
+		if (lit) {
+			float J = dot(dir_l, -wi) / d_light2;
+			float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+			if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+			sh.cast = true;
+			sh.ray.o = P + 0.01f * wi;
+			sh.ray.d = wi;
+			sh.dist = sqrtf(d_light2) - 0.01f;
+		}
+		if (!cont) return false;
+		ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);            // :611
+		ps.ray.o = P + 0.01f * dir;
+		ps.ray.d = dir;
+		ps.show_lights = false;
+		ps.depth--;
+		return true;
+	}
 	if (!(dot(mat.shadingN, wi) < 0)) {
 		f3 brdf = merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(mat, wi, -rayDirection, N);
 		float J = dot(dir_l, -wi) / d_light2;
@@ -316,9 +368,9 @@ MIPT_DEV int path_vertex_fast(const DScene* __restrict__ sc, const DRender& R, P
 		ps.color = ps.color + ps.weight * cc;
 		return VERTEX_END;
 	}
-	if (mat.miroir || mat.transp) {                                      // mirror (:413-436) / Fresnel dielectric (:438-489): no NEE, no shadow ray
+	if ((mat.miroir & 1) || mat.transp) {                                // mirror (:413-436) / Fresnel dielectric (:438-489): no NEE, no shadow ray
 		ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;  // :411
-		if (mat.miroir) {
+		if (mat.miroir & 1) {
 			ps.ray.o = P + 0.001f * N;
 			ps.ray.d = reflect(rayDirection, N);
 			ps.depth--;

@@ -12,6 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   if [ $i -le $SKIP ]; then continue; fi
+  if [ -n "$LIMIT" ] && [ $i -gt $LIMIT ]; then break; fi
   date +%T
   timeout 240 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${tag}/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --pmc "$@" > $R/gpurun_out/pmc_${tag}_p$i.log 2>&1 || tail -3 $R/gpurun_out/pmc_${tag}_p$i.log
 done

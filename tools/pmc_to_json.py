@@ -1,9 +1,10 @@
-"""profiles/r3_pmc_counters.json from PMC summaries (tools/pmc.sh) and the bench line of one of the profiled runs: per kernel and
+"""profiles/r4_pmc_counters.json from PMC summaries (tools/pmc.sh) and the bench line of one of the profiled runs: per kernel and
 launch the counters, and per RAY of that launch what bench.py scales to its own run (L2 misses = fabric line fetches, TCP line
 lookups, HBM bytes, instructions by kind, mean vector-memory latency, wait share).  FETCH_SIZE is corrected as
 tools/fetch_calibration.py measured it on this device: the traversal kernels read by 64-byte gathers (factor `gather64`), the
 other kernels mostly by wide streaming accesses (factor `stream`, the 1/2 of MI355X_MICROARCH.md).  The file records the git
-commit and the hash of the library that was profiled: bench.py flags fractions derived from it when it runs another build.
+commit and the hash of the SOURCES + compiler flags of the library that was profiled (__graft_entry__.source_hash(); the binary is
+not bit-reproducible): bench.py marks what it derives from this file as stale when it runs another build.
 
 usage: python tools/pmc_to_json.py profiles/r2_fetch_calibration.json c2=<summary>:<log with the bench line>[:<path shown as source>] [c1=...]
 (on the GPU box there is no .git: MIPT_GIT_COMMIT names the commit of the snapshot)"""
@@ -50,7 +51,9 @@ for arg in sys.argv[2:]:
              "valu_instructions_per_launch": v.get("SQ_INSTS_VALU"), "salu_instructions_per_launch": v.get("SQ_INSTS_SALU"), "lds_instructions_per_launch": v.get("SQ_INSTS_LDS"),
              "gpu_cycles_per_launch": cyc, "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "waves": v.get("SQ_WAVES"),
              "wait_share_of_wave_cycles": v.get("SQ_WAIT_ANY", 0.0) / max(1.0, v.get("SQ_WAVE_CYCLES", 1.0)),
-             "mean_vmem_latency_cycles": v.get("TCP_TCP_LATENCY_sum", 0.0) / max(1.0, v.get("TCP_TA_TCP_STATE_READ_sum", 1.0))}
+             "mean_vmem_latency_cycles": v.get("TCP_TCP_LATENCY_sum", 0.0) / max(1.0, v.get("TCP_TA_TCP_STATE_READ_sum", 1.0)),
+             # mean active lanes of a vector instruction (thread-cycles / instruction-cycles): what bench.py prices a vector-memory instruction at
+             "active_lanes_per_vector_instruction": v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, v.get("SQ_ACTIVE_INST_VALU", 1.0))}
         if rays:
             e["rays_per_launch"] = rays
             e["tcp_accesses_per_ray"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays
@@ -63,11 +66,12 @@ for arg in sys.argv[2:]:
         kernels[k] = e
     out[wl] = {"source": shown + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
                                 "FETCH_SIZE factors from " + sys.argv[1], "kernels": kernels}
-lib = os.path.join(ROOT, "pathtracer_amd", "libmipt.so")
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
 out["_build"] = {"git_commit": os.environ.get("MIPT_GIT_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
-                 "libmipt_sha256_16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
-                 "flags": "__graft_entry__.HIPCC_FLAGS (default library)"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r3_pmc_counters.json"), "w"), indent=1)
+                 "source_sha256_16": ge.source_hash(),
+                 "flags": " ".join(ge.HIPCC_FLAGS) + " (default library)"}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r4_pmc_counters.json"), "w"), indent=1)
 for wl in out:
     if wl.startswith("_"):
         continue
