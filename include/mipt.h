@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 2
+#define MIPT_ABI_VERSION 3
 
 enum {
 	MIPT_OK = 0,
@@ -86,6 +86,9 @@ typedef struct mipt_mesh {
 	const mipt_triangle_indices* indices;
 	const float* uvs;                        /* TriMesh::uvs as Vector[n_uvs] (3 floats each) or NULL */
 	const float* tangentSoup;                /* Vector[3*n_triangles] or NULL (normal maps only) */
+	const struct mipt_device_mesh* device_mesh;   /* ABI 3: NULL, or the handle of mipt_device_mesh_build for THIS mesh: mipt_upload_scene then takes the
+	                                            * tree and the triangle records from the device that built them (device-to-device copies) and
+	                                            * nodes / triangleSoup / indices may be NULL; n_triangles / n_nodes must be the handle's */
 } mipt_mesh;
 
 enum { MIPT_OBJ_TRIMESH = 0, MIPT_OBJ_SPHERE = 1, MIPT_OBJ_PLANE = 2 };   /* ObjectType, Geometry.h:29 */
@@ -313,6 +316,31 @@ int mipt_measure_vmem_issue(mipt_ctx* ctx, int active_lanes, int iters, double* 
 int mipt_build_bvh(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri,
                    mipt_bvh_node* out_nodes, int node_capacity, int* out_n_nodes, int32_t* out_perm, double* out_seconds);
 const char* mipt_build_bvh_error(void);
+
+/* TriMesh::init's build_bvh AND the records the traversal reads, made on the device and LEFT there (round 4).  The analogue of
+ * TriangleMesh.cpp:718-885: build_bvh (as mipt_build_bvh: same tree, same triangle order), then per reordered triangle the Triangle
+ * constructor's terms (TriangleMesh.h:70-78) and the gather of corner normals / UVs (:812-829) — written straight into the layout
+ * the kernels traverse (64-byte fat nodes holding both children's boxes, 64-byte intersection and shading records) instead of
+ * coming back to the host as bvh.nodes / triangleSoup and going up again repacked.  Pass the handle in mipt_mesh::device_mesh.
+ *   vertices / normals / uvs   nverts / nnormals / nuvs x 3 floats as TriMesh::init leaves them before build_bvh (normals, uvs: may be 0)
+ *   indices                    the TriangleIndices records in INPUT order (the permutation stays on the device)
+ * mipt_device_mesh_download gives the reference's views when somebody wants them: bvh.nodes (node_capacity >= info.n_nodes) and the
+ * permutation (perm[i] = input triangle at position i); either pointer may be NULL.  The handle belongs to device_id; a context on
+ * another device (a group's other members) copies from it peer to peer; a context on the SAME device whose scene has this one mesh
+ * renders from the handle's buffers in place (no second copy of 128 bytes per triangle; the scene holds a reference).  The handle is
+ * reference-counted: mipt_device_mesh_free drops the caller's reference any time after the last mipt_upload_scene that names it has
+ * returned; the buffers go when the last scene using them is replaced or its context destroyed.  Errors: mipt_build_bvh_error(). */
+typedef struct mipt_device_mesh mipt_device_mesh;
+typedef struct mipt_device_mesh_info {
+	int32_t n_triangles, n_nodes, n_inner, device_id;
+	int32_t has_tangents, _pad;               /* setup_tangents (TriangleMesh.cpp:572-711) ran on the device too (mesh with UVs and normals) */
+	double build_seconds, records_seconds;    /* device time of the tree build / of the record (+ tangent) kernels (HIP events) */
+} mipt_device_mesh_info;
+int mipt_device_mesh_build(int device_id, const float* vertices, int nverts, const float* normals, int nnormals, const float* uvs, int nuvs,
+                           const mipt_triangle_indices* indices, int ntri, mipt_device_mesh** out, mipt_device_mesh_info* info);
+int mipt_device_mesh_download(const mipt_device_mesh* m, mipt_bvh_node* nodes, int node_capacity, int32_t* perm);
+int mipt_device_mesh_download_tangents(const mipt_device_mesh* m, float* tangent_soup /* 9 floats per triangle: TriMesh::tangentSoup */);
+void mipt_device_mesh_free(mipt_device_mesh* m);
 
 /* Statistics of the last render call (rays counted like the oracle does, kernel time from HIP
  * events on the render stream). */

@@ -28,7 +28,8 @@ MIPT_ERR_UNSUPPORTED = 4
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
                 "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_measure_vmem_issue", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
-                "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs"]
+                "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs",
+                "mipt_device_mesh_build", "mipt_device_mesh_download", "mipt_device_mesh_download_tangents", "mipt_device_mesh_free"]
 
 _f = C.c_float
 _i = C.c_int
@@ -54,7 +55,7 @@ class MiptBvhNode(C.Structure):
 class MiptMesh(C.Structure):
     _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_uvs", C.c_int32), ("nodes", C.POINTER(MiptBvhNode)),
                 ("bvh_bbox_min", _f * 3), ("bvh_bbox_max", _f * 3), ("triangleSoup", C.c_void_p), ("indices", C.c_void_p),
-                ("uvs", C.POINTER(_f)), ("tangentSoup", C.POINTER(_f))]
+                ("uvs", C.POINTER(_f)), ("tangentSoup", C.POINTER(_f)), ("device_mesh", C.c_void_p)]
 
 
 class MiptObject(C.Structure):
@@ -133,6 +134,12 @@ def set_bvh_builder(mode, device=0):
     """Which builder the host mirror's TriMesh::init uses: 'host' (the recursion), 'gpu' (mipt_build_bvh; an error
     without a device) or 'auto' (GPU when a device is present; default)."""
     load()[1].mh_set_bvh_builder({"host": 0, "gpu": 1, "auto": 2}[mode], int(device))
+
+
+def set_device_resident(on=True):
+    """With a GPU builder: TriMesh::init leaves the tree, the Triangle records and the tangents on the device
+    (mipt_device_mesh_build; default) or fetches bvh.nodes back and builds triangleSoup / tangentSoup on the host as in round 3."""
+    load()[1].mh_set_device_resident(1 if on else 0)
 
 
 def build_bvh(vertices, tri_vtx, device=0):
@@ -360,10 +367,14 @@ class HostRaytracer:
         return t, inv, r
 
     def mesh_bvh_builder(self, obj):
-        """('gpu' | 'host', seconds TriMesh::init spent in build_bvh, device seconds of the GPU build)."""
+        """('gpu' | 'host', seconds TriMesh::init spent in build_bvh, device seconds of the GPU build).  'gpu' covers both GPU forms:
+        mesh_on_device() says whether the tree and the records stayed on the device (mipt_device_mesh_build)."""
         a, b = C.c_double(0), C.c_double(0)
         who = self.host.mh_mesh_bvh_builder(self.h, obj, C.byref(a), C.byref(b))
-        return ("gpu" if who == 1 else "host"), a.value, b.value
+        return ("gpu" if who in (1, 2) else "host"), a.value, b.value
+
+    def mesh_on_device(self, obj):
+        return self.host.mh_mesh_bvh_builder(self.h, obj, None, None) == 2
 
     def mesh_dump(self, obj):
         c = [_i(0) for _ in range(5)]
@@ -378,6 +389,14 @@ class HostRaytracer:
         self.host.mh_mesh_dump(self.h, obj, _p(perm, _i), _p(nodes_i, _i), _p(nodes_bb, _f), _p(soup, _f), _p(groups, _i), _p(root, _f))
         return dict(perm=perm, nodes_i=nodes_i, nodes_bb=nodes_bb, soup=soup, groups=groups, root_bb=root,
                     nverts=c[2].value, nnormals=c[3].value, nuvs=c[4].value)
+
+    def mesh_tangents(self, obj):
+        """TriMesh::tangentSoup as [3 * ntri, 3] (empty for a mesh without UVs)."""
+        n = self.host.mh_mesh_tangents(self.h, obj, None)
+        out = np.zeros((n // 3, 3), np.float32)
+        if n:
+            self.host.mh_mesh_tangents(self.h, obj, _p(out, _f))
+        return out
 
     # ---- the C-ABI, called directly with the descriptions the host side built
     @property

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py)
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdarg>
@@ -346,6 +347,7 @@ struct mipt_ctx {
 	bool is_member = false;           // a context owned by a group (members 1..n-1), not handed to the caller
 	std::string err;
 	std::vector<void*> scene_allocs;
+	std::vector<const mipt_device_mesh*> scene_shared;   // device meshes whose buffers the scene uses in place (one reference each, dropped by free_scene)
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
@@ -417,9 +419,12 @@ extern "C" int mipt_abi_version(void) { return MIPT_ABI_VERSION; }
 
 extern "C" const char* mipt_last_error(const mipt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+extern "C" void mipt_device_mesh_free(mipt_device_mesh* m);
 static void free_scene(mipt_ctx* c) {
 	for (void* p : c->scene_allocs) hipFree(p);
 	c->scene_allocs.clear();
+	for (const mipt_device_mesh* m : c->scene_shared) mipt_device_mesh_free(const_cast<mipt_device_mesh*>(m));
+	c->scene_shared.clear();
 	c->d_scene = nullptr;
 	c->has_scene = false;
 }
@@ -636,14 +641,23 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 	return upload(c, h.data(), (size_t)n, dev);
 }
 
+// a mesh built by mipt_device_mesh_build (defined with the builder, further down): its records are already on a device
+struct mipt_device_mesh;
+static int adopt_device_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, struct MeshStaging& stg);
+static int copy_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, DFatNode* dn, DTriIsect* dt, DTriShade* dsh, uint32_t node_base, uint32_t tri_base);
+static bool device_mesh_on(const mipt_device_mesh* dm, int device);
+static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFatNode** dn, const DTriIsect** dt, const DTriShade** dsh);
+
 // staging of all meshes' traversal records (one device buffer each)
 // (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
-struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0; };
+struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0;
+                   const mipt_device_mesh* dev = nullptr; uint32_t node_base = 0, tri_base = 0; };     // dev: the records are on a device already (no host arrays)
 struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; };
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
 static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging& stg) {
+	if (m && m->device_mesh) return adopt_device_mesh(c, m, d, stg);
 	if (!m || m->n_triangles <= 0 || m->n_nodes <= 0 || !m->nodes || !m->triangleSoup || !m->indices) return fail(c, MIPT_ERR_INVALID, "incomplete mesh description");
 	const int nn = m->n_nodes, nt = m->n_triangles;
 	if ((unsigned)nt > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
@@ -892,13 +906,24 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	}
 	const DTriShade* all_shade = nullptr;
 	int rc;
-	if (stg.nt_total > 0) {   // one device buffer per record kind, the meshes' chunks copied to their offsets
+	if (stg.chunks.size() == 1 && stg.chunks[0].dev && device_mesh_on(stg.chunks[0].dev, c->device)) {
+		// the scene's only mesh was built on this device: its records are used where they are (no second copy of 128 bytes per triangle
+		// + 64 per inner node; the scene holds a reference on the handle)
+		int rc2 = share_device_chunk(c, stg.chunks[0].dev, &H.all_nodes, &H.all_tris, &all_shade);
+		if (rc2) return rc2;
+	} else if (stg.nt_total > 0) {   // one device buffer per record kind, the meshes' chunks copied to their offsets
 		void *dn = nullptr, *dt = nullptr, *dsh = nullptr;
 		HIPCHK(c, hipMalloc(&dn, stg.nfat_total * sizeof(DFatNode))); c->scene_allocs.push_back(dn);
 		HIPCHK(c, hipMalloc(&dt, stg.nt_total * sizeof(DTriIsect))); c->scene_allocs.push_back(dt);
 		HIPCHK(c, hipMalloc(&dsh, stg.nt_total * sizeof(DTriShade))); c->scene_allocs.push_back(dsh);
 		size_t on = 0, ot = 0;
 		for (const MeshChunk& ch : stg.chunks) {
+			if (ch.dev) {
+				int rc2 = copy_device_chunk(c, ch.dev, (DFatNode*)dn + on, (DTriIsect*)dt + ot, (DTriShade*)dsh + ot, ch.node_base, ch.tri_base);
+				if (rc2) return rc2;
+				on += ch.nfat; ot += ch.nt;
+				continue;
+			}
 			HIPCHK(c, hipMemcpy((DFatNode*)dn + on, ch.fat.get(), ch.nfat * sizeof(DFatNode), hipMemcpyHostToDevice));
 			HIPCHK(c, hipMemcpy((DTriIsect*)dt + ot, ch.ti.get(), ch.nt * sizeof(DTriIsect), hipMemcpyHostToDevice));
 			HIPCHK(c, hipMemcpy((DTriShade*)dsh + ot, ch.ts.get(), ch.nt * sizeof(DTriShade), hipMemcpyHostToDevice));
@@ -1875,7 +1900,7 @@ namespace {
 struct DevPool {     // device allocations of one build, released on every exit path
 	std::vector<void*> p;
 	~DevPool() { release(); }
-	void release() { for (void* q : p) hipFree(q); p.clear(); }
+	void release() { for (void* q : p) if (q) hipFree(q); p.clear(); }
 	template <class T> bool get(T** out, size_t count) {
 		void* q = nullptr;
 		if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
@@ -1891,8 +1916,20 @@ int build_fail(int code, const char* fmt, ...) {
 }
 #define BHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return build_fail(MIPT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri,
-                              mipt_bvh_node* out_nodes, int node_capacity, int* out_n_nodes, int32_t* out_perm, double* out_seconds) {
+namespace {
+// what a finished build leaves on the device (owned by `pool` until the caller detaches it)
+struct BuiltTree {
+	DevPool pool;
+	bvhb::ONode* d_out = nullptr;      // the reference's node vector (depth-first)
+	uint32_t* d_perm = nullptr;        // position i of the reordered mesh holds input triangle d_perm[i]
+	float* d_vtx = nullptr;            // the vertices as uploaded
+	char* d_tri = nullptr;             // the caller's triangle records as uploaded (tri_stride_bytes apart)
+	int total = 0;                     // nodes
+	double device_seconds = 0;
+};
+}
+// The build itself (the level-synchronous phase, the small subtrees, numbering and emission): everything stays on the device.
+static int bvh_build_core(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri, size_t tri_upload_bytes, BuiltTree& bt) {
 	using namespace bvhb;
 	static_assert(sizeof(ONode) == sizeof(mipt_bvh_node), "node layout");
 	g_build_err.clear();
@@ -1905,7 +1942,7 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 		fprintf(stderr, "[mipt_build_bvh] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
 		t_last = t;
 	};
-	if (!vertices || nverts <= 0 || !tri_vtx || tri_stride_bytes < 12 || (tri_stride_bytes & 3) || ntri <= 0 || !out_nodes || !out_n_nodes || !out_perm) return build_fail(MIPT_ERR_INVALID, "bad arguments");
+	if (!vertices || nverts <= 0 || !tri_vtx || tri_stride_bytes < 12 || (tri_stride_bytes & 3) || ntri <= 0) return build_fail(MIPT_ERR_INVALID, "bad arguments");
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return build_fail(MIPT_ERR_NO_DEVICE, "no usable HIP device");
 	BHIP(hipSetDevice(device_id));
@@ -1913,12 +1950,12 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	hipEvent_t e0, e1;
 	BHIP(hipEventCreate(&e0)); BHIP(hipEventCreate(&e1));
 	struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
-	DevPool pool;
+	DevPool& pool = bt.pool;
 	const int maxseg = n / (BVHB_SMALL + 1) + 2;
 	float* d_vtx; char* d_tv; float4* d_rec; int* d_bad; uint32_t *d_order[2], *d_S, *d_tpos, *d_acc, *d_bins, *d_bsum; int* d_segof[2]; uint8_t* d_pf;
 	Seg* d_segs[2]; float* d_planes; LNode* d_ln; int* d_smalls; Counters* d_cnt; ONode *d_sn, *d_out;
 	const int nscanblk = (n + BVHB_SCAN_TILE - 1) / BVHB_SCAN_TILE;
-	bool ok = pool.get(&d_vtx, (size_t)nverts * 3) && pool.get(&d_tv, (size_t)n * tri_stride_bytes) && pool.get(&d_bad, 1) && pool.get(&d_rec, (size_t)n * 3)
+	bool ok = pool.get(&d_vtx, (size_t)nverts * 3) && pool.get(&d_tv, std::max((size_t)n * tri_stride_bytes, tri_upload_bytes)) && pool.get(&d_bad, 1) && pool.get(&d_rec, (size_t)n * 3)
 	       && pool.get(&d_order[0], n) && pool.get(&d_order[1], n) && pool.get(&d_segof[0], n) && pool.get(&d_segof[1], n)
 	       && pool.get(&d_S, (size_t)n + 1) && pool.get(&d_tpos, n) && pool.get(&d_pf, n) && pool.get(&d_bsum, nscanblk)
 	       && pool.get(&d_segs[0], maxseg) && pool.get(&d_segs[1], maxseg) && pool.get(&d_acc, (size_t)maxseg * 12)
@@ -1928,7 +1965,7 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for a %d-triangle build", n);
 	phase("hipMalloc");
 	BHIP(hipMemcpy(d_vtx, vertices, (size_t)nverts * 12, hipMemcpyHostToDevice));
-	BHIP(hipMemcpy(d_tv, tri_vtx, (size_t)(n - 1) * tri_stride_bytes + 12, hipMemcpyHostToDevice));   // the records as they are (TriangleIndices: 44 bytes apart)
+	BHIP(hipMemcpy(d_tv, tri_vtx, tri_upload_bytes ? tri_upload_bytes : (size_t)(n - 1) * tri_stride_bytes + 12, hipMemcpyHostToDevice));   // the records as they are (TriangleIndices: 44 bytes apart)
 	BHIP(hipMemsetAsync(d_bad, 0, 4, 0));
 	phase("upload");
 	BHIP(hipEventRecord(e0, 0));
@@ -2005,14 +2042,243 @@ extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, 
 	BHIP(hipGetLastError());
 	const int total = root.size;
 	if (total <= 0 || total > 2 * n) return build_fail(MIPT_ERR_HIP, "inconsistent node count %d", total);
-	if (total > node_capacity) return build_fail(MIPT_ERR_INVALID, "node_capacity %d is too small for %d nodes", node_capacity, total);
-	BHIP(hipMemcpy(out_nodes, d_out, (size_t)total * sizeof(ONode), hipMemcpyDeviceToHost));
-	BHIP(hipMemcpy(out_perm, d_order[cur], (size_t)n * 4, hipMemcpyDeviceToHost));
-	phase("numbering + download");
-	pool.release();
+	phase("numbering");
+	bt.d_out = d_out; bt.d_perm = d_order[cur]; bt.d_vtx = d_vtx; bt.d_tri = d_tv; bt.total = total;
+	{ float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); bt.device_seconds = ms * 1e-3; }
+	return MIPT_OK;
+}
+
+extern "C" int mipt_build_bvh(int device_id, const float* vertices, int nverts, const void* tri_vtx, int tri_stride_bytes, int ntri,
+                              mipt_bvh_node* out_nodes, int node_capacity, int* out_n_nodes, int32_t* out_perm, double* out_seconds) {
+	if (!out_nodes || !out_n_nodes || !out_perm) { g_build_err = "bad arguments"; return MIPT_ERR_INVALID; }
+	BuiltTree bt;
+	const int rc = bvh_build_core(device_id, vertices, nverts, tri_vtx, tri_stride_bytes, ntri, 0, bt);
+	if (rc) return rc;
+	if (bt.total > node_capacity) return build_fail(MIPT_ERR_INVALID, "node_capacity %d is too small for %d nodes", node_capacity, bt.total);
+	BHIP(hipMemcpy(out_nodes, bt.d_out, (size_t)bt.total * sizeof(bvhb::ONode), hipMemcpyDeviceToHost));
+	BHIP(hipMemcpy(out_perm, bt.d_perm, (size_t)ntri * 4, hipMemcpyDeviceToHost));
+	*out_n_nodes = bt.total;
+	if (out_seconds) *out_seconds = bt.device_seconds;
+	return MIPT_OK;
+}
+
+// =====================================================================================
+// A mesh whose tree AND traversal records are made on the device and stay there (round 4)
+// =====================================================================================
+// TriMesh::init used to fetch the tree back (58 MB of nodes + the permutation at 2.5 M triangles), build 310 MB of Triangle records on
+// the host, and mipt_upload_scene re-packed both into fat nodes and 64-byte records and sent 420 MB up again.  Here the device that built
+// the tree derives the traversal's records from it; mipt_upload_scene adopts them with device-to-device copies (mipt_mesh::device_mesh);
+// the reference-layout views (bvh.nodes, the permutation) are downloaded only when somebody asks (mipt_device_mesh_download).
+struct mipt_device_mesh {
+	uint32_t magic = 0x4d444d31u;      // 'MDM1'
+	int device = 0;
+	int ntri = 0, nnodes = 0, nfat = 0, nuvs = 0;
+	uint32_t root_ref = 0;
+	bvhb::ONode* d_nodes = nullptr; uint32_t* d_perm = nullptr;
+	DFatNode* d_fat = nullptr; DTriIsect* d_ti = nullptr; DTriShade* d_ts = nullptr; int* d_uvidx = nullptr;
+	float* d_tangent = nullptr;        // TriMesh::tangentSoup (9 floats per triangle) when the mesh has UVs and normals
+	mutable std::atomic<int> refs{1};  // the creator's reference + one per scene that uses the buffers in place (mipt_upload_scene on the same device)
+};
+
+extern "C" void mipt_device_mesh_free(mipt_device_mesh* m) {
+	if (!m || m->magic != 0x4d444d31u) return;
+	if (m->refs.fetch_sub(1) > 1) return;          // a scene still renders from these buffers: they go when it is replaced or its context destroyed
+	int prev = 0; hipGetDevice(&prev);
+	hipSetDevice(m->device);
+	for (void* p : {(void*)m->d_nodes, (void*)m->d_perm, (void*)m->d_fat, (void*)m->d_ti, (void*)m->d_ts, (void*)m->d_uvidx, (void*)m->d_tangent}) if (p) hipFree(p);
+	hipSetDevice(prev);
+	m->magic = 0;
+	delete m;
+}
+
+extern "C" int mipt_device_mesh_build(int device_id, const float* vertices, int nverts, const float* normals, int nnormals, const float* uvs, int nuvs,
+                                      const mipt_triangle_indices* indices, int ntri, mipt_device_mesh** out, mipt_device_mesh_info* info) {
+	using namespace bvhb;
+	if (!out || !indices || (nnormals > 0 && !normals) || (nuvs > 0 && !uvs) || nnormals < 0 || nuvs < 0) { g_build_err = "bad arguments"; return MIPT_ERR_INVALID; }
+	*out = nullptr;
+	if ((unsigned)ntri > MIPT_LEAF_FIRST_MASK) return build_fail(MIPT_ERR_UNSUPPORTED, "mesh has more than 2^26 triangles");
+	const bool trace = getenv("MIPT_BUILD_TRACE") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char* what) {
+		if (!trace) return;
+		hipDeviceSynchronize();
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[mipt_device_mesh_build] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
+	BuiltTree bt;
+	int rc = bvh_build_core(device_id, vertices, nverts, &indices[0].vtxi, (int)sizeof(mipt_triangle_indices), ntri, (size_t)ntri * sizeof(mipt_triangle_indices), bt);
+	if (rc) return rc;
+	phase("tree");
+	const int total = bt.total;
+	hipEvent_t e0, e1;
+	BHIP(hipEventCreate(&e0)); BHIP(hipEventCreate(&e1));
+	struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
+	// (until the end the device buffers belong to the pools `tmp` / `keep` / `bt.pool`; the handle's pointers are only views: a failure path deletes the plain struct)
+	std::unique_ptr<mipt_device_mesh> m(new mipt_device_mesh);
+	m->device = device_id; m->ntri = ntri; m->nnodes = total; m->nuvs = nuvs;
+	DevPool tmp;                        // scratch of this stage
+	DevPool keep;                       // what the handle will own
+	float *d_normals = nullptr, *d_uvs = nullptr; uint32_t *d_irank = nullptr, *d_bsum = nullptr, *d_root = nullptr; uint8_t* d_depth = nullptr; int* d_bad = nullptr;
+	const int nrb = (total + BVHB_RANK_TILE - 1) / BVHB_RANK_TILE;
+	bool ok = tmp.get(&d_irank, (size_t)total) && tmp.get(&d_bsum, (size_t)nrb) && tmp.get(&d_depth, (size_t)total) && tmp.get(&d_bad, 4) && tmp.get(&d_root, 1)
+	       && (nnormals == 0 || tmp.get(&d_normals, (size_t)nnormals * 3)) && (nuvs == 0 || tmp.get(&d_uvs, (size_t)nuvs * 3));
+	if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for the records of a %d-triangle mesh", ntri);
+	if (nnormals) BHIP(hipMemcpyAsync(d_normals, normals, (size_t)nnormals * 12, hipMemcpyHostToDevice, 0));
+	if (nuvs) BHIP(hipMemcpyAsync(d_uvs, uvs, (size_t)nuvs * 12, hipMemcpyHostToDevice, 0));
+	BHIP(hipMemsetAsync(d_bad, 0, 16, 0));
+	phase("normals / uvs upload");
+	BHIP(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL(k_rank_sums, dim3((unsigned)nrb), dim3(256), 0, 0, bt.d_out, total, d_bsum);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, 0, d_bsum, nrb);
+	hipLaunchKernelGGL(k_rank_apply, dim3((unsigned)nrb), dim3(256), 0, 0, bt.d_out, total, d_bsum, d_irank);
+	const unsigned nb = (unsigned)((total + 255) / 256);
+	hipLaunchKernelGGL(k_depth_init, dim3(nb), dim3(256), 0, 0, d_depth, total);
+	for (int level = 1; level <= MIPT_STACK_DEPTH; level++) hipLaunchKernelGGL(k_depth_pass, dim3(nb), dim3(256), 0, 0, bt.d_out, total, d_depth, level);
+	// the number of inner nodes = rank of a virtual node behind the last one: read back with the flags below
+	uint32_t last_rank = 0; ONode last_node;
+	BHIP(hipMemcpy(&last_rank, d_irank + (total - 1), 4, hipMemcpyDeviceToHost));
+	BHIP(hipMemcpy(&last_node, bt.d_out + (total - 1), sizeof last_node, hipMemcpyDeviceToHost));
+	const int nfat = (int)last_rank + (last_node.isleaf ? 0 : 1);
+	m->nfat = nfat;
+	phase("ranks + depths");
+	ok = keep.get(&m->d_fat, (size_t)std::max(nfat, 1)) && keep.get(&m->d_ti, (size_t)ntri) && keep.get(&m->d_ts, (size_t)ntri) && (nuvs == 0 || keep.get(&m->d_uvidx, (size_t)ntri * 3));
+	if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for the records of a %d-triangle mesh", ntri);
+	BHIP(hipMemsetAsync(m->d_fat, 0, sizeof(DFatNode), 0));
+	hipLaunchKernelGGL(k_fat_nodes, dim3(nb), dim3(256), 0, 0, bt.d_out, total, ntri, d_irank, d_depth, (int)MIPT_STACK_DEPTH, m->d_fat, d_bad, d_root);
+	hipLaunchKernelGGL(k_tri_records, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, 0, bt.d_vtx, d_normals, nnormals, d_uvs, nuvs, bt.d_tri, (int)sizeof(mipt_triangle_indices),
+	                   bt.d_perm, ntri, m->d_ti, m->d_ts, m->d_uvidx, d_bad);
+	phase("fat nodes + records");
+	if (nuvs > 0 && nnormals > 0) {      // setup_tangents (the host runs it whenever the mesh has UVs; it reads the vertex normals)
+		float *d_sdir = nullptr, *d_tan = nullptr; uint8_t* d_has = nullptr; uint32_t *d_first = nullptr, *d_fill = nullptr, *d_corner = nullptr, *d_vsum = nullptr;
+		const int nvb = (nverts + BVHB_RANK_TILE - 1) / BVHB_RANK_TILE;
+		ok = tmp.get(&d_sdir, (size_t)ntri * 3) && tmp.get(&d_has, (size_t)ntri) && tmp.get(&d_first, (size_t)nverts + 1) && tmp.get(&d_fill, (size_t)nverts + 1)
+		  && tmp.get(&d_corner, (size_t)ntri * 3) && tmp.get(&d_tan, (size_t)nverts * 3) && tmp.get(&d_vsum, (size_t)nvb) && keep.get(&m->d_tangent, (size_t)ntri * 9);
+		if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for the tangents of a %d-triangle mesh", ntri);
+		const unsigned tb = (unsigned)((ntri + 255) / 256);
+		BHIP(hipMemsetAsync(d_first, 0, ((size_t)nverts + 1) * 4, 0));
+		hipLaunchKernelGGL(k_tan_face, dim3(tb), dim3(256), 0, 0, bt.d_vtx, d_uvs, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm, ntri, d_sdir, d_has, d_first);
+		hipLaunchKernelGGL(k_u32_sums, dim3((unsigned)nvb), dim3(256), 0, 0, d_first, (size_t)nverts, d_vsum);
+		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, 0, d_vsum, nvb);
+		hipLaunchKernelGGL(k_u32_apply, dim3((unsigned)nvb), dim3(256), 0, 0, d_first, (size_t)nverts, d_vsum);
+		BHIP(hipMemcpyAsync(d_fill, d_first, (size_t)nverts * 4, hipMemcpyDeviceToDevice, 0));
+		hipLaunchKernelGGL(k_tan_fill, dim3(tb), dim3(256), 0, 0, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm, ntri, d_fill, d_corner);
+		hipLaunchKernelGGL(k_tan_vertex, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, 0, d_normals, nnormals, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm,
+		                   d_first, d_fill, d_corner, d_sdir, d_has, nverts, d_tan);
+		hipLaunchKernelGGL(k_tan_soup, dim3(tb), dim3(256), 0, 0, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm, ntri, d_tan, m->d_tangent);
+	}
+	phase("tangents");
+	BHIP(hipEventRecord(e1, 0));
+	int bad[4] = {0, 0, 0, 0};
+	BHIP(hipMemcpy(bad, d_bad, 16, hipMemcpyDeviceToHost));
+	BHIP(hipMemcpy(&m->root_ref, d_root, 4, hipMemcpyDeviceToHost));
+	BHIP(hipGetLastError());
+	auto drop = [&]() { m->d_fat = nullptr; m->d_ti = nullptr; m->d_ts = nullptr; m->d_uvidx = nullptr; m->d_tangent = nullptr; };     // (still owned by `keep`)
+	if (bad[0]) { drop(); return build_fail(MIPT_ERR_INVALID, "BVH child index out of order / leaf range out of bounds"); }
+	if (bad[1]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles (max %d)", bad[1], MIPT_LEAF_MAX_TRIS); }
+	if (bad[2]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "BVH with more than %d levels of inner nodes: the traversal stack holds %d", MIPT_STACK_DEPTH, MIPT_STACK_DEPTH); }
+	if (bad[3]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "material group index above 2^30"); }
+	// the handle keeps the reference-layout nodes and the permutation for mipt_device_mesh_download; everything else of the build goes
+	auto detach = [](DevPool& p, void* q) { for (auto& x : p.p) if (x == q) { x = nullptr; return; } };
+	m->d_nodes = bt.d_out; m->d_perm = bt.d_perm;
+	detach(bt.pool, bt.d_out); detach(bt.pool, bt.d_perm);
+	for (void* q : {(void*)m->d_fat, (void*)m->d_ti, (void*)m->d_ts, (void*)m->d_uvidx, (void*)m->d_tangent}) if (q) detach(keep, q);
+	if (info) {
+		float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+		info->n_triangles = ntri; info->n_nodes = total; info->n_inner = nfat; info->device_id = device_id;
+		info->build_seconds = bt.device_seconds; info->records_seconds = ms * 1e-3; info->has_tangents = m->d_tangent ? 1 : 0;
+	}
+	*out = m.release();
+	tmp.release(); keep.release(); bt.pool.release();
 	phase("hipFree");
-	*out_n_nodes = total;
-	if (out_seconds) { float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); *out_seconds = ms * 1e-3; }
+	return MIPT_OK;
+}
+
+extern "C" int mipt_device_mesh_download(const mipt_device_mesh* m, mipt_bvh_node* nodes, int node_capacity, int32_t* perm) {
+	if (!m || m->magic != 0x4d444d31u) { g_build_err = "not a device mesh"; return MIPT_ERR_INVALID; }
+	int prev = 0; hipGetDevice(&prev);
+	BHIP(hipSetDevice(m->device));
+	if (nodes) {
+		if (node_capacity < m->nnodes) return build_fail(MIPT_ERR_INVALID, "node_capacity %d is too small for %d nodes", node_capacity, m->nnodes);
+		BHIP(hipMemcpy(nodes, m->d_nodes, (size_t)m->nnodes * sizeof(bvhb::ONode), hipMemcpyDeviceToHost));
+	}
+	if (perm) BHIP(hipMemcpy(perm, m->d_perm, (size_t)m->ntri * 4, hipMemcpyDeviceToHost));
+	hipSetDevice(prev);
+	return MIPT_OK;
+}
+extern "C" int mipt_device_mesh_download_tangents(const mipt_device_mesh* m, float* tangent_soup) {
+	if (!m || m->magic != 0x4d444d31u || !tangent_soup) { g_build_err = "not a device mesh"; return MIPT_ERR_INVALID; }
+	if (!m->d_tangent) return build_fail(MIPT_ERR_INVALID, "the device mesh has no tangents (a mesh without UVs or without normals)");
+	int prev = 0; hipGetDevice(&prev);
+	BHIP(hipSetDevice(m->device));
+	BHIP(hipMemcpy(tangent_soup, m->d_tangent, (size_t)m->ntri * 9 * sizeof(float), hipMemcpyDeviceToHost));
+	hipSetDevice(prev);
+	return MIPT_OK;
+}
+
+// mipt_upload_scene on a mesh that names a device handle: no host arrays are read; the scene's buffers are filled by device-to-device
+// copies (peer copies when the handle lives on another device of a group), child references moved to the mesh's place in the scene.
+static int adopt_device_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging& stg) {
+	const mipt_device_mesh* dm = m->device_mesh;
+	if (dm->magic != 0x4d444d31u) return fail(c, MIPT_ERR_INVALID, "mipt_mesh::device_mesh is not a handle of mipt_device_mesh_build");
+	if (m->n_triangles != dm->ntri || m->n_nodes != dm->nnodes) return fail(c, MIPT_ERR_INVALID, "mipt_mesh counts (%d triangles, %d nodes) are not the device mesh's (%d, %d)", m->n_triangles, m->n_nodes, dm->ntri, dm->nnodes);
+	if (stg.nt_total + (size_t)dm->ntri > MIPT_LEAF_FIRST_MASK) return fail(c, MIPT_ERR_UNSUPPORTED, "scene has more than 2^26 triangles");
+	MeshChunk chunk;
+	chunk.dev = dm; chunk.nfat = (size_t)std::max(dm->nfat, 1); chunk.nt = (size_t)dm->ntri;
+	chunk.node_base = (uint32_t)stg.nfat_total; chunk.tri_base = (uint32_t)stg.nt_total;
+	d.node_base = chunk.node_base; d.tri_base = chunk.tri_base;
+	d.root_ref = (dm->root_ref & MIPT_LEAF_BIT) ? dm->root_ref + chunk.tri_base : chunk.node_base;        // (an inner root is inner node 0 of the mesh)
+	memcpy(d.root_min, m->bvh_bbox_min, 12); memcpy(d.root_max, m->bvh_bbox_max, 12);
+	stg.nfat_total += chunk.nfat; stg.nt_total += chunk.nt;
+	stg.chunks.push_back(std::move(chunk));
+	d.ntri = dm->ntri;
+	const bool has_uv = m->n_uvs > 0 && m->uvs && dm->nuvs == m->n_uvs;
+	d.nuvs = has_uv ? m->n_uvs : 0;
+	d.uvs = nullptr; d.uvidx = nullptr; d.tangent_soup = nullptr;
+	if (m->n_uvs > 0 && m->uvs && dm->nuvs != m->n_uvs) return fail(c, MIPT_ERR_INVALID, "mipt_mesh::n_uvs is not the device mesh's");
+	if (has_uv) {
+		int rc;
+		if ((rc = upload(c, m->uvs, (size_t)m->n_uvs * 3, &d.uvs))) return rc;
+		const bool here = dm->device == c->device;
+		if (here) { dm->refs.fetch_add(1); c->scene_shared.push_back(dm); }          // the index triples and the tangents are read in place
+		if (here) d.uvidx = dm->d_uvidx;
+		else {
+			void* p = nullptr;
+			HIPCHK(c, hipMalloc(&p, (size_t)dm->ntri * 3 * sizeof(int)));
+			c->scene_allocs.push_back(p);
+			HIPCHK(c, hipMemcpyPeer(p, c->device, dm->d_uvidx, dm->device, (size_t)dm->ntri * 3 * sizeof(int)));
+			d.uvidx = (const int*)p;
+		}
+		if (dm->d_tangent && here) d.tangent_soup = dm->d_tangent;      // setup_tangents ran on the device: 36 bytes per triangle that never cross PCIe
+		else if (dm->d_tangent) {
+			void* q = nullptr;
+			HIPCHK(c, hipMalloc(&q, (size_t)dm->ntri * 9 * sizeof(float)));
+			c->scene_allocs.push_back(q);
+			HIPCHK(c, hipMemcpyPeer(q, c->device, dm->d_tangent, dm->device, (size_t)dm->ntri * 9 * sizeof(float)));
+			d.tangent_soup = (const float*)q;
+		} else if (m->tangentSoup && (rc = upload(c, m->tangentSoup, (size_t)dm->ntri * 9, &d.tangent_soup))) return rc;
+	}
+	return MIPT_OK;
+}
+static bool device_mesh_on(const mipt_device_mesh* dm, int device) { return dm->device == device; }
+static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFatNode** dn, const DTriIsect** dt, const DTriShade** dsh) {
+	dm->refs.fetch_add(1);
+	c->scene_shared.push_back(dm);
+	*dn = dm->d_fat; *dt = dm->d_ti; *dsh = dm->d_ts;
+	return MIPT_OK;
+}
+static int copy_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, DFatNode* dn, DTriIsect* dt, DTriShade* dsh, uint32_t node_base, uint32_t tri_base) {
+	const size_t nfat = (size_t)std::max(dm->nfat, 1), nt = (size_t)dm->ntri;
+	const bool same = dm->device == c->device;
+	auto copy = [&](void* dst, const void* src, size_t bytes) { return same ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, c->device, src, dm->device, bytes); };
+	HIPCHK(c, copy(dt, dm->d_ti, nt * sizeof(DTriIsect)));
+	HIPCHK(c, copy(dsh, dm->d_ts, nt * sizeof(DTriShade)));
+	HIPCHK(c, copy(dn, dm->d_fat, nfat * sizeof(DFatNode)));
+	if (node_base || tri_base) {       // not the scene's first mesh: the copy above is rewritten in place with scene-wide references
+		hipLaunchKernelGGL(bvhb::k_rebase_nodes, dim3((unsigned)((nfat + 255) / 256)), dim3(256), 0, 0, dn, (const DFatNode*)dn, nfat, node_base, tri_base);
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipDeviceSynchronize());
+	}
 	return MIPT_OK;
 }
 

@@ -595,4 +595,230 @@ __global__ void k_emit(const LNode* __restrict__ ln, int nln, const ONode* __res
 	out[nd.pre] = o;
 }
 
+// ---- the traversal's own records, made on the device from the built tree (round 4: mipt_device_mesh_build) --------------------
+// What convert_mesh (mipt.hip) makes on the host from downloaded nodes and host-side Triangle records, made where the tree
+// already is: fat nodes (both children's boxes + references, inner nodes in the reference's depth-first order), the 64-byte
+// intersection and shading records of the permuted triangles, and the UV index triples of alpha-tested meshes.
+
+// inner rank of every node of the reference's node vector = number of inner nodes in front of it (exclusive scan of !isleaf)
+#define BVHB_RANK_TILE 1024
+__global__ __launch_bounds__(256) void k_rank_sums(const ONode* __restrict__ nodes, int total, uint32_t* __restrict__ bsum) {
+	__shared__ uint32_t ws[4];
+	const size_t base = (size_t)blockIdx.x * BVHB_RANK_TILE;
+	uint32_t c = 0;
+	for (int k = 0; k < BVHB_RANK_TILE / 256; k++) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < (size_t)total && !nodes[i].isleaf) c++; }
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void k_rank_apply(const ONode* __restrict__ nodes, int total, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ irank) {
+	// (one wave walks the tile in node order: 4 x 256 nodes, ballot prefix inside each group of 64)
+	__shared__ uint32_t wsum[4][4];
+	const size_t base = (size_t)blockIdx.x * BVHB_RANK_TILE;
+	const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t mine[4]; uint32_t cnt[4];
+	for (int k = 0; k < 4; k++) {
+		const size_t i = base + (size_t)k * 256 + threadIdx.x;
+		const bool inner = i < (size_t)total && !nodes[i].isleaf;
+		const unsigned long long m = __ballot(inner);
+		mine[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		cnt[k] = (uint32_t)__popcll(m);
+		if (lane == 0) wsum[k][w] = cnt[k];
+	}
+	__syncthreads();
+	uint32_t off = bsum[blockIdx.x];
+	for (int k = 0; k < 4; k++) {
+		uint32_t before = off;
+		for (unsigned ww = 0; ww < w; ww++) before += wsum[k][ww];
+		const size_t i = base + (size_t)k * 256 + threadIdx.x;
+		if (i < (size_t)total) irank[i] = before + mine[k];
+		off += wsum[k][0] + wsum[k][1] + wsum[k][2] + wsum[k][3];
+	}
+}
+// levels of inner nodes: depth[root] = 1, every pass hands depth + 1 to the inner children of the nodes that have one.  After P passes
+// every inner node of level <= P + 1 has its depth; a tree with more levels than the traversal stack holds leaves inner nodes at 0.
+__global__ void k_depth_init(uint8_t* __restrict__ depth, int total) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < (size_t)total) depth[i] = i == 0 ? 1 : 0;
+}
+__global__ void k_depth_pass(const ONode* __restrict__ nodes, int total, uint8_t* __restrict__ depth, int level) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)total || depth[i] != level || nodes[i].isleaf) return;
+	depth[nodes[i].fg] = (uint8_t)(level + 1); depth[nodes[i].fd] = (uint8_t)(level + 1);
+}
+// bad[0]: a child index out of order / a leaf range out of bounds, bad[1]: a leaf with more than 32 triangles, bad[2]: an inner node no pass
+// reached (tree deeper than `max_levels` levels of inner nodes), bad[3]: a material group above 2^30
+__global__ void k_fat_nodes(const ONode* __restrict__ nodes, int total, int ntri, const uint32_t* __restrict__ irank, const uint8_t* __restrict__ depth, int max_levels,
+                            DFatNode* __restrict__ fat, int* __restrict__ bad, uint32_t* __restrict__ root_ref) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)total) return;
+	const ONode nd = nodes[i];
+	auto child_ref = [&](int c) -> uint32_t {
+		const ONode ch = nodes[c];
+		if (!ch.isleaf) return irank[c];
+		const int cnt = ch.fd - ch.fg;
+		if (ch.fg < 0 || ch.fd > ntri || cnt <= 0) { atomicOr(&bad[0], 1); return 0u; }
+		if (cnt > MIPT_LEAF_MAX_TRIS) { atomicMax(&bad[1], cnt); return 0u; }
+		return MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (uint32_t)ch.fg;
+	};
+	if (i == 0) *root_ref = nd.isleaf ? (nd.fd - nd.fg > MIPT_LEAF_MAX_TRIS || nd.fd - nd.fg <= 0 ? (atomicMax(&bad[1], nd.fd - nd.fg), 0u) : (MIPT_LEAF_BIT | ((uint32_t)(nd.fd - nd.fg - 1) << 26) | (uint32_t)nd.fg)) : 0u;
+	if (nd.isleaf) return;
+	if (nd.fg <= (int)i || nd.fg >= total || nd.fd <= (int)i || nd.fd >= total) { atomicOr(&bad[0], 1); return; }
+	if (depth[i] == 0 || depth[i] > max_levels) atomicOr(&bad[2], 1);
+	DFatNode f;
+	const ONode l = nodes[nd.fg], r = nodes[nd.fd];
+	for (int k = 0; k < 3; k++) { f.l[k][0] = l.bmin[k]; f.l[k][1] = l.bmax[k]; f.r[k][0] = r.bmin[k]; f.r[k][1] = r.bmax[k]; }
+	f.lref = child_ref(nd.fg); f.rref = child_ref(nd.fd); f._pad[0] = f._pad[1] = 0;
+	fat[irank[i]] = f;
+}
+// Triangle's constructor (TriangleMesh.h:70-78) and the gather of corner normals / UVs (TriangleMesh.cpp:812-829) for position i of the
+// reordered mesh = input triangle order[i].  tri = the caller's TriangleIndices records (44 bytes: vtx ijk, uv ijk, n ijk, group, faceID).
+__global__ void k_tri_records(const float* __restrict__ vtx, const float* __restrict__ normals, int nnormals, const float* __restrict__ uvs, int nuvs,
+                              const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n,
+                              DTriIsect* __restrict__ ti, DTriShade* __restrict__ ts, int* __restrict__ uvidx, int* __restrict__ bad) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)n) return;
+	const int* t = reinterpret_cast<const int*>(tri + (size_t)order[i] * stride);
+	const int vi = t[0], vj = t[1], vk = t[2], ui = t[3], uj = t[4], uk = t[5], ni = t[6], nj = t[7], nk = t[8], group = t[9];
+	const float A[3] = {vtx[3 * (size_t)vi], vtx[3 * (size_t)vi + 1], vtx[3 * (size_t)vi + 2]};
+	float u[3], v[3];
+	for (int k = 0; k < 3; k++) { u[k] = vtx[3 * (size_t)vj + k] - A[k]; v[k] = vtx[3 * (size_t)vk + k] - A[k]; }
+	DTriIsect I;
+	for (int k = 0; k < 3; k++) { I.A[k] = A[k]; I.u[k] = u[k]; I.v[k] = v[k]; }
+	I.N[0] = u[1] * v[2] - u[2] * v[1]; I.N[1] = u[2] * v[0] - u[0] * v[2]; I.N[2] = u[0] * v[1] - u[1] * v[0];
+	I.m11 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+	I.m22 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+	I.m12 = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+	I.invdetm = 1.f / (I.m11 * I.m22 - I.m12 * I.m12);
+	ti[i] = I;
+	DTriShade S;
+	for (int k = 0; k < 9; k++) S.normals[k] = 0.f;
+	if (nnormals != 0) {
+		const int nidx[3] = {ni, nj, nk};
+		for (int c = 0; c < 3; c++) if ((unsigned)nidx[c] < (unsigned)nnormals) for (int k = 0; k < 3; k++) S.normals[3 * c + k] = normals[3 * (size_t)nidx[c] + k];      // (an index outside the list: zeros, where the host loop would read outside it)
+	}
+	for (int k = 0; k < 6; k++) S.uvs[k] = 0.f;
+	if (nuvs != 0) {
+		const int tidx[3] = {ui, uj, uk};
+		for (int c = 0; c < 3; c++) if ((unsigned)tidx[c] < (unsigned)nuvs) { S.uvs[2 * c] = uvs[3 * (size_t)tidx[c]]; S.uvs[2 * c + 1] = uvs[3 * (size_t)tidx[c] + 1]; }
+		if (uvidx) { uvidx[3 * i] = ui; uvidx[3 * i + 1] = uj; uvidx[3 * i + 2] = uk; }
+	}
+	S.group = group;
+	if (group > MIPT_GROUP_MASK) atomicOr(&bad[3], 1);
+	if (group >= 0 && nuvs != 0 && ui >= 0 && ui < nuvs) S.group |= MIPT_GROUP_UV_OK;
+	ts[i] = S;
+}
+// ---- TriMesh::setup_tangents (TriangleMesh.cpp:572-711) on the reordered mesh: per face (sdir, tdir) from the UV gradients, per vertex
+// the sum of its faces' sdir IN ASCENDING FACE ORDER (the reference walks the faces once: the order fixes the rounding), Gram-Schmidt
+// against the vertex normal, then the three corner tangents of every face.  Same operations as the host version (host/mipt_host.cpp).
+__global__ void k_tan_face(const float* __restrict__ vtx, const float* __restrict__ uvs, const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n,
+                           float* __restrict__ sdir, uint8_t* __restrict__ has, uint32_t* __restrict__ first) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)n) return;
+	const int* t = reinterpret_cast<const int*>(tri + (size_t)order[i] * stride);
+	const int vi = t[0], vj = t[1], vk = t[2], ui = t[3], uj = t[4], uk = t[5];
+	atomicAdd(&first[vi], 1u); atomicAdd(&first[vj], 1u); atomicAdd(&first[vk], 1u);      // incident corners per vertex (scanned into list starts)
+	const bool h = !(ui == -1 || uj == -1 || uk == -1);
+	has[i] = h ? 1 : 0;
+	if (!h) return;
+	float vA[3], vB[3];
+	for (int k = 0; k < 3; k++) { vA[k] = vtx[3 * (size_t)vj + k] - vtx[3 * (size_t)vi + k]; vB[k] = vtx[3 * (size_t)vk + k] - vtx[3 * (size_t)vi + k]; }
+	const float sA0 = uvs[3 * (size_t)uj] - uvs[3 * (size_t)ui], sA1 = uvs[3 * (size_t)uj + 1] - uvs[3 * (size_t)ui + 1];
+	const float sB0 = uvs[3 * (size_t)uk] - uvs[3 * (size_t)ui], sB1 = uvs[3 * (size_t)uk + 1] - uvs[3 * (size_t)ui + 1];
+	const float det = sA0 * sB1 - sB0 * sA1;
+	for (int k = 0; k < 3; k++) sdir[3 * i + k] = det != 0 ? (sB1 * vA[k] - sA1 * vB[k]) / det : 0.00001f * vA[k];
+}
+// generic exclusive scan of uint32 (tile sums, k_scan_top on the sums, apply): first[] of the vertex -> corner table
+__global__ __launch_bounds__(256) void k_u32_sums(const uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ bsum) {
+	__shared__ uint32_t ws[4];
+	const size_t base = (size_t)blockIdx.x * BVHB_RANK_TILE;
+	uint32_t c = 0;
+	for (int k = 0; k < BVHB_RANK_TILE / 256; k++) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < n) c += a[i]; }
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void k_u32_apply(uint32_t* __restrict__ a, size_t n, const uint32_t* __restrict__ bsum) {      // in place: a[i] <- sum of a[0 .. i-1]
+	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0) carry = bsum[blockIdx.x];
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * BVHB_RANK_TILE;
+	for (int k = 0; k < BVHB_RANK_TILE / 256; k++) {
+		const size_t i = base + (size_t)k * 256 + threadIdx.x;
+		const uint32_t v = i < n ? a[i] : 0u;
+		uint32_t incl = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= (unsigned)o) incl += t; }
+		if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (unsigned w = 0; w < (threadIdx.x >> 6); w++) woff += wsum[w];
+		const uint32_t c = carry;
+		if (i < n) a[i] = c + woff + incl - v;
+		__syncthreads();
+		if (threadIdx.x == 255) carry = c + woff + incl;
+		__syncthreads();
+	}
+}
+__global__ void k_tan_fill(const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n, uint32_t* __restrict__ fill, uint32_t* __restrict__ corner) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)n) return;
+	const int* t = reinterpret_cast<const int*>(tri + (size_t)order[i] * stride);
+	for (int k = 0; k < 3; k++) corner[atomicAdd(&fill[t[k]], 1u)] = 3u * (uint32_t)i + (uint32_t)k;
+}
+// first[] is the table's start per vertex, fill[] (advanced by k_tan_fill) its end.  A vertex's list arrives in arbitrary order: it is
+// sorted here (heap sort: the poles of a UV sphere have a thousand incident faces) before the sum runs in ascending face order.
+__global__ void k_tan_vertex(const float* __restrict__ normals, int nnormals, const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order,
+                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ fill, uint32_t* __restrict__ corner, const float* __restrict__ sdir,
+                             const uint8_t* __restrict__ has, int nv, float* __restrict__ tangents) {
+	const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= (size_t)nv) return;
+	uint32_t* a = corner + first[v];
+	const int m = (int)(fill[v] - first[v]);
+	auto sift = [&](int root, int end) {
+		for (;;) {
+			int child = 2 * root + 1;
+			if (child >= end) return;
+			if (child + 1 < end && a[child] < a[child + 1]) child++;
+			if (a[root] >= a[child]) return;
+			const uint32_t t = a[root]; a[root] = a[child]; a[child] = t;
+			root = child;
+		}
+	};
+	for (int r = m / 2 - 1; r >= 0; r--) sift(r, m);
+	for (int e = m - 1; e > 0; e--) { const uint32_t t = a[0]; a[0] = a[e]; a[e] = t; sift(0, e); }
+	float t1[3] = {0.f, 0.f, 0.f};
+	int nidx = 0;
+	for (int e = 0; e < m; e++) {
+		const uint32_t f = a[e] / 3u, k = a[e] % 3u;
+		if (has[f]) for (int c = 0; c < 3; c++) t1[c] = t1[c] + sdir[3 * (size_t)f + c];
+		nidx = reinterpret_cast<const int*>(tri + (size_t)order[f] * stride)[6 + k];
+	}
+	float N[3] = {0.f, 0.f, 0.f};
+	if ((unsigned)nidx < (unsigned)nnormals) for (int c = 0; c < 3; c++) N[c] = normals[3 * (size_t)nidx + c];
+	{ const float len = sqrtf(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]); N[0] = N[0] / len; N[1] = N[1] / len; N[2] = N[2] / len; }
+	const float d = t1[0] * N[0] + t1[1] * N[1] + t1[2] * N[2];
+	float r[3] = {t1[0] - d * N[0], t1[1] - d * N[1], t1[2] - d * N[2]};
+	{ const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]); r[0] = r[0] / len; r[1] = r[1] / len; r[2] = r[2] / len; }
+	for (int c = 0; c < 3; c++) tangents[3 * v + c] = r[c];
+}
+__global__ void k_tan_soup(const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n, const float* __restrict__ tangents, float* __restrict__ soup) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)n) return;
+	const int* t = reinterpret_cast<const int*>(tri + (size_t)order[i] * stride);
+	for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) soup[9 * i + 3 * k + c] = tangents[3 * (size_t)t[k] + c];
+}
+
+// a mesh that is not the scene's first: child references are scene-wide (inner: + node_base; leaf: first triangle + tri_base)
+__global__ void k_rebase_nodes(DFatNode* __restrict__ dst, const DFatNode* __restrict__ src, size_t n, uint32_t node_base, uint32_t tri_base) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	DFatNode f = src[i];
+	f.lref = (f.lref & MIPT_LEAF_BIT) ? f.lref + tri_base : f.lref + node_base;
+	f.rref = (f.rref & MIPT_LEAF_BIT) ? f.rref + tri_base : f.rref + node_base;
+	dst[i] = f;
+}
+
 }   // namespace bvhb

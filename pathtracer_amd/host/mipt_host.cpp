@@ -213,10 +213,11 @@ static void parallel_for(int n, F f) {
 TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt, const float* uv,
                  int nf, const int* fv, const int* fn, const int* ft, bool center) {
 	type = OT_TRIMESH; interp_normals = true; name = "mesh";
+	const auto t_ctor = std::chrono::steady_clock::now();
 	vertices.resize(nv); normals.resize(nn); uvs.resize(nt);
 	parallel_for(nv, [&](int a, int b) { for (int i = a; i < b; i++) vertices[i] = Vector(verts[3 * (size_t)i], verts[3 * (size_t)i + 1], verts[3 * (size_t)i + 2]); });
 	parallel_for(nn, [&](int a, int b) { for (int i = a; i < b; i++) normals[i] = Vector(norms[3 * (size_t)i], norms[3 * (size_t)i + 1], norms[3 * (size_t)i + 2]); });
-	for (int i = 0; i < nt; i++) uvs[i] = Vector(uv[2 * i], uv[2 * i + 1], 0);
+	parallel_for(nt, [&](int a, int b) { for (int i = a; i < b; i++) uvs[i] = Vector(uv[2 * (size_t)i], uv[2 * (size_t)i + 1], 0); });
 	indices.resize(nf);
 	parallel_for(nf, [&](int a, int b) {
 	for (int i = a; i < b; i++) {
@@ -232,12 +233,15 @@ TriMesh::TriMesh(int nv, const float* verts, int nn, const float* norms, int nt,
 	});
 	groupNames["Default"] = 0;
 	add_default_group_materials(1);
+	if (getenv("MIPT_BUILD_TRACE")) fprintf(stderr, "[TriMesh::TriMesh] %-26s %8.2f ms\n", "arrays -> members", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ctor).count());
 	finish_init(center);
 }
 
 // which builder TriMesh::init uses: 0 = host recursion, 1 = GPU (an error if there is no device), 2 = GPU when a device
 // is present, host recursion otherwise (default)
 static int g_bvh_builder_mode = 2, g_bvh_builder_device = 0;
+static int g_device_resident = 1;     // builder on the GPU: leave the tree and the records there (mipt_device_mesh_build) instead of fetching them back
+extern "C" void mh_set_device_resident(int on) { g_device_resident = on; }
 extern "C" void mh_set_obj_slicing(int slice_bytes, int max_slices);   // test hook: how readOBJ cuts the text into concurrently parsed slices
 extern "C" void mh_set_bvh_builder(int mode, int device) { g_bvh_builder_mode = mode; g_bvh_builder_device = device; }
 
@@ -263,15 +267,15 @@ void TriMesh::finish_init(bool center) {
 	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	// axis swap (x,y,z) -> (-z,y,x) (TriangleMesh.cpp:742-751)
 	const int nvtx = (int)vertices.size();
-	parallel_for(nvtx, [&](int a, int b) { for (int i = a; i < b; i++) { Vector& v = vertices[i]; std::swap(v[0], v[2]); v[0] = -v[0]; } });
 	parallel_for(nn, [&](int a, int b) { for (int i = a; i < b; i++) { Vector& v = normals[i]; std::swap(v[0], v[2]); v[0] = -v[0]; } });
 	float bmin[3] = {1E9f, 1E9f, 1E9f}, bmax[3] = {-1E9f, -1E9f, -1E9f};
 	{   // min / max over chunks, joined in chunk order: std::min / std::max keep the earlier of equal values either way
+		// (the swap of the vertices rides in the same pass: one trip through 142 MB instead of two at 23.7 M triangles)
 		std::mutex mu;
 		std::map<int, std::array<float, 6>> part;
 		parallel_for(nvtx, [&](int a, int b) {
 			std::array<float, 6> q = {1E9f, 1E9f, 1E9f, -1E9f, -1E9f, -1E9f};
-			for (int i = a; i < b; i++) for (int k = 0; k < 3; k++) { q[k] = std::min(q[k], vertices[i][k]); q[3 + k] = std::max(q[3 + k], vertices[i][k]); }
+			for (int i = a; i < b; i++) { Vector& v = vertices[i]; std::swap(v[0], v[2]); v[0] = -v[0]; for (int k = 0; k < 3; k++) { q[k] = std::min(q[k], v[k]); q[3 + k] = std::max(q[3 + k], v[k]); } }
 			std::lock_guard<std::mutex> g(mu);
 			part[a] = q;
 		});
@@ -282,13 +286,23 @@ void TriMesh::finish_init(bool center) {
 		float c[3] = {(bmin[0] + bmax[0]) * 0.5f, (bmin[1] + bmax[1]) * 0.5f, (bmin[2] + bmax[2]) * 0.5f};
 		parallel_for(nvtx, [&](int a, int b) { for (int i = a; i < b; i++) for (int k = 0; k < 3; k++) vertices[i][k] = (vertices[i][k] - c[k]) / s * 1.f + 0.f; });
 	}
-	permuted_triangle_index.resize(nf);
-	parallel_for(nf, [&](int a, int b) { for (int i = a; i < b; i++) permuted_triangle_index[i] = i; });
 	phase("axis swap, bounds, centring");
 	// build_bvh (:878-885): on the GPU (mipt_build_bvh, same tree and triangle order) or with the host recursion below
 	build_bbox(0, nf, bvh.bbox);
 	const auto t_build = std::chrono::steady_clock::now();
 	bvh_builder = 0;
+	if (g_bvh_builder_mode != 0 && g_device_resident && build_device_resident()) {
+		// the tree, the reordered Triangle records and the tangents are on the device and stay there; the host arrays that mirror
+		// them are filled by sync_host() / sync_tangents() when something reads them
+		bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
+		phase("mipt_device_mesh_build");
+		memcpy(bbox, bvh.bbox, sizeof bbox);           // build_bbox(0, nf, bbox) (:804): the box of all triangles again, whatever their order
+		rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
+		phase("bounds");
+		return;
+	}
+	permuted_triangle_index.resize(nf);       // (with the tree on the device this happens in sync_host(), when somebody asks for the permutation)
+	parallel_for(nf, [&](int a, int b) { for (int i = a; i < b; i++) permuted_triangle_index[i] = i; });
 	if (g_bvh_builder_mode != 0 && !build_bvh_gpu()) {
 		if (g_bvh_builder_mode == 1 || !bvh_gpu_unavailable) { loaded = false; return; }   // forced, or bad input: say so
 	}
@@ -300,7 +314,16 @@ void TriMesh::finish_init(bool center) {
 	bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
 	phase("build_bvh");
 	build_bbox(0, nf, bbox);
-	// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
+	build_triangle_soup();
+	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
+	phase("triangle soup");
+	if (nt != 0) setup_tangents();
+	phase("tangents");
+}
+
+// triangle soup, after the reorder (:812-829; Triangle ctor TriangleMesh.h:70-78)
+void TriMesh::build_triangle_soup() {
+	const int nn = (int)normals.size(), nt = (int)uvs.size(), nf = (int)indices.size();
 	triangleSoup.resize(nf);
 	parallel_for(nf, [&](int i0, int i1) {
 	for (int i = i0; i < i1; i++) {
@@ -321,10 +344,59 @@ void TriMesh::finish_init(bool center) {
 		}
 	}
 	});
-	rotation_center = Vector((bbox[0] + bbox[3]) * 0.5f, (bbox[1] + bbox[4]) * 0.5f, (bbox[2] + bbox[5]) * 0.5f);   // :831-835
-	phase("triangle soup");
-	if (nt != 0) setup_tangents();
-	phase("tangents");
+}
+
+TriMesh::~TriMesh() { if (device_mesh) mipt_device_mesh_free(device_mesh); }
+
+// mipt_device_mesh_build (include/mipt.h): build_bvh, the Triangle records and setup_tangents on the device, nothing fetched back.
+bool TriMesh::build_device_resident() {
+	const int nf = (int)indices.size();
+	mipt_device_mesh_info info;
+	memset(&info, 0, sizeof info);
+	mipt_device_mesh* dm = nullptr;
+	const int rc = mipt_device_mesh_build(g_bvh_builder_device, &vertices[0][0], (int)vertices.size(), normals.empty() ? nullptr : &normals[0][0], (int)normals.size(),
+	                                      uvs.empty() ? nullptr : &uvs[0][0], (int)uvs.size(), indices.data(), nf, &dm, &info);
+	if (rc != MIPT_OK) {
+		// no device / out of memory: the next builder in line takes over; a tree the traversal cannot hold (too deep, fat leaves) is
+		// reported by the upload of the host-built arrays exactly as before
+		load_error = std::string("mipt_device_mesh_build: ") + mipt_build_bvh_error();
+		return false;
+	}
+	device_mesh = dm; device_nodes = info.n_nodes;
+	host_views_current = false;
+	tangents_current = uvs.empty();      // (a mesh without UVs has no tangentSoup)
+	bvh_builder = 2;
+	bvh_device_seconds = info.build_seconds + info.records_seconds;
+	bvh.nodes.clear(); triangleSoup.clear(); tangentSoup.clear();
+	load_error.clear();
+	return true;
+}
+
+void TriMesh::sync_host() {
+	if (host_views_current) return;
+	const int nf = (int)indices.size();
+	bvh.nodes.resize((size_t)device_nodes);
+	std::vector<int32_t> perm(nf);
+	if (mipt_device_mesh_download(device_mesh, reinterpret_cast<mipt_bvh_node*>(bvh.nodes.data()), device_nodes, perm.data()) != MIPT_OK) {
+		load_error = std::string("mipt_device_mesh_download: ") + mipt_build_bvh_error();
+		bvh.nodes.clear();
+		return;
+	}
+	PodVec<mipt_triangle_indices> dst(nf);
+	permuted_triangle_index.resize(nf);
+	parallel_for(nf, [&](int i0, int i1) { for (int i = i0; i < i1; i++) { dst[i] = indices[perm[i]]; permuted_triangle_index[i] = perm[i]; } });
+	indices.swap(dst);
+	build_triangle_soup();
+	host_views_current = true;
+}
+
+void TriMesh::sync_tangents() {
+	sync_host();
+	if (tangents_current) return;
+	const int nf = (int)indices.size();
+	tangentSoup.resize((size_t)nf * 3);
+	if (mipt_device_mesh_download_tangents(device_mesh, &tangentSoup[0][0]) != MIPT_OK) setup_tangents();      // (a mesh with UVs but no normals: the host loop)
+	tangents_current = true;
 }
 
 // ---------------------------------------------------------------- OBJ / MTL ingestion
@@ -1553,12 +1625,20 @@ void Raytracer::build_descs() {
 		} else {
 			TriMesh* g = static_cast<TriMesh*>(o);
 			mipt_mesh& m = desc_meshes_[i];
-			m.n_triangles = (int)g->indices.size(); m.n_nodes = (int)g->bvh.nodes.size(); m.n_uvs = (int)g->uvs.size();
-			m.nodes = reinterpret_cast<const mipt_bvh_node*>(g->bvh.nodes.data());
+			memset(&m, 0, sizeof m);
+			m.n_triangles = (int)g->indices.size(); m.n_nodes = g->node_count(); m.n_uvs = (int)g->uvs.size();
 			memcpy(m.bvh_bbox_min, g->bvh.bbox, 12); memcpy(m.bvh_bbox_max, g->bvh.bbox + 3, 12);
-			m.triangleSoup = g->triangleSoup.data(); m.indices = g->indices.data();
 			m.uvs = g->uvs.empty() ? nullptr : &g->uvs[0][0];
-			m.tangentSoup = g->tangentSoup.empty() ? nullptr : &g->tangentSoup[0][0];
+			if (g->device_handle()) {
+				// the records are on the device already (mipt_device_mesh_build): the upload copies them device to device; the host views
+				// (bvh.nodes, triangleSoup, the reordered indices) are not needed and not materialised
+				m.device_mesh = g->device_handle();
+				if (!g->uvs.empty() && g->normals.empty()) { g->sync_tangents(); m.tangentSoup = g->tangentSoup.empty() ? nullptr : &g->tangentSoup[0][0]; }   // (UVs without normals: tangents from the host loop)
+			} else {
+				m.nodes = reinterpret_cast<const mipt_bvh_node*>(g->bvh.nodes.data());
+				m.triangleSoup = g->triangleSoup.data(); m.indices = g->indices.data();
+				m.tangentSoup = g->tangentSoup.empty() ? nullptr : &g->tangentSoup[0][0];
+			}
 			d.mesh = &m;
 		}
 	}
@@ -1925,7 +2005,7 @@ void mh_get_object_matrices(mh_raytracer* h, int obj, float* t, float* inv, floa
 }
 void mh_mesh_counts(mh_raytracer* h, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs) {
 	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
-	*ntri = (int)g->indices.size(); *nnodes = (int)g->bvh.nodes.size(); *nverts = (int)g->vertices.size(); *nnormals = (int)g->normals.size(); *nuvs = (int)g->uvs.size();
+	*ntri = (int)g->indices.size(); *nnodes = g->node_count(); *nverts = (int)g->vertices.size(); *nnormals = (int)g->normals.size(); *nuvs = (int)g->uvs.size();
 }
 int mh_mesh_bvh_builder(mh_raytracer* h, int obj, double* seconds, double* device_seconds) {
 	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
@@ -1933,8 +2013,17 @@ int mh_mesh_bvh_builder(mh_raytracer* h, int obj, double* seconds, double* devic
 	if (device_seconds) *device_seconds = g->bvh_device_seconds;
 	return g->bvh_builder;
 }
+int mh_mesh_tangents(mh_raytracer* h, int obj, float* out) {
+	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
+	g->sync_tangents();
+	if (g->tangentSoup.empty()) return 0;
+	const size_t n = g->tangentSoup.size() * 3;
+	if (out) memcpy(out, &g->tangentSoup[0][0], n * sizeof(float));
+	return (int)n;
+}
 void mh_mesh_dump(mh_raytracer* h, int obj, int* perm, int* nodes_i, float* nodes_bb, float* soup, int* groups, float* root_bb) {
 	TriMesh* g = static_cast<TriMesh*>(h->rt.s.objects[obj]);
+	g->sync_host();                       // (a mesh built on the device: this is where its reference-layout views are fetched)
 	const int nt = (int)g->indices.size();
 	for (int i = 0; i < nt; i++) {
 		if (perm) perm[i] = g->permuted_triangle_index[i];

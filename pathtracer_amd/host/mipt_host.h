@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include <sys/mman.h>
 #include <cstdlib>
@@ -64,7 +65,10 @@ template <class T> struct default_init_allocator : std::allocator<T> {
 		return static_cast<T*>(p);
 	}
 	void deallocate(T* p, size_t) noexcept { free(p); }
-	template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+	// (default construction of a trivially copyable element is skipped altogether: `Vector` has a zeroing default constructor, and the
+	//  vertex / normal arrays of a 23.7 M-triangle mesh were zero-filled by ONE thread — page faults included — before the threads of the
+	//  constructor overwrote them: 70 ms.  Every PodVec in this library is written completely before it is read.)
+	template <class U> void construct(U* p) noexcept { if constexpr (!(std::is_trivially_copyable<U>::value && std::is_trivially_destructible<U>::value)) ::new (static_cast<void*>(p)) U; else (void)p; }
 	template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
 };
 template <class T> using PodVec = std::vector<T, default_init_allocator<T>>;
@@ -138,16 +142,30 @@ public:
 	bool loaded = true;
 	std::string load_error;
 	std::map<std::string, int> groupNames;   // usemtl name -> material group (TriangleMesh.h:228)
-	std::vector<Vector> vertices, normals, uvs;
+	PodVec<Vector> vertices, normals, uvs;    // (not zero-filled on resize: the constructors write every element on their threads)
 	PodVec<mipt_triangle_indices> indices;
 	PodVec<mipt_triangle> triangleSoup;       // (not zero-filled on resize: TriMesh::init writes every record on its threads)
 	PodVec<Vector> tangentSoup;
-	std::vector<int> permuted_triangle_index;
+	PodVec<int> permuted_triangle_index;
 	struct { float bbox[6]; PodVec<BVHNodes> nodes; } bvh;
 	float bbox[6];
-	int bvh_builder = 0;                 // who built bvh.nodes: 0 = the host recursion, 1 = mipt_build_bvh on the GPU
+	int bvh_builder = 0;                 // who built bvh.nodes: 0 = the host recursion, 1 = mipt_build_bvh on the GPU, 2 = mipt_device_mesh_build (tree + records stay on the device)
 	double bvh_build_seconds = 0, bvh_device_seconds = 0;
+	// Round 4: with builder 2 the tree, the reordered Triangle records and the tangents exist on the DEVICE after init; the members
+	// above that mirror the reference's host arrays — bvh.nodes, triangleSoup, tangentSoup, the REORDERED indices and
+	// permuted_triangle_index — are views that sync_host() downloads / derives on first use (until then `indices` is in input order and
+	// the others are empty).  Everything inside this library that reads them calls sync_host() first; so must outside code.
+	~TriMesh();
+	void sync_host();                    // materialise bvh.nodes, the permutation, the reordered indices and triangleSoup (no-op when they are current)
+	void sync_tangents();                // + tangentSoup (downloaded from the device, or setup_tangents on the host)
+	int node_count() const { return device_mesh ? device_nodes : (int)bvh.nodes.size(); }
+	const mipt_device_mesh* device_handle() const { return device_mesh; }
 private:
+	mipt_device_mesh* device_mesh = nullptr;
+	int device_nodes = 0;
+	bool host_views_current = true, tangents_current = true;
+	bool build_device_resident();
+	void build_triangle_soup();
 	bool bvh_gpu_unavailable = false;
 	bool build_bvh_gpu();
 	bool readOBJ(const char* obj, bool load_textures);
@@ -302,6 +320,7 @@ int  mh_add_mesh(mh_raytracer*, int nv, const float* verts, int nn, const float*
                  int nf, const int* fv, const int* fn, const int* ft, float scale, int center);
 void mh_set_obj_slicing(int slice_bytes, int max_slices);    // test hook: readOBJ parses slices of the file concurrently (default 1 MiB, one per hardware thread)
 void mh_set_bvh_builder(int mode, int device);              // 0 host recursion, 1 GPU, 2 GPU if present else host (default)
+void mh_set_device_resident(int on);                        // GPU builder: 1 (default) the tree and the records stay on the device (mipt_device_mesh_build), 0 fetched back (mipt_build_bvh)
 int  mh_mesh_bvh_builder(mh_raytracer*, int obj, double* seconds, double* device_seconds);   // 0 host / 1 GPU built this mesh
 void mh_set_build_thresholds(int fork_tris, int planes_tris);   // test hook: when the (tree-identical) parallel BVH build forks
 void mh_set_object_flags(mh_raytracer*, int obj, int miroir, int flip_normals);
@@ -340,4 +359,5 @@ void mh_get_tables(mh_raytracer*, float* randomPerPixel, float* samples2d, float
 void mh_get_object_matrices(mh_raytracer*, int obj, float* trans12, float* inv12, float* rot9);
 void mh_mesh_counts(mh_raytracer*, int obj, int* ntri, int* nnodes, int* nverts, int* nnormals, int* nuvs);
 void mh_mesh_dump(mh_raytracer*, int obj, int* perm, int* nodes_i, float* nodes_bb, float* soup, int* groups, float* root_bb);
+int mh_mesh_tangents(mh_raytracer*, int obj, float* out9_per_triangle);     // TriMesh::tangentSoup (synchronised from the device first); returns the number of floats written (0: a mesh without UVs)
 }

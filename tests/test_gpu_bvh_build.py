@@ -127,6 +127,67 @@ def test_gpu_bvh_against_the_reference_goldens(name):
     assert np.array_equal(d["groups"], g["groups"])
 
 
+@pytest.mark.parametrize("name", ["cornell", "blob32", "glossy", "glass", "textured", "cutout", "merl"])
+def test_device_resident_mesh_against_the_reference_goldens(name):
+    """Round 4: TriMesh::init leaves the tree, the Triangle records and the tangents on the device (mipt_device_mesh_build).  The
+    reference-layout views the host mirror fetches on demand are the compiled reference's, like the round-3 path's above."""
+    from helpers import load_golden
+    g = load_golden(f"scene_{name}.npz")
+    capi.set_bvh_builder("gpu", 0)
+    try:
+        H = capi.HostRaytracer()
+        mesh, cfg, oid = setup_scene_no_device(H, name)
+        assert H.mesh_bvh_builder(oid)[0] == "gpu" and H.mesh_on_device(oid)
+        d = H.mesh_dump(oid)              # sync_host(): downloads bvh.nodes + the permutation, derives the reordered indices and triangleSoup
+    finally:
+        capi.set_bvh_builder("auto", 0)
+    assert np.array_equal(d["perm"], g["perm"]) and np.array_equal(d["nodes_i"], g["nodes_i"]) and np.array_equal(d["nodes_bb"], g["nodes_bb"])
+    assert np.array_equal(d["soup"][:, :16].view(np.uint32), g["soup16"].view(np.uint32)) and np.array_equal(d["groups"], g["groups"])
+
+
+@pytest.mark.parametrize("name", ["textured", "cutout", "glossy", "merl"])
+def test_device_made_records_render_like_host_made_ones(name):
+    """The records the device derives from its tree (fat nodes, intersection / shading records, UV index triples, tangents) against
+    those convert_mesh packs on the host from the downloaded tree: per-sample radiance of the golden scene, bit for bit — it covers
+    textures through the UVs, the alpha test through the index triples, normal interpolation, the tangent frame (every OBJ-style mesh
+    carries a null normal map: TriangleMesh.cpp:952-970 runs whenever the list exists)."""
+    from make_golden import golden_scene
+    out = {}
+    for resident in (True, False):
+        capi.set_device_resident(resident)
+        try:
+            H = capi.HostRaytracer(device=0)
+            mesh, cfg, mat = golden_scene(name)
+            H.apply_config(cfg)
+            oid = H.add_mesh(mesh)
+            assert H.mesh_on_device(oid) == resident
+            scenes.install_material(H, oid, mat)
+            H.prepare()
+            pix = np.stack(np.meshgrid(np.arange(0, cfg.H, 3), np.arange(0, cfg.W, 3), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+            out[resident] = H.sample_radiance(pix, 0, min(cfg.spp, 4))[0]
+        finally:
+            capi.set_device_resident(True)
+    assert np.array_equal(out[True].view(np.uint32), out[False].view(np.uint32))
+
+
+def test_device_tangents_are_the_host_loop_s():
+    """setup_tangents on the device (per-vertex sums in ascending face order, a UV sphere's poles with a thousand incident faces)
+    against the host loop, bit for bit, through the lazily downloaded tangentSoup."""
+    H = capi.HostRaytracer()
+    H.apply_config(scenes.config_c1(16, 16, 1))
+    mesh = scenes.blob_mesh(96, with_uv=True)
+    a = H.add_mesh(mesh)
+    capi.set_device_resident(False)
+    try:
+        b = H.add_mesh(mesh)
+    finally:
+        capi.set_device_resident(True)
+    assert H.mesh_on_device(a) and not H.mesh_on_device(b)
+    ta, tb = H.mesh_tangents(a), H.mesh_tangents(b)
+    assert ta.shape == tb.shape and ta.shape[0] == mesh.ntri * 3
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+
+
 def setup_scene_no_device(H, name):
     """tests/golden/make_golden.py's setup() without the upload at the end (the context has no device; only TriMesh::init runs)."""
     from make_golden import golden_scene

@@ -250,9 +250,13 @@ def test_degenerate_deep_bvh_is_refused_not_overrun():
     """A chain-shaped BVH deeper than the traversal stack (hand-built node array through the C ABI) must be refused at
     upload; the reference's own fixed-size stack is undefined behaviour there (TriangleMesh.cpp:1153)."""
     import ctypes as C
-    rt = capi.HostRaytracer(device=0)
-    rt.apply_config(scenes.config_c1(8, 8, 1))
-    oid = rt.add_mesh(scenes.blob_mesh(8))
+    capi.set_device_resident(False)                           # (the scene description must carry host arrays: the test swaps the node array)
+    try:
+        rt = capi.HostRaytracer(device=0)
+        rt.apply_config(scenes.config_c1(8, 8, 1))
+        oid = rt.add_mesh(scenes.blob_mesh(8))
+    finally:
+        capi.set_device_resident(True)
     rt.prepare()                                              # a valid upload first
     # now hand the ABI a 60-level chain: node i = inner(i+1, leaf), built over the first triangles of the same mesh
     desc = C.cast(rt.host.mh_scene_desc(rt.h), C.POINTER(capi.MiptSceneDesc)).contents

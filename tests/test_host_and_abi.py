@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     assert declared == set(capi.MIPT_SYMBOLS), declared ^ set(capi.MIPT_SYMBOLS)
     for s in declared:
         assert hasattr(mipt, s), s
-    assert mipt.mipt_abi_version() == 2
+    assert mipt.mipt_abi_version() == 3
 
 
 def test_no_device_means_error_not_fallback():

@@ -9,6 +9,7 @@ mesh, cfg, mat, text = scenes.workload(wl, spp=4)
 for rep in range(3):
     rt = capi.HostRaytracer(device=0)
     rt.apply_config(cfg)
+    os.environ['MIPT_CTOR_TRACE'] = '1'
     t0 = time.time(); oid = rt.add_mesh(mesh); t1 = time.time()
     who, s, dev = rt.mesh_bvh_builder(oid)
     t2 = time.time(); rt.prepare(); t3 = time.time()

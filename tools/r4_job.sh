@@ -1,2 +1,14 @@
-mkdir -p gpurun_out/r4e; rm -f gpurun_out/sweep.log
-bash tools/sweep_libs.sh "norl" "rl6" "rl6c" "rl5" "norl6" "rl6 --opt inner_min=36" "rl6 --opt refill_threshold=16" "rl6 --workload c3" "norl --workload c3" "rl6 --workload c1" "norl --workload c1" 2>&1 | tee gpurun_out/r4e/sweep_waves.txt
+mkdir -p gpurun_out/r4h
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r4h/gputests.txt 2>&1; head -6 gpurun_out/r4h/gputests.txt | tail -3
+python tools/init_time.py c2 2>&1 | grep -v "^\[" | tail -3
+python tools/init_time.py c4 > gpurun_out/r4h/init_c4.txt 2>&1; tail -18 gpurun_out/r4h/init_c4.txt
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r4h/bench_c2.json 2> gpurun_out/r4h/bench_c2.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4h/bench_c2.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','host_bvh_build_s','prepare_s','bvh_build')})
+PY
+python bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload c4 > gpurun_out/r4h/bench_c4.json 2> gpurun_out/r4h/bench_c4.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4h/bench_c4.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','host_bvh_build_s','prepare_s','bvh_build')})
+PY
