@@ -988,8 +988,58 @@ static int plane_reservoir_intersection(const o_obj* p, const o_ray* d, v3* P, f
 	query_material(p, 0, u, v, mat);
 	return 1;
 }
+/* Sphere::reservoir_sampling_intersection (Geometry.h:994-1068): the sphere's roots in [min_t, max_t), in root order, each drawing from
+   the engine; the kept one's material is looked up at spherical coordinates computed with DOUBLE intermediates (`1 - acos(N[1]) / M_PI`,
+   `(atan2(...) + M_PI) / (2.*M_PI)` narrowed to float) — unlike Sphere::intersection's all-float ones (:976-977). */
+static int sphere_reservoir_intersection(const o_obj* s, const o_ray* d, v3* P, float* t, o_mat* mat, int* triangle_id, int* current_nb_intersections,
+                                         float min_t, float max_t, pcg32_t* rng) {
+	if (s->has_envmap) return 0;
+	float b = vdot(d->direction, vsub(d->origin, s->O));
+	float a = vnorm2(d->direction);
+	float c = vnorm2(vsub(d->origin, s->O)) - s->R2;
+	float delta = b * b - a * c;
+	if (delta < 0) return 0;
+	float sqDelta = sqrtf(delta);
+	float inva = 1.f / a;
+	float t2 = (-b + sqDelta) * inva;
+	if (t2 < min_t) return 0;
+	float t1 = (-b - sqDelta) * inva;
+	int has_inter = 0;
+	if (t1 >= min_t) {
+		if (t1 < max_t) {
+			(*current_nb_intersections)++;
+			float r1 = pcg_uniform(rng);
+			if (r1 < 1.f / *current_nb_intersections) { *t = t1; has_inter = 1; }
+		}
+		if (t2 < max_t) {
+			(*current_nb_intersections)++;
+			float r1 = pcg_uniform(rng);
+			if (r1 < 1.f / *current_nb_intersections) { *t = t2; has_inter = 1; }
+		}
+	} else {
+		if (t2 < max_t) {
+			(*current_nb_intersections)++;
+			float r1 = pcg_uniform(rng);
+			if (r1 < 1.f / *current_nb_intersections) { *t = t2; has_inter = 1; }
+		}
+	}
+	if (!has_inter) return 0;
+	*P = vadd(d->origin, vscale(*t, d->direction));
+	v3 N = vsub(*P, s->O);
+	if (s->ntex[T_KD] != 0 || s->ntex[T_KS] != 0 || s->ntex[T_NE] != 0 || s->ntex[T_TRANSP] != 0 || s->ntex[T_REFR] != 0) {
+		N = vfast_normalize(N);
+		float theta = 1 - acosf(N.y) / M_PI;
+		float phi = (atan2f(-N.z, N.x) + M_PI) / (2. * M_PI);
+		query_material(s, 0, theta, phi, mat);
+	}
+	mat->shadingN = N;
+	mat->Ke = V(0.f, 0.f, 0.f);
+	if (s->flip_normals) mat->shadingN = vneg(mat->shadingN);
+	*triangle_id = -1;
+	return 1;
+}
 /* Scene::get_random_intersection (Geometry.cpp:339-470) restricted to one object (sphere_id != -1), which is how the
-   subsurface branch calls it; meshes and planes (a sphere has no subsurface colour in scope: textured spheres are not). */
+   subsurface branch calls it. */
 static int scene_get_random_intersection(const o_ctx* c, const o_ray* d, v3* P, int sphere_id, float* min_t, o_mat* mat, int* triangle_id, float tmin, float tmax, pcg32_t* rng) {
 	int has_inter = 0;
 	*min_t = INFINITY;
@@ -1000,6 +1050,7 @@ static int scene_get_random_intersection(const o_ctx* c, const o_ray* d, v3* P, 
 	tr.origin = apply_inverse_transformation(o, d->origin);
 	if (o->type == OT_TRIMESH) has_inter = mesh_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
 	else if (o->type == OT_PLANE) has_inter = plane_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
+	else has_inter = sphere_reservoir_intersection(o, &tr, P, min_t, mat, triangle_id, &nb_intersections, tmin, tmax, rng);
 	if (has_inter) {
 		*P = apply_transformation(o, *P);
 		mat->shadingN = apply_rotation(o, mat->shadingN);

@@ -832,8 +832,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		for (int k = 0; k < o.n_subsurface; k++) {   // a subsurface colour (constant or image): the scene is rendered by the queue kernel
 			const mipt_texture& t = o.subsurface[k];
 			if (t.W > 0 || t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0) {
-				if (o.type == MIPT_OBJ_SPHERE) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: subsurface scattering on a sphere", i);
-				scene_ghost = true; scene_subs = true;
+				scene_ghost = true; scene_subs = true;      // (on a sphere too since round 4: Sphere::reservoir_sampling_intersection, mipt_compositing.h)
 			}
 		}
 		for (int sl = 0; sl < MIPT_TEX_SLOTS; sl++) {
@@ -936,6 +935,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (d.type != MIPT_OBJ_TRIMESH) continue;
 		d.nodes = H.all_nodes; d.tris = H.all_tris; d.shade = all_shade + d.tri_base;
 	}
+	if (scene_subs && sphere_extra) scene_inherit = true;      // Ksub inherited like Kd / Ks / Ne: the reference's loop as it runs
 	H.inherit_material = scene_inherit ? 1 : 0;
 	const DScene* dsc = nullptr;
 	rc = upload(c, hs.data(), 1, &dsc);
@@ -945,7 +945,9 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;
 	c->scene_has_subsurface = scene_subs;
-	if (scene_subs && sphere_extra) return fail(c, MIPT_ERR_UNSUPPORTED, "a sphere without material lists in a scene with subsurface colours (it leaves the Ksub of the object tested before it in place; a sphere with lists writes Ksub = 0 and is fine)");
+	// (a sphere without material lists — mirror or not — beside subsurface colours: it leaves the Ksub of the object tested before it in
+	//  place, and getColor reads Ksub before the mirror branch (Raytracer.cpp:271, 318).  Since round 4 the one-thread-per-sample loop
+	//  carries that Ksub too (scene_intersect_inherit): the scene is rendered, H.inherit_material was set above.)
 	c->d_background = nullptr; c->backgroundW = c->backgroundH = 0;
 	if (s->background && s->backgroundW > 0 && s->backgroundH > 0) {
 		int rc = upload(c, s->background, (size_t)s->backgroundW * s->backgroundH * 3, &c->d_background);

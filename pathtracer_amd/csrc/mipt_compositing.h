@@ -89,34 +89,26 @@ __device__ __attribute__((noinline)) bool mesh_reservoir(const DObject& o, f3 or
 	}
 	return has_inter;
 }
-// MaterialValues::Ksub of a hit (Object::queryMaterial, Geometry.h:418-424): subsurface[group] at the hit's texture
-// coordinates for a mesh (TriMesh::getMaterial), subsurface[0] at (x, z)/10 for a plane (Geometry.h:1150-1155); a sphere in
-// scope has no material lists.  `Pl` = the hit point in the object's frame.
-MIPT_DEV f3 hit_ksub(const DObject& o, const Hit& h, f3 Pl) {
-	if (o.type == 2) {
-		if (o.ntex[MT_KSUB] <= 0) return mk3(0, 0, 0);
-		return tex_getVec(o.tex[MT_KSUB][0], tex_wrap(Pl.x * 0.1f), tex_wrap(Pl.z * 0.1f));
-	}
-	if (o.type != 0 || h.tri < 0) return mk3(0, 0, 0);
-	const float4* q = reinterpret_cast<const float4*>(o.shade + h.tri);
-	const float4 q2 = q[2], q3 = q[3];
-	const int graw = __float_as_int(q3.w);
-	const int group = graw >= 0 ? (graw & MIPT_GROUP_MASK) : graw;
-	if ((unsigned)group >= (unsigned)o.ntex[MT_KSUB]) return mk3(0, 0, 0);
-	float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;        // as hit_material_obj / mesh_material
-	if (isnan(alpha) && isnan(beta) && isnan(gamma)) { alpha = 1; beta = 0; gamma = 0; }
-	if (isnan(alpha)) alpha = 0;
-	if (isnan(beta)) beta = 0;
-	if (isnan(gamma)) gamma = 0;
-	if (isinf(alpha)) alpha = 1;
-	if (isinf(beta)) beta = 1;
-	if (isinf(gamma)) gamma = 1;
-	float u = 0, v = 0;
-	if (o.nuvs != 0 && graw >= 0 && (graw & MIPT_GROUP_UV_OK)) {
-		u = (q2.y * alpha + q2.w * beta + q3.y * gamma);
-		v = (q2.z * alpha + q3.x * beta + q3.z * gamma);
-	}
-	return tex_getVec(o.tex[MT_KSUB][group], tex_wrap(u), tex_wrap(v));
+// Sphere::reservoir_sampling_intersection (Geometry.h:994-1050): the roots in [min_t, max_t) in root order, one engine draw each, the
+// second replacing the first with probability 1/2 (`r1 < 1.f / count`, float).  The material follows in hit_material_obj(.., probe = true).
+MIPT_DEV bool sphere_reservoir(const DObject& s, f3 o, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out) {
+	if (s.has_envmap) return false;
+	const f3 oc = o - ld3(s.O);
+	const float b = dot(d, oc);
+	const float a = norm2(d);
+	const float c = norm2(oc) - s.R2;
+	const float delta = b * b - a * c;
+	if (delta < 0) return false;
+	const float sqDelta = sqrtf(delta);
+	const float inva = 1.f / a;
+	const float t2 = (-b + sqDelta) * inva;
+	if (t2 < min_t) return false;
+	const float t1 = (-b - sqDelta) * inva;
+	bool has_inter = false;
+	int count = 0;
+	if (t1 >= min_t && t1 < max_t) { count++; const float r1 = pcg_uniform(rng); if (r1 < 1.f / (float)count) { t_out = t1; has_inter = true; } }
+	if (t2 < max_t) { count++; const float r1 = pcg_uniform(rng); if (r1 < 1.f / (float)count) { t_out = t2; has_inter = true; } }
+	return has_inter;
 }
 // Plane::reservoir_sampling_intersection (Geometry.h:1159-1183): the single intersection, kept with probability 1/count
 MIPT_DEV bool plane_reservoir(const DObject& p, f3 o, f3 d, float min_t, float max_t, uint64_t& rng, float& t_out) {
@@ -292,7 +284,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 		}
 		const DObject& obj = sc->obj[h.obj];
 		const double* const merl = obj.merl;
-		f3 Ksub = hit_ksub(obj, h, xf_point(obj.inv, currentRay.o) + h.t * xf_dir(obj.inv, currentRay.d));
+		f3 Ksub = sc->inherit_material ? m.Ksub : hit_ksub(obj, h, xf_point(obj.inv, currentRay.o) + h.t * xf_dir(obj.inv, currentRay.d));     // (inherit: what Scene::intersection's one MaterialValues held for the winner)
 		const bool is_subsurface = norm2(Ksub) > 1E-8;                      // :271
 		const float subsProba = (hadSS || !is_subsurface) ? 0.f : 0.6f;     // :318
 		const float inv1MSubsProba = 1.f / (1.f - subsProba);
@@ -332,11 +324,12 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 			Hit sh; sh.obj = h.obj; sh.tri = -1; sh.t = 0; sh.beta = sh.gamma = 0;
 			const f3 po = xf_point(obj.inv, probe.o), pd = xf_dir(obj.inv, probe.d);
 			const bool subsinter = obj.type == 2 ? plane_reservoir(obj, po, pd, 0.f, tmax, ps.rng, sh.t)
+			                     : obj.type == 1 ? sphere_reservoir(obj, po, pd, 0.f, tmax, ps.rng, sh.t)
 			                                     : mesh_reservoir(obj, po, pd, 0.f, tmax, ps.rng, sh.t, sh.tri, sh.beta, sh.gamma, stk);
 			if (subsinter) {
 				f3 localP2; Mat subsmat;
 				subsmat.shadingN = mk3(0, 1, 0); subsmat.Kd = mk3(0.5f, 0.5f, 0.5f); subsmat.Ks = mk3(0, 0, 0); subsmat.Ne = mk3(100, 100, 100); subsmat.Ke = mk3(0, 0, 0); subsmat.transp = false; subsmat.refr_index = 0;
-				hit_material_obj(obj, probe, sh, localP2, subsmat);
+				hit_material_obj(obj, probe, sh, localP2, subsmat, false, true);
 				const float chris = (float)pt_exp64((double)(-norm2(P - localP2)) / (2. * (double)sigmasub * (double)sigmasub));
 				const double d0 = 0.5 * (double)dot(subsmat.shadingN, N), d1 = 0.25 * (double)dot(subsmat.shadingN, Tg), d2 = 0.25 * (double)dot(subsmat.shadingN, Tg2);
 				const float sumpdfs = (float)((d0 * d0 + d1 * d1) + d2 * d2);
@@ -347,7 +340,7 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 				if (r1s < 0.5f) subsW = subsW * 2.f; else subsW = subsW * 4.f;
 				subsW = subsW * (Ksub / (float)MIPT_PI);
 				m = subsmat;
-				Ksub = hit_ksub(obj, sh, po + sh.t * pd);
+				Ksub = hit_ksub(obj, sh, po + sh.t * pd, true);
 				N = m.shadingN;
 			}
 		}

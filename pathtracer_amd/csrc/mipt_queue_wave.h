@@ -463,7 +463,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					Ray probe; probe.o = subsOrigin; probe.d = axis;
 					Hit sh; sh.obj = h.obj; sh.tri = -1; sh.t = 0; sh.beta = sh.gamma = 0;
 					const f3 po = xf_point(obj.inv, probe.o), pd = xf_dir(obj.inv, probe.d);
-					if (obj.type != 2 && !a1_from_probe) {                       // a mesh: get_random_intersection is the probe stage's
+					if (obj.type == 0 && !a1_from_probe) {                       // a mesh: get_random_intersection is the probe stage's
 						FRS(12, hr);
 						FRS(6, make_float4(gauss0, gauss1, gauss2, r1s));
 						FRS(7, make_float4(r2_low ? 1.f : 0.f, 0.f, 0.f, 0.f));
@@ -479,11 +479,11 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 						const float4 pr = QW_LD(&wf.hit[id]);
 						subsinter = __float_as_uint(pr.w) != MIPT_HIT_MISS;
 						sh.t = pr.x; sh.beta = pr.y; sh.gamma = pr.z; sh.tri = (int)__float_as_uint(pr.w);
-					} else subsinter = plane_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t);
+					} else subsinter = obj.type == 1 ? sphere_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t) : plane_reservoir(obj, po, pd, 0.f, tmax, S.rng, sh.t);
 					if (subsinter) {
 						f3 localP2; Mat subsmat;
 						subsmat.shadingN = mk3(0, 1, 0); subsmat.Kd = mk3(0.5f, 0.5f, 0.5f); subsmat.Ks = mk3(0, 0, 0); subsmat.Ne = mk3(100, 100, 100); subsmat.Ke = mk3(0, 0, 0); subsmat.transp = false; subsmat.refr_index = 0;
-						hit_material_obj(obj, probe, sh, localP2, subsmat);
+						hit_material_obj(obj, probe, sh, localP2, subsmat, false, true);
 						const float chris = (float)pt_exp64((double)(-norm2(P - localP2)) / (2. * (double)sigmasub * (double)sigmasub));
 						const double d0 = 0.5 * (double)dot(subsmat.shadingN, Nn), d1 = 0.25 * (double)dot(subsmat.shadingN, Tg), d2 = 0.25 * (double)dot(subsmat.shadingN, Tg2);
 						const float sumpdfs = (float)((d0 * d0 + d1 * d1) + d2 * d2);
@@ -494,7 +494,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 						if (r1s < 0.5f) subsW = subsW * 2.f; else subsW = subsW * 4.f;
 						subsW = subsW * (Ksub / (float)MIPT_PI);
 						m = subsmat;
-						Ksub = hit_ksub(obj, sh, po + sh.t * pd);
+						Ksub = hit_ksub(obj, sh, po + sh.t * pd, true);
 						Nn = m.shadingN;
 					}
 				}

@@ -13,6 +13,7 @@ struct Ray { f3 o, d; };
 
 struct Mat {                       // MaterialValues (BRDF.h:7-20)
 	f3 shadingN, Kd, Ks, Ne, Ke;
+	f3 Ksub;                       // filled by scene_intersect_inherit only (elsewhere the vertex logic asks hit_ksub)
 	bool transp;
 	float refr_index;
 	// of the object that was hit (not MaterialValues: read with the object's first 64 bytes by hit_material_obj, so that the
@@ -457,7 +458,10 @@ MIPT_DEV void mesh_material(const DObject& o, int tri, float alpha, float beta, 
 // Sphere material (Geometry.h:948-991)
 // inherit: `mat` is the ONE MaterialValues of Scene::intersection's loop (scene_intersect_inherit below) — a sphere without lists leaves
 // in it what the object tested before wrote; otherwise such a sphere (the light; upload lets no other one through) gets the defaults
-MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat, bool inherit = false) {
+// probe: the hit comes from Sphere::reservoir_sampling_intersection (the subsurface probe, Geometry.h:1053-1068), whose spherical
+// coordinates are computed with double intermediates (`1 - acos(N[1]) / M_PI`, `(atan2(..) + M_PI) / (2.*M_PI)`) where
+// Sphere::intersection's are all float (:976-977)
+MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat, bool inherit = false, bool probe = false) {
 	f3 N = Plocal - ld3(s.O);
 	// MaterialValues() defaults for the fields a texture-less sphere never writes (BRDF.h:9-16)
 	if (!inherit) { mat.Kd = mk3(0.5f, 0.5f, 0.5f); mat.Ks = mk3(0, 0, 0); mat.Ne = mk3(100, 100, 100); mat.transp = false; mat.refr_index = 0.f; }
@@ -478,6 +482,10 @@ MIPT_DEV void sphere_material(const DObject& s, f3 Plocal, Mat& mat, bool inheri
 		N = fast_normalize(N);
 		float theta = 1.f - mipt_acosf(N.y) / (float)MIPT_PI;
 		float phi = (mipt_atan2f(-N.z, N.x) + (float)MIPT_PI) / (2.f * (float)MIPT_PI);
+		if (probe) {
+			theta = (float)(1. - (double)mipt_acosf(N.y) / MIPT_PI);
+			phi = (float)(((double)mipt_atan2f(-N.z, N.x) + MIPT_PI) / (2. * MIPT_PI));
+		}
 		query_material(s, 0, theta, phi, mat);
 	}
 	mat.shadingN = s.flip_normals ? -N : N;
@@ -513,13 +521,13 @@ MIPT_DEV bool scene_closest(const DScene* __restrict__ sc, Ray r, Hit& h, STK& s
 
 // World-space hit point and MaterialValues of the winning object (tail of Scene::intersection,
 // Geometry.cpp:668-684, plus the winner's own material code).
-MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat, bool inherit = false) {
+MIPT_DEV void hit_material_obj(const DObject& o, Ray r, const Hit& h, f3& P, Mat& mat, bool inherit = false, bool probe = false) {
 	const ObjHot hot = load_obj_hot(o);                  // (issued together with the matrix loads below)
 	f3 d = xf_dir(o.inv, r.d);
 	f3 org = xf_point(o.inv, r.o);
 	f3 Pl = org + h.t * d;                               // P = d.origin + t*d.direction in the object's frame
 	mat.miroir = hot.miroir; mat.merl = hot.merl;
-	if (hot.type == 1) sphere_material(o, Pl, mat, inherit);
+	if (hot.type == 1) sphere_material(o, Pl, mat, inherit, probe);
 	else if (hot.type == 2) { mat.shadingN = ld3(o.vecN); query_material(o, hot.gmat, hot.ngroups, 0, Pl.x * 0.1f, Pl.z * 0.1f, mat); }
 	else {
 		float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;
@@ -540,6 +548,46 @@ MIPT_DEV void hit_material(const DScene* __restrict__ sc, Ray r, const Hit& h, f
 // (A wave-uniform loop over the objects, with scalar loads of the description, was measured slower in the shade stage:
 // the material chains of the distinct objects in a wave then run one after the other.)
 
+// MaterialValues::Ksub of a hit (Object::queryMaterial, Geometry.h:418-424): subsurface[group] at the hit's texture
+// coordinates for a mesh (TriMesh::getMaterial), subsurface[0] at (x, z)/10 for a plane (Geometry.h:1150-1155); a sphere with
+// lists: subsurface[0] at the spherical coordinates of the normal.  `Pl` = the hit point in the object's frame.
+MIPT_DEV f3 hit_ksub(const DObject& o, const Hit& h, f3 Pl, bool probe = false) {
+	if (o.type == 1) {
+		// a sphere: queryMaterial(0, theta, phi) runs only when one of the Kd / Ks / Ne / transparency / index lists exists (Geometry.h:975, 1056)
+		// — a sphere without them leaves Ksub as it was (upload keeps such scenes away) —, at the coordinates sphere_material computes
+		if (o.ntex[MT_KSUB] <= 0 || !(o.has_envmap || o.ntex[MT_KD] != 0 || o.ntex[MT_KS] != 0 || o.ntex[MT_NE] != 0 || o.ntex[MT_TRANSP] != 0 || o.ntex[MT_REFR] != 0)) return mk3(0, 0, 0);
+		const f3 N = fast_normalize(Pl - ld3(o.O));
+		float theta = 1.f - mipt_acosf(N.y) / (float)MIPT_PI;
+		float phi = o.has_envmap ? (float)(((double)mipt_atan2f(-N.z, N.x) + MIPT_PI) / (double)(2.f * (float)MIPT_PI)) : (mipt_atan2f(-N.z, N.x) + (float)MIPT_PI) / (2.f * (float)MIPT_PI);
+		if (probe) { theta = (float)(1. - (double)mipt_acosf(N.y) / MIPT_PI); phi = (float)(((double)mipt_atan2f(-N.z, N.x) + MIPT_PI) / (2. * MIPT_PI)); }
+		return tex_getVec(o.tex[MT_KSUB][0], tex_wrap(theta), tex_wrap(phi));
+	}
+	if (o.type == 2) {
+		if (o.ntex[MT_KSUB] <= 0) return mk3(0, 0, 0);
+		return tex_getVec(o.tex[MT_KSUB][0], tex_wrap(Pl.x * 0.1f), tex_wrap(Pl.z * 0.1f));
+	}
+	if (o.type != 0 || h.tri < 0) return mk3(0, 0, 0);
+	const float4* q = reinterpret_cast<const float4*>(o.shade + h.tri);
+	const float4 q2 = q[2], q3 = q[3];
+	const int graw = __float_as_int(q3.w);
+	const int group = graw >= 0 ? (graw & MIPT_GROUP_MASK) : graw;
+	if ((unsigned)group >= (unsigned)o.ntex[MT_KSUB]) return mk3(0, 0, 0);
+	float beta = h.beta, gamma = h.gamma, alpha = 1 - beta - gamma;        // as hit_material_obj / mesh_material
+	if (isnan(alpha) && isnan(beta) && isnan(gamma)) { alpha = 1; beta = 0; gamma = 0; }
+	if (isnan(alpha)) alpha = 0;
+	if (isnan(beta)) beta = 0;
+	if (isnan(gamma)) gamma = 0;
+	if (isinf(alpha)) alpha = 1;
+	if (isinf(beta)) beta = 1;
+	if (isinf(gamma)) gamma = 1;
+	float u = 0, v = 0;
+	if (o.nuvs != 0 && graw >= 0 && (graw & MIPT_GROUP_UV_OK)) {
+		u = (q2.y * alpha + q2.w * beta + q3.y * gamma);
+		v = (q2.z * alpha + q3.x * beta + q3.z * gamma);
+	}
+	return tex_getVec(o.tex[MT_KSUB][group], tex_wrap(u), tex_wrap(v));
+}
+
 // Scene::intersection as the reference runs it, for scenes with a sphere that has no material lists (DScene::inherit_material):
 // ONE MaterialValues serves all objects of the loop (`localmat`, Geometry.cpp:596), every object that reports a hit — closer than the
 // best so far or not — writes its material into it (a mesh reports only closer hits, TriangleMesh.cpp:1198), a sphere without lists
@@ -553,7 +601,7 @@ __device__ __attribute__((noinline)) bool scene_intersect_inherit(const DScene* 
 	float min_t = __int_as_float(0x7f800000);
 	Mat localmat;                          // MaterialValues() (BRDF.h:9-16); transp and refr_index are not initialised there: false / 0 as in the oracle
 	localmat.shadingN = mk3(0, 1, 0); localmat.Kd = mk3(0.5f, 0.5f, 0.5f); localmat.Ks = mk3(0, 0, 0); localmat.Ne = mk3(100, 100, 100); localmat.Ke = mk3(0, 0, 0);
-	localmat.transp = false; localmat.refr_index = 0.f; localmat.miroir = 0; localmat.merl = nullptr;
+	localmat.transp = false; localmat.refr_index = 0.f; localmat.miroir = 0; localmat.merl = nullptr; localmat.Ksub = mk3(0, 0, 0);
 	const int nobj = sc->nobj;
 	for (int i = 0; i < nobj; i++) {
 		const DObject& o = sc->obj[i];
@@ -568,6 +616,9 @@ __device__ __attribute__((noinline)) bool scene_intersect_inherit(const DScene* 
 		Hit hi; hi.obj = i; hi.tri = tri; hi.t = t; hi.beta = b; hi.gamma = g;
 		f3 Pi;
 		hit_material_obj(o, r, hi, Pi, localmat, true);
+		// Ksub rides in the same MaterialValues: every object whose material code runs queryMaterial writes it (0 beyond its list), a
+		// sphere without lists leaves what the object before it wrote (Geometry.h:975)
+		if (!(o.type == 1 && !o.has_envmap && !(o.ntex[MT_KD] != 0 || o.ntex[MT_KS] != 0 || o.ntex[MT_NE] != 0 || o.ntex[MT_TRANSP] != 0 || o.ntex[MT_REFR] != 0))) localmat.Ksub = hit_ksub(o, hi, org + t * d);
 		if (t < min_t) { min_t = t; h = hi; P = Pi; mat = localmat; }
 	}
 	h.t = min_t;

@@ -296,7 +296,7 @@ def main_fog():
     np.savez_compressed(os.path.join(OUT, "fog.npz"), **g)
 
 
-SSS_KINDS = ("ss", "ssglossy", "ssfog", "ssghost", "sstex", "ssdeep", "ssplane", "ssimage")
+SSS_KINDS = ("ss", "ssglossy", "ssfog", "ssghost", "sstex", "ssdeep", "ssplane", "ssimage", "sssphere", "ssspheretex", "ssbare")
 
 
 def subsurface_scene(X, kind):
@@ -322,6 +322,21 @@ def subsurface_scene(X, kind):
     if kind == "sstex":
         X.set_group_texture(oid, 0, 0, scenes.checker_texture())
         X.set_envmap(scenes.sky_envmap())
+    if kind in ("sssphere", "ssspheretex"):               # round 4: a sphere with material lists scatters too (Sphere::reservoir_sampling_intersection,
+        sp = X.add_sphere((16, -16, 6), 9.0)              # Geometry.h:994-1068: both roots in root order, spherical coordinates with double intermediates)
+        X.add_group_material(sp, (0.8, 0.7, 0.6), (0.1, 0.1, 0.1), (30, 30, 30), 1.0, 1.3)
+        X.add_col_subsurface(sp, (0.9, 0.4, 0.2))
+        sp2 = X.add_sphere((-18, -19, 10), 7.0, flip_normals=True)
+        X.add_group_material(sp2, (0.5, 0.6, 0.9), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
+        X.add_col_subsurface(sp2, (0.3, 0.5, 0.9))
+        if kind == "ssspheretex":                         # the sphere's Kd and subsurface colour from images, looked up at (theta, phi)
+            X.set_group_texture(sp, 0, 0, scenes.checker_texture(32, 16, 5, 4))
+            X.set_group_subsurface(sp, 0, (1.0, 1.0, 1.0))
+            X.set_group_texture(sp, 0, 7, scenes.checker_texture(32, 16, 9, 4))
+    if kind == "ssbare":                                  # spheres WITHOUT lists (one a mirror) beside subsurface colours: Ksub is inherited from the
+        X.add_col_subsurface(2, (0.7, 0.6, 0.2))          # object tested before them, like Kd / Ks / Ne (Geometry.cpp:596), and read before the mirror branch
+        X.add_sphere((16, -16, 6), 9.0)
+        X.add_sphere((-18, -19, 10), 7.0, mirror=True)
     X.prepare()
     return cfg
 

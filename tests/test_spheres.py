@@ -133,7 +133,8 @@ def test_sphere_without_material_lists_takes_the_material_of_the_object_before_i
 def test_subsurface_colour_beside_spheres_with_material_lists():
     """Rounds 1-2 refused every extra sphere in a scene with subsurface colours.  Only a sphere WITHOUT lists inherits Ksub (the shared
     MaterialValues of Scene::intersection); a sphere with lists writes Ksub = 0 (Geometry.h:399-445).  HIP path (wavefront stages
-    with the subsurface probe) against the oracle; the list-less case stays refused."""
+    with the subsurface probe) against the oracle; the list-less case (a mirror: getColor reads Ksub before the mirror branch) was
+    refused until round 4 and now runs on the one-thread-per-sample kernel, Ksub inherited like Kd / Ks / Ne."""
     from oracle.binding import Oracle
     outs = []
     for X in (Oracle(), capi.HostRaytracer(device=0)):
@@ -149,10 +150,14 @@ def test_subsurface_colour_beside_spheres_with_material_lists():
         X.prepare()
         outs.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
     assert_bits(outs[1], outs[0], "per-sample radiance, subsurface mesh between two spheres")
-    H = capi.HostRaytracer(device=0)
-    H.apply_config(scenes.config_c1(16, 16, 1))
-    m = H.add_mesh(scenes.blob_mesh(8))
-    H.set_group_subsurface(m, 0, (0.8, 0.5, 0.3))
-    H.add_sphere((0, -20, 5), 4.0, mirror=True)
-    with pytest.raises(capi.MiptError, match="without material lists in a scene with subsurface"):
-        H.prepare()
+    outs = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        cfg = scenes.config_c1(32, 24, 3)
+        X.apply_config(cfg)
+        m = X.add_mesh(scenes.blob_mesh(8))
+        X.set_group_subsurface(m, 0, (0.8, 0.5, 0.3))
+        X.add_sphere((0, -20, 5), 4.0, mirror=True)
+        X.add_sphere((12, -18, 9), 5.0)
+        X.prepare()
+        outs.append(X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0])
+    assert_bits(outs[1], outs[0], "per-sample radiance, spheres without material lists beside a subsurface mesh")

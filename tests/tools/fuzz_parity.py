@@ -43,7 +43,9 @@ for it in range(n_scenes):
         for k in range(int(rng.integers(1, 4))):
             sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 6 if BARE else 5)),
                             first=bool(rng.random() < 0.3), flip=bool(rng.random() < 0.15), Kd=rng.uniform(0.05, 1, 3), Ks=rng.uniform(0, 0.6, 3), Ne=rng.uniform(1, 200, 3)))
-    sph_lists = all(q["kind"] in (0, 2, 3, 4) for q in sph)      # subsurface colours go with spheres that have material lists (a sphere without — mirror or not — would inherit Ksub: refused)
+    sph_lists = True      # (rounds 1-3: subsurface colours only beside spheres WITH material lists; since round 4 a sphere without — mirror or not — inherits Ksub on the one-thread kernel)
+    for q in sph:         # round 4: a sphere with lists may carry a subsurface colour of its own (Sphere::reservoir_sampling_intersection)
+        q["ksub"] = tuple(float(v) for v in rng.uniform(0.05, 0.9, 3)) if (QUEUE and q["kind"] in (0, 2, 3) and rng.random() < 0.35) else None
     def put_spheres(X, first):
         for q in sph:
             if q["first"] != first: continue
@@ -54,6 +56,7 @@ for it in range(n_scenes):
                 X.add_group_material(o, (1, 1, 1), q["Ks"] * 0.5, q["Ne"], 1.0, 1.3)
                 X.set_group_texture(o, 0, 0, scenes.checker_texture(32, 16, 5, 4))
             if q["kind"] == 4: X.add_group_material(o, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, float(1.1 + q["Ks"][0]))
+            if q["ksub"]: X.add_col_subsurface(o, q["ksub"])
     for X in (Oracle(), capi.HostRaytracer(device=0)):
         X.apply_config(cfg)
         put_spheres(X, True)
@@ -98,8 +101,8 @@ for it in range(n_scenes):
     pix = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
     want = O.getcolor_samples(pix, 0, spp)[0]
     line = "%2d %-8s n=%-3d scale %-5g %3dx%-3d spp %d depth %d aperture %-4g" % (it, kind, n, scale, W, H, spp, cfg.nb_bounces, cfg.aperture)
-    line += " " + "+".join(feats) + (" spheres " + "".join("cmgtdb"[q["kind"]] for q in sph) if sph else "")
-    for pipeline in ((1,) if feats else (1, 0)):
+    line += " " + "+".join(feats) + (" spheres " + "".join("cmgtdb"[q["kind"]] + ("s" if q["ksub"] else "") for q in sph) if sph else "")
+    for pipeline in ((1,) if (feats or any(q["ksub"] for q in sph)) else (1, 0)):
         G.set_option("pipeline", pipeline)
         got = G.getcolor_samples(pix, 0, spp)[0]
         same = bits_equal(got, want).all(-1).mean()
