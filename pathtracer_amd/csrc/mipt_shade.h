@@ -162,6 +162,20 @@ MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N
 	return mk3((float)r, (float)g, (float)b);
 }
 __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N); }
+// Both evaluations of a vertex behind ONE call (MIPT_MERL_ONE_COPY = 2): the function's 12 callee-saved registers are saved and restored
+// once per vertex instead of twice (24 instead of 48 scratch accesses), its body is the same two-trip loop around the one inlined copy.
+struct MerlPair { f3 a, b; };
+__device__ __attribute__((noinline)) MerlPair merl_eval_pair(const double* __restrict__ data, f3 wi_a, f3 wi_b, f3 wo, f3 N, int which) {
+	MerlPair r; r.a = mk3(0, 0, 0); r.b = mk3(0, 0, 0);
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		if (which & (1 << k)) {
+			const f3 e = merl_eval_inline(data, k ? wi_b : wi_a, wo, N);
+			if (k) r.b = e; else r.a = e;
+		}
+	}
+	return r;
+}
 
 // ---------------------------------------------------------------- path state
 struct PathState {
@@ -272,38 +286,49 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	if (MERL && MIPT_MERL_ONE_COPY && merl) {
 		// measured BRDF: the light sample's evaluation (:540-544) and the continuation's (:603-607) are independent of each other
 		// (IsoMERLBRDF::sample is the cosine lobe and draws nothing from the engine, BRDF.h:198-203), so both directions are
-		// prepared first and evaluated by the two trips of one loop around the inlined evaluation
+		// prepared first and evaluated by the two trips of one loop around the inlined evaluation.  Everything that does not need
+		// a BRDF value is finished BEFORE the loop (the scalar factors of the direct term and of the weight update, the shadow
+		// request, the continuation ray), so that the fp64 code runs with two directions and two scalars alive instead of the vertex.
 		const bool lit = !(dot(mat.shadingN, wi) < 0);
-		bool cont = ps.depth > 1;
-		f3 dir = mk3(0, 0, 0);
-		float pdf = 0.f;
-		if (cont) {
-			float ip;
-			const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
-			const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
-			dir = random_cos(N, r1, r2);
-			pdf = (float)((double)dot(N, dir) / (MIPT_PI));
-			if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) cont = false;   // :593
-		}
-		f3 brdf = mk3(0, 0, 0), brdf_i = mk3(0, 0, 0);
-#pragma unroll 1
-		for (int k = 0; k < 2; k++) {
-			if (k ? cont : lit) {
-				const f3 e = merl_eval_inline(merl, k ? dir : wi, -rayDirection, N);
-				if (k) brdf_i = e; else brdf = e;
-			}
-		}
+		float lk = 0.f;                    // R.lightPower * max(0, N.wi) * J / proba, or 0 when proba <= 0 (:545-551)
+		bool lk_on = false;
 		if (lit) {
-			float J = dot(dir_l, -wi) / d_light2;
-			float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
-			if (proba > 0.f) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * (R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba)) * brdf;
+			const float J = dot(dir_l, -wi) / d_light2;
+			const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+			if (proba > 0.f) { lk = R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba; lk_on = true; }
 			sh.cast = true;
 			sh.ray.o = P + 0.01f * wi;
 			sh.ray.d = wi;
 			sh.dist = sqrtf(d_light2) - 0.01f;
 		}
+		bool cont = ps.depth > 1;
+		f3 dir = mk3(0, 0, 0);
+		float wk = 0.f;                    // dot(N, dir) / pdf (:611)
+		if (cont) {
+			float ip;
+			const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
+			const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
+			dir = random_cos(N, r1, r2);
+			const float pdf = (float)((double)dot(N, dir) / (MIPT_PI));
+			if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) cont = false;   // :593
+			else wk = dot(N, dir) / pdf;
+		}
+		const f3 wo = -rayDirection;
+		f3 brdf = mk3(0, 0, 0), brdf_i = mk3(0, 0, 0);
+		if (MIPT_MERL_ONE_COPY == 2) {
+			if (lit || cont) { MerlPair pr; pr = merl_eval_pair(merl, wi, dir, wo, N, (lit ? 1 : 0) | (cont ? 2 : 0)); brdf = pr.a; brdf_i = pr.b; }
+		} else {
+#pragma unroll 1
+			for (int k = 0; k < 2; k++) {
+				if (k ? cont : lit) {
+					const f3 e = merl_eval_inline(merl, k ? dir : wi, wo, N);
+					if (k) brdf_i = e; else brdf = e;
+				}
+			}
+		}
+		if (lk_on) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * lk) * brdf;
 		if (!cont) return false;
-		ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * (dot(N, dir) / pdf);            // :611
+		ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * wk;            // :611
 		ps.ray.o = P + 0.01f * dir;
 		ps.ray.d = dir;
 		ps.show_lights = false;

@@ -1,5 +1,2 @@
-mkdir -p gpurun_out/r4i
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r4i/gputests.txt 2>&1; head -8 gpurun_out/r4i/gputests.txt | tail -5; grep -E "^E |FAILED" gpurun_out/r4i/gputests.txt | head
-timeout 900 python tests/tools/fuzz_parity.py 250 41 --queue --spheres > gpurun_out/r4i/fuzz_queue_spheres_250.txt 2>&1; tail -2 gpurun_out/r4i/fuzz_queue_spheres_250.txt; grep -c "s " gpurun_out/r4i/fuzz_queue_spheres_250.txt
-timeout 900 python tests/tools/fuzz_parity.py 200 42 --queue --bare-spheres > gpurun_out/r4i/fuzz_queue_bare_spheres_200.txt 2>&1; tail -2 gpurun_out/r4i/fuzz_queue_bare_spheres_200.txt
-grep -v "identical 1.000000 max|err|/white 0$" gpurun_out/r4i/fuzz_*.txt | grep -v "identical 1.000000 max|err|/white 0  p" | head
+mkdir -p gpurun_out/r4j; rm -f gpurun_out/sweep.log
+bash tools/sweep_libs.sh "- --workload c4" "merl1w2 --workload c4" "merl1w3 --workload c4" "- --workload c4" 2>&1 | tee gpurun_out/r4j/sweep_c4_merl.txt
