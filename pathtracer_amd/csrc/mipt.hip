@@ -392,8 +392,8 @@ struct mipt_ctx {
 	int blk_nblocks = 0;
 	uint64_t blk_valid_pixels = 0;
 	int64_t opt_pipeline = 1;
-	int64_t opt_refill_threshold = MIPT_READY_LIST ? MIPT_RL_FILL_THRESHOLD : MIPT_REFILL_THRESHOLD;
-	int64_t opt_inner_min = MIPT_READY_LIST ? MIPT_RL_INNER_MIN : 16;
+	int64_t opt_refill_threshold = MIPT_REFILL_THRESHOLD;
+	int64_t opt_inner_min = 16;
 	int64_t opt_lane_limit = 0;       // probe: persistent traversal hands rays to the first N lanes of a wave only (0 = all)
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
@@ -1366,8 +1366,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (n_probe) {
 					TravQueue tq; tq.list = qw.prl[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_PROBE(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_PROBE(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
-					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq,
-					                   MIPT_READY_LIST ? MIPT_REFILL_THRESHOLD : thr, MIPT_READY_LIST ? ((imin & ~0xffff) | 16) : imin);      // (the probes run the loop without the ready list)
+					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[1]) {

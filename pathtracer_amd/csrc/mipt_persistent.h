@@ -13,9 +13,7 @@
 // stack traversal per mesh, same pruning); only WHICH lane runs it and WHEN changes.
 #pragma once
 
-#define MIPT_REFILL_THRESHOLD 36        // loop without the ready list (the subsurface probes): refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum), inner phase until < 16 lanes descend
-#define MIPT_RL_FILL_THRESHOLD 8        // with the ready list: fill when the list is empty and this many lanes are idle,
-#define MIPT_RL_INNER_MIN 32            // and end the inner phase when fewer than this many lanes descend (tests/tools/sched_sim.c)
+#define MIPT_REFILL_THRESHOLD 36        // refill as soon as this many lanes are idle (a refill runs the object loop for few lanes: measured optimum)
 #ifndef MIPT_EXTEND_WAVES
 #define MIPT_EXTEND_WAVES 7             // closest-hit kernel: 7 waves/SIMD with the derived triangle terms, made possible by MIPT_HIT_WRITE_THROUGH (round 1: 6 waves with the derived terms beat 7 with the fourth load)
 #endif
@@ -57,40 +55,14 @@ struct LaneState {
 	int count;              // reservoir: intersections accepted so far
 };
 
-// MIPT_READY_LIST (round 4; measured, NOT the default — DESIGN.md 4e): a per-wave list of rays that are already fetched,
-// transformed and root-tested, kept in LDS.  tests/tools/sched_sim.c replays the oracle's per-ray node sequences through this loop's
-// lane scheduling (it reproduces the instrumented kernel's counters to 1 %): with a refill at 36 idle lanes the inner steps of
-// configs[2] run at 38 of 64 lanes, and keeping the lanes full does not help by itself (32.5 lanes with a refill at 8: an inner phase
-// lasts until fewer than inner_min lanes descend, so more live lanes only make it longer).  What raises the lanes is both together:
-// lanes re-bound at every outer iteration AND the inner phase ended at 32 descending lanes (45 lanes per inner step, -17 % inner
-// steps at +3 % leaf phases) — affordable only if re-binding a lane costs no global round trip.  So: a FILL fetches and sets up rays
-// with every lane that is given one (idle lanes for themselves, in place; busy lanes for the list, beside the traversal state they
-// keep), when the list is empty and >= refill_threshold lanes are idle; a TAKE hands list entries to idle lanes at the one wave-level
-// point in front of the inner phase (one ballot, a prefix count, LDS reads; nothing inside the inner loop).  Every ray still performs
-// the reference's sequence of operations: the GPU parity suite is green with it (165 tests).
-// MEASURED (profiles/r4_b_*): 44.8 lanes per inner step, vector-memory instructions -15 %, vector -10 %, scalar -9.5 % per launch — and
-// the closest-hit stage of configs[2] 2.3 % SLOWER at 7 waves per SIMD (any-hit +5 %, configs[3] +6 %): L1->L2 requests +17 %, L2
-// misses +8 %, tag-conflict stalls +77 % (a sixth more rays in flight per CU thrash the 32 KB L1 and the L2 share).  At 6 waves it
-// beats the 6-wave loop without it by 4.3 % — which is 3.4 % behind 7 waves without it.  The kernel does not run at an instruction
-// rate (one more load instruction per inner step, +20 % of them, costs 6 %: profiles/r4_b_access_probes.txt).
-#ifndef MIPT_READY_LIST
-#define MIPT_READY_LIST 0
-#endif
-#ifndef MIPT_RL_CAP
-#define MIPT_RL_CAP 28                  // entries per wave (48 bytes each): stack of 8 + leaf map + list = 22 784 bytes per block, 7 blocks per CU
-#endif
-typedef float mipt_f4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) mipt_f4 lds_float4;      // (a plain vector type: HIP's float4 class has no constructors from LDS references)
-
-// the wave's slice of the block's ready list (nullptr without the feature)
-#if MIPT_READY_LIST
-#define MIPT_DECLARE_READY_LIST(rl) \
-	__shared__ mipt_f4 lds_ready_[(MIPT_TRAV_BLOCK / 64) * MIPT_RL_CAP * 3]; \
-	lds_float4* rl = (lds_float4*)lds_ready_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (MIPT_RL_CAP * 3)
-#else
-#define MIPT_DECLARE_READY_LIST(rl) lds_float4* rl = nullptr
-#endif
-
+// Round 4 built a per-wave READY LIST on top of this loop: rays fetched, transformed and root-tested by every lane of a
+// fill (idle lanes for themselves, busy lanes for a 28-entry LDS list), handed to lanes that run out of nodes at the one wave-level
+// point in front of the inner phase, the inner phase ended at 32 descending lanes.  It did what the scheduling simulator
+// (tests/tools/sched_sim.c) predicted — 44.8 instead of 38 lanes per inner step, vector-memory instructions -15 %, vector -10 %, scalar
+// -9.5 % per launch, parity suite green — and the closest-hit stage of configs[2] ran 2.3 % SLOWER (any-hit +5 %, configs[3] +6 %):
+// L1->L2 requests +17 %, L2 misses +8 %, tag-conflict stalls +77 %.  The loop does not run at an instruction rate (one more load per
+// inner step, +20 % vector-memory instructions, costs 6 %): DESIGN.md 4e, profiles/r4_b_*; the code is at git tag
+// r4-ready-list-experiment.  Kept from it: the lane state in st.cur (below) and v_mbcnt prefix counts.
 // A lane's state is kept in st.cur beside the node reference (no separate flags: at 72 registers two flags cost two registers):
 // an inner node (< MIPT_ST_NEED), a leaf (bit 31), or one of
 #define MIPT_ST_NEED 0x7ffffffdu        // the lane's ray must visit its next object(s)
@@ -162,11 +134,9 @@ struct TravQueue {
 // frame of ONE mesh (wf.ray_o.w = max_t, wf.ray_d.w = the object), the traversal is the closest-hit one with the far bound
 // fixed at max_t, and every triangle hit in [0, max_t) draws one number from the sample's engine (wf.rng) in visiting order and
 // replaces the kept one with probability 1/count.  Result: wf.hit (w = the mesh-local triangle or MIPT_HIT_MISS), wf.rng.
-template <bool SHADOW, bool RESV = false, bool RL = false>
+template <bool SHADOW, bool RESV = false>
 __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, const DWave& wf,
-                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap, lds_float4* rl_base = nullptr) {
-	static_assert(!RL || !RESV, "the ready list serves the closest-hit and any-hit queues");
-	static_assert(!RL || MIPT_HIT_WRITE_THROUGH, "the ready list keeps no best-hit registers");
+                                               const TravQueue tq, int refill_threshold, int inner_min_flags, LdsStack& stk, unsigned char* leafmap) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_literal = (inner_min_flags >> 16) & 1;     // test hook: every ray takes the literal slab chain
 	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;   // probe: only the first lanes take rays
@@ -193,9 +163,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 	unsigned chunk_next = 0, chunk_end = 0;   // wave-uniform: ids reserved from the global queue
 	unsigned ahead = 0, ahead_at = 0xffffffffu;   // MIPT_PREFETCH_IDS: entry ahead_at + lane of the list (valid while ahead_at == chunk_next)
 	bool drained = false;
-	unsigned rl_head = 0, rl_count = 0;           // ready list: wave-uniform
 	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
-	const uint32_t root_first = (RL && first_mesh < nobj) ? sc->obj[first_mesh].root_ref : MIPT_NONE;
 	const bool any_alpha = sc->any_alpha != 0;
 	auto pop_next = [&]() -> uint32_t {
 		while (st.sp > 0) {
@@ -211,9 +179,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		MIPT_PROF_CLOCK(c0);
 		if (MIPT_L_ALIVE) MIPT_PROF_COUNT(8)
 		// ---- refill idle lanes from the queue
-		unsigned long long idle = RL ? 0ull : __ballot(MIPT_L_IDLE && lane < lane_limit);
+		unsigned long long idle = __ballot(MIPT_L_IDLE && lane < lane_limit);
 		int nidle = __popcll(idle);
-		if (!RL && !drained && nidle >= refill_threshold) {
+		if (!drained && nidle >= refill_threshold) {
 			if (chunk_next >= chunk_end) {
 				// The first chunk of every wave is assigned statically (chunk number = wave number), later ones come
 				// from the shared counter: 8192 waves hitting one address at launch cost ~90 us (one same-address
@@ -274,7 +242,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					{ const uint2 rs = wf.rng[st.id]; st.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32); }
 				} else wf.hit[st.id] = make_float4(0.f, 0.f, 0.f, __uint_as_float(MIPT_HIT_MISS));      // no draw: the engine stays as it is
 			}
-		} else if (RL ? __builtin_expect(__ballot(MIPT_L_NEED) != 0, 0) : (__ballot(MIPT_L_NEED) != 0)) {      // (with the ready list: only rays between two meshes of a scene with several)
+		} else if (__ballot(MIPT_L_NEED) != 0) {
 			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
 			// (a ray that has left its last object only has to be settled below: it is not fetched again — 6 % of the kernel's
 			// vector-memory instructions on a one-mesh scene, and the kernel runs at the CU's rate of those: DESIGN.md 4d)
@@ -312,120 +280,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				st.cur = MIPT_ST_IDLE;
 			}
 		}
-		if (RL) {
-			// ---- ready list.  No lane is between two objects here (the object loop above has placed or settled those), so a lane
-			//      is idle exactly when it is not alive.
-			// TAKE: idle lane number j takes entry head + j.  Record: (o.x o.y 1/d.x 1/d.y) (o.z 1/d.z d.x d.y) (d.z t|dist id object).
-			auto take = [&]() {
-				const unsigned long long idle_m = __ballot(MIPT_L_IDLE);
-				const unsigned ntake = min((unsigned)__popcll(idle_m), rl_count);                   // wave-uniform
-				if (ntake == 0) return;
-				const unsigned j = below_count(idle_m);
-				if (MIPT_L_IDLE && j < ntake) {
-					const lds_float4* e = rl_base + 3u * (rl_head + j);
-					const mipt_f4 a = e[0], b = e[1], c = e[2];
-					st.o_xy = (mipt_f2){a.x, a.y}; st.i_xy = (mipt_f2){a.z, a.w}; st.oz_iz = (mipt_f2){b.x, b.y}; st.d = mk3(b.z, b.w, c.x);
-					if (SHADOW) { st.t = __int_as_float(0x7f800000); st.dist = c.y; st.best = 0; } else st.t = c.y;
-					st.id = __float_as_uint(c.z); st.obj = (int)__float_as_uint(c.w);
-					st.cur = st.obj == first_mesh ? root_first : sc->obj[st.obj].root_ref; st.sp = 0;
-				}
-				rl_head += ntake; rl_count -= ntake;
-			};
-			take();
-			const unsigned long long idle_m = __ballot(MIPT_L_IDLE);
-			const unsigned n_idle = (unsigned)__popcll(idle_m);
-			if (__builtin_expect(!drained && rl_count == 0 && n_idle >= (unsigned)refill_threshold, 0)) {       // (a fill is rare next to inner steps: tell the register allocator)
-				// FILL: the idle lanes fetch a ray each for themselves, the first MIPT_RL_CAP busy lanes one each for the list
-				if (chunk_next >= chunk_end) {
-					unsigned base = 0;
-					if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
-					else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
-					base = __builtin_amdgcn_readfirstlane(base);
-					if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
-					else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
-				}
-				if (!drained) {
-					const unsigned avail = chunk_end - chunk_next;
-					const unsigned n_own = min(n_idle, avail);
-					const unsigned n_extra = min(min((unsigned)MIPT_RL_CAP, avail - n_own), 64u - n_idle);
-					const unsigned r_idle = below_count(idle_m), r_busy = lane - r_idle;       // rank among the idle / the busy lanes
-					const bool own = MIPT_L_IDLE;
-					const bool fetch = own ? r_idle < n_own : r_busy < n_extra;
-					const unsigned idx = chunk_next + (own ? r_idle : n_own + r_busy);
-					chunk_next += n_own + n_extra;
-					bool entered = false;
-					unsigned nid = 0; int nobject = 0; float ntv = 0.f;
-					mipt_f2 no_xy = {0.f, 0.f}, ni_xy = {0.f, 0.f}, noz_iz = {0.f, 0.f}; f3 nd = mk3(0, 0, 0);
-					if (fetch) {
-						nid = identity ? idx : list[idx];
-						bool valid = true;
-						if (identity) valid = (__float_as_uint(wf.wgt[nid].w) & MIPT_WF_VALID) != 0;
-						if (valid) {
-							MIPT_PROF_COUNT(10)
-							// (the stage that created the ray has already visited the analytic objects in front of the first mesh: closest-hit
-							//  rays arrive with the (t, object) found there, shadow rays arrive only if none of them occludes)
-							const float4 o4 = SHADOW ? wf.sh_o[nid] : wf.ray_o[nid];
-							const float4 d4 = SHADOW ? wf.sh_d[nid] : wf.ray_d[nid];
-							const f3 ro = mk3(o4.x, o4.y, o4.z), rd = mk3(d4.x, d4.y, d4.z);
-							float bt = SHADOW ? __int_as_float(0x7f800000) : o4.w;            // closest: best t so far
-							if (!SHADOW) wf.hit[nid] = make_float4(o4.w, 0.f, 0.f, d4.w);
-							bool pending = true;
-							for (int i = first_mesh; i < nobj; i++) {
-								if (pending) {
-									const DObject& o = sc->obj[i];
-									if (SHADOW && tq.skip_ghosts && o.ghost) continue;
-									const f3 d = xf_dir(o.inv, rd);
-									const f3 org = xf_point(o.inv, ro);
-									if (o.type != 0) {                         // spheres / planes behind the first mesh (shadow rays: tested when the request was made)
-										if (!SHADOW) {
-											float tt;
-											const bool hit = (o.type == 1) ? sphere_test(o, org, d, tt) : plane_test(o, org, d, tt);
-											if (hit && tt < bt) { bt = tt; wf.hit[nid] = make_float4(tt, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI)); }
-										}
-										continue;
-									}
-									const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-									float t_root;
-									bool enter = box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
-									if (enter && t_root > bt) enter = false;
-									if (SHADOW && enter && t_root > o4.w) enter = false;
-									if (enter) {
-										pending = false; entered = true; nobject = i;
-										no_xy = (mipt_f2){org.x, org.y}; ni_xy = (mipt_f2){invd.x, invd.y}; noz_iz = (mipt_f2){org.z, invd.z}; nd = d;
-										ntv = SHADOW ? o4.w : bt;
-									}
-								}
-							}
-							if (SHADOW && pending) {                       // no mesh in the way: visible
-								if (tq.vis) tq.vis[nid] = 1.f;
-								else {
-									const float4 c = wf.out.col[nid], pc = wf.sh_c[nid];
-									wf.out.col[nid] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
-								}
-							}
-						}
-					}
-					const unsigned long long to_list = __ballot(entered && !own);
-					if (entered) {
-						if (own) {
-							st.o_xy = no_xy; st.i_xy = ni_xy; st.oz_iz = noz_iz; st.d = nd;
-							if (SHADOW) { st.t = __int_as_float(0x7f800000); st.dist = ntv; st.best = 0; } else st.t = ntv;
-							st.id = nid; st.obj = nobject;
-							st.cur = nobject == first_mesh ? root_first : sc->obj[nobject].root_ref; st.sp = 0;
-						} else {
-							lds_float4* e = rl_base + 3u * below_count(to_list);
-							e[0] = (mipt_f4){no_xy.x, no_xy.y, ni_xy.x, ni_xy.y};
-							e[1] = (mipt_f4){noz_iz.x, noz_iz.y, nd.x, nd.y};
-							e[2] = (mipt_f4){nd.z, ntv, __uint_as_float(nid), __uint_as_float((unsigned)nobject)};
-						}
-					}
-					rl_head = 0; rl_count = (unsigned)__popcll(to_list);
-					__builtin_amdgcn_wave_barrier();
-					take();                                        // idle lanes whose own ray missed every mesh
-				}
-			}
-			if (__ballot(MIPT_L_ALIVE) == 0) { if (drained && rl_count == 0) break; else continue; }
-		} else {
+		{
 			const int nalive = __popcll(__ballot(MIPT_L_ALIVE));
 			if (nalive == 0) { if (drained) break; else continue; }
 			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;      // rays that missed every mesh left their lanes idle again: top up first
@@ -622,21 +477,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				wf.rng[st.id] = make_uint2((unsigned)st.rng, (unsigned)(st.rng >> 32));
 			}
 		} else if (st.cur == MIPT_NONE) {
-			st.cur = MIPT_ST_IDLE;
-			if (RL && ((SHADOW && st.best) || st.obj + 1 >= nobj)) {
-				// the ray's last object: settled here, from what the lane holds (a closest-hit ray's record is already written)
-				if (SHADOW) {
-					if (tq.vis) tq.vis[st.id] = st.best ? 0.f : 1.f;
-					else if (!st.best) {
-						const float4 c = wf.out.col[st.id], pc = wf.sh_c[st.id];
-						wf.out.col[st.id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
-					}
-				}
-			} else {
-				st.cur = MIPT_ST_NEED;
-				// shadow: a hit with t >= 0.999*dist is not an occluder (Geometry.cpp:736) -> next object
-				st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
-			}
+			st.cur = MIPT_ST_NEED;
+			// shadow: a hit with t >= 0.999*dist is not an occluder (Geometry.cpp:736) -> next object
+			st.obj = (SHADOW && st.best) ? nobj : st.obj + 1;
 		}
 	}
 }
@@ -649,12 +492,11 @@ template <int MODE>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
-	MIPT_DECLARE_READY_LIST(rl);
 	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
 	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	if (MODE == 1 || MODE == 2) traverse_queue<true, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap, rl);
-	if (MODE == 0) traverse_queue<false, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap, rl);
-	if (MODE == 2) traverse_queue<false, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap, rl);
+	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap);
+	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap);
 }
 
 // The same traversal on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h): closest hits
@@ -663,8 +505,7 @@ template <bool SHADOW>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_TRAVERSE_WAVES : MIPT_EXTEND_WAVES))) k_q_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, TravQueue tq, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
-	MIPT_DECLARE_READY_LIST(rl);
-	traverse_queue<SHADOW, false, MIPT_READY_LIST != 0>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap, rl);
+	traverse_queue<SHADOW>(sc, nodes, tris, wf, tq, refill_threshold, inner_min_flags, stk, leafmap);
 }
 
 // The subsurface probes of one round of the contribution-queue pipeline (mipt_queue_wave.h).

@@ -100,11 +100,13 @@ MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, dou
 	double cx = axis[1] * v[2] - axis[2] * v[1], cy = axis[2] * v[0] - axis[0] * v[2], cz = axis[0] * v[1] - axis[1] * v[0];
 	out[0] += cx * sa; out[1] += cy * sa; out[2] += cz * sa;
 }
-// merl_eval_inline: the body.  The wavefront shade stage of scenes with a measured BRDF runs BOTH evaluations of a vertex through one
-// inlined copy of it (path_vertex<true>: a two-trip loop).  As a function it saved 12 callee-saved registers through scratch — 24
-// scratch accesses per call, two calls per vertex, every one a vector-memory instruction.
-// merl_eval: the same out of line for the other callers (pipeline 0 and the contribution-queue kernels), where the cold path must
-// not inflate the register allocation of the common one.
+// merl_eval_inline: the body; merl_eval: the same out of line — what every caller uses.  As a function it keeps 65 registers and saves 12
+// callee-saved ones through scratch (24 accesses per call, two calls per diffuse vertex).  Round 4 measured the alternative on
+// configs[4] (profiles/r4_c_c4_merl_inlined_variants_sweep.txt; code at git tag r4-merl-inline-experiment): both evaluations through
+// ONE inlined copy (a two-trip loop, everything that needs no BRDF value finished in front of it) — 67 spilled values at 3 waves
+// per SIMD, generate + shade 869 -> 1 089 ms per step; at 2 waves (256 registers, nothing spilled) 1 028 ms.  The stage wants its
+// third wave more than it minds the 48 scratch accesses per vertex; a function cannot be given a register budget
+// (amdgpu_num_vgpr is for kernels), and one call for both evaluations made the allocator take 248 registers for the callee.
 MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
@@ -162,20 +164,6 @@ MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N
 	return mk3((float)r, (float)g, (float)b);
 }
 __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N); }
-// Both evaluations of a vertex behind ONE call (MIPT_MERL_ONE_COPY = 2): the function's 12 callee-saved registers are saved and restored
-// once per vertex instead of twice (24 instead of 48 scratch accesses), its body is the same two-trip loop around the one inlined copy.
-struct MerlPair { f3 a, b; };
-__device__ __attribute__((noinline)) MerlPair merl_eval_pair(const double* __restrict__ data, f3 wi_a, f3 wi_b, f3 wo, f3 N, int which) {
-	MerlPair r; r.a = mk3(0, 0, 0); r.b = mk3(0, 0, 0);
-#pragma unroll 1
-	for (int k = 0; k < 2; k++) {
-		if (which & (1 << k)) {
-			const f3 e = merl_eval_inline(data, k ? wi_b : wi_a, wo, N);
-			if (k) r.b = e; else r.a = e;
-		}
-	}
-	return r;
-}
 
 // ---------------------------------------------------------------- path state
 struct PathState {
@@ -217,13 +205,6 @@ struct ShadowRequest {
 // be multiplied with once the shadow query is resolved (color += pathWeight*currentContrib).
 // MERL = false: the scene has no measured BRDF (the caller knows from the upload): the fp64 table evaluation is not
 // compiled into the kernel, which is what its register count is otherwise sized for.
-// MIPT_MERL_ONE_COPY (round 4, measured, off): both measured-BRDF evaluations of a vertex through one INLINED copy of merl_eval (a two-trip
-// loop) instead of two calls.  The calls save 12 callee-saved registers through scratch (24 accesses each); inlined, the kernel's own
-// allocation at 3 waves per SIMD spills 81 values (416 bytes of scratch per lane) around the fp64 code: generate + shade of configs[4]
-// 864 -> 1 095 ms per step (profiles/r4_c_c4_merl_one_inlined_copy_sweep.txt).
-#ifndef MIPT_MERL_ONE_COPY
-#define MIPT_MERL_ONE_COPY 0
-#endif
 template <bool MERL = true>
 MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathState& ps, bool has_inter, const Hit& h, f3 P, const Mat& mat,
                           int pix, int sampleID, ShadowRequest& sh, f3& weight_at_vertex) {
@@ -283,58 +264,6 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	f3 pt_l = dir_l * R.radiusLight + cl;
 	f3 wi = fast_normalize(pt_l - P);
 	float d_light2 = norm2(pt_l - P);
-	if (MERL && MIPT_MERL_ONE_COPY && merl) {
-		// measured BRDF: the light sample's evaluation (:540-544) and the continuation's (:603-607) are independent of each other
-		// (IsoMERLBRDF::sample is the cosine lobe and draws nothing from the engine, BRDF.h:198-203), so both directions are
-		// prepared first and evaluated by the two trips of one loop around the inlined evaluation.  Everything that does not need
-		// a BRDF value is finished BEFORE the loop (the scalar factors of the direct term and of the weight update, the shadow
-		// request, the continuation ray), so that the fp64 code runs with two directions and two scalars alive instead of the vertex.
-		const bool lit = !(dot(mat.shadingN, wi) < 0);
-		float lk = 0.f;                    // R.lightPower * max(0, N.wi) * J / proba, or 0 when proba <= 0 (:545-551)
-		bool lk_on = false;
-		if (lit) {
-			const float J = dot(dir_l, -wi) / d_light2;
-			const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
-			if (proba > 0.f) { lk = R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba; lk_on = true; }
-			sh.cast = true;
-			sh.ray.o = P + 0.01f * wi;
-			sh.ray.d = wi;
-			sh.dist = sqrtf(d_light2) - 0.01f;
-		}
-		bool cont = ps.depth > 1;
-		f3 dir = mk3(0, 0, 0);
-		float wk = 0.f;                    // dot(N, dir) / pdf (:611)
-		if (cont) {
-			float ip;
-			const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
-			const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
-			dir = random_cos(N, r1, r2);
-			const float pdf = (float)((double)dot(N, dir) / (MIPT_PI));
-			if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) cont = false;   // :593
-			else wk = dot(N, dir) / pdf;
-		}
-		const f3 wo = -rayDirection;
-		f3 brdf = mk3(0, 0, 0), brdf_i = mk3(0, 0, 0);
-		if (MIPT_MERL_ONE_COPY == 2) {
-			if (lit || cont) { MerlPair pr; pr = merl_eval_pair(merl, wi, dir, wo, N, (lit ? 1 : 0) | (cont ? 2 : 0)); brdf = pr.a; brdf_i = pr.b; }
-		} else {
-#pragma unroll 1
-			for (int k = 0; k < 2; k++) {
-				if (k ? cont : lit) {
-					const f3 e = merl_eval_inline(merl, k ? dir : wi, wo, N);
-					if (k) brdf_i = e; else brdf = e;
-				}
-			}
-		}
-		if (lk_on) sh.contrib = sh.contrib + (mk3(1.f, 1.f, 1.f) * lk) * brdf;
-		if (!cont) return false;
-		ps.weight = ((ps.weight * mk3(1.f, 1.f, 1.f)) * brdf_i) * wk;            // :611
-		ps.ray.o = P + 0.01f * dir;
-		ps.ray.d = dir;
-		ps.show_lights = false;
-		ps.depth--;
-		return true;
-	}
 	if (!(dot(mat.shadingN, wi) < 0)) {
 		f3 brdf = merl ? merl_eval(merl, wi, -rayDirection, N) : phong_eval(mat, wi, -rayDirection, N);
 		float J = dot(dir_l, -wi) / d_light2;

@@ -279,7 +279,7 @@ struct ScratchStack {            // private (scratch) memory: any occupancy, slo
 // global scratch buffer that is normally never touched.  Both pointers carry their address space in
 // the type so that pushes and pops compile to ds_* / global_* instructions, not flat ones.
 #ifndef MIPT_LDS_STACK
-#define MIPT_LDS_STACK 10         // (a build with the ready list of mipt_persistent.h needs -DMIPT_LDS_STACK=8 to keep 7 blocks per CU: 3 % of the inner steps of configs[2] push at depth >= 8, +0.5 % time)
+#define MIPT_LDS_STACK 10         // (round 4: 0.2 % of the inner steps of configs[2] push at depth >= 10 and reach the global spill column; 8 entries: 3 %, +0.5 % time)
 #endif
 #define MIPT_SPILL_STACK (MIPT_STACK_DEPTH - MIPT_LDS_STACK)
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
