@@ -11,7 +11,7 @@
 #pragma once
 #include <stdint.h>
 
-#define MIPT_MAX_OBJECTS 16
+#define MIPT_MAX_OBJECTS 31      // a hit record packs the object into the 5 bits above the 27-bit triangle index; object 31 + "no triangle" is MIPT_HIT_MISS (round 4: 16 -> 31; the reference's std::vector<Object*> is unbounded)
 #define MIPT_TEX_SLOTS 8
 // slot ids = the reference's Texture type codes (BRDF.h:256-264) + 7 for the subsurface list
 enum { MT_KD = 0, MT_KS = 1, MT_NORMAL = 2, MT_ALPHA = 3, MT_NE = 4, MT_TRANSP = 5, MT_REFR = 6, MT_KSUB = 7 };

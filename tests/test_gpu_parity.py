@@ -370,9 +370,9 @@ def test_partition_rank_splat_slices_are_deterministic():
 
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_object_table_full_and_one_too_many(pipeline):
-    """The scene table holds MIPT_MAX_OBJECTS = 16 objects (include/mipt.h): light, environment, ground plane, two meshes and
-    eleven spheres of every kind fill it — bit for bit against the oracle, depth 0 (nothing traced) and depth 3 —; a seventeenth
-    object is refused with a message, not truncated."""
+    """The scene table holds MIPT_MAX_OBJECTS = 31 objects (csrc/mipt_scene.h: the 5 bits a hit record has for the object, minus the
+    code of a miss; 16 until round 4): light, environment, ground plane, two meshes and 26 spheres of every kind fill it — bit for bit
+    against the oracle, depth 0 (nothing traced) and depth 3 —; a thirty-second object is refused with a message, not truncated."""
     from oracle.binding import Oracle
 
     def build(X, extra):
@@ -381,7 +381,7 @@ def test_object_table_full_and_one_too_many(pipeline):
         X.apply_config(cfg)
         rng = np.random.default_rng(7)
         X.add_mesh(scenes.blob_mesh(10), scale=12.0)
-        for k in range(11 + extra):
+        for k in range(26 + extra):
             c = (float(rng.uniform(-30, 30)), float(rng.uniform(-26, 0)), float(rng.uniform(-15, 25)))
             o = X.add_sphere(c, float(rng.uniform(2, 6)), mirror=(k % 4 == 1))
             if k % 4 == 0: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
@@ -394,10 +394,10 @@ def test_object_table_full_and_one_too_many(pipeline):
     for X in (O, G):
         cfg = build(X, 0)
         X.prepare()
-    assert G.num_objects() == 16                       # MIPT_MAX_OBJECTS
+    assert G.num_objects() == 31                       # MIPT_MAX_OBJECTS
     G.set_option("pipeline", pipeline)
     pix = all_pixels(cfg)
-    assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], O.getcolor_samples(pix, 0, cfg.spp)[0], "16 objects, depth 3")
+    assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], O.getcolor_samples(pix, 0, cfg.spp)[0], "31 objects, depth 3")
     for X in (O, G):
         X.set_render(cfg.W, cfg.H, cfg.spp, 0)
         X.prepare()
