@@ -358,6 +358,7 @@ struct mipt_ctx {
 	void* overflow_buf = nullptr; size_t overflow_buf_bytes = 0;     // 200-entry rings of the samples the wavefront queue abandoned
 	void* resolve_buf = nullptr; size_t resolve_buf_bytes = 0;       // partial images of the sliced splat (ranks of a partition)
 	bool scene_inherit = false;       // a sphere without material lists (DScene::inherit_material): no wavefront stages
+	bool scene_bare_mirror = false;   // a MIRROR sphere without material lists: its radiance needs no inherited material, the denoiser's albedo input at a first hit on it does
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
 	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
@@ -805,7 +806,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false, scene_inherit = false;
+	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false, scene_inherit = false, bare_mirror = false;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -882,6 +883,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			// round 3 — rounds 1 and 2 refused these scenes).
 			if (i >= 2 && !o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) scene_inherit = true;
 			if (i >= 2 && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) sphere_extra = true;   // (a mirror too: getColor looks at Ksub before the mirror branch)
+			if (i >= 2 && o.miroir && !(counts[MT_KD] || counts[MT_KS] || counts[MT_NE] || counts[MT_TRANSP] || counts[MT_REFR])) bare_mirror = true;
 			memcpy(d.O, o.O, 12); d.R = o.R; d.R2 = o.R * o.R;
 			d.has_envmap = o.has_envmap; d.envW = o.envW; d.envH = o.envH; d.envtex = nullptr;
 			if (o.has_envmap) {
@@ -958,6 +960,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	c->fog.phase_aniso = s->phase_aniso; c->fog.ground_level = s->fog_ground_level; c->fog.type = s->fog_type; c->fog.phase_type = s->fog_phase_type;
 	if (s->fog_density > 1E-8f && (s->n_objects < 3 || s->fog_type < 0 || s->fog_type > 1 || s->fog_phase_type < 0 || s->fog_phase_type > 2)) return fail(c, MIPT_ERR_INVALID, "bad fog description");
 	c->scene_has_ghost = scene_ghost || scene_inherit || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
+	c->scene_bare_mirror = bare_mirror;
 	c->scene_inherit = scene_inherit;  // a sphere without material lists: the one-thread-per-sample loop of the queue kernel (Scene::intersection with its one MaterialValues)
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	c->grid_qlogic[0] = 0;
@@ -1693,6 +1696,26 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	return rc;
 }
 
+// The denoiser's albedo input is Kd at the first hit (Raytracer.cpp:255-258).  On a MIRROR sphere without material lists that Kd is whatever
+// Scene::intersection's one MaterialValues held (Geometry.cpp:596) — the radiance never reads it, so such a scene normally keeps the wavefront
+// stages; for the calls that hand out the albedo it is rendered the way the reference's loop runs (scene_intersect_inherit, one thread per sample).
+struct InheritForAov {
+	mipt_ctx* c; bool on = false, ghost = false;
+	explicit InheritForAov(mipt_ctx* c_) : c(c_) {
+		if (!c->has_scene || !c->scene_bare_mirror || c->scene_inherit) return;
+		const int one = 1;
+		if (hipMemcpy((char*)c->d_scene + offsetof(DScene, inherit_material), &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return;
+		on = true; ghost = c->scene_has_ghost;
+		c->scene_inherit = true; c->scene_has_ghost = true;
+	}
+	~InheritForAov() {
+		if (!on) return;
+		const int zero = 0;
+		hipMemcpy((char*)c->d_scene + offsetof(DScene, inherit_material), &zero, sizeof zero, hipMemcpyHostToDevice);
+		c->scene_inherit = false; c->scene_has_ghost = ghost;
+	}
+};
+
 extern "C" int mipt_sample_denoiser_inputs(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1,
                                            float* out_rgb, float* out_normal, float* out_albedo) {
 	if (!c || !p || !pixels_ij || !out_rgb || !out_normal || !out_albedo || npix < 0 || k0 < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
@@ -1700,6 +1723,7 @@ extern "C" int mipt_sample_denoiser_inputs(mipt_ctx* c, const mipt_render_params
 	if ((size_t)npix * (size_t)(k1 - k0) == 0) return MIPT_OK;
 	mipt_render_params q = *p;
 	q.sample_begin = k0; q.sample_end = k1; q.tile_nranks = 1; q.tile_rank = 0;
+	InheritForAov as_the_loop_runs(c);
 	SampleDump dump{pixels_ij, npix, out_rgb, nullptr, out_normal, out_albedo};
 	int rc = render_impl(c, &q, nullptr, 0, nullptr, nullptr, nullptr, &dump);
 	hipDeviceSynchronize();
@@ -1718,7 +1742,8 @@ extern "C" int mipt_render_denoiser_inputs(mipt_ctx* c, const mipt_render_params
 	if (e == hipSuccess) e = hipMemcpy(d + npx * 4, albedo_rgb, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(d + npx * 7, normal_xyz, npx * 3 * sizeof(float), hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(d); return fail(c, MIPT_ERR_HIP, "upload of accumulators failed: %s", hipGetErrorString(e)); }
-	int rc = render_impl(c, p, d, 0, nullptr, nullptr, nullptr, nullptr, d + npx * 4);
+	int rc;
+	{ InheritForAov as_the_loop_runs(c); rc = render_impl(c, p, d, 0, nullptr, nullptr, nullptr, nullptr, d + npx * 4); hipDeviceSynchronize(); }
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
 	if (rc == MIPT_OK) {

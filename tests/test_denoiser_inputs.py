@@ -90,3 +90,48 @@ def test_gpu_denoiser_accumulation_and_host_mirror():
     cn = np.sqrt((img[..., 0] * img[..., 0] + img[..., 1] * img[..., 1]) + img[..., 2] * img[..., 2])
     with np.errstate(invalid="ignore"):                 # a black pixel gives 0/0 there, as in the reference
         assert np.allclose(normal_ref, img / cn[..., None], atol=1e-6, equal_nan=True)   # the reference's normalImage: colour sums, normalised (:1680)
+
+
+def _bare_mirror_scene(X):
+    """A MIRROR sphere without material lists in front of the floor and a mesh: the radiance never reads its material, the denoiser's
+    albedo input at a first hit on it is the Kd Scene::intersection's one MaterialValues held (Geometry.cpp:596)."""
+    from pathtracer_amd import scenes
+    cfg = scenes.config_c1(40, 28, 2)
+    cfg.nb_bounces = 3
+    X.apply_config(cfg)
+    m = X.add_mesh(scenes.blob_mesh(10), scale=14.0)
+    X.set_group_material(m, 0, (0.7, 0.3, 0.2), (0.1, 0.1, 0.1), (20., 20., 20.))
+    X.add_sphere((0, -18, 14), 8.0, mirror=True)
+    X.add_sphere((-16, -21, 4), 5.0, mirror=True, flip_normals=True)
+    X.prepare()
+    return cfg
+
+
+def test_oracle_albedo_on_a_mirror_sphere_without_lists_against_live_reference():
+    from oracle import binding
+    if not binding.ref_available():
+        pytest.skip("compiled reference not present")
+    outs = []
+    for X in (binding.Ref(), binding.Oracle()):
+        cfg = _bare_mirror_scene(X)
+        outs.append(X.getcolor_samples_aov(all_pixels(cfg), 0, 2))
+    for a, b, what in zip(outs[0], outs[1], ("rgb", "normal", "albedo")):
+        assert_bits(b, a, what)
+    assert not (outs[0][2] == 0.5).all(-1).any()                      # never MaterialValues()'s default Kd: the sphere shows the Kd of the floor / the mesh / the environment tested before it
+
+
+@pytest.mark.gpu
+def test_gpu_albedo_on_a_mirror_sphere_without_lists():
+    """such a scene keeps the wavefront stages for its radiance (the mirror branch reads no material); the calls that hand out
+    the albedo render it the way the reference's loop runs.  Per sample, the accumulated images, and the plain render unchanged."""
+    from oracle.binding import Oracle
+    O, H = Oracle(), capi.HostRaytracer(device=0)
+    cfg = _bare_mirror_scene(O)
+    _bare_mirror_scene(H)
+    pix = all_pixels(cfg)
+    for a, b, what in zip(H.getcolor_samples_aov(pix, 0, 2), O.getcolor_samples_aov(pix, 0, 2), ("rgb", "normal", "albedo")):
+        assert_bits(a, b, what)
+    for a, b, what in zip(H.render_denoiser_inputs(), O.render_denoiser_inputs(), ("img", "cnt", "albedo sum", "normal sum")):
+        assert_bits(a, b, what)
+    assert_bits(H.getcolor_samples(pix, 0, 2)[0], O.getcolor_samples(pix, 0, 2)[0], "radiance through the wavefront stages")
+    assert H.stats()["pipeline"] == 1                      # the plain render stays on the wavefront pipeline
