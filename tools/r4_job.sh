@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r4l
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r4l/gputests.txt 2>&1; head -6 gpurun_out/r4l/gputests.txt | tail -2; grep -E "^E |FAILED" gpurun_out/r4l/gputests.txt | head
+mkdir -p gpurun_out/r4m; rm -f gpurun_out/sweep.log
+bash tools/sweep_libs.sh "-" "- --opt state_skew=1" "- --opt state_skew=17" "- --opt state_skew=65" "- --opt state_skew=1025" "- --opt state_skew=4113" "-" "- --opt state_skew=17" 2>&1 | tee gpurun_out/r4m/sweep_skew.txt
