@@ -364,6 +364,8 @@ struct mipt_ctx {
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
 	unsigned grid_qlogic[3] = {0, 0, 0};  // closest-hit list, any-hit list, fast tier of the closest-hit list
 	int64_t opt_queue_fast_tier = 1;  // 0: the general build of the logic stage for every sample (measurement / test hook)
+	int64_t opt_queue_lambert = 1;    // 0: fog scenes of Lambert materials use the general build too (measurement / test hook)
+	bool scene_lambert = false;       // no measured BRDF, every specular list a constant 0, every exponent list a constant >= 0 (a heuristic for the build: the vertex checks itself)
 	int qlogic_fog = -1;              // which build of the logic stage grid_qlogic was measured for
 	unsigned grid_qtrav[2] = {0, 0};  // resident blocks of k_q_traverse<false / true>
 	bool scene_has_merl = false;      // some object carries a measured BRDF: the general shade tier with the table evaluation is used
@@ -598,6 +600,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "paths_per_pass")) { if (value < 64) return fail(c, MIPT_ERR_INVALID, "paths_per_pass too small"); c->opt_paths_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_ring")) { if (value < 1) return fail(c, MIPT_ERR_INVALID, "queue_ring must be >= 1"); c->opt_queue_ring = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_wavefront")) { c->opt_queue_wavefront = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "queue_lambert")) { if (value < 0 || value > 2) return fail(c, MIPT_ERR_INVALID, "queue_lambert must be 0, 1 or 2"); c->opt_queue_lambert = value; return MIPT_OK; }
 	if (!strcmp(name, "queue_fast_tier")) { c->opt_queue_fast_tier = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
@@ -806,7 +809,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
-	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false, scene_inherit = false, bare_mirror = false;
+	bool scene_merl = false, scene_ghost = false, scene_subs = false, sphere_extra = false, scene_inherit = false, bare_mirror = false, all_lambert = true;
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
@@ -830,6 +833,11 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		lists[MT_TRANSP] = o.transparent_map; counts[MT_TRANSP] = o.n_transparent_map;
 		lists[MT_REFR] = o.refr_index_map; counts[MT_REFR] = o.n_refr_index_map;
 		lists[MT_KSUB] = o.subsurface; counts[MT_KSUB] = o.n_subsurface;
+		if (i >= 2) {                   // (the light and the environment never reach a BRDF)
+			if (o.brdf_kind == MIPT_BRDF_MERL) all_lambert = false;
+			for (int k = 0; k < o.n_specularmap; k++) if (o.specularmap[k].W > 0 || o.specularmap[k].multiplier[0] != 0 || o.specularmap[k].multiplier[1] != 0 || o.specularmap[k].multiplier[2] != 0) all_lambert = false;
+			for (int k = 0; k < o.n_roughnessmap; k++) if (o.roughnessmap[k].W > 0 || !(o.roughnessmap[k].multiplier[0] >= 0 && o.roughnessmap[k].multiplier[1] >= 0 && o.roughnessmap[k].multiplier[2] >= 0)) all_lambert = false;
+		}
 		for (int k = 0; k < o.n_subsurface; k++) {   // a subsurface colour (constant or image): the scene is rendered by the queue kernel
 			const mipt_texture& t = o.subsurface[k];
 			if (t.W > 0 || t.multiplier[0] != 0 || t.multiplier[1] != 0 || t.multiplier[2] != 0) {
@@ -961,6 +969,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	if (s->fog_density > 1E-8f && (s->n_objects < 3 || s->fog_type < 0 || s->fog_type > 1 || s->fog_phase_type < 0 || s->fog_phase_type > 2)) return fail(c, MIPT_ERR_INVALID, "bad fog description");
 	c->scene_has_ghost = scene_ghost || scene_inherit || c->d_background != nullptr || s->fog_density != 0;   // fog_density in (0, 1e-8]: no fog, but a ray that hits nothing ends the sample (:654-657)
 	c->scene_bare_mirror = bare_mirror;
+	c->scene_lambert = all_lambert;
 	c->scene_inherit = scene_inherit;  // a sphere without material lists: the one-thread-per-sample loop of the queue kernel (Scene::intersection with its one MaterialValues)
 	c->grid_stage[0] = 0;             // the stage grids depend on which shade tier the scene uses
 	c->grid_qlogic[0] = 0;
@@ -1318,13 +1327,18 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const bool fog_on = R.fog_density > 1E-8;                       // the build without the fog code for scenes without fog
 			const logic_fn logic_tab[2][2][2] = {{{(logic_fn)k_q_logic<false, false, false>, (logic_fn)k_q_logic<false, true, false>}, {(logic_fn)k_q_logic<false, false, true>, (logic_fn)k_q_logic<false, true, true>}},
 			                                     {{(logic_fn)k_q_logic<true, false, false>, (logic_fn)k_q_logic<true, true, false>}, {(logic_fn)k_q_logic<true, false, true>, (logic_fn)k_q_logic<true, true, true>}}};
-			const logic_fn logic_k[2] = {logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][0],       // over a closest-hit list (or all samples)
-			                             logic_tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][1]};      // over an any-hit list
+			// fog scenes whose materials are all Lambert: the builds that inline only the Lambert vertex (LAMBERT, mipt_queue_wave.h)
+			const logic_fn lambert_tab[2][2][2] = {{{(logic_fn)k_q_logic<false, false, false, false, true>, (logic_fn)k_q_logic<false, true, false, false, true>}, {(logic_fn)k_q_logic<false, false, true, false, true>, (logic_fn)k_q_logic<false, true, true, false, true>}},
+			                                       {{(logic_fn)k_q_logic<true, false, false, false, true>, (logic_fn)k_q_logic<true, true, false, false, true>}, {(logic_fn)k_q_logic<true, false, true, false, true>, (logic_fn)k_q_logic<true, true, true, false, true>}}};
+			const bool lambert = c->opt_queue_lambert && (c->scene_lambert || c->opt_queue_lambert == 2);      // (2: test hook — the Lambert builds whatever the materials: every other vertex abandons its sample to the one-thread loop)
+			const logic_fn (*const tab)[2][2] = lambert ? lambert_tab : logic_tab;
+			const logic_fn logic_k[2] = {tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][0],       // over a closest-hit list (or all samples)
+			                             tab[c->scene_has_subsurface ? 1 : 0][fog_on ? 1 : 0][1]};      // over an any-hit list
 			// the fast tier of the closest-hit-list stage (scenes without fog and subsurface groups): what it leaves goes to logic_k[0] in the same round
 			const bool fast_tier = MIPT_QW_FAST && !fog_on && !c->scene_has_subsurface && c->opt_queue_fast_tier;
 			const logic_fn logic_fast = (logic_fn)k_q_logic<false, false, false, true>;
-			if (c->grid_qlogic[0] == 0 || c->qlogic_fog != (fog_on ? 1 : 0)) {                                 // resident blocks of the logic stage (of the build in use)
-				c->qlogic_fog = fog_on ? 1 : 0;
+			if (c->grid_qlogic[0] == 0 || c->qlogic_fog != (fog_on ? 1 : 0) + (lambert ? 2 : 0)) {                                 // resident blocks of the logic stage (of the build in use)
+				c->qlogic_fog = (fog_on ? 1 : 0) + (lambert ? 2 : 0);
 				for (int k = 0; k < 3; k++) {
 					int nb = 0;
 					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k == 2 ? (const void*)logic_fast : (const void*)logic_k[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;

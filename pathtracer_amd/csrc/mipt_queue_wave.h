@@ -181,7 +181,14 @@ MIPT_DEV bool has_fog_early(const DRender& R) { return R.fog_density > 1E-8; }
 // (mipt_shade.h: eval = Kd / pi, the diffuse lobe picked, pdf = dot / pi): the arithmetic of the general code with the terms
 // that are exactly zero left out.  Without the Phong lobe (fp64 pow), the measured BRDF, the ghost / fog / subsurface segments
 // and the frame the build needs 128 registers instead of 206: 4 waves per SIMD instead of 2.
-template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false>
+// LAMBERT (round 4): a build of the general stage for scenes whose materials are all Lambert (upload: no measured BRDF, every specular list a
+// constant 0, every exponent list a constant >= 0).  The two BRDF evaluations and the lobe pick of a vertex that IS plain (checked per vertex,
+// like the fast tier: Ks = 0, Ne >= 0, no table) are path_vertex_fast's — eval = Kd / pi, the diffuse lobe unless the engine returns
+// u = 1.0f, pdf = dot / pi —; a vertex that is not (in a scene chosen for this build: the 2^-25 lobe event) abandons its sample to the
+// one-thread-per-sample loop exactly like a ring overflow does (the sample is recomputed from its first ray).  Round 3 measured where the
+// general builds' registers go by compiling them with pieces left out: 220 -> 189 (fog, closest-hit list) and 200 -> 156 (fog, any-hit
+// list) without the glossy / measured BRDF inline.
+template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false, bool LAMBERT = false>
 __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const DRender& R, const DPass& ps, const DWave& wf, const DQueueWave& qw, const unsigned id,
                                        unsigned& n_closest, unsigned& n_shadow) {
 	const unsigned N = qw.N;
@@ -638,7 +645,12 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					push(pathWeight, currentRay, nbrebonds, show_lights, show_envmap, hadSS);
 					// (currentRay itself is replaced: the fog event below, in this call, uses it)
 				} else {                                                        // :538-553
-					const f3 brdf = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, wi, -rayDirection, Nn) : phong_eval(m, wi, -rayDirection, Nn));
+					f3 brdf;
+					if (LAMBERT) {
+						const bool plain = merl == nullptr && m.Ks.x == 0.f && m.Ks.y == 0.f && m.Ks.z == 0.f && m.Ne.x >= 0.f && m.Ne.y >= 0.f && m.Ne.z >= 0.f;
+						if (!sub_interaction && !plain) { S.overflow = true; st = ST_POP; break; }      // not a Lambert vertex: the sample is abandoned to the one-thread loop (below)
+						brdf = (sub_interaction ? Ksub : m.Kd) / (float)MIPT_PI;
+					} else brdf = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, wi, -rayDirection, Nn) : phong_eval(m, wi, -rayDirection, Nn));
 					const float J = dot(dir_l, -wi) / d_light2;
 					const float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
 					if (proba > 0.f) contrib = contrib + (subsW * (R.lightPower * fmaxf(0.f, dot(Nn, wi)) * J / proba)) * brdf;
@@ -727,6 +739,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	if (!FAST && st == ST_A3) do {
 			const DObject& obj = sc->obj[objid];
 			const double* const merl = obj.merl;
+			const bool plain3 = LAMBERT && merl == nullptr && m.Ks.x == 0.f && m.Ks.y == 0.f && m.Ks.z == 0.f && m.Ne.x >= 0.f && m.Ne.y >= 0.f && m.Ne.z >= 0.f;
 			float ip;
 			const float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * k], &ip);
 			const float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * k + 1], &ip);
@@ -736,10 +749,22 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			else {
 				uint64_t peek = S.rng;
 				has_sampled_diffuse = (float)pcg_next(peek) / 4294967296.f < 1 - (m.Ks.x + m.Ks.y + m.Ks.z) / 3.f;
-				dir = phong_sample(m, -rayDirection, Nn, pdf, r1, r2, S.rng);
+				if (LAMBERT && plain3 && has_sampled_diffuse) {
+					// PhongBRDF::sample with p = 1 - 0/3.f = 1 and the diffuse lobe picked (BRDF.h:73-82): one engine draw, the cosine lobe, and
+					// pdf = p*dot/pi + (1-p)*proba_phong = dot/pi + 0 — proba_phong is finite when dot(R, dir) >= 0, and the sample is
+					// rejected by the reflect test below whatever pdf is otherwise (path_vertex_fast, mipt_shade.h)
+					S.rng = peek;
+					dir = random_cos(Nn, r1, r2);
+					pdf = (float)((double)(1.f * dot(Nn, dir)) / (MIPT_PI) + (double)(0.f));
+				} else if (LAMBERT) { S.overflow = true; st = ST_POP; break; }      // a specular material, or the 2^-25 event of the Phong lobe at p = 1
+				else dir = phong_sample(m, -rayDirection, Nn, pdf, r1, r2, S.rng);
 			}
 			if (dot(dir, Nn) < 0 || dot(dir, reflect(rayDirection, Nn)) < 0 || pdf <= 0) { st = ST_POP; break; }   // :593
-			const f3 brdf_i = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, dir, -rayDirection, Nn) : phong_eval(m, dir, -rayDirection, Nn));
+			f3 brdf_i;
+			if (LAMBERT) {
+				if (!sub_interaction && !plain3) { S.overflow = true; st = ST_POP; break; }
+				brdf_i = (sub_interaction ? Ksub : m.Kd) / (float)MIPT_PI;
+			} else brdf_i = sub_interaction ? Ksub / (float)MIPT_PI : (merl ? merl_eval(merl, dir, -rayDirection, Nn) : phong_eval(m, dir, -rayDirection, Nn));
 			f3 nw = ((pathWeight * subsW) * brdf_i) * (dot(Nn, dir) / pdf);    // :611
 			if (obj.ghost && has_bg) {                                          // :614-621
 				const f3 bg = background_pixel(R, pi, pj);
@@ -771,7 +796,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 }
 
 // One round of the logic stage over one id list of the previous round (or, round 0, over all path slots).
-template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false>
+template <bool SUBS, bool SHADOW_LIST, bool FOG, bool FAST = false, bool LAMBERT = false>
 __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(FAST ? MIPT_QW_FAST_WAVES : ((SHADOW_LIST && !FOG) ? MIPT_QW_LOGIC_WAVES + 1 : MIPT_QW_LOGIC_WAVES)))) k_q_logic(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DQueueWave qw,
                                                                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ n_ptr, unsigned n_imm,
                                                                                                 unsigned* __restrict__ head, int out_slot, int out_parity, DCounters* __restrict__ cnt) {
@@ -786,7 +811,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			if (idx >= n) continue;
 			const unsigned id = list ? list[idx] : idx;
-			const int r = qw_advance<SUBS, SHADOW_LIST, FOG, FAST>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
+			const int r = qw_advance<SUBS, SHADOW_LIST, FOG, FAST, LAMBERT>(sc, R, ps, wf, qw, id, n_closest, n_shadow);
 			if (r < 0) over_bits |= 1u << u;
 			else if (FAST && r == 16) slow_bits |= 1u << u;
 			else {

@@ -159,3 +159,18 @@ def test_gpu_logic_stage_tiers_agree(kind):
             H.set_option(k, v)
         rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
         assert_bits(rgb, g[kind + "_rgb"], f"per-sample radiance with {opts or 'the default tiers'}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lambert", [0, 2])
+def test_gpu_lambert_builds_of_the_logic_stage(lambert):
+    """Round 4: the builds of the queue's logic stage that inline only the Lambert vertex (k_q_logic<.., LAMBERT>; chosen at upload for
+    scenes whose materials are all Lambert) against the general builds (`queue_lambert` = 0) and forced on every scene (= 2: a glossy
+    vertex abandons its sample to the one-thread-per-sample loop), on the seven ghost / photo goldens."""
+    g = np.load(GOLD)
+    for kind in COMPOSITING_KINDS:
+        H = capi.HostRaytracer(device=0)
+        cfg = compositing_scene(H, kind)
+        H.set_option("queue_lambert", lambert)
+        rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+        assert_bits(rgb, g[kind + "_rgb"], f"per-sample radiance, compositing scene {kind}, queue_lambert {lambert}")

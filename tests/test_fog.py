@@ -95,3 +95,22 @@ def test_gpu_queue_forms_agree_and_overflow_falls_back(kind):
             assert_bits(img, first[0], f"image, {name}")
             assert_bits(cnt, first[1], f"weights, {name}")
     assert seen["wavefront"] == 0 and seen["thread"] == 0 and seen["ring2"] > 0, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,lambert", [("uniform", 0), ("exp", 0), ("ghostfog", 0), ("glossyfog", 2), ("mirrorfog", 2), ("glassfog", 2)])
+def test_gpu_lambert_builds_of_the_logic_stage_in_fog(kind, lambert):
+    """Round 4: fog scenes whose materials are all Lambert run builds of the logic stage that inline only the Lambert vertex
+    (k_q_logic<.., LAMBERT>); a vertex that is not one abandons its sample to the one-thread-per-sample loop.  `queue_lambert` = 0:
+    the general builds on a Lambert scene (same bits as the default, which is the Lambert build there); = 2: the Lambert builds forced
+    on scenes with a glossy / mirror / glass mesh — the abandonment path must reproduce the goldens through the fallback."""
+    g = np.load(GOLD)
+    H = capi.HostRaytracer(device=0)
+    cfg = fog_scene(H, kind)
+    H.set_option("queue_lambert", lambert)
+    rgb, _ = H.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+    st = H.stats()
+    assert st["pipeline"] == 2
+    assert_bits(rgb, g[kind + "_rgb"], f"per-sample radiance, fog scene {kind}, queue_lambert {lambert}")
+    if kind == "glossyfog":
+        assert st["reserved"] > 0                           # glossy vertices went through the fallback

@@ -1,2 +1,5 @@
-mkdir -p gpurun_out/r4m; rm -f gpurun_out/sweep.log
-bash tools/sweep_libs.sh "-" "- --opt state_skew=1" "- --opt state_skew=17" "- --opt state_skew=65" "- --opt state_skew=1025" "- --opt state_skew=4113" "-" "- --opt state_skew=17" 2>&1 | tee gpurun_out/r4m/sweep_skew.txt
+mkdir -p gpurun_out/r4n
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r4n/gputests.txt 2>&1; head -6 gpurun_out/r4n/gputests.txt | tail -2; grep -E "^E |FAILED" gpurun_out/r4n/gputests.txt | head
+timeout 600 python tools/queue_kernel_rate.py 64 > gpurun_out/r4n/queue_rate.jsonl 2>&1; cut -c1-330 gpurun_out/r4n/queue_rate.jsonl
+timeout 300 python tools/queue_kernel_rate.py 64 queue_lambert=0 only=fog > gpurun_out/r4n/queue_rate_fog_general.jsonl 2>&1; cut -c1-330 gpurun_out/r4n/queue_rate_fog_general.jsonl
+timeout 600 python tests/tools/fuzz_parity.py 150 77 --queue > gpurun_out/r4n/fuzz_queue_150.txt 2>&1; tail -1 gpurun_out/r4n/fuzz_queue_150.txt
