@@ -31,3 +31,8 @@ PY
 head -7 gpurun_out/${S}_kstats.txt
 cut -c1-240 gpurun_out/${S}_queue_rate_wavefront_64spp.jsonl
 ls gpurun_out | grep ${S}
+# differential fuzzing on the same library (test infrastructure: the oracle is the checker)
+timeout 900 python tests/tools/fuzz_parity.py 500 401 > gpurun_out/${S}_fuzz_parity_500_scenes.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_500_scenes.txt
+timeout 900 python tests/tools/fuzz_parity.py 300 402 --queue > gpurun_out/${S}_fuzz_parity_300_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue.txt
+timeout 900 python tests/tools/fuzz_parity.py 250 403 --queue --spheres > gpurun_out/${S}_fuzz_parity_250_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_250_scenes_queue_spheres.txt
+timeout 900 python tests/tools/fuzz_parity.py 150 404 --queue --bare-spheres > gpurun_out/${S}_fuzz_parity_150_scenes_queue_bare_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_150_scenes_queue_bare_spheres.txt
