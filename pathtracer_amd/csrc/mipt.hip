@@ -403,6 +403,7 @@ struct mipt_ctx {
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
+	int64_t opt_merl_batch = 0;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h: measured equal, not the default); 0 = tier 3
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
 	int64_t opt_resolve_rows = 12;          // splat: destination rows per band of the column-scan kernel (0 = the per-pixel gather kernel)
@@ -614,6 +615,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "merl_batch")) { c->opt_merl_batch = value != 0; c->grid_stage[0] = 0; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
@@ -823,7 +825,16 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (o.ghost) scene_ghost = true;
 		memcpy(d.inv, o.inv_trans_matrix, 48); memcpy(d.trans, o.trans_matrix, 48); memcpy(d.rot, o.rot_matrix, 36);
 		d.brdf_kind = o.brdf_kind; d.merl = nullptr;
-		if (o.brdf_kind == MIPT_BRDF_MERL) { int rc = upload(c, o.merl_data, (size_t)3 * 90 * 90 * 180, &d.merl); if (rc) return rc; scene_merl = true; }
+		if (o.brdf_kind == MIPT_BRDF_MERL) {
+			// the table in cells of {r, g, b, 0} (merl_eval_inline, mipt_shade.h): uploaded as it is, rearranged on the device
+			const double* planar = nullptr;
+			int rc = upload(c, o.merl_data, (size_t)3 * MIPT_MERL_CELLS, &planar); if (rc) return rc;
+			void* cells = nullptr;
+			HIPCHK(c, hipMalloc(&cells, (size_t)MIPT_MERL_CELL * MIPT_MERL_CELLS * sizeof(double))); c->scene_allocs.push_back(cells);
+			hipLaunchKernelGGL(k_merl_interleave, dim3((MIPT_MERL_CELLS + 255) / 256), dim3(256), 0, 0, planar, (double*)cells);
+			HIPCHK(c, hipGetLastError());
+			d.merl = (const double*)cells; scene_merl = true; H.merl_mask |= 1u << i;
+		}
 		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
 		lists[MT_KD] = o.textures; counts[MT_KD] = o.n_textures;
 		lists[MT_KS] = o.specularmap; counts[MT_KS] = o.n_specularmap;
@@ -1299,10 +1310,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	// chunk statically: a block that only starts when another one has finished would hold its chunk back until then)
 	if (c->grid_stage[0] == 0) {
 		const void* kern[8] = {(const void*)k_wf_traverse<0>, (const void*)k_wf_traverse<1>, (const void*)k_wf_traverse<2>, (const void*)k_wf_shade<0>,
-		                       (const void*)k_wf_shade<1>, (const void*)(c->scene_has_merl ? k_wf_shade<3> : k_wf_shade<2>), (const void*)k_wf_extend, (const void*)k_wf_shadow};
+		                       (const void*)k_wf_shade<1>, (const void*)(c->scene_has_merl ? (c->opt_merl_batch ? k_wf_shade<4> : k_wf_shade<3>) : k_wf_shade<2>), (const void*)k_wf_extend, (const void*)k_wf_shadow};
 		for (int k = 0; k < 8; k++) {
 			int nb = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+			const size_t lds = k == 4 ? MIPT_SHADE_LDS_BYTES(1) : (k == 5 ? (c->scene_has_merl ? (c->opt_merl_batch ? MIPT_SHADE_LDS_BYTES(4) : MIPT_SHADE_LDS_BYTES(3)) : MIPT_SHADE_LDS_BYTES(2)) : 0);
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern[k], MIPT_BLOCK, lds) != hipSuccess || nb <= 0) nb = 1;
 			c->grid_stage[k] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
 		}
 	}
@@ -1456,9 +1468,10 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				}
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_fast_shade) {
-					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					if (c->scene_has_merl) hipLaunchKernelGGL(k_wf_shade<3>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					else hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(1), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					if (c->scene_has_merl && c->opt_merl_batch) hipLaunchKernelGGL(k_wf_shade<4>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE4_LDS_BYTES, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					else if (c->scene_has_merl) hipLaunchKernelGGL(k_wf_shade<3>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(3), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+					else hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(2), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");

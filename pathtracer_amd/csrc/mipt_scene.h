@@ -106,6 +106,7 @@ struct DScene {
 	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
 	int inherit_material;        // some sphere beyond objects 0 / 1 has no material lists and is not a mirror: Scene::intersection's ONE MaterialValues for all objects
 	                             // of its loop decides what it is shaded with (Geometry.cpp:596); such scenes are rendered by the one-thread-per-sample kernel (mipt_trace.h)
+	unsigned merl_mask;          // bit i: object i carries a measured BRDF (the fast shade tier hands its hits on before it looks at their material)
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
 	DObject obj[MIPT_MAX_OBJECTS];

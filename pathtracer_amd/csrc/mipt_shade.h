@@ -107,6 +107,15 @@ MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, dou
 // per SIMD, generate + shade 869 -> 1 089 ms per step; at 2 waves (256 registers, nothing spilled) 1 028 ms.  The stage wants its
 // third wave more than it minds the 48 scratch accesses per vertex; a function cannot be given a register budget
 // (amdgpu_num_vgpr is for kernels), and one call for both evaluations made the allocator take 248 registers for the callee.
+#define MIPT_MERL_CELL 4
+#define MIPT_MERL_CELLS (90 * 90 * 180)
+// planar table as the reference holds it (red, green, blue planes) -> cells of {r, g, b, 0}
+__global__ void k_merl_interleave(const double* __restrict__ planar, double* __restrict__ cells) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= MIPT_MERL_CELLS) return;
+	cells[MIPT_MERL_CELL * (size_t)i] = planar[i]; cells[MIPT_MERL_CELL * (size_t)i + 1] = planar[i + MIPT_MERL_CELLS];
+	cells[MIPT_MERL_CELL * (size_t)i + 2] = planar[i + 2 * MIPT_MERL_CELLS]; cells[MIPT_MERL_CELL * (size_t)i + 3] = 0.0;
+}
 MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
@@ -158,9 +167,15 @@ MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N
 	int pd = (int)(fi_diff / MIPT_PI * 360 / 2);
 	int pd_idx = pd < 0 ? 0 : (pd < 179 ? pd : 179);
 	int ind = pd_idx + td_idx * 180 + th_idx * 180 * 90;
-	double r = data[ind] * (1.0 / 1500.0);
-	double g = data[ind + 90 * 90 * 180] * (1.15 / 1500.0);
-	double b = data[ind + 90 * 90 * 360] * (1.66 / 1500.0);
+	// lookup_brdf_val reads brdf[ind], brdf[ind + 90*90*180], brdf[ind + 90*90*360] (MERLBRDFRead.cpp:196-203): three cache lines
+	// 11.7 MB apart.  The device copy of the table keeps the three values of a cell side by side (32-byte cells, MIPT_MERL_CELL
+	// doubles each: mipt_upload_scene, k_merl_interleave): one line per evaluation.
+	typedef double v2d_ __attribute__((ext_vector_type(2)));
+	const __attribute__((address_space(1))) v2d_* cell = (const __attribute__((address_space(1))) v2d_*)(data + (size_t)MIPT_MERL_CELL * (size_t)ind);
+	const v2d_ rg = cell[0], bx = cell[1];
+	double r = rg.x * (1.0 / 1500.0);
+	double g = rg.y * (1.15 / 1500.0);
+	double b = bx.x * (1.66 / 1500.0);
 	return mk3((float)r, (float)g, (float)b);
 }
 __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N); }
@@ -296,6 +311,54 @@ MIPT_DEV bool path_vertex(const DScene* __restrict__ sc, const DRender& R, PathS
 	return true;
 }
 
+
+// The diffuse branch of path_vertex for a surface with a measured BRDF, with its two table evaluations LEFT OUT and handed
+// back as requests (shade tier 4, mipt_wavefront.h: the requests of many vertices are evaluated together, 64 to a trip).
+// Both requests are known before either value is needed: wi comes from the light sample, dir from the lattice point
+// (IsoMERLBRDF::sample draws nothing from the engine).  What the values are multiplied with travels with the request:
+//   A (next-event estimation): contrib = 0 + ((1,1,1) * sa) * brdf,   sa = lightPower * max(0, N.wi) * J / proba     (:548)
+//   B (continuation):          weight  = ((w * (1,1,1)) * brdf) * fb, fb = N.dir / pdf                               (:611)
+// Only called for a vertex that path_vertex would take through the measured BRDF: a hit on an object other than the light and
+// the environment sphere, neither mirror nor transparent, mat.merl != nullptr.  ps.weight is NOT updated (request B does it).
+MIPT_DEV void path_vertex_merl_requests(const DRender& R, PathState& ps, f3 P, const Mat& mat, int pix, int sampleID, ShadowRequest& sh,
+                                        bool& reqA, f3& xa, float& sa, bool& reqB, f3& xb, float& fb) {
+	sh.diffuse = true;
+	sh.cast = false;
+	sh.contrib = mk3(0, 0, 0);
+	reqA = false; reqB = false;
+	const f3 N = mat.shadingN;
+	const f3 rayDirection = ps.ray.d;
+	ps.color = ps.color + (ps.weight * mat.Ke) * R.envmap_intensity;     // :411
+	f3 cl = ld3(R.centerLight);
+	f3 axeOP = fast_normalize(P - cl);
+	float l1 = pcg_uniform(ps.rng);
+	float l2 = pcg_uniform(ps.rng);
+	f3 dir_l = random_cos(axeOP, l1, l2);
+	f3 pt_l = dir_l * R.radiusLight + cl;
+	f3 wi = fast_normalize(pt_l - P);
+	float d_light2 = norm2(pt_l - P);
+	if (!(dot(mat.shadingN, wi) < 0)) {
+		float J = dot(dir_l, -wi) / d_light2;
+		float proba = (float)((double)dot(axeOP, dir_l) / (MIPT_PI * (double)R.radiusLight * (double)R.radiusLight));
+		if (proba > 0.f) { reqA = true; xa = wi; sa = R.lightPower * fmaxf(0.f, dot(N, wi)) * J / proba; }
+		sh.cast = true;
+		sh.ray.o = P + 0.01f * wi;
+		sh.ray.d = wi;
+		sh.dist = sqrtf(d_light2) - 0.01f;
+	}
+	if (ps.depth <= 1) return;
+	float ip;
+	float r1 = modff(R.randomPerPixel[2 * (size_t)pix] + R.samples2d[2 * sampleID], &ip);
+	float r2 = modff(R.randomPerPixel[2 * (size_t)pix + 1] + R.samples2d[2 * sampleID + 1], &ip);
+	f3 dir = random_cos(N, r1, r2);                                      // IsoMERLBRDF::sample (BRDF.h:198-203)
+	float pdf = (float)((double)dot(N, dir) / (MIPT_PI));
+	if (dot(dir, N) < 0 || dot(dir, reflect(rayDirection, N)) < 0 || pdf <= 0) return;   // :593
+	reqB = true; xb = dir; fb = dot(N, dir) / pdf;
+	ps.ray.o = P + 0.01f * dir;
+	ps.ray.d = dir;
+	ps.show_lights = false;
+	ps.depth--;
+}
 
 // Fast tier of the shade stage: the same vertex logic restricted to what a plain diffuse vertex needs
 // (miss, light / environment sphere, Lambert-only Phong material with the diffuse lobe picked).

@@ -79,8 +79,14 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 // One same-address atomic costs ~11 ns chip-wide (MI355X_MICROARCH.md "dequeue": one word saturates at
 // ~88 ops/us), so queue traffic is batched: a wave pulls MIPT_WF_UNROLL*64 entries per atomic and
 // appends the survivors of all its sub-chunks with one atomic per destination queue.
+// Round 4: 8 sub-chunks (512 entries) per atomic instead of 4.  A shade launch over 300 M vertices makes 1.2 M chunks at 256 entries,
+// and each chunk costs an atomic on the queue head, one on the pair of destination sizes and (fast tier) one on the slow list's size:
+// at ~11 ns per same-address atomic that is a floor of ~13 ms per launch whatever the vertices cost.  configs[2] / [1] sat just above
+// it (their fast tier is bound by its arithmetic: 372 / 303 ms per step at 4, 8 and 16 sub-chunks; 502 ms at 2), configs[4] sat ON it: its fast
+// tier hands two thirds of its vertices on and does little else (generate + shade 849 -> 776 ms per step at 8, 781 at 16;
+// profiles/r4_i_shade_stage_experiments.txt).
 #ifndef MIPT_WF_UNROLL
-#define MIPT_WF_UNROLL 4
+#define MIPT_WF_UNROLL 8
 #endif
 #define MIPT_WF_CHUNK (64u * MIPT_WF_UNROLL)
 
@@ -206,6 +212,35 @@ __device__ __forceinline__ void queue_push2(unsigned* __restrict__ list_a, unsig
 	}
 }
 
+// queue_push2 with `n_extra` more entries for list_b, taken from a wave-private LDS buffer (shade tier 4: the paths whose
+// continuation was decided by an evaluation trip): still one atomic
+__device__ __forceinline__ void queue_push2x(unsigned* __restrict__ list_a, unsigned* __restrict__ list_b, unsigned long long* __restrict__ count2,
+                                             unsigned bits_a, unsigned bits_b, const unsigned* __restrict__ src, unsigned src_base, const unsigned* extra, unsigned n_extra) {
+	unsigned long long ma[MIPT_WF_UNROLL], mb[MIPT_WF_UNROLL];
+	unsigned total_a = 0, total_b = 0;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+		ma[u] = __ballot((bits_a >> u) & 1u); total_a += (unsigned)__popcll(ma[u]);
+		mb[u] = __ballot((bits_b >> u) & 1u); total_b += (unsigned)__popcll(mb[u]);
+	}
+	if ((total_a | total_b | n_extra) == 0) return;
+	unsigned lane = lane_id();
+	unsigned long long base2 = 0;
+	if (lane == 0) base2 = atomicAdd(count2, (unsigned long long)total_a | ((unsigned long long)(total_b + n_extra) << 32));
+	unsigned base_a = __builtin_amdgcn_readfirstlane((unsigned)base2), base_b = __builtin_amdgcn_readfirstlane((unsigned)(base2 >> 32));
+	unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+		unsigned idx = src_base + 64u * u + lane;
+		unsigned id = 0;
+		if (((bits_a | bits_b) >> u) & 1u) id = src ? src[idx] : idx;
+		if ((bits_a >> u) & 1u) list_a[base_a + (unsigned)__popcll(ma[u] & below)] = id;
+		if ((bits_b >> u) & 1u) list_b[base_b + (unsigned)__popcll(mb[u] & below)] = id;
+		base_a += (unsigned)__popcll(ma[u]); base_b += (unsigned)__popcll(mb[u]);
+	}
+	for (unsigned k = lane; k < n_extra; k += 64u) list_b[base_b + k] = extra[k];
+}
+
 // bit 31 of wgt.w marks a path slot that holds a live path (slots of 8x8 blocks that stick out of
 // the image never do); depth 0 of a pass uses the identity list, so generation needs no queue.
 #define MIPT_WF_VALID 0x80000000u
@@ -293,12 +328,53 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #ifndef MIPT_SHADE3_WAVES
 #define MIPT_SHADE3_WAVES 3             // tiers 0 and 3 (general code with the measured BRDF)
 #endif
+#ifndef MIPT_SHADE_EARLY_DEFER
+#define MIPT_SHADE_EARLY_DEFER 1
+#endif
+#ifndef MIPT_SHADE4_WAVES
+#define MIPT_SHADE4_WAVES 3             // tier 4 (general code, measured-BRDF evaluations batched)
+#endif
+// TIER 4 (round 4): tier 3 with the table evaluations of the measured BRDF taken OUT of the vertex code.  In tier 3 a vertex calls
+// merl_eval twice, each time with the lanes its own branch left (light above the horizon: ~55 %; a continuation that survives
+// Raytracer.cpp:593 and is not the path's last: ~35 %), and the evaluation is ~85 % of the tier's vector instructions: the tier ran
+// at 33 of 64 lanes.  Here a vertex only FILES its requests (path_vertex_merl_requests, mipt_shade.h) in a per-wave list in LDS — 15
+// words each: the direction, the factor, wo, N, the path weight, the path id, kind / object / depth — and whenever 64 have come
+// together the wave evaluates them in ONE trip with every lane busy, whichever vertices (of this chunk or an earlier one) they
+// belong to.  The lane that evaluates a request also finishes it: A writes weight * contrib where the shadow stage expects it,
+// B computes the new path weight, tests path_alive (Raytracer.cpp:240-241) and, if the path lives, writes the weight and files the
+// path id for the next depth's queue (appended with the chunk's other continuations, one atomic per chunk as before).  Same
+// operations on the same operands as path_vertex: bit-identical.  The one copy of the evaluation is inlined at the top level of the
+// sub-chunk loop, where nothing of a vertex is live: no call, no callee-saved registers through scratch.
+// A vertex with a request A always goes through the shadow queue (tier 3 adds the light term at once when the shadow ray misses
+// the root box of every mesh; the shadow stage then adds the same product to the same colour).
+#define MIPT_MERL_RQ 128                // request slots per wave: < 64 carried over + at most 64 filed at a time
+#define MIPT_MERL_RQ_WORDS 15
+#define MIPT_MERL_ALIVE (64 + 64 * MIPT_WF_UNROLL)   // path ids of continuing paths per wave between two chunk ends: <= 63 carried + one chunk's
+#define MIPT_MERL_LDS_WORDS (MIPT_MERL_RQ * MIPT_MERL_RQ_WORDS + MIPT_MERL_ALIVE)
+// MIPT_SHADE_GLDS (experiment of round 4, off): the path state of sub-chunk u+1 is requested while sub-chunk u is shaded, as round 1's
+// software pipeline did — but by LDS-DMA (global_load_lds: the data lands in LDS, no register is held while it is in flight),
+// tiers 1 to 3.  Per wave: 5 x 64 float4 (weight, origin, direction, hit, colour) + 64 uint2.  Bit-identical (GPU suite and 300 fuzz
+// scenes), and within the run-to-run spread of the stage on every config (configs[2]: 373 / 373 ms with, 383 / 363 without;
+// configs[1] 316 / 308 and 308 / 316; configs[3] 591 / 591; configs[4] 866 / 864): the first of a vertex's dependent round trips
+// is not what the stage waits for (profiles/r4_i_shade_stage_experiments.txt).
+#ifndef MIPT_SHADE_GLDS
+#define MIPT_SHADE_GLDS 0
+#endif
+#define MIPT_GLDS_WORDS (5 * 256 + 128)
+#define MIPT_SHADE_LDS_BYTES(TIER) ((TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
+#define MIPT_SHADE4_LDS_BYTES MIPT_SHADE_LDS_BYTES(4)
+extern __shared__ unsigned mipt_shade_lds[];
 template <int TIER>
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : MIPT_SHADE3_WAVES)))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
-	const unsigned n = TIER >= 2 ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
-	unsigned* head = &wf.counters[MIPT_CNT((TIER >= 2 ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
-	const unsigned* __restrict__ list = TIER >= 2 ? wf.list_slow : wf.list[b & 1];
-	const bool identity = TIER < 2 && b == 0;
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : (TIER == 4 ? MIPT_SHADE4_WAVES : MIPT_SHADE3_WAVES))))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+	static_assert(TIER != 4 || MIPT_SHADE_ROLLED, "tier 4 is written into the rolled form of the sub-chunk loop");
+	// (tier 4's code over the WHOLE queue of a depth, no fast tier in front of it, was measured too: configs[4] generate + shade 864 ms
+	// against 771 with the fast tier, and the traversal stages 3 % slower on the queues it leaves)
+	constexpr bool SLOW_LIST = TIER >= 2;
+	constexpr bool BATCH = TIER == 4;
+	const unsigned n = SLOW_LIST ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
+	unsigned* head = &wf.counters[MIPT_CNT((SLOW_LIST ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
+	const unsigned* __restrict__ list = SLOW_LIST ? wf.list_slow : wf.list[b & 1];
+	const bool identity = !SLOW_LIST && b == 0;
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
@@ -314,7 +390,14 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			in.rs = wf_ld(&wf.rng[id]);
 		}
 	};
-	while (q.pull(head, n, base)) {
+	// tier 4: this wave's request list and its list of continuing path ids (LDS), both wave-uniform counts
+	unsigned* const rq = BATCH ? mipt_shade_lds + (threadIdx.x >> 6) * MIPT_MERL_LDS_WORDS : nullptr;
+	unsigned* const alive_buf = BATCH ? rq + MIPT_MERL_RQ * MIPT_MERL_RQ_WORDS : nullptr;
+	unsigned rq_count = 0, n_alive = 0;
+	for (;;) {
+		// tier 4 runs the body once more after the last chunk, without a chunk, to evaluate the requests that are left
+		const bool got = q.pull(head, n, base);
+		if (!got && (!BATCH || rq_count == 0)) break;
 		unsigned cont_bits = 0, cast_bits = 0, slow_bits = 0;
 #if MIPT_SHADE_ROLLED
 		// The loop over the sub-chunks is NOT unrolled: one copy of the vertex code is ~4 600 instructions (37 KB), four copies
@@ -328,11 +411,44 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		In cur, nxt;
 		cur.w = cur.o = cur.d = cur.hr = cur.col = make_float4(0.f, 0.f, 0.f, 0.f); cur.rs = make_uint2(0u, 0u); nxt = cur;
 		if (MIPT_SHADE_PREFETCH) fetch(id_cur, id_cur != 0xffffffffu, cur);
+		constexpr bool GLDS = MIPT_SHADE_GLDS && (TIER == 1 || TIER == 2 || TIER == 3);
+		typedef __attribute__((address_space(3))) unsigned lds_u32;
+		typedef const __attribute__((address_space(1))) void* gptr_t;
+		lds_u32* const gl = (lds_u32*)(mipt_shade_lds + (GLDS ? (threadIdx.x >> 6) * MIPT_GLDS_WORDS : 0));
+		auto glds_issue = [&](unsigned pid) {
+			if (pid != 0xffffffffu) {
+				__builtin_amdgcn_global_load_lds((gptr_t)&wf.wgt[pid], gl + 0, 16, 0, 2);
+				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_o[pid], gl + 256, 16, 0, 2);
+				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_d[pid], gl + 512, 16, 0, 2);
+				__builtin_amdgcn_global_load_lds((gptr_t)&wf.hit[pid], gl + 768, 16, 0, 2);
+				if (TIER != 1) __builtin_amdgcn_global_load_lds((gptr_t)&wf.out.col[pid], gl + 1024, 16, 0, 2);
+				__builtin_amdgcn_global_load_lds((gptr_t)&wf.rng[pid], gl + 1280, 4, 0, 2);
+				__builtin_amdgcn_global_load_lds((gptr_t)((const unsigned*)&wf.rng[pid] + 1), gl + 1344, 4, 0, 2);
+			}
+		};
+		if (GLDS) glds_issue(id_cur);
 #pragma unroll 1
-		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
+		for (int u = 0; u < (BATCH && !got ? 1 : (int)MIPT_WF_UNROLL); u++) {
 			const unsigned id = id_cur;
 			id_nn = load_id(u + 2);
-			if (MIPT_SHADE_PREFETCH) fetch(id_nxt, id_nxt != 0xffffffffu, nxt);       // in flight while this sub-chunk is shaded; moved into `cur` at the end of the body
+			// tier 4: what this lane's vertex files (bit 0: request A, bit 1: request B)
+			unsigned req_bits = 0, req_meta = 0;
+			f3 req_xa = mk3(0, 0, 0), req_xb = mk3(0, 0, 0), req_wo = mk3(0, 0, 0), req_n = mk3(0, 0, 0), req_w = mk3(0, 0, 0);
+			float req_sa = 0.f, req_fb = 0.f;
+			if (GLDS) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (id_cur != 0xffffffffu) {
+					const unsigned l = lane_id();
+					typedef __attribute__((address_space(3))) mipt_v4f lds_f4;
+					const lds_f4* g4 = (const lds_f4*)gl;
+					const mipt_v4f a0 = g4[l], a1 = g4[64 + l], a2 = g4[128 + l], a3 = g4[192 + l];
+					cur.w = make_float4(a0.x, a0.y, a0.z, a0.w); cur.o = make_float4(a1.x, a1.y, a1.z, a1.w); cur.d = make_float4(a2.x, a2.y, a2.z, a2.w); cur.hr = make_float4(a3.x, a3.y, a3.z, a3.w);
+					if (TIER != 1) { const mipt_v4f a4 = g4[256 + l]; cur.col = make_float4(a4.x, a4.y, a4.z, a4.w); }
+					cur.rs = make_uint2(gl[1280 + l], gl[1344 + l]);
+				}
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				glds_issue(id_nxt);                                                   // lands while this sub-chunk is shaded
+			} else if (MIPT_SHADE_PREFETCH) fetch(id_nxt, id_nxt != 0xffffffffu, nxt);       // in flight while this sub-chunk is shaded; moved into `cur` at the end of the body
 			else fetch(id_cur, id_cur != 0xffffffffu, cur);
 			const In sin = cur;
 			do {
@@ -376,6 +492,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				MIPT_PROF_COUNT(16)
 				if (has_inter && h.obj == 1) MIPT_PROF_COUNT(20)
 				if (!has_inter || h.obj == 0) MIPT_PROF_COUNT(22)
+				// a hit on an object with a measured BRDF is the general tier's whatever its material says: handed on BEFORE the
+				// material is fetched (round 4; until then this tier fetched the material of such a vertex — shading record, group
+				// record, the lot — only to find mat.merl set and defer it, and the general tier fetched it again)
+				if (MIPT_SHADE_EARLY_DEFER && has_inter && ((sc->merl_mask >> h.obj) & 1u)) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
 			}
 			if (has_inter) hit_material(sc, p.ray, h, P, m);
 			// pixel of this path (for the per-pixel Cranley-Patterson rotation) and its sample index
@@ -389,7 +509,16 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				if (r == VERTEX_DEFER) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
 				if (sh.diffuse) MIPT_PROF_COUNT(18)
 				c = r == VERTEX_CONTINUE;
-			} else c = path_vertex<TIER != 2>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			} else if (BATCH && has_inter && h.obj != 0 && h.obj != 1 && !(m.miroir & 1) && !m.transp && m.merl != nullptr) {
+				// exactly the vertices path_vertex takes through the measured BRDF
+				wv = p.weight;
+				req_wo = -p.ray.d; req_n = m.shadingN; req_w = p.weight;
+				bool ra, rb;
+				path_vertex_merl_requests(R, p, P, m, pi * R.W + pj, ps.k0 + kk, sh, ra, req_xa, req_sa, rb, req_xb, req_fb);
+				req_bits = (ra ? 1u : 0u) | (rb ? 2u : 0u);
+				req_meta = ((unsigned)h.obj << 1) | ((unsigned)p.depth << 8);      // p.depth: already the continuation's
+				c = false;                                                        // (request B decides; see below)
+			} else c = path_vertex<TIER != 2 && !BATCH>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
 			// The shadow request of this vertex: an analytic occluder settles it here (never queued); so does a ray that
 			// misses the root box of every mesh — TriMesh::intersection_shadow returns before it visits a node
@@ -402,9 +531,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				sh_queue = true;                                          // measurement probe: no analytic / root tests for the shadow request
 #else
 				if (!analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
-					if (MIPT_SHADE_ROOT_TEST && meshes_missed(sc, sh.ray.o, sh.ray.d, sh.dist)) p.color = p.color + wv * sh.contrib;
+					if (BATCH && (req_bits & 1u)) sh_queue = true;        // its weight * contrib is written by the lane that evaluates request A
+					else if (MIPT_SHADE_ROOT_TEST && meshes_missed(sc, sh.ray.o, sh.ray.d, sh.dist)) p.color = p.color + wv * sh.contrib;
 					else sh_queue = true;
-				}
+				} else req_bits &= ~1u;                                       // nobody needs the value
 #endif
 			}
 			if (TIER == 1) {
@@ -420,10 +550,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
 				wf_st(&wf.sh_o[id], make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist));
 				wf_st(&wf.sh_d[id], make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f));
-				wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
+				if (!(BATCH && (req_bits & 1u))) wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
 			}
 			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
-			if (c) {
+			if (c || (BATCH && (req_bits & 2u))) {
 				float t0; unsigned best0;
 #if MIPT_PERTURB == 2
 				t0 = __int_as_float(0x7f800000); best0 = MIPT_HIT_MISS;         // measurement probe: no analytic prefix for the continuation ray
@@ -432,7 +562,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 #endif
 				wf_st(&wf.ray_o[id], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
 				wf_st(&wf.ray_d[id], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
-				wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
+				// (a vertex with a request B: the weight — and whether the path goes on — is written by the lane that evaluates it)
+				if (c) wf_st(&wf.wgt[id], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
 				wf_st(&wf.rng[id], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 			if (c) cont_bits |= 1u << u;
@@ -441,10 +572,66 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			if (MIPT_SHADE_PREFETCH) cur = nxt;
 			id_cur = id_nxt; id_nxt = id_nn;
 #endif
+			if (BATCH) {
+				// File this sub-chunk's requests (A of all lanes, then B of all lanes), and evaluate the 64 filed last whenever
+				// that many have come together.  A request is complete in itself, so the order of evaluation does not matter.
+#pragma unroll 1
+				for (int kind = 0; kind < 2; kind++) {
+					const bool has = (req_bits >> kind) & 1u;
+					const unsigned long long hm = __ballot(has);
+					if (has) {
+						const unsigned e = rq_count + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+						const f3 x = kind ? req_xb : req_xa;
+						rq[0 * MIPT_MERL_RQ + e] = __float_as_uint(x.x); rq[1 * MIPT_MERL_RQ + e] = __float_as_uint(x.y); rq[2 * MIPT_MERL_RQ + e] = __float_as_uint(x.z);
+						rq[3 * MIPT_MERL_RQ + e] = __float_as_uint(kind ? req_fb : req_sa);
+						rq[4 * MIPT_MERL_RQ + e] = __float_as_uint(req_wo.x); rq[5 * MIPT_MERL_RQ + e] = __float_as_uint(req_wo.y); rq[6 * MIPT_MERL_RQ + e] = __float_as_uint(req_wo.z);
+						rq[7 * MIPT_MERL_RQ + e] = __float_as_uint(req_n.x); rq[8 * MIPT_MERL_RQ + e] = __float_as_uint(req_n.y); rq[9 * MIPT_MERL_RQ + e] = __float_as_uint(req_n.z);
+						rq[10 * MIPT_MERL_RQ + e] = __float_as_uint(req_w.x); rq[11 * MIPT_MERL_RQ + e] = __float_as_uint(req_w.y); rq[12 * MIPT_MERL_RQ + e] = __float_as_uint(req_w.z);
+						rq[13 * MIPT_MERL_RQ + e] = id; rq[14 * MIPT_MERL_RQ + e] = req_meta | (unsigned)kind;
+					}
+					rq_count += (unsigned)__popcll(hm);
+					const bool drain = !got && kind == 1;                      // after the last chunk: whatever is left
+					if (rq_count >= 64u || (drain && rq_count > 0u)) {
+						const unsigned take = rq_count < 64u ? rq_count : 64u;
+						rq_count -= take;
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+						unsigned alive_id = 0xffffffffu;
+						if (lane_id() < take) {
+							const unsigned e = rq_count + lane_id();
+							const f3 x = mk3(__uint_as_float(rq[0 * MIPT_MERL_RQ + e]), __uint_as_float(rq[1 * MIPT_MERL_RQ + e]), __uint_as_float(rq[2 * MIPT_MERL_RQ + e]));
+							const float fac = __uint_as_float(rq[3 * MIPT_MERL_RQ + e]);
+							const f3 wo = mk3(__uint_as_float(rq[4 * MIPT_MERL_RQ + e]), __uint_as_float(rq[5 * MIPT_MERL_RQ + e]), __uint_as_float(rq[6 * MIPT_MERL_RQ + e]));
+							const f3 nn = mk3(__uint_as_float(rq[7 * MIPT_MERL_RQ + e]), __uint_as_float(rq[8 * MIPT_MERL_RQ + e]), __uint_as_float(rq[9 * MIPT_MERL_RQ + e]));
+							const f3 w0 = mk3(__uint_as_float(rq[10 * MIPT_MERL_RQ + e]), __uint_as_float(rq[11 * MIPT_MERL_RQ + e]), __uint_as_float(rq[12 * MIPT_MERL_RQ + e]));
+							const unsigned rid = rq[13 * MIPT_MERL_RQ + e], meta = rq[14 * MIPT_MERL_RQ + e];
+							const f3 brdf = merl_eval_inline(sc->obj[(meta >> 1) & 31u].merl, x, wo, nn);
+							if (!(meta & 1u)) {                                   // A: Raytracer.cpp:548, then weight * contrib for the shadow stage
+								const f3 contrib = mk3(0, 0, 0) + (mk3(1.f, 1.f, 1.f) * fac) * brdf;
+								const f3 pc = w0 * contrib;
+								wf_st(&wf.sh_c[rid], make_float4(pc.x, pc.y, pc.z, 0.f));
+							} else {                                              // B: :611, then :240-241
+								PathState np;
+								np.weight = ((w0 * mk3(1.f, 1.f, 1.f)) * brdf) * fac;
+								np.depth = (int)((meta >> 8) & 0xffffu);
+								if (path_alive(np)) {
+									wf_st(&wf.wgt[rid], make_float4(np.weight.x, np.weight.y, np.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)np.depth)));
+									alive_id = rid;
+								}
+							}
+						}
+						const unsigned long long am = __ballot(alive_id != 0xffffffffu);
+						if (alive_id != 0xffffffffu) alive_buf[n_alive + __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u))] = alive_id;
+						n_alive += (unsigned)__popcll(am);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					}
+				}
+			}
 		}
 		const unsigned* src = identity ? nullptr : list;
-		queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);
+		if (BATCH) { queue_push2x(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base, alive_buf, n_alive); n_alive = 0; }
+		else queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);
 		if (TIER == 1) queue_push(wf.list_slow, &wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)], slow_bits, src, base);
+		if (BATCH && !got) break;
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);

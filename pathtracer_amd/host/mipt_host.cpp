@@ -203,7 +203,10 @@ Plane::Plane(const Vector& A_, const Vector& N) { type = OT_PLANE; A = A_; vecN 
 // contiguous chunks of [0, n) on the host's hardware threads (mesh-sized loops whose iterations are independent)
 template <class F>
 static void parallel_for(int n, F f) {
-	const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n / 65536));
+	// (at most MIPT_HOST_THREADS, default 32: these loops are bound by memory, and starting 256 threads — the GPU box's hardware_concurrency —
+	// costs a few milliseconds per loop, six loops per TriMesh::init)
+	static const int cap = [] { const char* e = getenv("MIPT_HOST_THREADS"); const int v = e ? atoi(e) : 32; return v > 0 ? v : 32; }();
+	const int nt = std::max(1, std::min(std::min((int)std::thread::hardware_concurrency(), cap), n / 65536));
 	if (nt <= 1) { f(0, n); return; }
 	std::vector<std::thread> th;
 	for (int t = 0; t < nt; t++) th.emplace_back([=] { f((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });

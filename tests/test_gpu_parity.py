@@ -408,3 +408,44 @@ def test_object_table_full_and_one_too_many(pipeline):
     build(G2, 1)
     with pytest.raises(capi.MiptError, match="n_objects"):
         G2.prepare()
+
+
+@pytest.mark.parametrize("batch", [0, 1])
+def test_measured_brdf_tiers_against_golden_and_oracle(batch):
+    """Scenes with a measured BRDF, general shade tier in both forms: every vertex evaluating its own table entries (`merl_batch` 0,
+    the default) and the evaluations filed in LDS and run 64 to a trip (1; round 4).  The golden scene of the compiled reference,
+    then a scene where the measured surface sits beside a glossy Phong mesh, a mirror sphere and a glass sphere (the tier takes the
+    other vertices through the general code), at a depth where requests of several chunks share a trip — against the oracle, per
+    sample and through the splat; ray counts equal between the two forms."""
+    from oracle.binding import Oracle
+    g = load_golden("scene_merl.npz")
+    rt, (mesh, cfg, oid) = gpu("merl", merl_batch=batch)
+    rgb, _ = rt.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+    assert_bits(rgb, g["sample_rgb"], f"golden MERL scene, merl_batch {batch}")
+    outs = []
+    for X in (Oracle(), capi.HostRaytracer(device=0)):
+        cfg = scenes.config_c1(72, 48, 5)
+        cfg.nb_bounces = 6
+        X.apply_config(cfg)
+        a = X.add_mesh(scenes.blob_mesh(28), scale=16.0)
+        X.set_brdf_merl(a, scenes.synthetic_merl_table())
+        b = X.add_mesh(scenes.blob_mesh(12), scale=7.0)
+        X.set_group_material(b, 0, (0.7, 0.3, 0.2), (0.4, 0.4, 0.4), (30, 30, 30))
+        X.add_sphere((16, -14, 8), 5.0, mirror=True)
+        s = X.add_sphere((-15, -16, 10), 4.0)
+        X.add_group_material(s, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, 1.4)
+        if isinstance(X, capi.HostRaytracer):
+            X.set_option("merl_batch", batch)
+        X.prepare()
+        outs.append((X.getcolor_samples(all_pixels(cfg), 0, cfg.spp)[0], X.render_seeded()))
+        if isinstance(X, capi.HostRaytracer):
+            st = X.stats()
+            assert st["pipeline"] == 1
+            outs.append((st["rays_closest"], st["rays_shadow"]))
+    assert_bits(outs[1][0], outs[0][0], f"per-sample radiance, merl_batch {batch}")
+    assert_bits(outs[1][1][1], outs[0][1][1], "splat weights")
+    assert_bits(outs[1][1][0], outs[0][1][0], "splatted image")
+    assert (outs[0][0] != 0).any(-1).mean() > 0.5
+    key = "_merl_tier_ray_counts"
+    prev = globals().setdefault(key, outs[2])
+    assert prev == outs[2], "the two forms of the tier count different rays"
