@@ -403,7 +403,7 @@ struct mipt_ctx {
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
-	int64_t opt_merl_batch = 0;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h: measured equal, not the default); 0 = tier 3
+	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
 	int64_t opt_resolve_rows = 12;          // splat: destination rows per band of the column-scan kernel (0 = the per-pixel gather kernel)

@@ -369,6 +369,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	static_assert(TIER != 4 || MIPT_SHADE_ROLLED, "tier 4 is written into the rolled form of the sub-chunk loop");
 	// (tier 4's code over the WHOLE queue of a depth, no fast tier in front of it, was measured too: configs[4] generate + shade 864 ms
 	// against 771 with the fast tier, and the traversal stages 3 % slower on the queues it leaves)
+	// (a classification pass in front of the fast tier — hits on measured-BRDF objects straight to list_slow, the fast tier over the rest
+	// with all its lanes — was measured as well, git tag r4-classify-experiment: the pass costs 7.3 ms per launch, one atomic per 512
+	// entries IS its time, and the fast tier over a third of the vertices still takes 12.3 ms of its 13.2: configs[4] 875 ms against 787)
 	constexpr bool SLOW_LIST = TIER >= 2;
 	constexpr bool BATCH = TIER == 4;
 	const unsigned n = SLOW_LIST ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
