@@ -474,7 +474,7 @@ def main():
                 verts = rays_c                                            # one shade vertex per closest-hit ray
                 state_bytes = 88 + 128 + 64
                 shade_secs = (shade_ms - 0.0) * 1e-3
-                rsh = {"kernel": "k_wf_generate + k_wf_shade<1,2> (per step)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_vertex": state_bytes,
+                rsh = {"kernel": "k_wf_generate + k_wf_shade<fast tier, general tier> (per step)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_vertex": state_bytes,
                        "frac_definition": "algorithmic path-state bytes per vertex x vertices / stage time / HBM peak 8 TB/s",
                        "vertices_per_step": verts / args.steps, "ms_per_step": shade_ms / args.steps,
                        "achieved": verts * state_bytes / shade_secs / 1e9, "frac": verts * state_bytes / shade_secs / 8e12}
