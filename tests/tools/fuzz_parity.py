@@ -4,7 +4,9 @@ compared bit for bit on both pipelines.  usage: python tests/tools/fuzz_parity.p
 --queue: every scene also draws from the features of the contribution-queue kernel (ghost objects, background photo, fog in
 both media with the three phase functions, subsurface colours), alone and combined.
 --spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh.
---bare-spheres: the same, and a sphere may have no material lists at all (such scenes run on the one-thread-per-sample kernel)."""
+--bare-spheres: the same, and a sphere may have no material lists at all (such scenes run on the one-thread-per-sample kernel).
+--kind=<diffuse|glossy|mirror|glass|textured|merl|two|fat>: every scene's mesh gets this material kind (default: drawn per scene).
+--merl-tiers: pipeline 1 is checked with both forms of the measured-BRDF tier (`merl_batch` 1 and 0)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -15,6 +17,8 @@ from oracle.binding import Oracle
 QUEUE = "--queue" in sys.argv
 SPHERES = "--spheres" in sys.argv or "--bare-spheres" in sys.argv
 BARE = "--bare-spheres" in sys.argv      # spheres may also come WITHOUT material lists (kind 5: shaded with the material of the object tested before, Geometry.cpp:596)
+KIND = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--kind=")), None)
+MERL_TIERS = "--merl-tiers" in sys.argv
 argv = [a for a in sys.argv if not a.startswith("--")]
 n_scenes = int(argv[1]) if len(argv) > 1 else 20
 rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
@@ -32,6 +36,7 @@ for it in range(n_scenes):
         cfg.cam_dir = (0.0, float(np.sin(ang)), float(-np.cos(ang)))
         cfg.cam_up = (0.0, float(np.cos(ang)), float(np.sin(ang)))
     kind = rng.choice(["diffuse", "glossy", "mirror", "glass", "textured", "merl", "two", "fat"])
+    if KIND: kind = KIND
     n = int(rng.integers(6, 70))
     mesh = scenes.blob_mesh(n, fine_detail=bool(rng.integers(0, 2)), with_uv=(kind == "textured"))
     if kind == "fat":
@@ -104,11 +109,13 @@ for it in range(n_scenes):
     line += " " + "+".join(feats) + (" spheres " + "".join("cmgtdb"[q["kind"]] + ("s" if q["ksub"] else "") for q in sph) if sph else "")
     for pipeline in ((1,) if (feats or any(q["ksub"] for q in sph)) else (1, 0)):
         G.set_option("pipeline", pipeline)
-        got = G.getcolor_samples(pix, 0, spp)[0]
-        same = bits_equal(got, want).all(-1).mean()
-        err = np.abs(got.astype(np.float64) - want).max() / WHITE
-        line += "  p%d: identical %.6f max|err|/white %.2g" % (pipeline, same, err)
-        if same < 1.0:
-            bad += 1
+        for batch in ((1, 0) if (MERL_TIERS and pipeline == 1) else (None,)):
+            if batch is not None: G.set_option("merl_batch", batch)
+            got = G.getcolor_samples(pix, 0, spp)[0]
+            same = bits_equal(got, want).all(-1).mean()
+            err = np.abs(got.astype(np.float64) - want).max() / WHITE
+            line += "  p%d%s: identical %.6f max|err|/white %.2g" % (pipeline, "" if batch is None else "/batch%d" % batch, same, err)
+            if same < 1.0:
+                bad += 1
     print(line, flush=True)
 print("scenes with any differing sample:", bad)

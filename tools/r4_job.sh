@@ -1,1 +1,3 @@
-python tools/rank_probe.py c3 > gpurun_out/r4_i_rank_cost_c3_rerun.jsonl 2>/dev/null; cut -c1-200 gpurun_out/r4_i_rank_cost_c3_rerun.jsonl
+mkdir -p gpurun_out/r4m
+timeout 1200 python tests/tools/fuzz_parity.py 250 4410 --kind=merl --merl-tiers --spheres > gpurun_out/r4_i_fuzz_parity_250_scenes_measured_brdf_both_tiers_spheres.txt 2>&1; tail -2 gpurun_out/r4_i_fuzz_parity_250_scenes_measured_brdf_both_tiers_spheres.txt | cut -c1-300
+bash tools/kstats.sh r4_i_c4 --workload c4 | head -8
