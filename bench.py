@@ -12,8 +12,8 @@ One STEP = the hot path (camera rays -> getColor -> splat) over the whole frame 
 With N GPUs the frame's 32x32-pixel tiles are dealt round-robin to the ranks (one process per GPU, scene replicated) and
 the per-rank accumulators are summed by ONE all-reduce at the end (RCCL).
   --scaling strong (default)  the job is fixed: a step is the metric's frame, 1024 spp at 1080p (256 at 4K), whatever N is;
-        a rank renders all samples of its 1/N of the tiles.  The library cuts a step into passes of at most 2^29 paths
-        (~86 GB of path state, sized for 288 GB of HBM): 4 passes of 256 spp on one GPU, one pass of 1024 spp on its
+        a rank renders all samples of its 1/N of the tiles.  The library cuts a step into passes of at most 2^30 paths
+        (~172 GB of path state, sized for 288 GB of HBM): 2 passes of 512 spp on one GPU, one pass of 1024 spp on its
         eighth of the frame on each of 8 — every pass stays large (the per-launch ramp and drain of the persistent
         kernels is amortised over a large batch: 3.72 Grays/s at 64 spp per pass, 3.82 at 128, 3.94 at 256, 3.98 at 512).
   --scaling weak              the job grows with N: a step renders N x 256 spp, so every rank keeps one 531 M-path pass per
@@ -59,7 +59,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_PASS = 256          # at 1080p; scaled down with the pixel count so that a pass keeps <= 2^29 paths (~86 GB of path state)
+SPP_PER_PASS = 256          # a quarter of the step at 1080p (the library itself cuts a step into passes of at most 2^30 paths, ~172 GB of path state); scaled down with the pixel count
 SEED_STRIDE = 65536         # sample k of pixel p draws from pcg32(p * 65536 + k): a run may use at most 65536 samples per pixel
 
 

@@ -375,7 +375,7 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
  *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again
- *   "paths_per_pass"  upper bound on paths in flight per pass (default 2^29, ~86 GB of path state).  Whatever its value, a pass
+ *   "paths_per_pass"  upper bound on paths in flight per pass (default 2^30, ~172 GB of path state).  Whatever its value, a pass
  *                     is sized so that its state fits in ~80 % of the device memory that is free when the render starts
  *                     (hipMemGetInfo) and holds at most 2^31 paths; if the allocation still fails the pass is halved and retried
  *   "pass_memory_limit" test hook: > 0 = size the pass as if only this many bytes were free (0 = ask the device)

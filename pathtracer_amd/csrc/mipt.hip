@@ -408,7 +408,7 @@ struct mipt_ctx {
 	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
 	int64_t opt_resolve_rows = 12;          // splat: destination rows per band of the column-scan kernel (0 = the per-pixel gather kernel)
 	int64_t opt_pass_memory_limit = 0;      // test hook: > 0 = size the pass as if only this many bytes were free on the device
-	int64_t opt_paths_per_pass = 1 << 29;   // 537 M paths (259 spp at 1080p), ~86 GB of path state: sized for 288 GB of HBM
+	int64_t opt_paths_per_pass = 1 << 30;   // 1 074 M paths (517 spp at 1080p), ~172 GB of path state: sized for 288 GB of HBM (round 4: 2^29 until then; configs[2] +1.1 %, configs[1] +1.3 % — half the stage launches, each with its ramp and drain; 2^28: -3.2 %).  Whatever the value, a pass takes at most 80 % of the memory that is free
 };
 
 static int fail(mipt_ctx* c, int code, const char* fmt, ...) {
@@ -833,6 +833,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			HIPCHK(c, hipMalloc(&cells, (size_t)MIPT_MERL_CELL * MIPT_MERL_CELLS * sizeof(double))); c->scene_allocs.push_back(cells);
 			hipLaunchKernelGGL(k_merl_interleave, dim3((MIPT_MERL_CELLS + 255) / 256), dim3(256), 0, 0, planar, (double*)cells);
 			HIPCHK(c, hipGetLastError());
+			// (the planar copy, 35 MB, stays until the scene is freed: releasing it here costs a device synchronisation and a hipFree, 4-10 ms of the upload)
 			d.merl = (const double*)cells; scene_merl = true; H.merl_mask |= 1u << i;
 		}
 		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
@@ -1215,7 +1216,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
 	}
 	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? MIPT_QW_FIFO : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
-	// The pass is sized for the memory that is actually free (the default of 2^29 paths is ~86 GB of state, sized for an
+	// The pass is sized for the memory that is actually free (the default of 2^30 paths is ~172 GB of state, sized for an
 	// otherwise empty 288 GB device): at most ~80 % of free + what this context already holds for passes, path ids < 2^31.
 	{
 		size_t free_b = 0, total_b = 0;

@@ -36,6 +36,9 @@
 #define MIPT_QW_LOGIC_WAVES 3            // general builds of the logic stage (188-237 registers unconstrained; round 3, after sinf / cosf lost their selected constants: 3 waves with 20-70 spilled values beat 2 without — subsurface logic 59.5 -> 51.8 ms, fog 110.7 -> 107.8, ghost +-0); + 1 for the any-hit-list stage of the build without the fog code
 #endif
 #ifndef MIPT_QW_FAST_WAVES
+#ifndef MIPT_QW_UNROLL
+#define MIPT_QW_UNROLL 4                 // sub-chunks of 64 entries per queue atomic in the logic stage
+#endif
 #define MIPT_QW_FAST_WAVES 4             // the fast tier of the closest-hit-list stage (scenes without fog / subsurface groups)
 #endif
 #ifndef MIPT_QW_FAST
@@ -803,11 +806,13 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	const unsigned n = n_ptr ? *n_ptr : n_imm;
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
-	QueuePuller q; q.init();
+	// (chunks of MIPT_QW_UNROLL x 64 entries, not the 512 of pipeline 1's stages: an entry here costs thousands of instructions, the atomics are
+	// nowhere near a floor, and the appends of 8 sub-chunks — 16 more scalar registers each — cost the logic stage 1-3 %)
+	QueuePullerT<64u * MIPT_QW_UNROLL> q; q.init();
 	while (q.pull(head, n, base)) {
 		unsigned closest_bits = 0, shadow_bits = 0, over_bits = 0, probe_bits = 0, add_bits = 0, slow_bits = 0;
 #pragma unroll 1
-		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
+		for (int u = 0; u < (int)MIPT_QW_UNROLL; u++) {
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			if (idx >= n) continue;
 			const unsigned id = list ? list[idx] : idx;
@@ -821,11 +826,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				if (r & 8) add_bits |= 1u << u;
 			}
 		}
-		queue_push2(qw.shl[out_parity], qw.live[out_parity], reinterpret_cast<unsigned long long*>(&qw.counters[MIPT_QW_PAIR(out_slot)]), shadow_bits, closest_bits, list, base);
-		queue_push(qw.overflow, &qw.counters[MIPT_QW_N_OVERFLOW], over_bits, list, base);
-		if (SUBS && !SHADOW_LIST) queue_push(qw.prl[out_parity], &qw.counters[MIPT_QW_N_PROBE(out_slot)], probe_bits, list, base);
-		if (!SHADOW_LIST) queue_push(qw.sha[out_parity], &qw.counters[MIPT_QW_N_SHADOW_ADD(out_slot)], add_bits, list, base);
-		if (FAST) queue_push(qw.slow, &qw.counters[MIPT_QW_N_SLOW(out_slot)], slow_bits, list, base);
+		queue_push2<MIPT_QW_UNROLL>(qw.shl[out_parity], qw.live[out_parity], reinterpret_cast<unsigned long long*>(&qw.counters[MIPT_QW_PAIR(out_slot)]), shadow_bits, closest_bits, list, base);
+		queue_push<MIPT_QW_UNROLL>(qw.overflow, &qw.counters[MIPT_QW_N_OVERFLOW], over_bits, list, base);
+		if (SUBS && !SHADOW_LIST) queue_push<MIPT_QW_UNROLL>(qw.prl[out_parity], &qw.counters[MIPT_QW_N_PROBE(out_slot)], probe_bits, list, base);
+		if (!SHADOW_LIST) queue_push<MIPT_QW_UNROLL>(qw.sha[out_parity], &qw.counters[MIPT_QW_N_SHADOW_ADD(out_slot)], add_bits, list, base);
+		if (FAST) queue_push<MIPT_QW_UNROLL>(qw.slow, &qw.counters[MIPT_QW_N_SLOW(out_slot)], slow_bits, list, base);
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);

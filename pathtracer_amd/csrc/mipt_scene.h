@@ -62,7 +62,7 @@ struct DGroupMat {
 // The first 64 bytes are what the shade stage needs of an object before it can fetch anything else (four 16-byte loads issued
 // together with the three matrices, one dependent round trip instead of six: the stage runs 4 waves per SIMD and waits on its
 // chain of dependent loads).
-struct DObject {
+struct alignas(64) DObject {   // (64-byte aligned and sized: the first 64 bytes of every object are ONE cache line and its 16-byte loads are aligned — at 440 bytes every other object's were not, and which ones changed with every field added in front of DScene::obj)
 	int type, miroir, flip_normals, interp_normals;   // miroir: bit 0 = Object::miroir, bit 1 = Object::ghost (both reach the shade stage with the first 16 bytes)
 	int nuvs, ngroups, ntex_normal, alpha_test;   // ntex_normal = ntex[MT_NORMAL]; alpha_test: an alpha texture list exists and the mesh has UVs (TriangleMesh.cpp:1200)
 	const DTriShade* shade; const DGroupMat* gmat; // gmat[ngroups + 1]: groups 0 .. ngroups-1 (ngroups = the longest of the Kd / Ks / Ne / transp / refr lists), then the all-defaults record
@@ -95,7 +95,7 @@ struct DObject {
 #include <stddef.h>
 static_assert(offsetof(DObject, type) == 0 && offsetof(DObject, nuvs) == 16 && offsetof(DObject, shade) == 32 && offsetof(DObject, gmat) == 40 &&
               offsetof(DObject, tangent_soup) == 48 && offsetof(DObject, merl) == 56 && offsetof(DObject, inv) == 64, "DObject: the shade stage loads its first 64 bytes as four 16-byte words");
-static_assert(sizeof(DObject) % 8 == 0, "DObject holds pointers: DScene::obj[] must keep them aligned");
+static_assert(sizeof(DObject) % 64 == 0 && alignof(DObject) == 64, "DObject: whole cache lines, so that DScene::obj[i] keeps the first 64 bytes of every object in one line");
 static_assert(sizeof(DGroupMat) == 64 && offsetof(DGroupMat, transp_val) == 36 && offsetof(DGroupMat, image_mask) == 44 && offsetof(DGroupMat, kd_values) == 48 &&
               offsetof(DGroupMat, kdW) == 56, "DGroupMat: one 64-byte record per material group, read as four 16-byte words (image_mask in r2.w)");
 static_assert(sizeof(DFatNode) == 64 && sizeof(DTriIsect) == 64 && sizeof(DTriShade) == 64, "64-byte records");

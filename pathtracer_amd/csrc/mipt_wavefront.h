@@ -94,25 +94,29 @@ __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi
 // of a launch hitting one counter at start is ~90 us even for an empty queue.  Later chunks come from the shared
 // counter, and the atomic for chunk i+1 is issued when chunk i is handed out, so its round trip (a few us, comparable
 // to the work of one chunk) overlaps with the work instead of stalling the wave between chunks.
-struct QueuePuller {
+template <unsigned CHUNK>
+struct QueuePullerT {
 	unsigned next;        // lane 0: base of the chunk to hand out next
-	__device__ __forceinline__ void init() { next = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * MIPT_WF_CHUNK; }
+	__device__ __forceinline__ void init() { next = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * CHUNK; }
 	__device__ __forceinline__ bool pull(unsigned* __restrict__ head, unsigned n, unsigned& base) {
 		base = __builtin_amdgcn_readfirstlane(next);
 		if (base >= n) return false;
-		if (lane_id() == 0) next = atomicAdd(head, MIPT_WF_CHUNK) + gridDim.x * (blockDim.x >> 6) * MIPT_WF_CHUNK;
+		if (lane_id() == 0) next = atomicAdd(head, CHUNK) + gridDim.x * (blockDim.x >> 6) * CHUNK;
 		return true;
 	}
 };
+typedef QueuePullerT<MIPT_WF_CHUNK> QueuePuller;
 
 // wave-aggregated append for the lanes whose bit u of `bits` is set (sub-chunk u of the chunk at
 // `base` of the source list; src == nullptr means the identity list): one atomic for all sub-chunks
+// (NU: the sub-chunks the caller's chunk has — the stages of the contribution queue keep 4, mipt_queue_wave.h)
+template <int NU = MIPT_WF_UNROLL>
 __device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned* __restrict__ count, unsigned bits,
                                            const unsigned* __restrict__ src, unsigned src_base) {
-	unsigned long long m[MIPT_WF_UNROLL];
+	unsigned long long m[NU];
 	unsigned total = 0;
 #pragma unroll
-	for (int u = 0; u < MIPT_WF_UNROLL; u++) { m[u] = __ballot((bits >> u) & 1u); total += (unsigned)__popcll(m[u]); }
+	for (int u = 0; u < NU; u++) { m[u] = __ballot((bits >> u) & 1u); total += (unsigned)__popcll(m[u]); }
 	if (total == 0) return;
 	unsigned lane = lane_id();
 	unsigned base = 0;
@@ -120,7 +124,7 @@ __device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned
 	base = __builtin_amdgcn_readfirstlane(base);
 	unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+	for (int u = 0; u < NU; u++) {
 		if ((bits >> u) & 1u) {
 			unsigned idx = src_base + 64u * u + lane;
 			list[base + (unsigned)__popcll(m[u] & below)] = src ? src[idx] : idx;
@@ -186,12 +190,13 @@ MIPT_DEV bool meshes_missed(const DScene* __restrict__ sc, f3 ro, f3 rd, float d
 }
 
 // the same for two destination queues whose sizes share one 64-bit word (low: list_a, high: list_b): one atomic
+template <int NU = MIPT_WF_UNROLL>
 __device__ __forceinline__ void queue_push2(unsigned* __restrict__ list_a, unsigned* __restrict__ list_b, unsigned long long* __restrict__ count2,
                                             unsigned bits_a, unsigned bits_b, const unsigned* __restrict__ src, unsigned src_base) {
-	unsigned long long ma[MIPT_WF_UNROLL], mb[MIPT_WF_UNROLL];
+	unsigned long long ma[NU], mb[NU];
 	unsigned total_a = 0, total_b = 0;
 #pragma unroll
-	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+	for (int u = 0; u < NU; u++) {
 		ma[u] = __ballot((bits_a >> u) & 1u); total_a += (unsigned)__popcll(ma[u]);
 		mb[u] = __ballot((bits_b >> u) & 1u); total_b += (unsigned)__popcll(mb[u]);
 	}
@@ -202,7 +207,7 @@ __device__ __forceinline__ void queue_push2(unsigned* __restrict__ list_a, unsig
 	unsigned base_a = __builtin_amdgcn_readfirstlane((unsigned)base2), base_b = __builtin_amdgcn_readfirstlane((unsigned)(base2 >> 32));
 	unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-	for (int u = 0; u < MIPT_WF_UNROLL; u++) {
+	for (int u = 0; u < NU; u++) {
 		unsigned idx = src_base + 64u * u + lane;
 		unsigned id = 0;
 		if (((bits_a | bits_b) >> u) & 1u) id = src ? src[idx] : idx;
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __rest
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
 	bool valid = false, alive = false;
-	if (tid < total) wf_st(&wf.wgt[tid], make_float4(0.f, 0.f, 0.f, 0.f));      // not a live path until proven otherwise
+	float4 wgt0 = make_float4(0.f, 0.f, 0.f, 0.f);                             // not a live path until proven otherwise (ONE store of the slot's weight word, at the end)
 	if (tid < total) {
 		int kk = (int)(tid / ps.npix_slots);
 		int slot = (int)(tid % ps.npix_slots);
@@ -267,10 +272,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __rest
 				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);       // rides in the unused .w of the ray's two float4s
 				wf_st(&wf.ray_o[tid], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
 				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
-				wf_st(&wf.wgt[tid], make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u))));
+				wgt0 = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
 				wf_st(&wf.rng[tid], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 		}
+		wf_st(&wf.wgt[tid], wgt0);
 	}
 	(void)valid; (void)cnt;     // paths are counted on the host (valid pixels x samples)
 }
