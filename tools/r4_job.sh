@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r4m
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r4m/gputests.txt 2>&1; grep -E "passed|failed" gpurun_out/r4m/gputests.txt; grep -E "^E |FAILED" gpurun_out/r4m/gputests.txt | head
-for i in 1 2; do timeout 600 python tools/queue_kernel_rate.py 64 > gpurun_out/r4m/queue_rate$i.jsonl 2>&1; cut -c1-330 gpurun_out/r4m/queue_rate$i.jsonl | grep -v '"none"' | cut -c1-40,100-140,180-300; done
-timeout 900 python tests/tools/fuzz_parity.py 150 4420 --queue > gpurun_out/r4m/fuzz_q150.txt 2>&1; tail -1 gpurun_out/r4m/fuzz_q150.txt
+python tools/init_time.py c2 2>&1 | grep -v "^\[" | cut -c88-260
+for i in 1 2 3; do python bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp-per-step 64 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench init', round(d['host_bvh_build_s'],4), round(d['prepare_s'],4), d['bvh_build'])"; done
