@@ -412,8 +412,8 @@ def test_object_table_full_and_one_too_many(pipeline):
 
 @pytest.mark.parametrize("batch", [0, 1])
 def test_measured_brdf_tiers_against_golden_and_oracle(batch):
-    """Scenes with a measured BRDF, general shade tier in both forms: every vertex evaluating its own table entries (`merl_batch` 0,
-    the default) and the evaluations filed in LDS and run 64 to a trip (1; round 4).  The golden scene of the compiled reference,
+    """Scenes with a measured BRDF, general shade tier in both forms: every vertex evaluating its own table entries (`merl_batch` 0)
+    and the evaluations filed in LDS and run 64 to a trip (1, the default since round 4).  The golden scene of the compiled reference,
     then a scene where the measured surface sits beside a glossy Phong mesh, a mirror sphere and a glass sphere (the tier takes the
     other vertices through the general code), at a depth where requests of several chunks share a trip — against the oracle, per
     sample and through the splat; ray counts equal between the two forms."""
