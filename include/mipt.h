@@ -366,8 +366,9 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     every ray (normally only for rays with a zero direction component)
  *   "queue_wavefront" scenes with ghost objects / a background photo / fog / subsurface colours: 1 = getColor's contribution queue as
  *                     wavefront stages (default), 0 = one thread per sample with the queue in HBM (the round-1 kernel; same results)
- *   "queue_ring"      test hook: pending contributions a sample may hold in the wavefront stages (default and maximum 32); samples that
- *                     need more are rendered by the one-thread-per-sample loop with the reference's 200-entry ring (same results)
+ *   "queue_ring"      pending contributions a sample may hold in the wavefront stages of the contribution queue, which is also the memory of its
+ *                     ring (default 16, at most 32; 48 bytes each); samples that need more are rendered by the one-thread-per-sample loop with
+ *                     the reference's 200-entry ring (same results).  Small values are a test hook for that fallback
  *   "queue_fast_tier" wavefront stages of the contribution queue, scenes without fog and subsurface colours: 1 = the closest-hit list goes
  *                     through a fast tier first and the general build takes what it leaves (default), 0 = general build only (same results)
  *   "reduce"          groups only: 0 = RCCL when its communicators exist (default; a reduce that cannot be enqueued falls back to 2 and

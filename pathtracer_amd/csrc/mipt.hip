@@ -360,7 +360,7 @@ struct mipt_ctx {
 	bool scene_inherit = false;       // a sphere without material lists (DScene::inherit_material): no wavefront stages
 	bool scene_bare_mirror = false;   // a MIRROR sphere without material lists: its radiance needs no inherited material, the denoiser's albedo input at a first hit on it does
 	bool scene_has_subsurface = false; // some object carries a subsurface colour: the logic stage of the queue pipeline is compiled with the probe
-	int64_t opt_queue_ring = MIPT_QW_FIFO; // test hook: a smaller ring sends more samples through the overflow fallback
+	int64_t opt_queue_ring = MIPT_QW_RING; // pending contributions a sample may hold in the wavefront stages of the queue (1 .. MIPT_QW_FIFO; also the memory of its ring): a sample that needs more goes through the overflow fallback
 	int64_t opt_queue_wavefront = 1;  // scenes with ghosts / photo / fog / subsurface: 1 = the contribution queue as wavefront stages (mipt_queue_wave.h), 0 = one thread per sample
 	unsigned grid_qlogic[3] = {0, 0, 0};  // closest-hit list, any-hit list, fast tier of the closest-hit list
 	int64_t opt_queue_fast_tier = 1;  // 0: the general build of the logic stage for every sample (measurement / test hook)
@@ -1215,7 +1215,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 10 * sizeof(unsigned);
 		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
 	}
-	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? MIPT_QW_FIFO : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
+	const unsigned queue_ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
+	const size_t per_path_queue = pipeline == 2 ? (queue_wave ? queue_ring : MIPT_SIZE_CIRC_ARRAY) * sizeof(QContrib) : 0;
 	// The pass is sized for the memory that is actually free (the default of 2^30 paths is ~172 GB of state, sized for an
 	// otherwise empty 288 GB device): at most ~80 % of free + what this context already holds for passes, path ids < 2^31.
 	{
@@ -1282,7 +1283,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		qw.slow = (unsigned*)carve(N * sizeof(unsigned));
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
-		qw.ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
+		qw.ring = queue_ring;
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * (MIPT_BLOCK > MIPT_TRAV_BLOCK ? MIPT_BLOCK : MIPT_TRAV_BLOCK) * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
 		if (c->grid_qtrav[0] == 0) {
@@ -1386,9 +1387,12 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				const bool first = r == 0;                                   // round 0: the camera rays of all path slots (k_q_begin), identity queue
 				if (first) pair[1] = p->nb_bounces > 0 ? (unsigned)total : 0u;
 				else {
-					HIPCHK(c, hipMemcpyAsync(pair, &qw.counters[MIPT_QW_PAIR(slot)], 8, hipMemcpyDeviceToHost, st));
-					HIPCHK(c, hipMemcpyAsync(more, &qw.counters[MIPT_QW_N_PROBE(slot)], 8, hipMemcpyDeviceToHost, st));
+					// ONE read-back per round (the pair at word 0 of the slot, the probe / add counts at words 160-161: 648 bytes cost what 8 do,
+					// and a second copy was another ~20 us of an idle device per round)
+					unsigned hb[MIPT_QW_N_SHADOW_ADD(0) + 1];
+					HIPCHK(c, hipMemcpyAsync(hb, &qw.counters[MIPT_QW_PAIR(slot)], sizeof hb, hipMemcpyDeviceToHost, st));
 					HIPCHK(c, hipStreamSynchronize(st));
+					pair[0] = hb[0]; pair[1] = hb[1]; more[0] = hb[MIPT_QW_N_PROBE(0)]; more[1] = hb[MIPT_QW_N_SHADOW_ADD(0)];
 				}
 				const unsigned n_probe = more[0], n_add = more[1];
 				if (pair[0] == 0 && pair[1] == 0 && n_probe == 0 && n_add == 0) break;

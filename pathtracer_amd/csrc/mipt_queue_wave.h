@@ -24,13 +24,21 @@
 //   traversal in its reservoir mode, mipt_persistent.h) runs it with the sample's engine and A1 is entered again: it recomputes the deterministic head of the vertex from the saved closest hit,
 //   takes the numbers it had drawn from the frame and goes on behind the call.
 // * The reference's FIFO has 200 entries (Raytracer.h:114); 200 x 48 B per sample would cap a pass at 2 M samples and
-//   the persistent kernels need far larger batches.  A sample gets a ring of MIPT_QW_FIFO entries here; the rare sample
+//   the persistent kernels need far larger batches.  A sample gets a ring of `DQueueWave::ring` entries here (option `queue_ring`,
+//   default MIPT_QW_RING, at most MIPT_QW_FIFO); the rare sample
 //   that needs more is abandoned (nothing of it is kept) and rendered afterwards by trace_path_queue with the full
 //   200-entry ring (k_render_paths_queue_list), which starts it again from its seed: same result either way.
+//   Round 4: the ring's MEMORY is `ring` entries too (it was MIPT_QW_FIFO = 32 whatever the option said: 1 536 of a sample's 1 950 bytes,
+//   which cut the 1080p x 64 spp frame of the rate probe into two passes).  On the probe's three scenes no sample ever holds more than 8
+//   pending contributions (ring 8: 0 samples through the fallback, ring 4: 333 of 133 M in the fog scene); the default of 16 entries
+//   makes the frame ONE pass of 157 GB.
 #pragma once
 
 #ifndef MIPT_QW_FIFO
-#define MIPT_QW_FIFO 32
+#define MIPT_QW_FIFO 32                  // the largest ring a sample can be given
+#endif
+#ifndef MIPT_QW_RING
+#define MIPT_QW_RING 16                  // the default ring
 #endif
 #ifndef MIPT_QW_LOGIC_WAVES
 #define MIPT_QW_LOGIC_WAVES 3            // general builds of the logic stage (188-237 registers unconstrained; round 3, after sinf / cosf lost their selected constants: 3 waves with 20-70 spilled values beat 2 without — subsurface logic 59.5 -> 51.8 ms, fog 110.7 -> 107.8, ghost +-0); + 1 for the any-hit-list stage of the build without the fog code
@@ -75,7 +83,7 @@ enum { QW_POP = 0, QW_A1 = 1, QW_A2 = 2, QW_F1 = 3, QW_DONE = 4, QW_PROBE = 5, Q
 #define MIPT_QW_COUNTERS (4 * MIPT_QW_SLOT_WORDS + 32)
 
 struct DQueueWave {
-	QContrib* fifo;                  // [N][MIPT_QW_FIFO]
+	QContrib* fifo;                  // [N][ring]
 	float4 *cur_w, *cur_o, *cur_d;   // the contribution being processed (w.w: its depth / flag bits)
 	float4* acc;                     // xyz: the sample's colour so far; w: attenuationFactor (Raytracer.cpp:206, kept across contributions).
 	                                 // The same array as wf.out.col: the any-hit stage adds a pending direct term to it (below)
@@ -91,7 +99,7 @@ struct DQueueWave {
 	unsigned* counters;
 	float4 *aov_n, *aov_kd;          // denoiser inputs or null
 	unsigned N;
-	unsigned ring;                   // pending contributions a sample may hold here (<= MIPT_QW_FIFO; smaller: test hook for the fallback)
+	unsigned ring;                   // pending contributions a sample may hold here = entries of its ring in `fifo` (<= MIPT_QW_FIFO)
 };
 
 // shadow rays of getColor ignore ghost objects (avoid_ghosts = true, Raytracer.cpp:513; Geometry.cpp:722)
@@ -217,7 +225,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 	};
 	if (FOG && has_fog_early(R)) load_color();
 	S.head = ctl & 0xffu; S.count = (ctl >> 8) & 0xffu; S.overflow = false;
-	QContrib* const fifo = qw.fifo + (size_t)id * MIPT_QW_FIFO;
+	QContrib* const fifo = qw.fifo + (size_t)id * qw.ring;
 	auto FRL = [&](int slot) -> float4 { return QW_LD(&qw.fr[(size_t)slot * N + id]); };
 	auto FRS = [&](int slot, float4 v) { QW_ST(&qw.fr[(size_t)slot * N + id], v); };
 	const bool has_bg = R.backgroundW > 0 && R.background != nullptr;       // :220
@@ -237,7 +245,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 		c.w = make_float4(w.x, w.y, w.z, __uint_as_float((unsigned)(depth & 0xffff) | (lights ? 0x10000u : 0u) | (env ? 0x20000u : 0u) | (hadSS ? 0x40000u : 0u)));
 		c.o = make_float4(r.o.x, r.o.y, r.o.z, 0.f); c.d = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
 		if (S.count == 0) { front = c; have_front = true; }         // into an empty ring: handed to POP in registers (written by save() if the call ends first)
-		else { QContrib* const e = fifo + (S.head + S.count) % MIPT_QW_FIFO; QW_ST(&e->w, c.w); QW_ST(&e->o, c.o); QW_ST(&e->d, c.d); }
+		else { unsigned at = S.head + S.count; if (at >= qw.ring) at -= qw.ring; QContrib* const e = fifo + at; QW_ST(&e->w, c.w); QW_ST(&e->o, c.o); QW_ST(&e->d, c.d); }   // (head < ring, count < ring)
 		S.count++;
 	};
 	auto save = [&](int ph, int st) {
@@ -786,7 +794,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			QContrib c;
 			if (have_front) { c = front; have_front = false; }
 			else { const QContrib* const e = fifo + S.head; c.w = QW_LD(&e->w); c.o = QW_LD(&e->o); c.d = QW_LD(&e->d); }
-			S.head = (S.head + 1) % MIPT_QW_FIFO; S.count--;
+			S.head = S.head + 1 == qw.ring ? 0u : S.head + 1; S.count--;
 			const unsigned bits = __float_as_uint(c.w.w);
 			if ((int)(bits & 0xffffu) == 0) continue;                            // :240
 			if (norm2(mk3(c.w.x, c.w.y, c.w.z)) < sqr(0.01f)) continue;          // :241
