@@ -150,9 +150,10 @@ def test_gpu_logic_stage_tiers_agree(kind):
     """Round 3: the closest-hit-list logic stage runs as a fast tier (Lambert / mirror / dielectric / miss vertices, ghosts up to
     their any-hit request) plus the general build over what it leaves (csrc/mipt_queue_wave.h, FAST).  Both orders of work —
     tiers, general build alone, and the tiers with a two-entry ring (samples abandoned to the 200-entry fallback) — give
-    the golden radiance bit for bit."""
+    the golden radiance bit for bit.  Round 4: a sample's ring takes `queue_ring` entries of pass memory (default 16): the rings
+    of 2, 3 (not a power of two: the wrap is a compare, not a mask) and 32 entries, the largest."""
     g = np.load(GOLD)
-    for opts in ({}, {"queue_fast_tier": 0}, {"queue_ring": 2}):
+    for opts in ({}, {"queue_fast_tier": 0}, {"queue_ring": 2}, {"queue_ring": 3}, {"queue_ring": 32}):
         H = capi.HostRaytracer(device=0)
         cfg = compositing_scene(H, kind)
         for k, v in opts.items():
