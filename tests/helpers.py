@@ -76,3 +76,24 @@ def check_scene_against(X, g, name, what):
     img, cnt = X.render_seeded()
     assert_bits(cnt, g["count"], f"{what}:{name}:splat weights")
     assert_bits(img, g["image"], f"{what}:{name}:splatted image")
+
+
+def spawn_ranks(fn, nprocs, *args):
+    """torch.multiprocessing.spawn(fn, args=(nprocs, port, *args)) on a free local port.  The port is found by binding to 0 and closed
+    before the children open it (another process can take it in between, and gloo opens further ports of its own): a rendezvous that
+    fails with a SOCKET error is attempted once more on a fresh port; any other failure of a rank is the test's."""
+    import socket
+    import torch.multiprocessing as mp
+    for attempt in (0, 1):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        try:
+            mp.spawn(fn, args=(nprocs, port, *args), nprocs=nprocs, join=True)
+            return
+        except Exception as e:                                      # ProcessRaisedException carries the rank's traceback as text
+            text = str(e)
+            socket_trouble = any(k in text for k in ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "connectFullMesh", "Socket", "socket", "timed out", "Timed out"))
+            if attempt == 1 or not socket_trouble:
+                raise
+            print("rendezvous failed on port %d, trying another one:\n%s" % (port, text[-600:]))

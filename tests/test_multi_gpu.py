@@ -18,7 +18,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import WHITE, load_golden, setup_scene
+from helpers import WHITE, load_golden, setup_scene, spawn_ranks
 from pathtracer_amd import capi, scenes
 
 pytestmark = pytest.mark.gpu
@@ -128,12 +128,8 @@ def _rank(rank, world, port, out):
 
 
 def test_two_processes_reduce_real_partial_frames(tmp_path):
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "sum.npy")
-    mp.spawn(_rank, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_rank, 2, out)
     one = capi.HostRaytracer(device=0)
     mesh, cfg, oid = setup_scene(one, "blob32")
     img1, cnt1 = one.render()
@@ -204,12 +200,8 @@ def _rank_nccl(rank, world, port, out):
 
 @needs_two
 def test_two_processes_on_two_devices_reduce_over_rccl(tmp_path):
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "sum.npy")
-    mp.spawn(_rank_nccl, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_rank_nccl, 2, out)
     one = capi.HostRaytracer(device=0)
     mesh, cfg, oid = setup_scene(one, "blob32")
     img1, cnt1 = one.render()

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from helpers import spawn_ranks
 from pathtracer_amd import capi
 
 W, H, TS = 80, 48, 16
@@ -67,11 +68,8 @@ def test_partition_is_a_partition():
 
 
 def test_two_rank_reduce_matches_single_rank(tmp_path):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "sum.npy")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_worker, 2, out)
     full = splat(owners(1), None, make_samples())
     np.testing.assert_allclose(np.load(out), full, rtol=1e-12, atol=1e-12)
 
