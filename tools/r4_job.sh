@@ -1,2 +1,6 @@
-for i in 1 2 3; do timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r4m_gputests_run$i.txt 2>&1; grep -E "passed|failed" gpurun_out/r4m_gputests_run$i.txt | tail -1; done
-for i in 1 2 3; do if grep -q "failed" gpurun_out/r4m_gputests_run$i.txt; then grep -n "^E " gpurun_out/r4m_gputests_run$i.txt | head -30; fi; done
+S=r4_k_extra
+timeout 1200 python tests/tools/fuzz_parity.py 600 5101 > gpurun_out/${S}_fuzz_parity_600_scenes.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_600_scenes.txt
+timeout 1200 python tests/tools/fuzz_parity.py 400 5102 --queue > gpurun_out/${S}_fuzz_parity_400_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_400_scenes_queue.txt
+timeout 1200 python tests/tools/fuzz_parity.py 300 5103 --queue --spheres > gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt
+timeout 1200 python tests/tools/fuzz_parity.py 200 5104 --queue --bare-spheres > gpurun_out/${S}_fuzz_parity_200_scenes_queue_bare_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_queue_bare_spheres.txt
+timeout 1200 python tests/tools/fuzz_parity.py 250 5105 --kind=merl --merl-tiers --spheres > gpurun_out/${S}_fuzz_parity_250_scenes_measured_brdf_both_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_250_scenes_measured_brdf_both_tiers.txt
