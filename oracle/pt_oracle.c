@@ -41,6 +41,8 @@ static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x 
 static inline float vget(v3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 static inline void vset(v3* a, int k, float v) { if (k == 0) a->x = v; else if (k == 1) a->y = v; else a->z = v; }
 static inline float sqrf(float x) { return x * x; }
+static v3 vmin3(v3 a, v3 b);
+static v3 vmax3(v3 a, v3 b);
 static inline double sqr_d(double x) { return x * x; }
 
 /* Vector.h:294-309 invSqRoot.  The reference reads the float through a `long*`; the intended
@@ -502,8 +504,178 @@ static int mesh_intersection(const o_obj* o, const o_ray* d, v3* P, float* t, o_
 	return has_inter;
 }
 
+
+/* ------------------------------------------------------------------ diagnostic: visiting orders of the any-hit traversal
+   (test infrastructure for tools/anyhit_study.py; it changes nothing the oracle returns).  intersection_shadow's result is
+   "does a reachable occluder (t < 0.999 dist) exist"; the orders below visit the tree without the reference's near / far
+   ordering and without its `tnear > t` prune and count what they would cost:
+     [0] calls  [1] reference: inner pops  [2] leaf pops  [3] triangle tests
+     unordered binary, nearer child first:  [4] inner  [5] leaves  [6] triangles  [7] results differing from the reference
+     unordered binary, left child first:    [8] inner  [9] leaves  [10] triangles
+     four-wide (grandchildren tested directly), nearest slot first: [11] wide steps  [12] leaves  [13] triangles  [14] differing
+     four-wide, first passing slot:         [15] wide steps  [16] leaves  [17] triangles
+     [18] rays that passed a box with t_box >= 0.998 dist (the only ones whose result can depend on the order)
+     [19] of those, rays that found an occluder (they are replayed in the reference's order)
+     [20] max stack depth of the four-wide walk  [21] four-wide slot tests  [22] reference box tests  [23] occluded (reference) */
+static _Thread_local uint64_t tl_any[24];
+_Thread_local uint64_t tl_any_q4[6];
+static uint64_t g_any_q4[6];
+static uint64_t g_any[24];
+static int g_any_study = 0;
+void o_anyhit_study(int on) { g_any_study = on; if (on) { memset(g_any, 0, sizeof g_any); memset(g_any_q4, 0, sizeof g_any_q4); } }
+void o_anyhit_study_get_q4(uint64_t* out6) {
+	#pragma omp parallel
+	{ for (int k = 0; k < 6; k++) { __atomic_fetch_add(&g_any_q4[k], tl_any_q4[k], __ATOMIC_RELAXED); tl_any_q4[k] = 0; } }
+	memcpy(out6, g_any_q4, sizeof g_any_q4);
+}
+void o_anyhit_study_get(uint64_t* out24) {
+	#pragma omp parallel
+	{ for (int k = 0; k < 24; k++) { if (k == 20) { uint64_t v = tl_any[k], cur = __atomic_load_n(&g_any[k], __ATOMIC_RELAXED); while (v > cur && !__atomic_compare_exchange_n(&g_any[k], &cur, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} } else __atomic_fetch_add(&g_any[k], tl_any[k], __ATOMIC_RELAXED); tl_any[k] = 0; } }
+	memcpy(out24, g_any, sizeof g_any);
+}
+static int study_leaf(const o_obj* o, const o_ray* d, int fg, int fd, float dist_light, uint64_t* ntri) {
+	const o_mesh* g = o->mesh;
+	v3 localP; float localt, alpha, beta, gamma;
+	for (int i = fg; i < fd; i++) {
+		(*ntri)++;
+		if (tri_intersection(&g->soup[i], d, &localP, &localt, &alpha, &beta, &gamma)) {
+			if (mesh_alpha_rejects(o, i, alpha, beta, gamma)) continue;
+			if (localt < dist_light * 0.999) return 1;
+		}
+	}
+	return 0;
+}
+static void anyhit_study(const o_obj* o, const o_ray* d, float dist_light, int ref_result, uint64_t ref_inner, uint64_t ref_leaf, uint64_t ref_tri, uint64_t ref_box) {
+	const o_mesh* g = o->mesh;
+	o_ray invd; invd.origin = d->origin;
+	invd.direction = V(1.f / d->direction.x, 1.f / d->direction.y, 1.f / d->direction.z);
+	char signs[3] = { invd.direction.x >= 0, invd.direction.y >= 0, invd.direction.z >= 0 };
+	tl_any[0]++; tl_any[1] += ref_inner; tl_any[2] += ref_leaf; tl_any[3] += ref_tri; tl_any[22] += ref_box; tl_any[23] += ref_result != 0;
+	float tb;
+	if (!box_invd(g->root_min, g->root_max, invd.origin, invd.direction, signs, &tb) || tb > dist_light) return;
+	int stack[256];
+	for (int variant = 0; variant < 2; variant++) {          /* unordered binary */
+		int sp = 0, found = 0, flagged = 0;
+		uint64_t inner = 0, leaves = 0, tris = 0;
+		stack[sp++] = 0;
+		while (sp > 0 && !found) {
+			const int cur = stack[--sp];
+			const o_node* n = &g->nodes[cur];
+			if (n->isleaf) { leaves++; found = study_leaf(o, d, n->fg, n->fd, dist_light, &tris); continue; }
+			inner++;
+			float tl, tr;
+			const int gl = box_invd(g->nodes[n->fg].bmin, g->nodes[n->fg].bmax, invd.origin, invd.direction, signs, &tl) && tl < dist_light;
+			const int gr = box_invd(g->nodes[n->fd].bmin, g->nodes[n->fd].bmax, invd.origin, invd.direction, signs, &tr) && tr < dist_light;
+			if ((gl && tl >= 0.998f * dist_light) || (gr && tr >= 0.998f * dist_light)) flagged = 1;
+			if (gl && gr) {
+				if (variant == 0 ? (tl < tr) : 1) { stack[sp++] = n->fd; stack[sp++] = n->fg; }
+				else { stack[sp++] = n->fg; stack[sp++] = n->fd; }
+			} else if (gl) stack[sp++] = n->fg;
+			else if (gr) stack[sp++] = n->fd;
+		}
+		if (variant == 0) {
+			tl_any[4] += inner; tl_any[5] += leaves; tl_any[6] += tris;
+			if (found != (ref_result != 0) && !flagged) tl_any[7]++;
+			if (flagged) { tl_any[18]++; if (found) tl_any[19]++; }
+		} else { tl_any[8] += inner; tl_any[9] += leaves; tl_any[10] += tris; }
+	}
+	{          /* four-wide with 8-bit boxes (mipt_anyhit.h, DQuadNode): planes origin + q * 2^e per axis, rounded outwards; first passing slot */
+		int sp = 0, found = 0;
+		uint64_t wide = 0, leaves = 0, tris = 0, unverified = 0;
+		stack[sp++] = 0;
+		if (g->nodes[0].isleaf) { sp = 0; }
+		while (sp > 0 && !found) {
+			const int cur = stack[--sp];
+			const o_node* n = &g->nodes[cur];
+			if (n->isleaf) {
+				leaves++;
+				if (study_leaf(o, d, n->fg, n->fd, dist_light, &tris)) {
+					float t;                                      /* an occluder counts if the leaf's own float box is reached */
+					if (box_invd(n->bmin, n->bmax, invd.origin, invd.direction, signs, &t) && t < dist_light) found = 1; else unverified++;
+				}
+				continue;
+			}
+			wide++;
+			int slot[4], ns = 0;
+			const int ch[2] = { n->fg, n->fd };
+			for (int c = 0; c < 2; c++) {
+				const o_node* m = &g->nodes[ch[c]];
+				if (m->isleaf) slot[ns++] = ch[c];
+				else { slot[ns++] = m->fg; slot[ns++] = m->fd; }
+			}
+			v3 nmin = g->nodes[slot[0]].bmin, nmax = g->nodes[slot[0]].bmax;
+			for (int k = 1; k < ns; k++) { nmin = vmin3(nmin, g->nodes[slot[k]].bmin); nmax = vmax3(nmax, g->nodes[slot[k]].bmax); }
+			float scale[3];
+			for (int a = 0; a < 3; a++) {
+				int e = -100;
+				const float ext = vget(nmax, a) - vget(nmin, a);
+				if (ext > 0) { e = (int)ceilf(log2f(ext / 255.f)) - 1; if (e < -100) e = -100; }
+				while (fmaf(255.f, ldexpf(1.f, e), vget(nmin, a)) < vget(nmax, a)) e++;
+				scale[a] = ldexpf(1.f, e);
+			}
+			int pass[4], np = 0;
+			for (int k = 0; k < ns; k++) {
+				v3 qmin, qmax;
+				for (int a = 0; a < 3; a++) {
+					const float org = vget(nmin, a), lo = vget(g->nodes[slot[k]].bmin, a), hi = vget(g->nodes[slot[k]].bmax, a);
+					int ql = (int)floorf((lo - org) / scale[a]); if (ql < 0) ql = 0; if (ql > 255) ql = 255;
+					while (ql > 0 && fmaf((float)ql, scale[a], org) > lo) ql--;
+					int qh = (int)ceilf((hi - org) / scale[a]); if (qh < 0) qh = 0; if (qh > 255) qh = 255;
+					while (qh < 255 && fmaf((float)qh, scale[a], org) < hi) qh++;
+					vset(&qmin, a, fmaf((float)ql, scale[a], org)); vset(&qmax, a, fmaf((float)qh, scale[a], org));
+				}
+				float t;
+				if (box_invd(qmin, qmax, invd.origin, invd.direction, signs, &t) && t < dist_light) pass[np++] = slot[k];
+			}
+			for (int k = np - 1; k >= 0; k--) stack[sp++] = pass[k];
+		}
+		tl_any_q4[0] += wide; tl_any_q4[1] += leaves; tl_any_q4[2] += tris; tl_any_q4[3] += unverified;
+		if (!g->nodes[0].isleaf && found != (ref_result != 0)) tl_any_q4[4]++;
+	}
+	for (int variant = 0; variant < 2; variant++) {          /* four-wide */
+		int sp = 0, found = 0, flagged = 0, maxsp = 0;
+		uint64_t wide = 0, leaves = 0, tris = 0, tests = 0;
+		stack[sp++] = 0;
+		if (g->nodes[0].isleaf) { leaves++; found = study_leaf(o, d, g->nodes[0].fg, g->nodes[0].fd, dist_light, &tris); sp = 0; }
+		while (sp > 0 && !found) {
+			const int cur = stack[--sp];
+			const o_node* n = &g->nodes[cur];
+			if (n->isleaf) { leaves++; found = study_leaf(o, d, n->fg, n->fd, dist_light, &tris); continue; }
+			wide++;
+			int slot[4], ns = 0;
+			const int ch[2] = { n->fg, n->fd };
+			for (int c = 0; c < 2; c++) {
+				const o_node* m = &g->nodes[ch[c]];
+				if (m->isleaf) slot[ns++] = ch[c];
+				else { slot[ns++] = m->fg; slot[ns++] = m->fd; }
+			}
+			int pass[4]; float ts[4]; int np = 0;
+			for (int k = 0; k < ns; k++) {
+				float t;
+				tests++;
+				if (box_invd(g->nodes[slot[k]].bmin, g->nodes[slot[k]].bmax, invd.origin, invd.direction, signs, &t) && t < dist_light) {
+					if (t >= 0.998f * dist_light) flagged = 1;
+					pass[np] = slot[k]; ts[np] = t; np++;
+				}
+			}
+			if (variant == 0 && np > 1) {                       /* the nearest passing slot is taken first: it goes to the top */
+				int best = 0;
+				for (int k = 1; k < np; k++) if (ts[k] < ts[best]) best = k;
+				const int tmp = pass[best]; pass[best] = pass[0]; pass[0] = tmp;
+			}
+			for (int k = np - 1; k >= 0; k--) stack[sp++] = pass[k];
+			if (sp > maxsp) maxsp = sp;
+		}
+		if (variant == 0) {
+			tl_any[11] += wide; tl_any[12] += leaves; tl_any[13] += tris; tl_any[21] += tests;
+			if (found != (ref_result != 0) && !flagged) tl_any[14]++;
+			if ((uint64_t)maxsp > tl_any[20]) tl_any[20] = (uint64_t)maxsp;
+		} else { tl_any[15] += wide; tl_any[16] += leaves; tl_any[17] += tris; }
+	}
+}
+
 /* ------------------------------------------------------------------ TriMesh::intersection_shadow (TriangleMesh.cpp:1239-1319) */
-static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, float cur_best_t, float dist_light) {
+static int mesh_intersection_shadow_impl(const o_obj* o, const o_ray* d, float* t, float cur_best_t, float dist_light, uint64_t* study4) {
 	const o_mesh* g = o->mesh;
 	*t = cur_best_t;
 	int has_inter = 0;
@@ -556,6 +728,7 @@ static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, fl
 				if (goright) { l[++idx_back] = fd; tnear[idx_back] = t_box_right; }
 			}
 		} else {
+			if (study4) study4[1]++;
 			for (int i = fg; i < fd; i++) {
 				c_tri++;
 				if (tri_intersection(&g->soup[i], d, &localP, &localt, &alpha, &beta, &gamma)) {
@@ -563,14 +736,22 @@ static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, fl
 						if (mesh_alpha_rejects(o, i, alpha, beta, gamma)) continue;
 						has_inter = 1;
 						*t = localt;
-						if (*t < dist_light * 0.999) { tl_cnt[3] += c_box; tl_cnt[4] += c_node; tl_cnt[5] += c_tri; return 1; }  /* double compare */
+						if (*t < dist_light * 0.999) { tl_cnt[3] += c_box; tl_cnt[4] += c_node; tl_cnt[5] += c_tri; if (study4) { study4[0] = c_node; study4[2] = c_tri; study4[3] = c_box; } return 1; }  /* double compare */
 					}
 				}
 			}
 		}
 	}
 	tl_cnt[3] += c_box; tl_cnt[4] += c_node; tl_cnt[5] += c_tri;
+	if (study4) { study4[0] = c_node; study4[2] = c_tri; study4[3] = c_box; }
 	return has_inter;
+}
+static int mesh_intersection_shadow(const o_obj* o, const o_ray* d, float* t, float cur_best_t, float dist_light) {
+	if (!g_any_study) return mesh_intersection_shadow_impl(o, d, t, cur_best_t, dist_light, NULL);
+	uint64_t s4[4] = { 0, 0, 0, 0 };
+	const int r = mesh_intersection_shadow_impl(o, d, t, cur_best_t, dist_light, s4);
+	anyhit_study(o, d, dist_light, r && (*t < dist_light * 0.999), s4[0] - s4[1], s4[1], s4[2], s4[3]);
+	return r;
 }
 
 /* ------------------------------------------------------------------ Sphere (Geometry.h:918-992, 1071-1094) */

@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 
 #include "mipt_wavefront.h"
 #include "mipt_persistent.h"
+#include "mipt_anyhit.h"
 #include "mipt_build.h"
 #include "mipt_compositing.h"
 #include "mipt_queue_wave.h"
@@ -351,6 +352,7 @@ struct mipt_ctx {
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
+	const DWideNode* d_wide_nodes = nullptr;   // four-wide nodes of the order-free any-hit traversal (mipt_anyhit.h), one per fat node
 	bool scene_has_ghost = false;     // a ghost object, a background photo or fog: rendered by the queue kernel (mipt_compositing.h)
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
 	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
@@ -401,6 +403,9 @@ struct mipt_ctx {
 	int64_t opt_literal_slab = 0;     // test hook: persistent traversal uses the literal early-out chain for every ray
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
+	int64_t opt_anyhit_wide = 1;      // pipeline 1: the shadow stage as the order-free four-wide traversal (mipt_anyhit.h) + ordered replay of the rays it may not decide; 0 = the ordered kernel for every ray
+	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
+	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
@@ -613,6 +618,8 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "literal_slab")) { c->opt_literal_slab = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "anyhit_wide")) { c->opt_anyhit_wide = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "anyhit_flag_all")) { c->opt_anyhit_flag_all = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merl_batch")) { c->opt_merl_batch = value != 0; c->grid_stage[0] = 0; return MIPT_OK; }
@@ -951,6 +958,14 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			on += ch.nfat; ot += ch.nt;
 		}
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
+	}
+	c->d_wide_nodes = nullptr;
+	if (H.all_nodes && stg.nfat_total > 0) {      // the four-wide nodes of the any-hit stage, derived on the device from the fat nodes wherever those came from
+		void* dw = nullptr;
+		HIPCHK(c, hipMalloc(&dw, stg.nfat_total * sizeof(DWideNode))); c->scene_allocs.push_back(dw);
+		hipLaunchKernelGGL(k_wide_nodes, dim3((unsigned)((stg.nfat_total + 255) / 256)), dim3(256), 0, 0, H.all_nodes, (DWideNode*)dw, stg.nfat_total);
+		HIPCHK(c, hipGetLastError());
+		c->d_wide_nodes = (const DWideNode*)dw;
 	}
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
@@ -1481,6 +1496,20 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+				else if (c->opt_refill && c->opt_anyhit_wide && c->d_wide_nodes) {
+					// order-free four-wide traversal, then the ordered kernel over the (normally empty) list of rays it may not decide; the list is
+					// the closest-hit queue of this depth, which shade(b) has consumed
+					if (c->grid_anyhit == 0) {
+						int nb = 0;
+						if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wf_anyhit, MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+						c->grid_anyhit = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
+					}
+					const dim3 ga(std::min(c->grid_anyhit, (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
+					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_wide_nodes, c->d_all_tris, wf, b, list_mem[b & 1], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
+					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false;
+					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
+					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
+				}
 				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
 				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");

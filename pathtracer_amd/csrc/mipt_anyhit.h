@@ -1,0 +1,319 @@
+// mipt_anyhit.h — the any-hit (shadow) stage of the wavefront pipeline as an ORDER-FREE traversal of four-wide nodes.
+//
+// What the reference computes.  Scene::intersection_shadow (Geometry.cpp:691-744) returns true as soon as some object reports a hit
+// with t < 0.999 dist_light; it hands every mesh cur_best_t = 1E99 (min_t is never updated), and TriMesh::intersection_shadow
+// (TriangleMesh.cpp:1239-1319) returns at the first accepted triangle with t < 0.999 dist_light.  A triangle with t < 0.999 dist is
+// always accepted when it is tested (the running t only ever holds values >= 0.999 dist until then), and the alpha test does not
+// depend on the order.  So the result is
+//       "is there an occluder (t < 0.999 dist, alpha map permitting) in a leaf the traversal REACHES",
+// and the only thing the visiting order can change is which leaves are reached: the reference skips a node whose box distance is
+// >= the running t, which is some accepted t in [0.999 dist, dist) — the other prune, box distance < dist_light, is the same in any order.
+//
+// What this file does instead.  It reaches every leaf whose ancestors all pass `slab test && t_box < dist_light` — a superset of
+// what the reference reaches in any order — and visits them in whatever order is cheapest:
+//   * no near / far ordering, no t_near on the stack (4-byte entries), no running t;
+//   * FOUR-WIDE nodes (DWideNode, 128 B = one fabric line): the boxes of the four GRANDCHILDREN of a binary node (a child that is a
+//     leaf takes one slot with its own box).  The children's own tests are skipped: boxes nest exactly (a parent's box is the union
+//     of its triangles' boxes, TriangleMesh.cpp:843-858) and (plane - o) * invd is monotone in the plane under round-to-nearest, so
+//     a grandchild that passes implies its parent passes with a smaller-or-equal distance — the set of reached leaves is the same as
+//     with binary steps, at half the dependent round trips (tests/tools/anyhit_study.py: 27.7 -> 15.2 rounds per ray on configs[2]).
+// Exactness.  "No occluder among the reached leaves" is exact: the reference reaches a subset.  "An occluder found" can differ from the
+// reference only if the reference pruned an ancestor of that leaf, i.e. only if some box on the way passed with
+// t_box >= 0.999 dist.  A ray remembers whether ANY box it passed had t_box >= 0.998f dist (sticky, conservative); if such a ray
+// finds an occluder it is not decided here: its id goes to a replay list that the ORDERED kernel (traverse_queue<true>,
+// mipt_persistent.h) works off in the reference's order.  Rays with an infinite inverse-direction component (the packed slab test
+// is not valid for them, mipt_trace.h) go to the replay list as well.  On the bench scenes the replay list stays empty.
+#pragma once
+
+struct DWideNode {             // 128 B, 128-B aligned
+	float box[4][3][2];        // slot k: (min, max) pairs per axis, as in DFatNode; an unused slot holds (+inf, -inf): never passes
+	uint32_t ref[4];           // inner: index of the slot's own DWideNode (= its binary inner node); bit 31: leaf (first triangle | count-1 << 26)
+	uint32_t _pad[4];
+};
+static_assert(sizeof(DWideNode) == 128, "one 128-byte line per wide node");
+
+// One wide node per fat (binary inner) node.  Only the nodes an even number of inner levels below a root are ever visited (plus
+// wherever a leaf child shortens a side); building all of them keeps the references those of the fat array.
+__global__ void k_wide_nodes(const DFatNode* __restrict__ fat, DWideNode* __restrict__ wide, size_t n) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const DFatNode f = fat[i];
+	DWideNode w;
+	const float inf = __int_as_float(0x7f800000);
+	int ns = 0;
+	auto put = [&](const float (*b)[2], uint32_t ref) { for (int a = 0; a < 3; a++) { w.box[ns][a][0] = b[a][0]; w.box[ns][a][1] = b[a][1]; } w.ref[ns] = ref; ns++; };
+	for (int side = 0; side < 2; side++) {
+		const uint32_t cref = side ? f.rref : f.lref;
+		if ((cref & MIPT_LEAF_BIT) || cref >= n) put(side ? f.r : f.l, cref);              // (cref >= n: the zero-filled node of a mesh whose root is a leaf, never visited)
+		else { const DFatNode c = fat[cref]; put(c.l, c.lref); put(c.r, c.rref); }
+	}
+	for (; ns < 4; ns++) { for (int a = 0; a < 3; a++) { w.box[ns][a][0] = inf; w.box[ns][a][1] = -inf; } w.ref[ns] = MIPT_LEAF_BIT; }
+	for (int k = 0; k < 4; k++) w._pad[k] = 0;
+	wide[i] = w;
+}
+
+#ifndef MIPT_ANY_LDS_STACK
+#define MIPT_ANY_LDS_STACK 14          // 4-byte entries in LDS per lane: 14 KB per block of 256 + 4 KB of ray slots + 1 KB of leaf maps, 8 blocks per CU = 152 of 160 KB
+#endif
+#ifndef MIPT_ANYHIT_WAVES
+#define MIPT_ANYHIT_WAVES 8
+#endif
+// (the spill columns are the ones of the ordered kernels, read as 4-byte entries: twice as many)
+#define MIPT_ANY_SPILL_STACK (2 * MIPT_SPILL_STACK)
+typedef __attribute__((address_space(3))) unsigned lds_uint1;
+typedef __attribute__((address_space(1))) unsigned glb_uint1;
+// Entry sp of a lane: LDS word (sp * block + thread) for sp < MIPT_ANY_LDS_STACK, else word ((sp - MIPT_ANY_LDS_STACK) * grid threads + global
+// thread) of the spill columns.  Nothing per lane is kept in registers: the wave's bases are scalar and the lane index is recomputed with
+// v_mbcnt at every access (at 64 registers the per-lane addresses were the first values the compiler spilled — a scratch reload with a
+// wait for ALL outstanding loads in front of every push).
+struct LdsStack4 {
+	lds_uint1* wave_base;         // &lds[first thread of the wave]            (wave-uniform)
+	glb_uint1* spill_wave;        // &spill[first global thread of the wave]   (wave-uniform)
+	unsigned spill_stride;        // total threads of the grid
+	MIPT_DEV void push(int sp, uint32_t r) {
+		const unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+		if (sp < MIPT_ANY_LDS_STACK) wave_base[(unsigned)sp * MIPT_TRAV_BLOCK + l] = r;
+		else spill_wave[(unsigned)(sp - MIPT_ANY_LDS_STACK) * spill_stride + l] = r;
+	}
+	MIPT_DEV uint32_t pop(int sp) const {
+		const unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+		if (sp < MIPT_ANY_LDS_STACK) return wave_base[(unsigned)sp * MIPT_TRAV_BLOCK + l];
+		return spill_wave[(unsigned)(sp - MIPT_ANY_LDS_STACK) * spill_stride + l];
+	}
+};
+
+// Which shadow rays a launch works on, where the answers go and where the rays it may not decide go.
+struct AnyQueue {
+	const unsigned* list;        // path ids
+	const unsigned* n_ptr;       // number of entries (on the device)
+	unsigned* head;              // shared chunk counter
+	float* vis;                  // nullptr: add the pending direct term to the path's colour when visible; else 1.f / 0.f to vis[id]
+	bool skip_ghosts;
+	unsigned* replay_list;       // ids the ordered kernel decides afterwards
+	unsigned* replay_n;
+};
+
+// flag bits of inner_min_flags beyond those of traverse_queue: bit 24 = every ray counts as "passed a box near its far end"
+// (test hook: every occluded ray goes through the replay list)
+// What the leaf tests need of a ray and the node steps do not — its direction in the mesh's frame and the occlusion bound — waits in
+// LDS (16 bytes per lane, `rayslot` = the wave's 64 slots) instead of in four registers: a test lane reads its OWNER's slot with one
+// ds_read_b128 where it would gather four registers with ds_bpermute.
+// (the lane index where it is only needed on rare paths: recomputed on the spot and opaque to the optimiser, which otherwise hoists the
+// derived LDS address out of the kernel's loop into a register that it then spills)
+__device__ __forceinline__ unsigned lane_id_now() { unsigned l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+typedef float lds_f4_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_f4_ lds_float4v;
+template <bool DERIVE>
+__device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, const float4* __restrict__ wide, const DTriIsect* __restrict__ tris, const DWave& wf,
+                                             const AnyQueue tq, int refill_threshold, int inner_min_flags, LdsStack4& stk, unsigned char* leafmap, lds_float4v* rayslot) {
+	const int inner_min = inner_min_flags & 0xffff;
+	const bool force_replay = (inner_min_flags >> 16) & 1;      // test hook `literal_slab`: every ray is decided by the ordered kernel's literal chain
+	const unsigned lane_limit = ((inner_min_flags >> 17) & 127) ? ((inner_min_flags >> 17) & 127) : 64u;
+	const bool flag_all = (inner_min_flags >> 24) & 1;
+	const unsigned n = *tq.n_ptr;
+	unsigned* head = tq.head;
+	const unsigned* __restrict__ list = tq.list;
+	const unsigned nwaves = gridDim.x * (MIPT_TRAV_BLOCK / 64), wave_id = blockIdx.x * (MIPT_TRAV_BLOCK / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	bool first_pull = true;
+	const unsigned pull_chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)max(64u, min(MIPT_PULL_CHUNK, (n / (gridDim.x * (MIPT_TRAV_BLOCK / 64) * MIPT_PULL_DIV)) & ~63u)));
+	const unsigned lane = lane_id();
+	auto below_count = [](unsigned long long m) -> unsigned { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+
+	// lane state (cur: a wide node, a leaf (bit 31) or MIPT_ST_NEED / MIPT_ST_IDLE / MIPT_NONE as in traverse_queue)
+	mipt_f2 o_xy = {0.f, 0.f}, i_xy = {0.f, 0.f}, oz_iz = {0.f, 0.f};
+	float dist = 0.f;                      // (occ_below, in the ray slot: the smallest float F with (double)F >= (double)dist * 0.999, so that  t < F  <=>  (double)t < dist * 0.999  (TriangleMesh.cpp:1309)
+	uint32_t cur = MIPT_ST_IDLE;
+	int sp = 0, obj = 0;
+	unsigned id = 0;
+	bool near_end = false;
+	unsigned chunk_next = 0, chunk_end = 0;
+	bool drained = false;
+	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
+	const bool any_alpha = sc->any_alpha != 0;
+	const float inf = __int_as_float(0x7f800000);
+	auto to_replay = [&]() { const unsigned k = atomicAdd(tq.replay_n, 1u); tq.replay_list[k] = id; };
+
+	for (;;) {
+		// ---- refill idle lanes from the queue (as traverse_queue)
+		const unsigned long long idle = __ballot(cur == MIPT_ST_IDLE && lane < lane_limit);
+		const int nidle = __popcll(idle);
+		if (!drained && nidle >= refill_threshold) {
+			if (chunk_next >= chunk_end) {
+				unsigned base = 0;
+				if (first_pull) { base = wave_id * pull_chunk; first_pull = false; }
+				else if (lane == 0) base = atomicAdd(head, pull_chunk) + nwaves * pull_chunk;
+				base = __builtin_amdgcn_readfirstlane(base);
+				if (base >= n) { drained = true; chunk_next = chunk_end = 0; }
+				else { chunk_next = base; chunk_end = min(base + pull_chunk, n); }
+			}
+			const unsigned take = min((unsigned)nidle, chunk_end - chunk_next);
+			const unsigned prefix = below_count(idle);
+			if (cur == MIPT_ST_IDLE && lane < lane_limit && prefix < take) {
+				id = list[chunk_next + prefix]; obj = first_mesh; cur = MIPT_ST_NEED; near_end = flag_all;
+			}
+			chunk_next += take;
+		}
+		// ---- object loop (wave-uniform index): a ray stops at the first mesh whose root box it enters
+		if (__ballot(cur == MIPT_ST_NEED) != 0) {
+			f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+			float occ_below = 0.f;
+			if (cur == MIPT_ST_NEED && obj < nobj) {
+				const float4 o4 = wf.sh_o[id], d4 = wf.sh_d[id];
+				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
+				dist = o4.w;
+				const double D = (double)dist * 0.999;
+				float F = (float)D;
+				if ((double)F < D) F = __uint_as_float(F >= 0.f ? __float_as_uint(F) + 1u : __float_as_uint(F) - 1u);
+				occ_below = F;
+			}
+			for (int i = first_mesh; i < nobj; i++) {
+				if (cur == MIPT_ST_NEED && obj == i) {
+					const DObject& o = sc->obj[i];
+					obj = i + 1;
+					if (o.type != 0 || (tq.skip_ghosts && o.ghost)) continue;           // spheres / planes were tested when the request was made; ghosts: Geometry.cpp:722
+					const f3 d = xf_dir(o.inv, rd), org = xf_point(o.inv, ro);
+					const f3 invd = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+					float t_root;
+					bool enter = box_test<false>(ld3(o.root_min), ld3(o.root_max), org, invd, invd.x >= 0, invd.y >= 0, invd.z >= 0, t_root);
+					if (enter && t_root > dist) enter = false;                            // TriangleMesh.cpp:1257 (cur_best_t is 1E99)
+					if (!enter) continue;
+					if (force_replay || fabsf(invd.x) == inf || fabsf(invd.y) == inf || fabsf(invd.z) == inf) { to_replay(); cur = MIPT_ST_IDLE; continue; }
+					o_xy = (mipt_f2){org.x, org.y}; i_xy = (mipt_f2){invd.x, invd.y}; oz_iz = (mipt_f2){org.z, invd.z};
+					rayslot[lane_id_now()] = (lds_f4_){d.x, d.y, d.z, occ_below};
+					cur = o.root_ref; sp = 0; obj = i;
+				}
+			}
+			if (cur == MIPT_ST_NEED) {                                        // no object left: the light sample is visible
+				if (tq.vis) tq.vis[id] = 1.f;
+				else {
+					const float4 c = wf.out.col[id], pc = wf.sh_c[id];
+					wf.out.col[id] = make_float4(c.x + pc.x, c.y + pc.y, c.z + pc.z, 0.f);    // Raytracer.cpp:566
+				}
+				cur = MIPT_ST_IDLE;
+			}
+		}
+		{
+			const int nalive = __popcll(__ballot(cur - MIPT_ST_NEED >= 2u));
+			if (nalive == 0) { if (drained) break; else continue; }
+			if (!drained && (int)lane_limit - nalive >= refill_threshold) continue;
+		}
+		// ---- wide-node phase: every live lane descends until it holds a leaf or runs out of nodes
+		{
+			const bool sx = i_xy.x >= 0, sy = i_xy.y >= 0, sz = oz_iz.y >= 0;
+			const float near_thr = 0.998f * dist;
+			for (;;) {
+				const bool inner = cur < MIPT_ST_NEED;
+				const unsigned long long mi = __ballot(inner);
+				if (mi == 0) break;
+				if (__popcll(mi) < inner_min && __ballot(cur >= MIPT_NONE) != 0) break;
+				if (!inner) continue;
+				const float4* q = wide + 8 * (size_t)cur;
+				const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+				float t0, t1, t2, t3;
+				bool p0 = box_test_pairs<false>((mipt_f2){q0.x, q0.y}, (mipt_f2){q0.z, q0.w}, (mipt_f2){q1.x, q1.y}, o_xy, i_xy, oz_iz, sx, sy, sz, t0);
+				bool p1 = box_test_pairs<false>((mipt_f2){q1.z, q1.w}, (mipt_f2){q2.x, q2.y}, (mipt_f2){q2.z, q2.w}, o_xy, i_xy, oz_iz, sx, sy, sz, t1);
+				bool p2 = box_test_pairs<false>((mipt_f2){q3.x, q3.y}, (mipt_f2){q3.z, q3.w}, (mipt_f2){q4.x, q4.y}, o_xy, i_xy, oz_iz, sx, sy, sz, t2);
+				bool p3 = box_test_pairs<false>((mipt_f2){q4.z, q4.w}, (mipt_f2){q5.x, q5.y}, (mipt_f2){q5.z, q5.w}, o_xy, i_xy, oz_iz, sx, sy, sz, t3);
+				p0 = p0 && (t0 < dist); p1 = p1 && (t1 < dist); p2 = p2 && (t2 < dist); p3 = p3 && (t3 < dist);      // TriangleMesh.cpp:1278-1279 without `< t`
+				near_end = near_end || (p0 && t0 >= near_thr) || (p1 && t1 >= near_thr) || (p2 && t2 >= near_thr) || (p3 && t3 >= near_thr);
+				const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
+				// the first passing slot is taken, the others wait on the stack (lower slots on top)
+				if (p3 && (p0 || p1 || p2)) { stk.push(sp, r3); sp++; }
+				if (p2 && (p0 || p1)) { stk.push(sp, r2); sp++; }
+				if (p1 && p0) { stk.push(sp, r1); sp++; }
+				if (p0) cur = r0;
+				else if (p1) cur = r1;
+				else if (p2) cur = r2;
+				else if (p3) cur = r3;
+				else if (sp > 0) { --sp; cur = stk.pop(sp); }
+				else cur = MIPT_NONE;
+			}
+		}
+		// ---- leaf phase: the (ray, triangle) tests of all lanes that hold a leaf, packed densely over the wave (as traverse_queue);
+		//      an owner only needs to know whether ANY of its tests found an occluder: one ballot instead of the walk in leaf order
+		{
+			const bool leaf = (int)cur < 0;
+			const int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
+			const int count = leaf ? (int)((cur >> 26) & 31u) + 1 : 0;
+			bool per_lane = leaf, occluded = false;
+			if (!any_alpha) {
+				const int cnt = count <= 4 ? count : 0;
+				const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
+				if (b1 != 0) {
+					unsigned pfx = 0;
+					for (const unsigned long long m : {b1, b2, b3, b4}) pfx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, pfx));
+					const int prefix = (int)pfx;
+					const int total = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
+					for (int k = 0; k < 4; k++) if (k < cnt) leafmap[prefix + k] = (unsigned char)(lane | ((unsigned)k << 6));
+					__builtin_amdgcn_wave_barrier();
+					for (int base = 0; base < total; base += 64) {
+						const int j = base + (int)lane;
+						const unsigned m = j < total ? (unsigned)leafmap[j] : 0u;
+						const int src = (int)((m & 63u) << 2), slot = (int)(m >> 6);
+						const int f = __builtin_amdgcn_ds_bpermute(src, first);
+						f3 ro, rd;
+						ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o_xy.x)));
+						ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o_xy.y)));
+						ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oz_iz.x)));
+						const lds_f4_ rs = rayslot[m & 63u];
+						rd = mk3(rs.x, rs.y, rs.z);
+						const float below = rs.w;
+						bool occ = false;
+						if (j < total) {
+							float a, bb, gg;
+							if (tri_test<DERIVE>(tris + f + slot, ro, rd, a, bb, gg)) occ = a < below;
+						}
+						const unsigned long long om = __ballot(occ);
+						// this lane's tests are entries prefix .. prefix + cnt - 1 of the packed list
+						const int lo = prefix - base;
+						if (cnt > 0 && lo < 64 && lo + cnt > 0) {
+							const unsigned long long mine = lo >= 0 ? (((1ull << cnt) - 1ull) << lo) : (((1ull << cnt) - 1ull) >> (-lo));
+							if (om & mine) occluded = true;
+						}
+					}
+					if (cnt > 0) per_lane = false;
+				}
+			}
+			if (per_lane) {
+				const lds_f4_ rs = rayslot[lane_id_now()];
+				for (int i = first; i < first + count; i++) {
+					float lt, lb, lg;
+					if (tri_test<DERIVE>(tris + i, mk3(o_xy.x, o_xy.y, oz_iz.x), mk3(rs.x, rs.y, rs.z), lt, lb, lg) && lt < rs.w) {
+						const DObject& o = sc->obj[obj];
+						if (o.alpha_test && alpha_rejects(o, i - (int)o.tri_base, 1 - lb - lg, lb, lg)) continue;      // TriangleMesh.cpp:1300-1307
+						occluded = true;
+						break;
+					}
+				}
+			}
+			if (leaf) {
+				if (occluded) {
+					// (an occluded ray adds nothing to its path's colour)
+					if (near_end) to_replay();
+					else if (tq.vis) tq.vis[id] = 0.f;
+					cur = MIPT_ST_IDLE; sp = 0;
+				} else if (sp > 0) { --sp; cur = stk.pop(sp); }
+				else cur = MIPT_NONE;
+			}
+		}
+		// ---- mesh finished without an occluder: on to the objects behind it
+		if (cur == MIPT_NONE) { cur = MIPT_ST_NEED; obj = obj + 1; }
+	}
+}
+
+// The shadow queue of depth b of the wavefront pipeline (the rays shade(b) asked for).
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_ANYHIT_WAVES))) k_wf_anyhit(const DScene* __restrict__ sc, const float4* __restrict__ wide, const DTriIsect* __restrict__ tris, DWave wf, int b,
+                                                                                                                   unsigned* replay_list, int refill_threshold, int inner_min_flags) {
+	__shared__ unsigned lds_stack4_[MIPT_ANY_LDS_STACK * MIPT_TRAV_BLOCK];
+	__shared__ unsigned char lds_leafmap4_[4 * MIPT_TRAV_BLOCK];
+	__shared__ float4 lds_rayslot4_[MIPT_TRAV_BLOCK];
+	LdsStack4 stk;
+	const unsigned wave_in_block = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	stk.wave_base = (lds_uint1*)lds_stack4_ + wave_in_block * 64u;
+	stk.spill_wave = (glb_uint1*)wf.spill + (size_t)blockIdx.x * MIPT_TRAV_BLOCK + wave_in_block * 64u; stk.spill_stride = gridDim.x * MIPT_TRAV_BLOCK;
+	unsigned char* leafmap = lds_leafmap4_ + wave_in_block * 256;
+	AnyQueue q;
+	q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(b)]; q.head = &wf.counters[MIPT_CNT_SH_HEAD(b)]; q.vis = nullptr; q.skip_ghosts = false;
+	q.replay_list = replay_list; q.replay_n = &wf.counters[MIPT_CNT_REPLAY(b)];
+	anyhit_queue<MIPT_DERIVE_SHADOW != 0>(sc, wide, tris, wf, q, refill_threshold, inner_min_flags, stk, leafmap, (lds_float4v*)lds_rayslot4_ + wave_in_block * 64u);
+}

@@ -68,6 +68,8 @@ template <class T> __device__ __forceinline__ void wf_st(T* p, T a) { *p = a; }
 #define MIPT_CNT_PAIR(b) MIPT_CNT(4 * (b))
 #define MIPT_CNT_EXT_HEAD(b) MIPT_CNT(4 * (b) + 1)
 #define MIPT_CNT_SH_HEAD(b) MIPT_CNT(4 * (b) + 2)
+// line 4b+3: word 0 = shadow rays of depth b the order-free any-hit kernel left to the ordered one (mipt_anyhit.h), word 8 = that list's head
+#define MIPT_CNT_REPLAY(b) MIPT_CNT(4 * (b) + 3)
 #define MIPT_N_SHADOW(wf, b) ((wf).counters[MIPT_CNT_PAIR(b)])
 #define MIPT_N_EXTEND(wf, b, n0) ((b) == 0 ? (n0) : (wf).counters[MIPT_CNT_PAIR((b) - 1) + 1])
 #define MIPT_WF_COUNTERS (MIPT_WF_NCOUNTERS * MIPT_CNT_STRIDE)
