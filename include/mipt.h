@@ -301,6 +301,12 @@ int mipt_measure_dependent_gather(mipt_ctx* ctx, uint64_t table_bytes, int steps
    against it.  (Measurement aid: no counterpart in the reference.) */
 int mipt_measure_vmem_issue(mipt_ctx* ctx, int active_lanes, int iters, double* ns_per_instruction_and_cu);
 
+/* Diagnostics of the any-hit stage: the number of shadow rays of the context's last render (pipeline 1) that the order-free
+   traversal did not decide itself and handed to the ordered one — rays that found an occluder in a leaf whose box lies within
+   0.2 % of the ray's far end (the only ones whose answer can depend on the visiting order of TriMesh::intersection_shadow,
+   TriangleMesh.cpp:1239-1319) and rays with an infinite inverse-direction component.  No counterpart in the reference. */
+int mipt_debug_anyhit_replayed(mipt_ctx* ctx, uint64_t* out);
+
 /* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
  * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes
  * compare equal as floats; a coordinate that is +0 in some vertices and -0 in others may come out with the other sign).

@@ -27,7 +27,7 @@ MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_measure_vmem_issue", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_measure_vmem_issue", "mipt_debug_anyhit_replayed", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
                 "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs",
                 "mipt_device_mesh_build", "mipt_device_mesh_download", "mipt_device_mesh_download_tangents", "mipt_device_mesh_free"]
 
@@ -592,6 +592,12 @@ class HostRaytracer:
         """ns of one CU per vector-memory wave-instruction at that many active lanes (mipt_measure_vmem_issue)."""
         out = C.c_double(0.0)
         self._check(self.mipt.mipt_measure_vmem_issue(self.ctx, int(active_lanes), int(iters), C.byref(out)), "mipt_measure_vmem_issue")
+        return out.value
+
+    def anyhit_replayed(self):
+        """Shadow rays of the last render that the order-free any-hit kernel left to the ordered one (mipt_debug_anyhit_replayed)."""
+        out = C.c_uint64(0)
+        self._check(self.mipt.mipt_debug_anyhit_replayed(self.ctx, C.byref(out)), "mipt_debug_anyhit_replayed")
         return out.value
 
     def stats(self):

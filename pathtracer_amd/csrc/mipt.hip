@@ -352,7 +352,9 @@ struct mipt_ctx {
 	DScene* d_scene = nullptr;
 	const DFatNode* d_all_nodes = nullptr;
 	const DTriIsect* d_all_tris = nullptr;
-	const DWideNode* d_wide_nodes = nullptr;   // four-wide nodes of the order-free any-hit traversal (mipt_anyhit.h), one per fat node
+	const DQuadNode* d_quad_nodes = nullptr;   // four-wide 8-bit nodes of the order-free any-hit traversal (mipt_anyhit.h), one per fat node
+	const float* d_leaf_box = nullptr;         // the float box of every leaf, 32 bytes at its first triangle's index
+	size_t n_quad_nodes = 0;
 	bool scene_has_ghost = false;     // a ghost object, a background photo or fog: rendered by the queue kernel (mipt_compositing.h)
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
 	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
@@ -406,6 +408,8 @@ struct mipt_ctx {
 	int64_t opt_anyhit_wide = 1;      // pipeline 1: the shadow stage as the order-free four-wide traversal (mipt_anyhit.h) + ordered replay of the rays it may not decide; 0 = the ordered kernel for every ray
 	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
 	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
+	unsigned grid_qanyhit = 0;        // ... of k_q_anyhit
+	unsigned* q_replay_list = nullptr; // (in the pass buffer)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
@@ -959,13 +963,50 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		}
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
 	}
-	c->d_wide_nodes = nullptr;
-	if (H.all_nodes && stg.nfat_total > 0) {      // the four-wide nodes of the any-hit stage, derived on the device from the fat nodes wherever those came from
-		void* dw = nullptr;
-		HIPCHK(c, hipMalloc(&dw, stg.nfat_total * sizeof(DWideNode))); c->scene_allocs.push_back(dw);
-		hipLaunchKernelGGL(k_wide_nodes, dim3((unsigned)((stg.nfat_total + 255) / 256)), dim3(256), 0, 0, H.all_nodes, (DWideNode*)dw, stg.nfat_total);
-		HIPCHK(c, hipGetLastError());
-		c->d_wide_nodes = (const DWideNode*)dw;
+	c->d_quad_nodes = nullptr; c->d_leaf_box = nullptr;
+	for (int i = 0; i < s->n_objects; i++) H.obj[i].quad_root = H.obj[i].root_ref;
+	if (H.all_nodes && stg.nfat_total > 0 && stg.nt_total > 0) {
+		// the nodes of the any-hit stage (mipt_anyhit.h), derived on the device from the fat nodes wherever those came from: mark the fat
+		// nodes that become quad nodes, number them (exclusive scan), build them densely
+		const size_t nf = stg.nfat_total;
+		const unsigned gb = (unsigned)((nf + 255) / 256);
+		uint32_t* d_mark = nullptr; uint32_t* d_index = nullptr; uint32_t* d_bsum = nullptr; int* d_changed = nullptr;
+		const size_t ntile = (nf + BVHB_RANK_TILE - 1) / BVHB_RANK_TILE;
+		auto cleanup = [&]() { hipFree(d_mark); hipFree(d_index); hipFree(d_bsum); hipFree(d_changed); };
+		if (hipMalloc((void**)&d_mark, nf * 4) != hipSuccess || hipMalloc((void**)&d_index, nf * 4) != hipSuccess || hipMalloc((void**)&d_bsum, (ntile + 1) * 4) != hipSuccess || hipMalloc((void**)&d_changed, 4) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "hipMalloc of the quad-node marks failed"); }
+		hipMemset(d_mark, 0, nf * 4);
+		const uint32_t one = 1;
+		for (int i = 0; i < s->n_objects; i++) if (H.obj[i].type == MIPT_OBJ_TRIMESH && !(H.obj[i].root_ref & MIPT_LEAF_BIT)) hipMemcpy(d_mark + H.obj[i].root_ref, &one, 4, hipMemcpyHostToDevice);
+		for (int pass = 0; pass <= MIPT_STACK_DEPTH; pass++) {
+			int changed = 0;
+			hipMemset(d_changed, 0, 4);
+			hipLaunchKernelGGL(k_quad_mark_pass, dim3(gb), dim3(256), 0, 0, H.all_nodes, d_mark, nf, d_changed);
+			if (hipMemcpy(&changed, d_changed, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "marking the quad nodes failed: %s", hipGetErrorString(hipGetLastError())); }
+			if (!changed) break;
+		}
+		hipLaunchKernelGGL(k_quad_mark_flags, dim3(gb), dim3(256), 0, 0, d_mark, nf);
+		hipMemcpy(d_index, d_mark, nf * 4, hipMemcpyDeviceToDevice);
+		hipLaunchKernelGGL(bvhb::k_u32_sums, dim3((unsigned)ntile), dim3(256), 0, 0, (const uint32_t*)d_index, nf, d_bsum);
+		hipLaunchKernelGGL(bvhb::k_scan_top, dim3(1), dim3(1024), 0, 0, d_bsum, (int)ntile);
+		hipLaunchKernelGGL(bvhb::k_u32_apply, dim3((unsigned)ntile), dim3(256), 0, 0, d_index, nf, (const uint32_t*)d_bsum);
+		uint32_t last_idx = 0, last_mark = 0;
+		if (hipMemcpy(&last_idx, d_index + nf - 1, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&last_mark, d_mark + nf - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "numbering the quad nodes failed: %s", hipGetErrorString(hipGetLastError())); }
+		const size_t nquad = (size_t)last_idx + last_mark;
+		void *dw = nullptr, *lb = nullptr;
+		if (hipMalloc(&dw, std::max<size_t>(nquad, 1) * sizeof(DQuadNode)) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "hipMalloc of the quad nodes failed"); }
+		c->scene_allocs.push_back(dw);
+		if (hipMalloc(&lb, stg.nt_total * 8 * sizeof(float)) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "hipMalloc of the leaf boxes failed"); }
+		c->scene_allocs.push_back(lb);
+		hipLaunchKernelGGL(k_leaf_box_init, dim3((unsigned)((8 * stg.nt_total + 255) / 256)), dim3(256), 0, 0, (float*)lb, stg.nt_total);
+		hipLaunchKernelGGL(k_quad_nodes, dim3(gb), dim3(256), 0, 0, H.all_nodes, (const uint32_t*)d_mark, (const uint32_t*)d_index, (DQuadNode*)dw, (float*)lb, nf);
+		for (int i = 0; i < s->n_objects; i++) if (H.obj[i].type == MIPT_OBJ_TRIMESH && !(H.obj[i].root_ref & MIPT_LEAF_BIT)) {
+			if (hipMemcpy(&H.obj[i].quad_root, d_index + H.obj[i].root_ref, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "reading a quad root failed"); }
+		}
+		const hipError_t qe = hipDeviceSynchronize();
+		cleanup();
+		if (qe != hipSuccess) return fail(c, MIPT_ERR_HIP, "building the quad nodes failed: %s", hipGetErrorString(qe));
+		c->d_quad_nodes = (const DQuadNode*)dw; c->d_leaf_box = (const float*)lb;
+		c->n_quad_nodes = nquad;
 	}
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
@@ -1227,7 +1268,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES + (c->opt_sort_rays ? sizeof(unsigned) : 0); fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned) + MIPT_SORT_BINS * 2048 * sizeof(unsigned) + 64; }
 	if (want_aov) per_path += 2 * sizeof(float4);
 	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
-		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 10 * sizeof(unsigned);
+		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 11 * sizeof(unsigned);
 		fixed_bytes += MIPT_QW_COUNTERS * sizeof(unsigned) + 1024;
 	}
 	const unsigned queue_ring = (unsigned)std::max<int64_t>(1, std::min<int64_t>(MIPT_QW_FIFO, c->opt_queue_ring));
@@ -1296,6 +1337,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		qw.sha[0] = (unsigned*)carve(N * sizeof(unsigned)); qw.sha[1] = (unsigned*)carve(N * sizeof(unsigned));
 		qw.overflow = (unsigned*)carve(N * sizeof(unsigned));
 		qw.slow = (unsigned*)carve(N * sizeof(unsigned));
+		unsigned* const q_replay = (unsigned*)carve(N * sizeof(unsigned));      // shadow requests the order-free any-hit kernel leaves to the ordered one
+		c->q_replay_list = q_replay;
 		qw.counters = (unsigned*)carve(MIPT_QW_COUNTERS * sizeof(unsigned));
 		qw.fifo = queues; qw.aov_n = aov_n; qw.aov_kd = aov_kd; qw.N = (unsigned)N;
 		qw.ring = queue_ring;
@@ -1392,6 +1435,23 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			auto q_traverse = [&](bool shadow, const TravQueue& tq, unsigned nq) {
 				const dim3 g(std::max(1u, std::min(c->grid_qtrav[shadow ? 1 : 0], (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
+				if (shadow && c->opt_anyhit_wide && c->d_quad_nodes) {
+					// order-free four-wide traversal + the ordered kernel over what it may not decide (mipt_anyhit.h); the replay count and head
+					// sit in the free words of the list's head line (cleared with the round's slot)
+					if (c->grid_qanyhit == 0) {
+						int nb = 0;
+						if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_q_anyhit, MIPT_TRAV_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+						c->grid_qanyhit = std::min((unsigned)c->n_cus * 8u, (unsigned)c->n_cus * (unsigned)nb);
+					}
+					AnyQueue aq; aq.list = tq.list; aq.n_ptr = tq.n_ptr; aq.head = tq.head; aq.vis = tq.vis; aq.skip_ghosts = tq.skip_ghosts;
+					aq.replay_list = c->q_replay_list; aq.replay_n = tq.head + 8; aq.replay_total = &c->d_cnt[0]._pad[0];
+					const dim3 ga(std::max(1u, std::min(c->grid_qanyhit, (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
+					hipLaunchKernelGGL(k_q_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, aq, thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
+					TravQueue rq = tq; rq.list = c->q_replay_list; rq.n_ptr = tq.head + 8; rq.n_imm = 0; rq.head = tq.head + 16; rq.identity = false;
+					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
+					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? g.x : std::min(g.x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
+					return;
+				}
 				if (shadow) hipLaunchKernelGGL(k_q_traverse<true>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 				else hipLaunchKernelGGL(k_q_traverse<false>, g, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 			};
@@ -1496,7 +1556,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
-				else if (c->opt_refill && c->opt_anyhit_wide && c->d_wide_nodes) {
+				else if (c->opt_refill && c->opt_anyhit_wide && c->d_quad_nodes) {
 					// order-free four-wide traversal, then the ordered kernel over the (normally empty) list of rays it may not decide; the list is
 					// the closest-hit queue of this depth, which shade(b) has consumed
 					if (c->grid_anyhit == 0) {
@@ -1505,7 +1565,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 						c->grid_anyhit = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
 					}
 					const dim3 ga(std::min(c->grid_anyhit, (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
-					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_wide_nodes, c->d_all_tris, wf, b, list_mem[b & 1], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
+					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, b, list_mem[b & 1], &c->d_cnt[0]._pad[0], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
 					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false;
 					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
 					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
@@ -1953,6 +2013,15 @@ __global__ void __launch_bounds__(256) k_vmem_issue(const float4* __restrict__ t
 		}
 	}
 	if (acc == 12345.f) sink[0] = acc;
+}
+// Diagnostics of the any-hit stage (mipt_anyhit.h): shadow rays of the last render that the order-free kernel handed to the ordered one.
+extern "C" int mipt_debug_anyhit_replayed(mipt_ctx* c, uint64_t* out) {
+	if (!c || !out || !c->d_cnt) return fail(c, MIPT_ERR_INVALID, "no render yet");
+	HIPCHK(c, hipSetDevice(c->device));
+	unsigned long long v = 0;
+	HIPCHK(c, hipMemcpy(&v, &c->d_cnt[0]._pad[0], sizeof v, hipMemcpyDeviceToHost));
+	*out = v;
+	return MIPT_OK;
 }
 extern "C" int mipt_measure_vmem_issue(mipt_ctx* c, int active_lanes, int iters, double* ns_per_instruction_and_cu) {
 	if (!c || !ns_per_instruction_and_cu || active_lanes < 1 || active_lanes > 64 || iters < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");

@@ -1,4 +1,4 @@
-// mipt_anyhit.h — the any-hit (shadow) stage of the wavefront pipeline as an ORDER-FREE traversal of four-wide nodes.
+// mipt_anyhit.h — the any-hit (shadow) stage of the wavefront pipeline as an ORDER-FREE traversal of four-wide nodes with 8-bit boxes.
 //
 // What the reference computes.  Scene::intersection_shadow (Geometry.cpp:691-744) returns true as soon as some object reports a hit
 // with t < 0.999 dist_light; it hands every mesh cur_best_t = 1E99 (min_t is never updated), and TriMesh::intersection_shadow
@@ -6,57 +6,132 @@
 // always accepted when it is tested (the running t only ever holds values >= 0.999 dist until then), and the alpha test does not
 // depend on the order.  So the result is
 //       "is there an occluder (t < 0.999 dist, alpha map permitting) in a leaf the traversal REACHES",
-// and the only thing the visiting order can change is which leaves are reached: the reference skips a node whose box distance is
-// >= the running t, which is some accepted t in [0.999 dist, dist) — the other prune, box distance < dist_light, is the same in any order.
-//
-// What this file does instead.  It reaches every leaf whose ancestors all pass `slab test && t_box < dist_light` — a superset of
-// what the reference reaches in any order — and visits them in whatever order is cheapest:
+// and a leaf is reached iff every box on the way passes `slab test && t_box < dist_light && t_box < running t`, the running t being
+// some accepted t in [0.999 dist, dist).  Boxes nest exactly (a node's box is the union of its triangles' boxes, TriangleMesh.cpp:843-858)
+// and (plane - o) * invd is monotone in the plane under round-to-nearest, so a box that passes implies that every box around it passes
+// with a smaller-or-equal distance:
+//       leaf L is reached  <=>  L's OWN box passes with t_box(L) < dist_light  [and no box on the way had t_box >= the running t, which
+//                               needs t_box(L) >= 0.999 dist].
+// What this file does instead.  It may therefore visit ANY superset of those leaves in ANY order, as long as an occluder only counts
+// when the leaf it was found in passes the reference's own test on the reference's own (float) box:
 //   * no near / far ordering, no t_near on the stack (4-byte entries), no running t;
-//   * FOUR-WIDE nodes (DWideNode, 128 B = one fabric line): the boxes of the four GRANDCHILDREN of a binary node (a child that is a
-//     leaf takes one slot with its own box).  The children's own tests are skipped: boxes nest exactly (a parent's box is the union
-//     of its triangles' boxes, TriangleMesh.cpp:843-858) and (plane - o) * invd is monotone in the plane under round-to-nearest, so
-//     a grandchild that passes implies its parent passes with a smaller-or-equal distance — the set of reached leaves is the same as
-//     with binary steps, at half the dependent round trips (tests/tools/anyhit_study.py: 27.7 -> 15.2 rounds per ray on configs[2]).
-// Exactness.  "No occluder among the reached leaves" is exact: the reference reaches a subset.  "An occluder found" can differ from the
-// reference only if the reference pruned an ancestor of that leaf, i.e. only if some box on the way passed with
-// t_box >= 0.999 dist.  A ray remembers whether ANY box it passed had t_box >= 0.998f dist (sticky, conservative); if such a ray
-// finds an occluder it is not decided here: its id goes to a replay list that the ORDERED kernel (traverse_queue<true>,
-// mipt_persistent.h) works off in the reference's order.  Rays with an infinite inverse-direction component (the packed slab test
-// is not valid for them, mipt_trace.h) go to the replay list as well.  On the bench scenes the replay list stays empty.
+//   * FOUR-WIDE nodes with 8-BIT planes (DQuadNode, 64 B): the boxes of the four GRANDCHILDREN of a binary node (a child that is a leaf
+//     takes one slot), each plane stored as origin + q * 2^e, rounded OUTWARDS and checked at build time with the very fma the kernel
+//     evaluates: the decoded box contains the float box, so (same monotonicity) it passes whenever the float box does.  One node is
+//     four 16-byte loads for four boxes where the ordered kernel needs four for two — and the traversal kernels run at the rate the
+//     CU issues vector-memory instructions (the exact-box form of this kernel, 7 loads per 4 boxes, halved the
+//     dependent rounds per ray, cut vector instructions by 21 %, scalar ones by 30 %, L2 requests by 32 % — and ran 3 % faster,
+//     as its 3.5 % fewer vector-memory instructions predict; profiles/r5_b_*).  tests/tools/anyhit_study.py: 13.5 wide steps per ray
+//     on configs[2] against 25.7 binary ones; the 8-bit planes cost 1.4 % more steps than exact ones;
+//   * when a leaf's triangles yield an occluder, the leaf's float box (leaf_box[first triangle], 32 B) is fetched and tested exactly as
+//     TriangleMesh.cpp:1278 tests it.  Fails: the reference never tests this leaf — the occluder does not count, the walk goes on.
+//     Passes with t_box < 0.998f dist: no box on the way can have been skipped for the running t — the reference reaches the leaf (or
+//     returned true before): occluded.  Passes with t_box >= 0.998f dist: the ray's id goes to a replay list that the ORDERED kernel
+//     (traverse_queue<true>, mipt_persistent.h) works off in the reference's order.
+// "No occluder found" is exact as it stands: every leaf the reference reaches was visited.  Rays with an infinite inverse-direction
+// component (the packed slab test is not valid for them, mipt_trace.h) go to the replay list as well.  On the bench scenes the replay
+// list stays empty.
 #pragma once
 
-struct DWideNode {             // 128 B, 128-B aligned
-	float box[4][3][2];        // slot k: (min, max) pairs per axis, as in DFatNode; an unused slot holds (+inf, -inf): never passes
-	uint32_t ref[4];           // inner: index of the slot's own DWideNode (= its binary inner node); bit 31: leaf (first triangle | count-1 << 26)
-	uint32_t _pad[4];
+struct DQuadNode {             // 64 B, 64-B aligned: four 16-byte words
+	float origin[3];           // word 0: the planes' origin (the minimum corner of the four boxes) ...
+	uint32_t exps;             //         ... and the biased exponent byte of each axis' power-of-two step (x | y << 8 | z << 16)
+	uint32_t lohi[3][2];       // word 1, first half of word 2: per axis the four slots' lower planes (byte k = slot k), then their upper planes
+	uint32_t _pad[2];
+	uint32_t ref[4];           // word 3: inner = index of the slot's own DQuadNode (= its binary inner node); bit 31: leaf (first triangle | count-1 << 26)
 };
-static_assert(sizeof(DWideNode) == 128, "one 128-byte line per wide node");
+static_assert(sizeof(DQuadNode) == 64, "one 64-byte line per quad node");
+// the decoded plane: origin + q * step, ONE rounding (q * step is exact); the builder checks its bytes with this very function
+__host__ __device__ __forceinline__ float quad_plane(float q, float step, float origin) { return __builtin_fmaf(q, step, origin); }
 
-// One wide node per fat (binary inner) node.  Only the nodes an even number of inner levels below a root are ever visited (plus
-// wherever a leaf child shortens a side); building all of them keeps the references those of the fat array.
-__global__ void k_wide_nodes(const DFatNode* __restrict__ fat, DWideNode* __restrict__ wide, size_t n) {
+// byte K of a word as a float (the compiler selects v_cvt_f32_ubyteK)
+template <int K> __device__ __forceinline__ float quad_byte(uint32_t w) { return (float)((w >> (8 * K)) & 255u); }
+
+// Which binary inner nodes become quad nodes: the roots, and from a quad node the inner ones among its (up to four) slots — every second
+// inner level of the tree, shifted wherever a leaf child shortens a side.  One pass marks the slots of the nodes marked so far; a tree of at
+// most MIPT_STACK_DEPTH inner levels needs MIPT_STACK_DEPTH / 2 passes (children follow their parents in the node array, so a pass often
+// reaches further: the loop on the host stops when a pass changes nothing).
+__global__ void k_quad_mark_pass(const DFatNode* __restrict__ fat, uint32_t* __restrict__ mark, size_t n, int* __restrict__ changed) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+	if (i >= n || mark[i] != 1u) return;
+	mark[i] = 2u;                                                   // expanded
 	const DFatNode f = fat[i];
-	DWideNode w;
-	const float inf = __int_as_float(0x7f800000);
-	int ns = 0;
-	auto put = [&](const float (*b)[2], uint32_t ref) { for (int a = 0; a < 3; a++) { w.box[ns][a][0] = b[a][0]; w.box[ns][a][1] = b[a][1]; } w.ref[ns] = ref; ns++; };
+	bool any = false;
 	for (int side = 0; side < 2; side++) {
 		const uint32_t cref = side ? f.rref : f.lref;
-		if ((cref & MIPT_LEAF_BIT) || cref >= n) put(side ? f.r : f.l, cref);              // (cref >= n: the zero-filled node of a mesh whose root is a leaf, never visited)
+		if ((cref & MIPT_LEAF_BIT) || cref >= n) continue;
+		const DFatNode c = fat[cref];
+		for (int s2 = 0; s2 < 2; s2++) {
+			const uint32_t g = s2 ? c.rref : c.lref;
+			if (!(g & MIPT_LEAF_BIT) && g < n && mark[g] == 0u) { mark[g] = 1u; any = true; }
+		}
+	}
+	if (any) *changed = 1;
+}
+__global__ void k_quad_mark_flags(uint32_t* __restrict__ mark, size_t n) {      // marks -> 0 / 1 for the scan that numbers the quad nodes
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) mark[i] = mark[i] ? 1u : 0u;
+}
+// The quad node of every marked fat node, at position index[i] of a dense array (the order of the fat nodes, i.e. the reference's depth-first
+// order, is kept: two quad nodes share a 128-byte line), and the float box of every leaf at leaf_box[8 * first triangle] as (min, max) pairs
+// per axis.  is_quad[i] / index[i]: the mark of fat node i and the exclusive scan of the marks.
+__global__ void k_quad_nodes(const DFatNode* __restrict__ fat, const uint32_t* __restrict__ is_quad, const uint32_t* __restrict__ index, DQuadNode* __restrict__ quad, float* __restrict__ leaf_box, size_t n) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !is_quad[i]) return;
+	const DFatNode f = fat[i];
+	float box[4][3][2];
+	uint32_t ref[4];
+	int ns = 0;
+	auto put = [&](const float (*b)[2], uint32_t r) {
+		for (int a = 0; a < 3; a++) { box[ns][a][0] = b[a][0]; box[ns][a][1] = b[a][1]; }
+		ref[ns] = (r & MIPT_LEAF_BIT) ? r : index[r]; ns++;
+		if (r & MIPT_LEAF_BIT) { float* lb = leaf_box + 8 * (size_t)(r & MIPT_LEAF_FIRST_MASK); for (int a = 0; a < 3; a++) { lb[2 * a] = b[a][0]; lb[2 * a + 1] = b[a][1]; } lb[6] = lb[7] = 0.f; }
+	};
+	for (int side = 0; side < 2; side++) {
+		const uint32_t cref = side ? f.rref : f.lref;
+		if ((cref & MIPT_LEAF_BIT) || cref >= n) put(side ? f.r : f.l, cref);              // (cref >= n cannot happen in a checked tree)
 		else { const DFatNode c = fat[cref]; put(c.l, c.lref); put(c.r, c.rref); }
 	}
-	for (; ns < 4; ns++) { for (int a = 0; a < 3; a++) { w.box[ns][a][0] = inf; w.box[ns][a][1] = -inf; } w.ref[ns] = MIPT_LEAF_BIT; }
-	for (int k = 0; k < 4; k++) w._pad[k] = 0;
-	wide[i] = w;
+	DQuadNode w;
+	w.exps = 0; w._pad[0] = w._pad[1] = 0;
+	for (int a = 0; a < 3; a++) {
+		float lo = box[0][a][0], hi = box[0][a][1];
+		for (int k = 1; k < ns; k++) { lo = fminf(lo, box[k][a][0]); hi = fmaxf(hi, box[k][a][1]); }
+		// the smallest power-of-two step whose 255th multiple reaches the upper end (boxes are finite: checked when the tree was made)
+		int e = 1;                                                        // biased exponent byte: step = 2^(e - 127); at least 2^-126
+		while (e < 254 && !(quad_plane(255.f, __uint_as_float((uint32_t)e << 23), lo) >= hi)) e++;
+		const float step = __uint_as_float((uint32_t)e << 23);
+		w.origin[a] = lo; w.exps |= (uint32_t)e << (8 * a);
+		uint32_t lows = 0, highs = 0;
+		for (int k = 0; k < 4; k++) {
+			int ql = 255, qh = 0;                                             // an unused slot: lower plane above the upper one, never passes
+			if (k < ns) {
+				ql = (int)floorf((box[k][a][0] - lo) / step); ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+				while (ql > 0 && quad_plane((float)ql, step, lo) > box[k][a][0]) ql--;          // (q = 0 decodes to lo itself, <= every slot's minimum)
+				qh = (int)ceilf((box[k][a][1] - lo) / step); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+				while (qh < 255 && quad_plane((float)qh, step, lo) < box[k][a][1]) qh++;        // (q = 255 decodes to >= hi by the choice of e)
+			}
+			lows |= (uint32_t)ql << (8 * k); highs |= (uint32_t)qh << (8 * k);
+		}
+		w.lohi[a][0] = lows; w.lohi[a][1] = highs;
+	}
+	for (int k = 0; k < 4; k++) w.ref[k] = k < ns ? ref[k] : MIPT_LEAF_BIT;
+	quad[index[i]] = w;
+}
+// leaf_box before k_quad_nodes: every entry the whole space (a mesh whose ROOT is a leaf has no node that would write its box; its root
+// box is tested by the object loop, and the entry of a triangle that does not start a leaf is never read)
+__global__ void k_leaf_box_init(float* __restrict__ leaf_box, size_t ntri) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= 8 * ntri) return;
+	const float inf = __int_as_float(0x7f800000);
+	leaf_box[i] = (i & 7) >= 6 ? 0.f : ((i & 1) ? inf : -inf);
 }
 
-#ifndef MIPT_ANY_LDS_STACK
-#define MIPT_ANY_LDS_STACK 14          // 4-byte entries in LDS per lane: 14 KB per block of 256 + 4 KB of ray slots + 1 KB of leaf maps, 8 blocks per CU = 152 of 160 KB
-#endif
 #ifndef MIPT_ANYHIT_WAVES
-#define MIPT_ANYHIT_WAVES 8
+#define MIPT_ANYHIT_WAVES 7            // 72 registers, no scratch.  8 waves (64 registers: 16 spilled values around the leaf phase and the object loop) is 8 % slower on configs[2]
+#endif                                 // (336 against 311 ms per step); the exact-box form of the kernel fitted 64 registers without scratch and gained nothing from the 8th wave either (371 / 366)
+#ifndef MIPT_ANY_LDS_STACK
+#define MIPT_ANY_LDS_STACK 16          // 4-byte entries in LDS per lane: 16 KB per block of 256 + 4 KB of ray slots + 1 KB of leaf maps, 7 blocks per CU = 147 of 160 KB
 #endif
 // (the spill columns are the ones of the ordered kernels, read as 4-byte entries: twice as many)
 #define MIPT_ANY_SPILL_STACK (2 * MIPT_SPILL_STACK)
@@ -91,9 +166,10 @@ struct AnyQueue {
 	bool skip_ghosts;
 	unsigned* replay_list;       // ids the ordered kernel decides afterwards
 	unsigned* replay_n;
+	unsigned long long* replay_total;   // running total of a render (diagnostics: mipt_debug_anyhit_replayed)
 };
 
-// flag bits of inner_min_flags beyond those of traverse_queue: bit 24 = every ray counts as "passed a box near its far end"
+// flag bits of inner_min_flags beyond those of traverse_queue: bit 24 = every leaf counts as "reached near the ray's far end"
 // (test hook: every occluded ray goes through the replay list)
 // What the leaf tests need of a ray and the node steps do not — its direction in the mesh's frame and the occlusion bound — waits in
 // LDS (16 bytes per lane, `rayslot` = the wave's 64 slots) instead of in four registers: a test lane reads its OWNER's slot with one
@@ -104,7 +180,7 @@ __device__ __forceinline__ unsigned lane_id_now() { unsigned l; asm volatile("v_
 typedef float lds_f4_ __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) lds_f4_ lds_float4v;
 template <bool DERIVE>
-__device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, const float4* __restrict__ wide, const DTriIsect* __restrict__ tris, const DWave& wf,
+__device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, const float4* __restrict__ quad, const float4* __restrict__ leaf_box, const DTriIsect* __restrict__ tris, const DWave& wf,
                                              const AnyQueue tq, int refill_threshold, int inner_min_flags, LdsStack4& stk, unsigned char* leafmap, lds_float4v* rayslot) {
 	const int inner_min = inner_min_flags & 0xffff;
 	const bool force_replay = (inner_min_flags >> 16) & 1;      // test hook `literal_slab`: every ray is decided by the ordered kernel's literal chain
@@ -125,13 +201,12 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 	uint32_t cur = MIPT_ST_IDLE;
 	int sp = 0, obj = 0;
 	unsigned id = 0;
-	bool near_end = false;
 	unsigned chunk_next = 0, chunk_end = 0;
 	bool drained = false;
 	const int nobj = sc->nobj, first_mesh = sc->first_mesh;
 	const bool any_alpha = sc->any_alpha != 0;
 	const float inf = __int_as_float(0x7f800000);
-	auto to_replay = [&]() { const unsigned k = atomicAdd(tq.replay_n, 1u); tq.replay_list[k] = id; };
+	auto to_replay = [&]() { const unsigned k = atomicAdd(tq.replay_n, 1u); tq.replay_list[k] = id; atomicAdd(tq.replay_total, 1ull); };
 
 	for (;;) {
 		// ---- refill idle lanes from the queue (as traverse_queue)
@@ -149,7 +224,7 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 			const unsigned take = min((unsigned)nidle, chunk_end - chunk_next);
 			const unsigned prefix = below_count(idle);
 			if (cur == MIPT_ST_IDLE && lane < lane_limit && prefix < take) {
-				id = list[chunk_next + prefix]; obj = first_mesh; cur = MIPT_ST_NEED; near_end = flag_all;
+				id = list[chunk_next + prefix]; obj = first_mesh; cur = MIPT_ST_NEED;
 			}
 			chunk_next += take;
 		}
@@ -180,7 +255,7 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 					if (force_replay || fabsf(invd.x) == inf || fabsf(invd.y) == inf || fabsf(invd.z) == inf) { to_replay(); cur = MIPT_ST_IDLE; continue; }
 					o_xy = (mipt_f2){org.x, org.y}; i_xy = (mipt_f2){invd.x, invd.y}; oz_iz = (mipt_f2){org.z, invd.z};
 					rayslot[lane_id_now()] = (lds_f4_){d.x, d.y, d.z, occ_below};
-					cur = o.root_ref; sp = 0; obj = i;
+					cur = o.quad_root; sp = 0; obj = i;
 				}
 			}
 			if (cur == MIPT_ST_NEED) {                                        // no object left: the light sample is visible
@@ -200,23 +275,25 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 		// ---- wide-node phase: every live lane descends until it holds a leaf or runs out of nodes
 		{
 			const bool sx = i_xy.x >= 0, sy = i_xy.y >= 0, sz = oz_iz.y >= 0;
-			const float near_thr = 0.998f * dist;
 			for (;;) {
 				const bool inner = cur < MIPT_ST_NEED;
 				const unsigned long long mi = __ballot(inner);
 				if (mi == 0) break;
 				if (__popcll(mi) < inner_min && __ballot(cur >= MIPT_NONE) != 0) break;
 				if (!inner) continue;
-				const float4* q = wide + 8 * (size_t)cur;
-				const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+				const float4* q = quad + 4 * (size_t)cur;
+				const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+				const uint32_t ex = __float_as_uint(q0.w);
+				const float stx = __uint_as_float((ex & 255u) << 23), sty = __uint_as_float(((ex >> 8) & 255u) << 23), stz = __uint_as_float(((ex >> 16) & 255u) << 23);
+				const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
 				float t0, t1, t2, t3;
-				bool p0 = box_test_pairs<false>((mipt_f2){q0.x, q0.y}, (mipt_f2){q0.z, q0.w}, (mipt_f2){q1.x, q1.y}, o_xy, i_xy, oz_iz, sx, sy, sz, t0);
-				bool p1 = box_test_pairs<false>((mipt_f2){q1.z, q1.w}, (mipt_f2){q2.x, q2.y}, (mipt_f2){q2.z, q2.w}, o_xy, i_xy, oz_iz, sx, sy, sz, t1);
-				bool p2 = box_test_pairs<false>((mipt_f2){q3.x, q3.y}, (mipt_f2){q3.z, q3.w}, (mipt_f2){q4.x, q4.y}, o_xy, i_xy, oz_iz, sx, sy, sz, t2);
-				bool p3 = box_test_pairs<false>((mipt_f2){q4.z, q4.w}, (mipt_f2){q5.x, q5.y}, (mipt_f2){q5.z, q5.w}, o_xy, i_xy, oz_iz, sx, sy, sz, t3);
-				p0 = p0 && (t0 < dist); p1 = p1 && (t1 < dist); p2 = p2 && (t2 < dist); p3 = p3 && (t3 < dist);      // TriangleMesh.cpp:1278-1279 without `< t`
-				near_end = near_end || (p0 && t0 >= near_thr) || (p1 && t1 >= near_thr) || (p2 && t2 >= near_thr) || (p3 && t3 >= near_thr);
-				const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
+#define MIPT_QUAD_SLOT(K, T) box_test_pairs<false>((mipt_f2){quad_plane(quad_byte<K>(lx), stx, q0.x), quad_plane(quad_byte<K>(hx), stx, q0.x)}, \
+                                                  (mipt_f2){quad_plane(quad_byte<K>(ly), sty, q0.y), quad_plane(quad_byte<K>(hy), sty, q0.y)}, \
+                                                  (mipt_f2){quad_plane(quad_byte<K>(lz), stz, q0.z), quad_plane(quad_byte<K>(hz), stz, q0.z)}, o_xy, i_xy, oz_iz, sx, sy, sz, T)
+				bool p0 = MIPT_QUAD_SLOT(0, t0), p1 = MIPT_QUAD_SLOT(1, t1), p2 = MIPT_QUAD_SLOT(2, t2), p3 = MIPT_QUAD_SLOT(3, t3);
+#undef MIPT_QUAD_SLOT
+				p0 = p0 && (t0 < dist); p1 = p1 && (t1 < dist); p2 = p2 && (t2 < dist); p3 = p3 && (t3 < dist);      // TriangleMesh.cpp:1278-1279 without `< t`, on boxes that contain the reference's
+				const uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y), r2 = __float_as_uint(q3.z), r3 = __float_as_uint(q3.w);
 				// the first passing slot is taken, the others wait on the stack (lower slots on top)
 				if (p3 && (p0 || p1 || p2)) { stk.push(sp, r3); sp++; }
 				if (p2 && (p0 || p1)) { stk.push(sp, r2); sp++; }
@@ -288,11 +365,17 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 			}
 			if (leaf) {
 				if (occluded) {
-					// (an occluded ray adds nothing to its path's colour)
-					if (near_end) to_replay();
-					else if (tq.vis) tq.vis[id] = 0.f;
-					cur = MIPT_ST_IDLE; sp = 0;
-				} else if (sp > 0) { --sp; cur = stk.pop(sp); }
+					// the leaf's own float box, tested as the reference tests it on its way down (TriangleMesh.cpp:1278-1279)
+					const float4* lb = leaf_box + 2 * (size_t)first;
+					const float4 b0 = lb[0], b1 = lb[1];
+					float tb;
+					const bool reached = box_test_pairs<false>((mipt_f2){b0.x, b0.y}, (mipt_f2){b0.z, b0.w}, (mipt_f2){b1.x, b1.y}, o_xy, i_xy, oz_iz, i_xy.x >= 0, i_xy.y >= 0, oz_iz.y >= 0, tb) && tb < dist;
+					if (!reached) occluded = false;                                   // the reference never looks into this leaf
+					else if (flag_all || tb >= 0.998f * dist) to_replay();             // a box on the way may have been skipped for the running t: the ordered kernel decides
+					else if (tq.vis) tq.vis[id] = 0.f;                                 // (an occluded ray adds nothing to its path's colour)
+				}
+				if (occluded) { cur = MIPT_ST_IDLE; sp = 0; }
+				else if (sp > 0) { --sp; cur = stk.pop(sp); }
 				else cur = MIPT_NONE;
 			}
 		}
@@ -302,8 +385,8 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 }
 
 // The shadow queue of depth b of the wavefront pipeline (the rays shade(b) asked for).
-__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_ANYHIT_WAVES))) k_wf_anyhit(const DScene* __restrict__ sc, const float4* __restrict__ wide, const DTriIsect* __restrict__ tris, DWave wf, int b,
-                                                                                                                   unsigned* replay_list, int refill_threshold, int inner_min_flags) {
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_ANYHIT_WAVES))) k_wf_anyhit(const DScene* __restrict__ sc, const float4* __restrict__ quad, const float4* __restrict__ leaf_box, const DTriIsect* __restrict__ tris, DWave wf, int b,
+                                                                                                                   unsigned* replay_list, unsigned long long* replay_total, int refill_threshold, int inner_min_flags) {
 	__shared__ unsigned lds_stack4_[MIPT_ANY_LDS_STACK * MIPT_TRAV_BLOCK];
 	__shared__ unsigned char lds_leafmap4_[4 * MIPT_TRAV_BLOCK];
 	__shared__ float4 lds_rayslot4_[MIPT_TRAV_BLOCK];
@@ -314,6 +397,20 @@ __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_p
 	unsigned char* leafmap = lds_leafmap4_ + wave_in_block * 256;
 	AnyQueue q;
 	q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(b)]; q.head = &wf.counters[MIPT_CNT_SH_HEAD(b)]; q.vis = nullptr; q.skip_ghosts = false;
-	q.replay_list = replay_list; q.replay_n = &wf.counters[MIPT_CNT_REPLAY(b)];
-	anyhit_queue<MIPT_DERIVE_SHADOW != 0>(sc, wide, tris, wf, q, refill_threshold, inner_min_flags, stk, leafmap, (lds_float4v*)lds_rayslot4_ + wave_in_block * 64u);
+	q.replay_list = replay_list; q.replay_n = &wf.counters[MIPT_CNT_REPLAY(b)]; q.replay_total = replay_total;
+	anyhit_queue<MIPT_DERIVE_SHADOW != 0>(sc, quad, leaf_box, tris, wf, q, refill_threshold, inner_min_flags, stk, leafmap, (lds_float4v*)lds_rayslot4_ + wave_in_block * 64u);
+}
+
+// The same stage on an explicitly described queue (the contribution-queue pipeline, mipt_queue_wave.h).
+__global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_ANYHIT_WAVES))) k_q_anyhit(const DScene* __restrict__ sc, const float4* __restrict__ quad, const float4* __restrict__ leaf_box, const DTriIsect* __restrict__ tris, DWave wf,
+                                                                                                                  AnyQueue q, int refill_threshold, int inner_min_flags) {
+	__shared__ unsigned lds_stack4_[MIPT_ANY_LDS_STACK * MIPT_TRAV_BLOCK];
+	__shared__ unsigned char lds_leafmap4_[4 * MIPT_TRAV_BLOCK];
+	__shared__ float4 lds_rayslot4_[MIPT_TRAV_BLOCK];
+	LdsStack4 stk;
+	const unsigned wave_in_block = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	stk.wave_base = (lds_uint1*)lds_stack4_ + wave_in_block * 64u;
+	stk.spill_wave = (glb_uint1*)wf.spill + (size_t)blockIdx.x * MIPT_TRAV_BLOCK + wave_in_block * 64u; stk.spill_stride = gridDim.x * MIPT_TRAV_BLOCK;
+	unsigned char* leafmap = lds_leafmap4_ + wave_in_block * 256;
+	anyhit_queue<MIPT_DERIVE_SHADOW != 0>(sc, quad, leaf_box, tris, wf, q, refill_threshold, inner_min_flags, stk, leafmap, (lds_float4v*)lds_rayslot4_ + wave_in_block * 64u);
 }

@@ -84,6 +84,7 @@ struct alignas(64) DObject {   // (64-byte aligned and sized: the first 64 bytes
 	uint32_t node_base, tri_base;
 	float root_min[3], root_max[3];
 	uint32_t root_ref;         // reference of node 0 (inner 0, or a leaf ref when the root is a leaf)
+	uint32_t quad_root;        // the same for the any-hit stage: the root's quad node (mipt_anyhit.h), or the leaf ref
 	int ntri;
 	int ghost;                 // Object::ghost (Geometry.h:721): only the queue kernel (mipt_compositing.h) renders such scenes
 	const float* uvs;          // Vector[nuvs]
