@@ -414,7 +414,11 @@ struct mipt_ctx {
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
-	int64_t opt_samples_per_pass = 0;       // > 0: a pass renders at most this many samples per pixel (progressive display: 1)
+	int64_t opt_samples_per_pass = 0;       // > 0: the running sums are published after every this many samples per pixel (progressive display: 1)
+	int64_t opt_progressive_lookahead = 4;  // progressive display through mipt_render: publish groups rendered per pass (their stages run together; every group is still splatted, published and reported on its own)
+	hipStream_t copy_stream = nullptr;      // downloads of published running sums, beside the compute stream
+	void* snap_buf = nullptr; size_t snap_buf_bytes = 0;   // snapshots of the accumulators, one per publish group of a pass (they are downloaded while the next pass is rendered)
+	hipEvent_t ev_pub = nullptr;
 	int64_t opt_resolve_rows = 12;          // splat: destination rows per band of the column-scan kernel (0 = the per-pixel gather kernel)
 	int64_t opt_pass_memory_limit = 0;      // test hook: > 0 = size the pass as if only this many bytes were free on the device
 	int64_t opt_paths_per_pass = 1 << 30;   // 1 074 M paths (517 spp at 1080p), ~172 GB of path state: sized for 288 GB of HBM (round 4: 2^29 until then; configs[2] +1.1 %, configs[1] +1.3 % — half the stage launches, each with its ramp and drain; 2^28: -3.2 %).  Whatever the value, a pass takes at most 80 % of the memory that is free
@@ -584,6 +588,9 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	if (c->queue_buf) hipFree(c->queue_buf);
 	if (c->overflow_buf) hipFree(c->overflow_buf);
 	if (c->resolve_buf) hipFree(c->resolve_buf);
+	if (c->snap_buf) hipFree(c->snap_buf);
+	if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+	if (c->ev_pub) hipEventDestroy(c->ev_pub);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
 	if (c->tab_buf) hipFree(c->tab_buf);
@@ -615,6 +622,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
 	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
+	if (!strcmp(name, "progressive_lookahead")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "progressive_lookahead must be in [1,64]"); c->opt_progressive_lookahead = value; return MIPT_OK; }
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
@@ -1143,7 +1151,9 @@ static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender&
 // Parity hook plumbing: instead of splatting, hand the per-sample results of ONE pass back to the host.
 struct SampleDump { const int32_t* ij; int npix; float* out_rgb; float* out_dxdy; float* out_normal; float* out_albedo; };
 static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<int>& blocks, std::vector<int>& pix2slot);
-static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov = nullptr);
+// the caller's HOST accumulators of mipt_render: with them render_impl publishes the running sums itself, pipelined with the next samples
+struct HostPublish { float* rgb; float* w; size_t npx; bool failed; };
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov = nullptr, HostPublish* hp = nullptr);
 
 extern "C" int mipt_sample_radiance(mipt_ctx* c, const mipt_render_params* p, const int32_t* pixels_ij, int npix, int k0, int k1, float* out_rgb, float* out_dxdy) {
 	if (!c || !pixels_ij || !out_rgb || npix < 0 || k1 < k0) return fail(c, MIPT_ERR_INVALID, "bad arguments");
@@ -1209,7 +1219,7 @@ static int build_blocks(mipt_ctx* c, const mipt_render_params* p, std::vector<in
 	return MIPT_OK;
 }
 
-static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov) {
+static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum, hipStream_t st, mipt_progress_cb cb, void* cb_user, volatile int* cancel, SampleDump* dump, float* d_aov, HostPublish* hp) {
 	if (!c->has_scene) return fail(c, MIPT_ERR_NO_SCENE, "no scene uploaded");
 	DRender R; float denom2;
 	int rc = make_render_consts(c, p, R, denom2, st);
@@ -1257,7 +1267,12 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	int spp_pass = (int)std::max<int64_t>(1, c->opt_paths_per_pass / npix_slots);
 	const bool queue_wave = c->scene_has_ghost && c->opt_queue_wavefront && !c->scene_inherit;
 	if (c->scene_has_ghost && !queue_wave) spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(spp_pass, ((int64_t)1 << 21) / npix_slots));   // 9.6 KB of queue per path in flight
-	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass);
+	// Progressive display (Raytracer::render_image, Raytracer.cpp:1444-1531: the buffers are valid after every sample).  Through mipt_render
+	// the publishes are pipelined (below), and a pass may then hold several publish groups: a one-sample pass at 1080p is 2 M paths — 4.5 per
+	// lane of the chip, thirteen launches that are all ramp and drain.
+	const bool pipelined_publish = hp && cb && !dump && !d_aov;
+	const int publish_group = c->opt_samples_per_pass > 0 ? (int)c->opt_samples_per_pass : 0;     // 0: once per pass
+	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass * (pipelined_publish ? c->opt_progressive_lookahead : 1));
 	spp_pass = std::min(spp_pass, ke - kb);
 	const bool want_aov = d_aov || (dump && dump->out_normal);
 	// 2 = the queue kernel (ghost objects, background photo); the denoiser inputs are a stage of the wavefront pipeline
@@ -1380,8 +1395,48 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	}
 	HIPCHK(c, hipEventRecord(c->ev0, st));
 	unsigned passes = 0;
+	// state of the pipelined publishes: the snapshots of the last pass's publish groups that still wait for their download (snapshot k of the
+	// pass in slot k), and the slot the caller saw last
+	const size_t acc_bytes = (size_t)R.W * R.H * 4 * sizeof(float);
+	struct PendingPublish { int slot, done; };
+	std::vector<PendingPublish> pub_pending;
+	int pub_last = -1;
+	const int pub_slots = pipelined_publish ? (publish_group > 0 ? (spp_pass + publish_group - 1) / publish_group : 1) : 0;
+	if (pipelined_publish) {
+		if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+		if (!c->ev_pub) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pub, hipEventDisableTiming));
+		if ((rc = ensure(c, &c->snap_buf, &c->snap_buf_bytes, (size_t)pub_slots * acc_bytes))) return rc;
+	}
+	// a cancelled render leaves the accumulators as the caller saw them last: what was splatted after that publish is taken back
+	auto cancel_pipelined = [&]() -> int {
+		hipStreamSynchronize(st);
+		if (pub_last >= 0) hipMemcpy(d_accum, (char*)c->snap_buf + (size_t)pub_last * acc_bytes, acc_bytes, hipMemcpyDeviceToDevice);
+		return fail(c, MIPT_ERR_CANCELLED, "cancelled");
+	};
+	// downloads the waiting snapshots in order, one progress call each (the compute stream keeps working on what was enqueued behind them)
+	auto flush_publishes = [&]() -> int {
+		const size_t n3 = hp->npx * 3 * sizeof(float);
+		for (size_t k = 0; k < pub_pending.size(); k++) {
+			const char* snap = (const char*)c->snap_buf + (size_t)pub_pending[k].slot * acc_bytes;
+			hipError_t e = k == 0 ? hipStreamWaitEvent(c->copy_stream, c->ev_pub, 0) : hipSuccess;      // (the event follows the pass's last snapshot)
+			if (e == hipSuccess) e = hipMemcpyAsync(hp->rgb, snap, n3, hipMemcpyDeviceToHost, c->copy_stream);
+			if (e == hipSuccess) e = hipMemcpyAsync(hp->w, snap + n3, hp->npx * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+			if (e != hipSuccess) { hp->failed = true; return fail(c, MIPT_ERR_HIP, "download of the running sums failed: %s", hipGetErrorString(e)); }
+			pub_last = pub_pending[k].slot;
+			cb(cb_user, pub_pending[k].done, ke - kb);
+			if (cancel && *cancel && pub_pending[k].done < ke - kb) { pub_pending.clear(); return cancel_pipelined(); }
+		}
+		pub_pending.clear();
+		return MIPT_OK;
+	};
 	for (int k0 = kb; k0 < ke; k0 += spp_pass) {
-		if (cancel && *cancel) { hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled"); }
+		if (cancel && *cancel) {
+			// (groups that are splatted and snapshot but not yet published: the caller gets the first of them, then the render ends)
+			if (pipelined_publish && !pub_pending.empty()) { rc = flush_publishes(); return rc ? rc : cancel_pipelined(); }
+			if (pipelined_publish) return cancel_pipelined();
+			hipStreamSynchronize(st); return fail(c, MIPT_ERR_CANCELLED, "cancelled");
+		}
 		P.k0 = k0; P.k1 = std::min(ke, k0 + spp_pass);
 		long long total = (long long)npix_slots * (P.k1 - P.k0);
 		const unsigned grid_all = (unsigned)((total + MIPT_BLOCK - 1) / MIPT_BLOCK);
@@ -1577,24 +1632,47 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			}
 			c->stats.traverse_merged = merge ? 1u : 0u;
 		}
-		if (!dump && d_aov) hipLaunchKernelGGL(k_resolve_aov, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, aov_n, aov_kd, d_accum, d_aov);
-		else if (!dump) {
+		// the splat of samples [a, b) of this pass into the accumulators
+		auto resolve_range = [&](int a, int b) -> int {
+			DPass Pr = P; Pr.k0 = P.k0 + a; Pr.k1 = P.k0 + b;
+			DSamples Sr = S; Sr.col = S.col + (size_t)a * npix_slots; Sr.dxdy = S.dxdy + (size_t)a * npix_slots;
 			if (timed_begin(3)) return fail(c, MIPT_ERR_HIP, "event record failed");
 			const int rows = (int)c->opt_resolve_rows;
 			// a rank of a partition: the pass's samples in slices along the sample index (see k_resolve_scan)
 			const int share = (int)std::min<uint64_t>(64, (uint64_t)R.W * (uint64_t)R.H / std::max<uint64_t>(1, c->blk_valid_pixels));     // 1 / (owned fraction of the frame)
-			const int zs = ((share > 1 || c->opt_resolve_slices > 1) && rows > 0 && (R.filter_size == 1 || R.filter_size == 2)) ? std::max(1, std::min((int)c->opt_resolve_slices > 0 ? (int)c->opt_resolve_slices : std::min(share, 8), P.k1 - P.k0)) : 1;
+			const int zs = ((share > 1 || c->opt_resolve_slices > 1) && rows > 0 && (R.filter_size == 1 || R.filter_size == 2)) ? std::max(1, std::min((int)c->opt_resolve_slices > 0 ? (int)c->opt_resolve_slices : std::min(share, 8), b - a)) : 1;
 			float* partial = nullptr;
 			if (zs > 1) {
-				if ((rc = ensure(c, &c->resolve_buf, &c->resolve_buf_bytes, (size_t)zs * 4 * (size_t)R.W * R.H * sizeof(float)))) return rc;
+				int rc2 = ensure(c, &c->resolve_buf, &c->resolve_buf_bytes, (size_t)zs * 4 * (size_t)R.W * R.H * sizeof(float));
+				if (rc2) return rc2;
 				partial = (float*)c->resolve_buf;
 			}
 			const dim3 sgrid((unsigned)((R.W + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)), (unsigned)zs);
-			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum, zs, partial);
-			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, P, S, denom2, rows, d_accum, zs, partial);
-			else hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, P, S, denom2, d_accum);
+			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, Pr, Sr, denom2, rows, d_accum, zs, partial);
+			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, Pr, Sr, denom2, rows, d_accum, zs, partial);
+			else hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, Pr, Sr, denom2, d_accum);
 			if (zs > 1) { const size_t n4 = 4 * (size_t)R.W * R.H; hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d_accum, (const float*)partial, zs, n4); }
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
+			return MIPT_OK;
+		};
+		const int nk_pass = P.k1 - P.k0;
+		if (!dump && d_aov) hipLaunchKernelGGL(k_resolve_aov, dim3((unsigned)(((long long)R.W * R.H + 255) / 256)), dim3(256), 0, st, R, P, S, aov_n, aov_kd, d_accum, d_aov);
+		else if (!dump && !pipelined_publish) { if ((rc = resolve_range(0, nk_pass))) return rc; }
+		else if (!dump) {
+			// Pipelined publishes.  The stages of this pass are enqueued; while they run, the publish groups of the PREVIOUS pass travel to
+			// the caller's buffers (download of a device snapshot on the copy stream + progress call, one by one).  Then every group of this
+			// pass is splatted and the accumulators are snapshot after each (33 MB at 1080p: ~10 us on the device): the caller sees exactly
+			// the sums through the group it is told about, whatever was rendered ahead of it.
+			if (!pub_pending.empty() && (rc = flush_publishes())) return rc;
+			const int grp = publish_group > 0 ? publish_group : nk_pass;
+			int slot = 0;
+			for (int a = 0; a < nk_pass; a += grp, slot++) {
+				const int b = std::min(nk_pass, a + grp);
+				if ((rc = resolve_range(a, b))) return rc;
+				HIPCHK(c, hipMemcpyAsync((char*)c->snap_buf + (size_t)slot * acc_bytes, d_accum, acc_bytes, hipMemcpyDeviceToDevice, st));
+				pub_pending.push_back({slot, P.k0 + b - kb});
+			}
+			HIPCHK(c, hipEventRecord(c->ev_pub, st));
 		}
 		HIPCHK(c, hipGetLastError());
 		if (dump) {
@@ -1626,8 +1704,9 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			}
 		}
 		passes++;
-		if (cb) { hipStreamSynchronize(st); cb(cb_user, P.k1 - kb, ke - kb); }
+		if (cb && !pipelined_publish) { hipStreamSynchronize(st); cb(cb_user, P.k1 - kb, ke - kb); }
 	}
+	if (pipelined_publish && !pub_pending.empty() && (rc = flush_publishes())) return rc;
 	HIPCHK(c, hipEventRecord(c->ev1, st));
 	c->stats.passes = passes;
 	c->host_paths = c->blk_valid_pixels * (uint64_t)(ke - kb);
@@ -1803,8 +1882,11 @@ extern "C" int mipt_render(mipt_ctx* c, const mipt_render_params* p, float* accu
 	const bool pin_rgb = cb && hipHostRegister(accum_rgb, npx * 3 * sizeof(float), hipHostRegisterDefault) == hipSuccess;
 	const bool pin_w = cb && hipHostRegister(accum_w, npx * sizeof(float), hipHostRegisterDefault) == hipSuccess;
 	if (cb) (void)hipGetLastError();
+	// one device: render_impl publishes by itself, pipelined with the samples that follow (HostPublish); a group: the blocking download per pass
+	HostPublish hp{accum_rgb, accum_w, npx, false};
 	int rc = c->group ? group_render(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel)
-	                  : render_impl(c, p, d_acc, 0, cb ? (mipt_progress_cb)trampoline : nullptr, &pub, cancel, nullptr);
+	                  : render_impl(c, p, d_acc, 0, cb, cb_user, cancel, nullptr, nullptr, cb ? &hp : nullptr);
+	if (hp.failed) pub.failed = true;
 	hipError_t es = hipDeviceSynchronize();
 	if (rc == MIPT_OK && es != hipSuccess) rc = fail(c, MIPT_ERR_HIP, "render failed: %s", hipGetErrorString(es));
 	if (rc == MIPT_OK || rc == MIPT_ERR_CANCELLED) {

@@ -7,6 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes   # noqa: E402
 
+opts = [a.split("=") for a in sys.argv[1:] if "=" in a]        # e.g. progressive_lookahead=8
 wall = {}
 for spp in (16, 64):
     mesh, cfg, mat, text = scenes.workload("c1", 1920, 1080, spp, None)
@@ -14,10 +15,12 @@ for spp in (16, 64):
     H.apply_config(cfg)
     scenes.install(H, mesh, mat)
     H.prepare()
+    for k, v in opts:
+        H.set_option(k, int(v))
     H.render_image()            # warm-up
     t0 = time.time(); H.render_image(); wall[spp] = time.time() - t0
     st = H.stats()
     rays = st["rays_closest"] + st["rays_shadow"]
     print("render_image %d spp: %.1f ms wall, GPU span %.1f ms, %.1f M rays" % (spp, wall[spp] * 1e3, st["render_ms"], rays / 1e6))
 per_pass = (wall[64] - wall[16]) / 48
-print("per one-sample pass: %.2f ms (%.0f Mrays/s); fixed per call: %.0f ms" % (per_pass * 1e3, rays / 64 / per_pass / 1e6, (wall[16] - 16 * per_pass) * 1e3))
+print(dict(opts), "per sample of Raytracer::render_image: %.2f ms (%.0f Mrays/s); fixed per call: %.0f ms" % (per_pass * 1e3, rays / 64 / per_pass / 1e6, (wall[16] - 16 * per_pass) * 1e3))

@@ -1,6 +1,3 @@
-S=r5_e
-timeout 2400 python -m pytest tests/test_anyhit.py tests/test_gpu_parity.py tests/test_gpu_bvh_build.py tests/test_fog.py -m gpu -x -q > gpurun_out/${S}_gputests.txt 2>&1; grep -E "passed|failed|error" gpurun_out/${S}_gputests.txt | tail -3
-rm -f gpurun_out/sweep.log
-bash tools/sweep_libs.sh "-" "- --workload c1" "- --workload c3 --steps 1" "- --workload c4 --steps 1"
-cp gpurun_out/sweep.log gpurun_out/${S}_sweep.log
-python tools/init_time.py c2 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_progressive.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r5_f_tests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_f_tests.txt | tail -5
+for l in 1 2 4 8 16; do python tools/progressive_rate.py progressive_lookahead=$l 2>&1 | tail -1; done
+bash tools/progressive_trace.sh after > /dev/null 2>&1; head -45 gpurun_out/ptrace_after.txt; tail -1 gpurun_out/ptrace_after.txt
