@@ -41,7 +41,7 @@ HIP events on the render stream).  Every fraction names its denominator:
                         active lanes) / duration: the figure the kernel runs against
   frac_l1_lookups, latency_model, instruction_issue   TCP line lookups against one per CU and cycle; achieved rays/s against resident
                         waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency); instruction counts x issue cost
-Per-ray counter values come from the committed PMC run of the same workload (profiles/r4_pmc_counters.json; separate --pmc passes).
+Per-ray counter values come from the committed PMC run of the same workload (profiles/pmc_counters.json; separate --pmc passes).
 derived_from_pmc_run.same_library_build compares __graft_entry__.source_hash() (csrc/* + include/mipt.h + hipcc flags) with the hash
 that run recorded; when they differ everything derived from the counters is null and derived_from_pmc_run.stale is true.
 roofline_shade_kernel: algorithmic path-state bytes per vertex x vertices / stage time against the HBM peak, and its measured traffic.
@@ -146,6 +146,16 @@ def cpu_baseline(mesh, mat, cfg_full, rays_per_path):
                 sample=f"{cfg.W}x{cfg.H}x{cfg.spp}spp of the same scene/camera/depth, {secs:.1f}s wall; "
                        f"{mpaths:.3f} Mpaths/s x {rays_per_path:.2f} rays/path (oracle count)",
                 mpaths_per_s=mpaths)
+
+
+# The headline fraction, FROZEN (it had meant four different things in four rounds).  tests/test_bench_contract.py asserts the text.
+ROOFLINE_FRAC_DEFINITION = ("SURVEY 8(d): algorithmic bytes per launch (24 n_box + 8 n_node + 64 n_tri from the oracle's counters of the reference's ordered traversal, "
+                            "x the rays of one launch) / mean launch time (HIP events on the render stream) / HBM peak 8 TB/s (MI355X_MICROARCH.md)")
+# What the traversal kernels' time follows (fitted on seven builds of rounds 4 and 5, profiles/r5_traversal_time_model.txt):
+# a compute unit issues one vector-memory wave-instruction per ~11.5 ns, a SIMD one vector instruction per ~1.7 ns
+TA_NS_PER_VMEM_INSTRUCTION = 11.5
+SIMD_NS_PER_VALU_INSTRUCTION = 1.7
+PMC_COUNTERS = "pmc_counters.json"      # profiles/: per-ray counters of the traversal kernels of the build named inside (tools/pmc_to_json.py)
 
 
 def main():
@@ -374,7 +384,7 @@ def main():
             # ---- the roofline object (task contract / SURVEY 8d): achieved = ALGORITHMIC bytes per launch / launch time, peak = HBM 8 TB/s,
             # traffic = HBM bytes per launch from the PMC counters.  Everything else names its own denominator: fractions against ceilings
             # this run measured itself (mipt_measure_*) sit under "ceilings_measured_in_this_run", what is scaled from the committed PMC run
-            # of the same workload (profiles/r4_pmc_counters.json: per ray of that run x the rays of this one) is dropped to null and
+            # of the same workload (profiles/pmc_counters.json: per ray of that run x the rays of this one) is dropped to null and
             # flagged stale when this run's library is not the build that was profiled (hash of csrc/* + flags, __graft_entry__.source_hash).
             scene_bytes = int(mesh.ntri) * 64 + int(mesh.ntri) * 64          # ~ one fat node per triangle pair + one record per triangle
             try:
@@ -384,8 +394,7 @@ def main():
             peak_l1 = n_cus * 64 * clock_ghz                            # GB/s: one 64-byte line lookup per CU and cycle
             secs = ms_per_launch * 1e-3
             rf = {"bound": "hbm", "achieved": alg_hbm, "peak": 8000.0, "unit": "GB/s", "frac": alg_hbm / 8000.0, "traffic": None,
-                  "frac_definition": "SURVEY 8(d): algorithmic bytes per launch (24 n_box + 8 n_node + 64 n_tri from the oracle's counters of the reference's ordered traversal, "
-                                     "x the rays of one launch) / mean launch time (HIP events on the render stream) / HBM peak 8 TB/s (MI355X_MICROARCH.md)",
+                  "frac_definition": ROOFLINE_FRAC_DEFINITION,
                   "frac_note": "a value > 1 means cache-served: most node fetches hit L1 / L2 / the Infinity Cache and never cross HBM; the bytes that do are `traffic` "
                                "(frac_hbm_measured = traffic / launch time / 8 TB/s)",
                   "kernel": kernel, "ms_per_launch": ms_per_launch, "launches": int(launches), "rays_per_launch": rays_per_launch,
@@ -395,20 +404,20 @@ def main():
                   "l1_lookups_per_ray_algorithmic": ob["lines_closest"], "oracle_sample": ob["sample"],
                   "frac_hbm_measured": None}
             ceil = {}
-            pmc_file = os.path.join(ROOT, "profiles", "r4_pmc_counters.json")
+            pmc_file = os.path.join(ROOT, "profiles", PMC_COUNTERS)
             pk = None
             try:   # per-ray counter values of the dominant kernel from the committed PMC run of the same workload
                 pall = json.load(open(pmc_file))
                 pj = pall[args.workload]
                 pk = pj["kernels"]["k_wf_traverse<2>" if merged else ("k_wf_traverse<0>" if pipeline == 1 else "k_render_paths")]
                 same = pall.get("_build", {}).get("source_sha256_16") == ge.source_hash() and not os.environ.get("MIPT_LIB_OVERRIDE")
-                rf["derived_from_pmc_run"] = {"file": "profiles/r4_pmc_counters.json", "source": pj["source"], "git_commit": pall.get("_build", {}).get("git_commit"),
+                rf["derived_from_pmc_run"] = {"file": "profiles/pmc_counters.json", "source": pj["source"], "git_commit": pall.get("_build", {}).get("git_commit"),
                                               "same_library_build": same, "stale": not same,
                                               "keyed_on": "sha256 of pathtracer_amd/csrc/*, include/mipt.h and the hipcc flags (the binary is not bit-reproducible)"}
                 if not same:
                     pk = None
             except Exception as e:
-                rf["pmc_note"] = "profiles/r4_pmc_counters.json has no entry for this workload / kernel (%s: %s)" % (type(e).__name__, e)
+                rf["pmc_note"] = "profiles/pmc_counters.json has no entry for this workload / kernel (%s: %s)" % (type(e).__name__, e)
             lanes_per_instr = 32
             if pk:
                 rf["traffic"] = pk["hbm_bytes_per_ray"] * rays_per_launch
@@ -416,23 +425,15 @@ def main():
                 rf["hbm_traffic_over_algorithmic_bytes"] = rf["traffic"] / bytes_per_launch
                 rf["l2_misses_per_ray"] = pk["l2_misses_per_ray"]
                 rf["l1_lookups_per_ray_measured"] = pk["tcp_accesses_per_ray"]
-                rf["frac_l1_lookups"] = {"frac": pk["tcp_accesses_per_ray"] * rays_per_launch * 64 / secs / 1e9 / peak_l1,
-                                         "denominator": "one 64-byte L1 (TCP) line lookup per CU and cycle (%d CUs x %.2f GHz)" % (n_cus, clock_ghz)}
-                # latency model: rays in flight at FULL lane occupancy / (dependent steps per ray x mean vector-memory latency)
-                waves_per_cu = pk["waves"] / n_cus
-                steps_per_ray = ob["lines_closest"]                    # one dependent fetch per inner node visited and per triangle record tested
-                lat_s = pk["mean_vmem_latency_cycles"] / (clock_ghz * 1e9)
-                attainable = waves_per_cu * 64 * n_cus / (steps_per_ray * lat_s)
-                rf["latency_model"] = {"frac": (rays_per_launch / secs) / attainable, "denominator": "resident waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency)",
-                                       "resident_waves_per_cu": waves_per_cu, "dependent_fetches_per_ray": steps_per_ray, "mean_vmem_latency_cycles": pk["mean_vmem_latency_cycles"],
-                                       "attainable_grays_per_s_at_full_lane_occupancy": attainable / 1e9, "wait_share_of_wave_cycles": pk["wait_share_of_wave_cycles"]}
-                # instruction issue: a vector instruction holds its SIMD 2 (add / mul / fma / mov / logic) or 4 cycles (min / max / compare / select /
-                # packed / DPP), a scalar one 4 cycles of the SIMD's scalar slot (profiles/r3_b_instruction_issue_rates.txt)
-                simd_cycles = 4 * n_cus * clock_ghz * 1e9 * secs
-                rf["instruction_issue"] = {"valu_issue_busy_2_to_4_cycles": [2 * pk["valu_per_ray"] * rays_per_launch / simd_cycles, 4 * pk["valu_per_ray"] * rays_per_launch / simd_cycles],
-                                           "salu_issue_busy": 4 * pk["salu_per_ray"] * rays_per_launch / simd_cycles,
-                                           "denominator": "issue cycles of the 4 SIMDs x %d CUs (cost per instruction: profiles/r3_b_instruction_issue_rates.txt)" % n_cus,
-                                           "active_lanes_per_vector_instruction": pk.get("active_lanes_per_vector_instruction")}
+                # What the kernel's time follows: the 28 waves of a CU circulate between its texture-address unit (one
+                # vector-memory wave-instruction per ~11.5 ns, whatever its width and almost whatever its lanes), their SIMD's vector pipe (~1.7 ns
+                # per instruction) and a fixed latency per traversal step; the busy shares of the two servers:
+                rf["issue_model"] = {"vmem_issue_busy": pk["vmem_per_ray"] * rays_per_launch / n_cus * TA_NS_PER_VMEM_INSTRUCTION * 1e-9 / secs,
+                                     "valu_issue_busy": pk["valu_per_ray"] * rays_per_launch / (4 * n_cus) * SIMD_NS_PER_VALU_INSTRUCTION * 1e-9 / secs,
+                                     "salu_issue_busy": 4 * pk["salu_per_ray"] * rays_per_launch / (4 * n_cus * clock_ghz * 1e9 * secs),
+                                     "vmem_instructions_per_ray": pk["vmem_per_ray"], "valu_instructions_per_ray": pk["valu_per_ray"],
+                                     "denominator": "issue time of one CU's vector-memory path at %.1f ns per wave-instruction / of a SIMD's vector pipe at %.1f ns per instruction (constants fitted on seven kernel builds, profiles/r5_traversal_time_model.txt); scalar: 4 cycles per instruction" % (TA_NS_PER_VMEM_INSTRUCTION, SIMD_NS_PER_VALU_INSTRUCTION),
+                                     "active_lanes_per_vector_instruction": pk.get("active_lanes_per_vector_instruction"), "wait_share_of_wave_cycles": pk.get("wait_share_of_wave_cycles")}
                 if pk.get("active_lanes_per_vector_instruction"):
                     lanes_per_instr = int(max(1, min(64, round(pk["active_lanes_per_vector_instruction"]))))
                 if cap_g:
@@ -454,15 +455,16 @@ def main():
             out["roofline"] = rf
             if pipeline == 1 and sh_launches:
                 sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
-                rs = {"kernel": "k_wf_traverse<1> (any-hit / shadow stage)", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
+                rs = {"kernel": "k_wf_anyhit (any-hit / shadow stage: order-free four-wide traversal, csrc/mipt_anyhit.h) + its ordered replay", "frac_algorithmic_hbm": sh_alg / 8000.0, "ms_per_launch": sh_ms / sh_launches,
                       "launches": int(sh_launches), "rays_per_launch": rays_s / sh_launches, "l1_lookups_per_ray_algorithmic": ob["lines_shadow"]}
                 try:
                     if not pk: raise KeyError("no current PMC run")
-                    pks = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_traverse<1>"]
+                    pks = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_anyhit"]
                     secs_s = sh_ms / sh_launches * 1e-3
                     rs["frac_dependent_gather"] = (pks["l2_misses_per_ray"] * rays_s / sh_launches * 128.0 / secs_s / 1e9) / (cap_g * 128.0) if cap_g else None
                     rs["l2_misses_per_ray"] = pks["l2_misses_per_ray"]
-                    rs["frac_l1_lookups"] = pks["tcp_accesses_per_ray"] * rays_s / sh_launches * 64 / secs_s / 1e9 / peak_l1
+                    rs["vmem_issue_busy"] = pks["vmem_per_ray"] * rays_s / sh_launches / n_cus * TA_NS_PER_VMEM_INSTRUCTION * 1e-9 / secs_s
+                    rs["vmem_instructions_per_ray"] = pks["vmem_per_ray"]
                     rs["frac_hbm_measured"] = pks["hbm_bytes_per_ray"] * rays_s / sh_launches / secs_s / 8e12
                 except Exception:
                     pass

@@ -44,6 +44,18 @@ static_assert(sizeof(DQuadNode) == 64, "one 64-byte line per quad node");
 // the decoded plane: origin + q * step, ONE rounding (q * step is exact); the builder checks its bytes with this very function
 __host__ __device__ __forceinline__ float quad_plane(float q, float step, float origin) { return __builtin_fmaf(q, step, origin); }
 
+// The slab test of box_test_pairs<false> (mipt_trace.h; BBoxT::intersection_invd, Geometry.h:114-142) on planes that arrive as (near, far)
+// pairs per axis — near = the minimum when the ray's inverse direction is >= 0 on that axis, else the maximum — instead of (min, max) pairs
+// and three sign flags: the same subtractions and multiplications, without the six selects.
+MIPT_DEV bool box_test_sorted(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mipt_f2 i_xy, mipt_f2 oz_iz, float& t_out) {
+	const mipt_f2 rx = X - __builtin_shufflevector(o_xy, o_xy, 0, 0), ry = Y - __builtin_shufflevector(o_xy, o_xy, 1, 1), rz = Z - __builtin_shufflevector(oz_iz, oz_iz, 0, 0);
+	const mipt_f2 tx = rx * __builtin_shufflevector(i_xy, i_xy, 0, 0), ty = ry * __builtin_shufflevector(i_xy, i_xy, 1, 1), tz = rz * __builtin_shufflevector(oz_iz, oz_iz, 1, 1);
+	const float t_enter = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+	const float t_exit = fminf(fminf(tx.y, ty.y), tz.y);
+	const bool ok = !(t_enter > t_exit) & !(t_exit < 0);
+	t_out = t_enter < 0 ? 0.f : t_enter;
+	return ok;
+}
 // byte K of a word as a float (the compiler selects v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float quad_byte(uint32_t w) { return (float)((w >> (8 * K)) & 255u); }
 
@@ -285,11 +297,15 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 				const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 				const uint32_t ex = __float_as_uint(q0.w);
 				const float stx = __uint_as_float((ex & 255u) << 23), sty = __uint_as_float(((ex >> 8) & 255u) << 23), stz = __uint_as_float(((ex >> 16) & 255u) << 23);
+				// the four slots' near and far planes per axis, chosen by the ray's sign on the PACKED words (two selects per axis for all four
+				// slots; choosing after the decode, as box_test_pairs does, is 24 selects per step — and the kernel's vector pipe is as busy as its
+				// vector-memory path).  The same operations on the same operands as the slab test of mipt_trace.h, in the same order.
 				const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+				const uint32_t nwx = sx ? lx : hx, fwx = sx ? hx : lx, nwy = sy ? ly : hy, fwy = sy ? hy : ly, nwz = sz ? lz : hz, fwz = sz ? hz : lz;
 				float t0, t1, t2, t3;
-#define MIPT_QUAD_SLOT(K, T) box_test_pairs<false>((mipt_f2){quad_plane(quad_byte<K>(lx), stx, q0.x), quad_plane(quad_byte<K>(hx), stx, q0.x)}, \
-                                                  (mipt_f2){quad_plane(quad_byte<K>(ly), sty, q0.y), quad_plane(quad_byte<K>(hy), sty, q0.y)}, \
-                                                  (mipt_f2){quad_plane(quad_byte<K>(lz), stz, q0.z), quad_plane(quad_byte<K>(hz), stz, q0.z)}, o_xy, i_xy, oz_iz, sx, sy, sz, T)
+#define MIPT_QUAD_SLOT(K, T) box_test_sorted((mipt_f2){quad_plane(quad_byte<K>(nwx), stx, q0.x), quad_plane(quad_byte<K>(fwx), stx, q0.x)}, \
+                                             (mipt_f2){quad_plane(quad_byte<K>(nwy), sty, q0.y), quad_plane(quad_byte<K>(fwy), sty, q0.y)}, \
+                                             (mipt_f2){quad_plane(quad_byte<K>(nwz), stz, q0.z), quad_plane(quad_byte<K>(fwz), stz, q0.z)}, o_xy, i_xy, oz_iz, T)
 				bool p0 = MIPT_QUAD_SLOT(0, t0), p1 = MIPT_QUAD_SLOT(1, t1), p2 = MIPT_QUAD_SLOT(2, t2), p3 = MIPT_QUAD_SLOT(3, t3);
 #undef MIPT_QUAD_SLOT
 				p0 = p0 && (t0 < dist); p1 = p1 && (t1 < dist); p2 = p2 && (t2 < dist); p3 = p3 && (t3 < dist);      // TriangleMesh.cpp:1278-1279 without `< t`, on boxes that contain the reference's

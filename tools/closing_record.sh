@@ -1,6 +1,6 @@
 # usage: tools/closing_record.sh <series> <git commit of the snapshot>   (e.g. r4_h abc1234; run on the GPU box)
 # The closing record of a round (files gpurun_out/<series>_*, to be copied into profiles/): kernel stats and PMC counters of all four
-# configs FIRST, so that profiles/r4_pmc_counters.json (copy: gpurun_out/<series>_pmc_counters.json) describes the very library the
+# configs FIRST, so that profiles/pmc_counters.json (copy: gpurun_out/<series>_pmc_counters.json) describes the very library the
 # bench lines below are measured with (bench.py compares __graft_entry__.source_hash()); then the default bench (with CPU baseline),
 # the other configs, the in-process / gloo two-rank lines on one device, the rank-cost probes and the queue-pipeline rates.
 S=${1:-r4_h}; export MIPT_GIT_COMMIT=${2:-unknown}
@@ -11,7 +11,7 @@ for wl in c2 c1 c3 c4; do
   cp gpurun_out/pmc_${S}_${wl}_p1.log gpurun_out/${S}_${wl}_pmc_bench_line.log; cp gpurun_out/pmc_${S}_${wl}_summary.txt gpurun_out/${S}_${wl}_pmc_summary.txt; rm -rf gpurun_out/pmc_${S}_${wl} gpurun_out/pmc_${S}_${wl}_p*.log
   ARGS="$ARGS ${wl}=gpurun_out/${S}_${wl}_pmc_summary.txt:gpurun_out/${S}_${wl}_pmc_bench_line.log:profiles/${S}_${wl}_pmc_summary.txt"
 done
-python tools/pmc_to_json.py profiles/r2_fetch_calibration.json $ARGS > gpurun_out/${S}_pmc_to_json.txt && cp profiles/r4_pmc_counters.json gpurun_out/${S}_pmc_counters.json
+python tools/pmc_to_json.py profiles/r2_fetch_calibration.json $ARGS > gpurun_out/${S}_pmc_to_json.txt && cp profiles/pmc_counters.json gpurun_out/${S}_pmc_counters.json
 python bench.py > gpurun_out/${S}_c2_bench.json 2> gpurun_out/${S}_c2_bench.err; tail -1 gpurun_out/${S}_c2_bench.err
 for wl in c1 c3 c4; do python bench.py --workload $wl --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/${S}_${wl}_bench.json 2> gpurun_out/${S}_${wl}_bench.err; done
 python bench.py --steps 2 --warmup 1 --gpus 2 --in-process 0,0 --no-cpu-baseline > gpurun_out/${S}_c2_bench_in_process_2x_same_gpu.json 2>/dev/null

@@ -1,4 +1,4 @@
-"""profiles/r4_pmc_counters.json from PMC summaries (tools/pmc.sh) and the bench line of one of the profiled runs: per kernel and
+"""profiles/pmc_counters.json from PMC summaries (tools/pmc.sh) and the bench line of one of the profiled runs: per kernel and
 launch the counters, and per RAY of that launch what bench.py scales to its own run (L2 misses = fabric line fetches, TCP line
 lookups, HBM bytes, instructions by kind, mean vector-memory latency, wait share).  FETCH_SIZE is corrected as
 tools/fetch_calibration.py measured it on this device: the traversal kernels read by 64-byte gathers (factor `gather64`), the
@@ -41,9 +41,9 @@ for arg in sys.argv[2:]:
     for k, v in ks.items():
         if "FETCH_SIZE" not in v:
             continue
-        trav = k.startswith("k_wf_traverse")
+        trav = k.startswith("k_wf_traverse") or k.startswith("k_wf_anyhit")
         factor = f_gather if trav else f_stream
-        rays = {"k_wf_traverse<0>": ls["rays_closest"] / max(1, ls["extend_launches"]), "k_wf_traverse<1>": ls["rays_shadow"] / max(1, ls["shadow_launches"])}.get(k)
+        rays = {"k_wf_traverse<0>": ls["rays_closest"] / max(1, ls["extend_launches"]), "k_wf_traverse<1>": ls["rays_shadow"] / max(1, ls["shadow_launches"]), "k_wf_anyhit": ls["rays_shadow"] / max(1, ls["shadow_launches"])}.get(k)
         cyc = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         e = {"fetch_size_kb_per_launch": v["FETCH_SIZE"], "write_size_kb_per_launch": v.get("WRITE_SIZE", 0.0), "fetch_size_factor": factor,
              "hbm_bytes_per_launch": v["FETCH_SIZE"] * 1024 / factor + v.get("WRITE_SIZE", 0.0) * 1024,
@@ -71,7 +71,7 @@ import __graft_entry__ as ge
 out["_build"] = {"git_commit": os.environ.get("MIPT_GIT_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
                  "source_sha256_16": ge.source_hash(),
                  "flags": " ".join(ge.HIPCC_FLAGS) + " (default library)"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r4_pmc_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_counters.json"), "w"), indent=1)
 for wl in out:
     if wl.startswith("_"):
         continue

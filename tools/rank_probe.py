@@ -10,7 +10,7 @@ measured without N devices.  Also printed: mean_r t_r, max / mean (the load bala
 
 usage: python tools/rank_probe.py [c2|c3|c4] [tile_size=32] [ranks=1,2,4,8] [option=value ...]"""
 import json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import capi, scenes
 
 # one ncclReduce of W*H*4 floats to rank 0 over xGMI: ring reduce, per-link bound (7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md); a
