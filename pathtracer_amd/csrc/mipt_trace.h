@@ -121,8 +121,11 @@ MIPT_DEV bool box_test_pairs(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mipt
 	const float t_exit = fminf(fminf(fx, fy), fz);
 	bool ok = !(t_enter > t_exit);
 	if (XSPLIT) {
-		const bool rejx = (sx & (rx.y < 0)) | (!sx & (rx.x > 0));
-		ok = ok & !rejx & !(fminf(fy, fz) < 0);
+		// the x slab is rejected on the sign of the UN-multiplied difference of its far plane (Geometry.h:146-204): rx.y < 0 for a ray that
+		// goes up in x, rx.x > 0 for one that goes down, i.e. -rx.x < 0 — one select and one compare (written as a choice between the two
+		// comparisons it compiled to seven vector instructions per box: both compares, their results as 0 / 1 integers, a select, a test)
+		const bool rejx = (sx ? rx.y : -rx.x) < 0;
+		ok = ok && !rejx && !(fminf(fy, fz) < 0);
 	} else {
 		ok = ok & !(t_exit < 0);
 	}
