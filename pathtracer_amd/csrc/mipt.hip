@@ -1907,6 +1907,7 @@ struct InheritForAov {
 	explicit InheritForAov(mipt_ctx* c_) : c(c_) {
 		if (!c->has_scene || !c->scene_bare_mirror || c->scene_inherit) return;
 		const int one = 1;
+		if (hipDeviceSynchronize() != hipSuccess) return;                   // (no earlier mipt_render_device work may still read the scene: ADVICE r4)
 		if (hipMemcpy((char*)c->d_scene + offsetof(DScene, inherit_material), &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return;
 		on = true; ghost = c->scene_has_ghost;
 		c->scene_inherit = true; c->scene_has_ghost = true;
@@ -1914,7 +1915,12 @@ struct InheritForAov {
 	~InheritForAov() {
 		if (!on) return;
 		const int zero = 0;
-		hipMemcpy((char*)c->d_scene + offsetof(DScene, inherit_material), &zero, sizeof zero, hipMemcpyHostToDevice);
+		hipDeviceSynchronize();
+		if (hipMemcpy((char*)c->d_scene + offsetof(DScene, inherit_material), &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) {
+			// the device scene still says "inherit": host and device must agree, so the context keeps rendering it the way the loop runs (slow, correct)
+			(void)hipGetLastError();
+			return;
+		}
 		c->scene_inherit = false; c->scene_has_ghost = ghost;
 	}
 };
@@ -2395,7 +2401,7 @@ extern "C" int mipt_device_mesh_build(int device_id, const float* vertices, int 
 		if (!ok) return build_fail(MIPT_ERR_HIP, "hipMalloc failed for the tangents of a %d-triangle mesh", ntri);
 		const unsigned tb = (unsigned)((ntri + 255) / 256);
 		BHIP(hipMemsetAsync(d_first, 0, ((size_t)nverts + 1) * 4, 0));
-		hipLaunchKernelGGL(k_tan_face, dim3(tb), dim3(256), 0, 0, bt.d_vtx, d_uvs, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm, ntri, d_sdir, d_has, d_first);
+		hipLaunchKernelGGL(k_tan_face, dim3(tb), dim3(256), 0, 0, bt.d_vtx, d_uvs, nuvs, bt.d_tri, (int)sizeof(mipt_triangle_indices), bt.d_perm, ntri, d_sdir, d_has, d_first);
 		hipLaunchKernelGGL(k_u32_sums, dim3((unsigned)nvb), dim3(256), 0, 0, d_first, (size_t)nverts, d_vsum);
 		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, 0, d_vsum, nvb);
 		hipLaunchKernelGGL(k_u32_apply, dim3((unsigned)nvb), dim3(256), 0, 0, d_first, (size_t)nverts, d_vsum);
@@ -2513,7 +2519,7 @@ static int copy_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, DFatNode* 
 	HIPCHK(c, copy(dsh, dm->d_ts, nt * sizeof(DTriShade)));
 	HIPCHK(c, copy(dn, dm->d_fat, nfat * sizeof(DFatNode)));
 	if (node_base || tri_base) {       // not the scene's first mesh: the copy above is rewritten in place with scene-wide references
-		hipLaunchKernelGGL(bvhb::k_rebase_nodes, dim3((unsigned)((nfat + 255) / 256)), dim3(256), 0, 0, dn, (const DFatNode*)dn, nfat, node_base, tri_base);
+		hipLaunchKernelGGL(bvhb::k_rebase_nodes, dim3((unsigned)((nfat + 255) / 256)), dim3(256), 0, 0, dn, nfat, node_base, tri_base);
 		HIPCHK(c, hipGetLastError());
 		HIPCHK(c, hipDeviceSynchronize());
 	}

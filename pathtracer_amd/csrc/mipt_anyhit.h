@@ -386,8 +386,9 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 					const float4 b0 = lb[0], b1 = lb[1];
 					float tb;
 					const bool reached = box_test_pairs<false>((mipt_f2){b0.x, b0.y}, (mipt_f2){b0.z, b0.w}, (mipt_f2){b1.x, b1.y}, o_xy, i_xy, oz_iz, i_xy.x >= 0, i_xy.y >= 0, oz_iz.y >= 0, tb) && tb < dist;
+					const bool far_end = flag_all || tb >= 0.998f * dist;             // (decided here: tb does not live on through the branches below)
 					if (!reached) occluded = false;                                   // the reference never looks into this leaf
-					else if (flag_all || tb >= 0.998f * dist) to_replay();             // a box on the way may have been skipped for the running t: the ordered kernel decides
+					else if (far_end) to_replay();                                     // a box on the way may have been skipped for the running t: the ordered kernel decides
 					else if (tq.vis) tq.vis[id] = 0.f;                                 // (an occluded ray adds nothing to its path's colour)
 				}
 				if (occluded) { cur = MIPT_ST_IDLE; sp = 0; }

@@ -662,7 +662,7 @@ __global__ void k_fat_nodes(const ONode* __restrict__ nodes, int total, int ntri
 		if (cnt > MIPT_LEAF_MAX_TRIS) { atomicMax(&bad[1], cnt); return 0u; }
 		return MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (uint32_t)ch.fg;
 	};
-	if (i == 0) *root_ref = nd.isleaf ? (nd.fd - nd.fg > MIPT_LEAF_MAX_TRIS || nd.fd - nd.fg <= 0 ? (atomicMax(&bad[1], nd.fd - nd.fg), 0u) : (MIPT_LEAF_BIT | ((uint32_t)(nd.fd - nd.fg - 1) << 26) | (uint32_t)nd.fg)) : 0u;
+	if (i == 0) *root_ref = nd.isleaf ? (nd.fd - nd.fg > MIPT_LEAF_MAX_TRIS || nd.fd - nd.fg <= 0 ? ((nd.fd - nd.fg <= 0 ? atomicOr(&bad[0], 1) : atomicMax(&bad[1], nd.fd - nd.fg)), 0u) : (MIPT_LEAF_BIT | ((uint32_t)(nd.fd - nd.fg - 1) << 26) | (uint32_t)nd.fg)) : 0u;
 	if (nd.isleaf) return;
 	if (nd.fg <= (int)i || nd.fg >= total || nd.fd <= (int)i || nd.fd >= total) { atomicOr(&bad[0], 1); return; }
 	if (depth[i] == 0 || depth[i] > max_levels) atomicOr(&bad[2], 1);
@@ -712,14 +712,16 @@ __global__ void k_tri_records(const float* __restrict__ vtx, const float* __rest
 // ---- TriMesh::setup_tangents (TriangleMesh.cpp:572-711) on the reordered mesh: per face (sdir, tdir) from the UV gradients, per vertex
 // the sum of its faces' sdir IN ASCENDING FACE ORDER (the reference walks the faces once: the order fixes the rounding), Gram-Schmidt
 // against the vertex normal, then the three corner tangents of every face.  Same operations as the host version (host/mipt_host.cpp).
-__global__ void k_tan_face(const float* __restrict__ vtx, const float* __restrict__ uvs, const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n,
+// (a UV index outside the list would be an out-of-bounds DEVICE read — a memory fault that ends the process, where the host loop
+// reads garbage: such a face counts as a face without UVs.  Vertex indices were range-checked by k_prepare before the tree was built.)
+__global__ void k_tan_face(const float* __restrict__ vtx, const float* __restrict__ uvs, int nuvs, const char* __restrict__ tri, int stride, const uint32_t* __restrict__ order, int n,
                            float* __restrict__ sdir, uint8_t* __restrict__ has, uint32_t* __restrict__ first) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (size_t)n) return;
 	const int* t = reinterpret_cast<const int*>(tri + (size_t)order[i] * stride);
 	const int vi = t[0], vj = t[1], vk = t[2], ui = t[3], uj = t[4], uk = t[5];
 	atomicAdd(&first[vi], 1u); atomicAdd(&first[vj], 1u); atomicAdd(&first[vk], 1u);      // incident corners per vertex (scanned into list starts)
-	const bool h = !(ui == -1 || uj == -1 || uk == -1);
+	const bool h = (unsigned)ui < (unsigned)nuvs && (unsigned)uj < (unsigned)nuvs && (unsigned)uk < (unsigned)nuvs;
 	has[i] = h ? 1 : 0;
 	if (!h) return;
 	float vA[3], vB[3];
@@ -812,13 +814,13 @@ __global__ void k_tan_soup(const char* __restrict__ tri, int stride, const uint3
 }
 
 // a mesh that is not the scene's first: child references are scene-wide (inner: + node_base; leaf: first triangle + tri_base)
-__global__ void k_rebase_nodes(DFatNode* __restrict__ dst, const DFatNode* __restrict__ src, size_t n, uint32_t node_base, uint32_t tri_base) {
+// (in place: ONE pointer, not a restrict-qualified source and destination that alias — ADVICE r4)
+__global__ void k_rebase_nodes(DFatNode* nodes, size_t n, uint32_t node_base, uint32_t tri_base) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	DFatNode f = src[i];
-	f.lref = (f.lref & MIPT_LEAF_BIT) ? f.lref + tri_base : f.lref + node_base;
-	f.rref = (f.rref & MIPT_LEAF_BIT) ? f.rref + tri_base : f.rref + node_base;
-	dst[i] = f;
+	const uint32_t l = nodes[i].lref, r = nodes[i].rref;
+	nodes[i].lref = (l & MIPT_LEAF_BIT) ? l + tri_base : l + node_base;
+	nodes[i].rref = (r & MIPT_LEAF_BIT) ? r + tri_base : r + node_base;
 }
 
 }   // namespace bvhb
