@@ -134,7 +134,9 @@ MIPT_DEV float int_exponential(float y0, float ysol, float beta, float s, float 
 MIPT_DEV f3 random_uniform_sphere(uint64_t& rng) {                                                // Vector.h:604-615, T = float
 	const float r1 = pcg_uniform(rng);
 	const float r2 = pcg_uniform(rng);
-	return mk3(2.f * pt_cosf((float)(2. * MIPT_PI) * r1) * sqrtf(r2 * (1 - r2)), 2.f * pt_sinf((float)(2. * MIPT_PI) * r1) * sqrtf(r2 * (1 - r2)), 1.f - 2.f * r2);
+	float sn, cs;
+	pt_sincosf((float)(2. * MIPT_PI) * r1, sn, cs);
+	return mk3(2.f * cs * sqrtf(r2 * (1 - r2)), 2.f * sn * sqrtf(r2 * (1 - r2)), 1.f - 2.f * r2);
 }
 struct FogEvent { f3 weight; Ray ray; };
 // One in-scattering event on [0, t] of ray r (fogContribution).  `attenuation` (the transmittance of the segment) is
@@ -299,7 +301,9 @@ __device__ __noinline__ f3 trace_path_queue(const DScene* __restrict__ sc, const
 			const float integ = 1.f - mipt_expf(-diskR * diskR / (2.f * sigmasub * sigmasub));
 			const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(ps.rng) * integ));
 			const float randangle = pcg_uniform(ps.rng) * 2.f * (float)MIPT_PI;
-			const float gauss0 = randR * pt_sinf(randangle), gauss1 = randR * pt_cosf(randangle), gauss2 = randR;
+			float sn_, cs_;
+			pt_sincosf(randangle, sn_, cs_);
+			const float gauss0 = randR * sn_, gauss1 = randR * cs_, gauss2 = randR;
 			const float gaussval = (float)((1. / (double)(sigmasub * sigmasub * 2.f * (float)MIPT_PI)) * (double)mipt_expf(-(gauss2 * gauss2) / (2.f * sigmasub * sigmasub)));
 			const float pdfgauss = gaussval / integ;
 			const f3 Tg = tangent_of(N);

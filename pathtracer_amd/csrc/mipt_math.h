@@ -73,6 +73,7 @@ MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.
 // Bit-exact with the host libm (see mipt_sincos.h; checked on every float of the range the path uses).
 MIPT_DEV float pt_sinf(float y) { return mipt_sincosf<false>(y); }
 MIPT_DEV float pt_cosf(float y) { return mipt_sincosf<true>(y); }
+MIPT_DEV void pt_sincosf(float y, float& s, float& c) { mipt_sincosf_pair(y, s, c); }
 
 // double-precision exp / pow / sincos of the host libm (mipt_libm64.h; 1.6 G arguments checked against libm by
 // tests/native/libm64_check.cpp).  Arguments outside the restated ranges (never reached by the path) go to the device library.

@@ -457,7 +457,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 					else {
 						const float randR = sigmasub * sqrtf(-2.f * mipt_logf(1.f - pcg_uniform(S.rng) * integ));
 						const float randangle = pcg_uniform(S.rng) * 2.f * (float)MIPT_PI;
-						gauss0 = randR * pt_sinf(randangle); gauss1 = randR * pt_cosf(randangle); gauss2 = randR;
+						{ float sn_, cs_; pt_sincosf(randangle, sn_, cs_); gauss0 = randR * sn_; gauss1 = randR * cs_; } gauss2 = randR;
 						r1s = pcg_uniform(S.rng);
 					}
 					const float gaussval = (float)((1. / (double)(sigmasub * sigmasub * 2.f * (float)MIPT_PI)) * (double)mipt_expf(-(gauss2 * gauss2) / (2.f * sigmasub * sigmasub)));

@@ -46,7 +46,9 @@ MIPT_DEV f3 random_cos(f3 N, float r1, float r2) {
 #endif
 	float sr2 = sqrtf(1.f - r2);
 	const float twopi = (float)(2. * MIPT_PI);
-	f3 loc = mk3(pt_cosf(twopi * r1) * sr2, pt_sinf(twopi * r1) * sr2, sqrtf(r2));
+	float sn, cs;
+	pt_sincosf(twopi * r1, sn, cs);
+	f3 loc = mk3(cs * sr2, sn * sr2, sqrtf(r2));
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
 	return loc.z * N + loc.x * t1 + loc.y * t2;

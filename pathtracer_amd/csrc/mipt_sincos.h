@@ -52,3 +52,29 @@ MIPT_HD float mipt_sincosf(float y) {
 	double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign table {1,-1,-1,1}
 	return mipt_sincos_poly(x * s, x * x, COS ? (n ^ 1) : n, (n & 2) != 0);
 }
+
+// sinf(y) AND cosf(y) of one argument (the samplers always want both: Vector.h:582-600): the same reduction and the same two polynomials as the
+// single functions above, each evaluated ONCE.  Taken one after the other the two calls evaluate four polynomials on a wave whose lanes
+// differ in the quadrant (each call runs the sine polynomial for its even-quadrant lanes and the cosine polynomial for the odd ones).
+MIPT_HD void mipt_sincosf_pair(float y, float& sin_out, float& cos_out) {
+	double x = (double)y;
+	int n = 0;
+	double xs = x;
+	bool neg = false;
+	if (mipt_abstop12(y) < mipt_abstop12(0x1.921FB6p-1f)) {          // |y| < pi/4
+		if (mipt_abstop12(y) < mipt_abstop12(0x1p-12f)) { sin_out = y; cos_out = 1.0f; return; }
+	} else {
+		double r = x * 0x1.45F306DC9C883p+23;
+		n = ((int)r + 0x800000) >> 24;
+		x = x - (double)n * 0x1.921FB54442D18p0;
+		const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+		xs = x * sg;
+		neg = (n & 2) != 0;
+	}
+	const double x2 = x * x;
+	const float S = mipt_sincos_poly(xs, x2, 0, false);             // the sine polynomial of the signed reduced argument
+	const float C0 = mipt_sincos_poly(xs, x2, 1, false);            // the cosine polynomial (even in x)
+	const float C = neg ? -C0 : C0;
+	sin_out = (n & 1) == 0 ? S : C;
+	cos_out = (n & 1) == 0 ? C : S;
+}

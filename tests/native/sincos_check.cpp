@@ -18,6 +18,10 @@ int main(int argc, char** argv) {
 		if (memcmp(&a, &b, 4)) bad_s++;
 		a = cosf(x); b = mipt_sincosf<true>(x);
 		if (memcmp(&a, &b, 4)) bad_c++;
+		float ps, pc;                              // the fused form (both of one argument, each polynomial once)
+		mipt_sincosf_pair(x, ps, pc);
+		a = sinf(x); if (memcmp(&a, &ps, 4)) bad_s++;
+		a = cosf(x); if (memcmp(&a, &pc, 4)) bad_c++;
 	}
 	printf("%u %ld %ld\n", uhi + 1, bad_s, bad_c);
 	return 0;
