@@ -3,7 +3,8 @@
 # configs FIRST, so that profiles/pmc_counters.json (copy: gpurun_out/<series>_pmc_counters.json) describes the very library the
 # bench lines below are measured with (bench.py compares __graft_entry__.source_hash()); then the default bench (with CPU baseline),
 # the other configs, the in-process / gloo two-rank lines on one device, the rank-cost probes and the queue-pipeline rates.
-S=${1:-r4_h}; export MIPT_GIT_COMMIT=${2:-unknown}
+S=${1:-r5_k}; export MIPT_GIT_COMMIT=${2:-unknown}
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/${S}_gputests.txt 2>&1; grep -E "passed|failed|error" gpurun_out/${S}_gputests.txt | tail -2
 bash tools/kstats.sh ${S} --workload c2 > gpurun_out/${S}_kstats.txt 2>&1; cp gpurun_out/kstats_${S}.csv gpurun_out/${S}_c2_kernel_stats.csv; rm -rf gpurun_out/kstats_${S}
 ARGS=""
 for wl in c2 c1 c3 c4; do
@@ -16,7 +17,9 @@ python bench.py > gpurun_out/${S}_c2_bench.json 2> gpurun_out/${S}_c2_bench.err;
 for wl in c1 c3 c4; do python bench.py --workload $wl --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/${S}_${wl}_bench.json 2> gpurun_out/${S}_${wl}_bench.err; done
 python bench.py --steps 2 --warmup 1 --gpus 2 --in-process 0,0 --no-cpu-baseline > gpurun_out/${S}_c2_bench_in_process_2x_same_gpu.json 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 2 --warmup 1 --backend gloo --share-gpu > gpurun_out/${S}_c2_bench_two_processes_same_gpu_gloo.json 2>/dev/null
-for wl in c2 c3 c4; do python tools/rank_probe.py $wl > gpurun_out/${S}_rank_cost_${wl}.jsonl 2>/dev/null; done
+for wl in c2 c3 c4; do python tools/rank_probe.py $wl > gpurun_out/${S}_all_ranks_${wl}.jsonl 2>/dev/null; done
+bash tools/pmc_issue.sh ${S} > /dev/null 2>&1; cp gpurun_out/pmci_${S}_summary.txt gpurun_out/${S}_c2_pmc_issue_summary.txt; rm -f gpurun_out/pmci_${S}_p*.log
+for l in 1 4 16; do python tools/progressive_rate.py progressive_lookahead=$l 2>&1 | tail -1; done > gpurun_out/${S}_progressive_rate.txt
 timeout 600 python tools/queue_kernel_rate.py 64 > gpurun_out/${S}_queue_rate_wavefront_64spp.jsonl 2>&1
 python - $S <<'PY'
 import json, sys
