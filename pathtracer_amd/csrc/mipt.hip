@@ -206,6 +206,9 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 // source to its left before the first sample of the source above it (Raytracer.cpp:1477-1497 run serially), so the three
 // visits of a sample lie a whole pass of samples apart.  Every destination pixel still receives its terms in the
 // reference's scan order (source row, source column, sample): the single-pass image stays bit-exact.
+#ifndef MIPT_RESOLVE_RECOMPUTE_JITTER
+#define MIPT_RESOLVE_RECOMPUTE_JITTER 1
+#endif
 #ifndef MIPT_RESOLVE_UNROLL
 #define MIPT_RESOLVE_UNROLL 8           // sample loads in flight per thread: the kernel runs ~2 waves per SIMD and lives on memory-level parallelism
 #endif
@@ -252,7 +255,16 @@ __global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSampl
 			const size_t stride = (size_t)ps.npix_slots;
 #pragma unroll MIPT_RESOLVE_UNROLL
 			for (int kk = ka; kk < kb; kk++) {
+#if MIPT_RESOLVE_RECOMPUTE_JITTER
+				// the sensor jitter of sample k of pixel (i, j) is the first two draws of its engine (path_begin): recomputed, not fetched
+				// (a third of the splat's bytes; the stored copy serves the gather splat and the per-sample entry points)
+				uint64_t eng = pcg_seed(((uint64_t)i * (uint64_t)W + (uint64_t)j) * R.seed_stride + (uint64_t)(ps.k0 + kk));
+				float2 jit;
+				jit.x = pcg_uniform(eng) - 0.5f;
+				jit.y = pcg_uniform(eng) - 0.5f;
+#else
 				const float2 jit = pj[(size_t)kk * stride];
+#endif
 				const float4 c = pc[(size_t)kk * stride];
 				const float sb = sqr(fdj - jit.x);
 #pragma unroll
@@ -297,9 +309,9 @@ __global__ void __launch_bounds__(256) k_wf_aov(const DScene* __restrict__ sc, D
 	const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
 	if (id >= n) return;
 	float4 on = make_float4(0.f, 0.f, 0.f, 0.f), okd = on;
-	const float4 w = wf.wgt[id];
-	if (__float_as_uint(w.w) & MIPT_WF_VALID) {
-		const float4 o = wf.ray_o[id], d = wf.ray_d[id], hr = wf.hit[id];
+	const float4 o = wf.ray_o[id];
+	if (o.w == o.w) {                                       // (a slot without a path carries MIPT_WF_DEAD_RAY)
+		const float4 d = wf.ray_d[id], hr = wf.hit[id];
 		const unsigned packed = __float_as_uint(hr.w);
 		if (packed != MIPT_HIT_MISS) {
 			Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
@@ -1528,25 +1540,25 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (pair[0] == 0 && pair[1] == 0 && n_probe == 0 && n_add == 0) break;
 				unsigned* pair_dev = &qw.counters[MIPT_QW_PAIR(slot)];
 				if (n_probe) {
-					TravQueue tq; tq.list = qw.prl[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_PROBE(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_PROBE(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false;
+					TravQueue tq; tq.list = qw.prl[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_PROBE(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_PROBE(slot)]; tq.identity = false; tq.vis = nullptr; tq.skip_ghosts = false; tq.valid_in_ray = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					hipLaunchKernelGGL(k_q_probe, dim3(std::max(1u, std::min(c->grid_qtrav[0], (n_probe + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK))), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, tq, thr, imin);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[1]) {
-					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = first ? nullptr : pair_dev + 1; tq.n_imm = pair[1]; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = first; tq.vis = nullptr; tq.skip_ghosts = false;
+					TravQueue tq; tq.list = qw.live[par]; tq.n_ptr = first ? nullptr : pair_dev + 1; tq.n_imm = pair[1]; tq.head = &qw.counters[MIPT_QW_HEAD_CLOSEST(slot)]; tq.identity = first; tq.vis = nullptr; tq.skip_ghosts = false; tq.valid_in_ray = false;
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					q_traverse(false, tq, pair[1]);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (pair[0]) {
-					TravQueue tq; tq.list = qw.shl[par]; tq.n_ptr = pair_dev; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW(slot)]; tq.identity = false; tq.vis = qw.vis; tq.skip_ghosts = true;
+					TravQueue tq; tq.list = qw.shl[par]; tq.n_ptr = pair_dev; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW(slot)]; tq.identity = false; tq.vis = qw.vis; tq.skip_ghosts = true; tq.valid_in_ray = false;
 					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					q_traverse(true, tq, pair[0]);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				}
 				if (n_add) {
-					TravQueue tq; tq.list = qw.sha[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_SHADOW_ADD(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW_ADD(slot)]; tq.identity = false; tq.vis = (R.fog_density > 1E-8) ? qw.vis : nullptr; tq.skip_ghosts = true;   // fog: the logic stage reads the answer later
+					TravQueue tq; tq.list = qw.sha[par]; tq.n_ptr = &qw.counters[MIPT_QW_N_SHADOW_ADD(slot)]; tq.n_imm = 0; tq.head = &qw.counters[MIPT_QW_HEAD_SHADOW_ADD(slot)]; tq.identity = false; tq.vis = (R.fog_density > 1E-8) ? qw.vis : nullptr; tq.skip_ghosts = true; tq.valid_in_ray = false;   // fog: the logic stage reads the answer later
 					if (timed_begin(1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 					q_traverse(true, tq, n_add);
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
@@ -1576,7 +1588,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		} else {
 			HIPCHK(c, hipMemsetAsync(wf.counters, 0, MIPT_WF_COUNTERS * sizeof(unsigned), st));
 			if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-			hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt);
+			{
+				// the sensor jitter is stored only for consumers that read it: the per-sample entry points, the denoiser-input resolve and the gather splat
+				const bool scan_splat = !dump && !d_aov && c->opt_resolve_rows > 0 && (R.filter_size == 1 || R.filter_size == 2);
+				hipLaunchKernelGGL(k_wf_generate, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, c->d_cnt, (MIPT_RESOLVE_RECOMPUTE_JITTER && scan_splat) ? 0 : 1);
+			}
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			auto G = [&](int k) { return dim3(std::min(c->grid_stage[k], k < 3 ? (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK) : grid_all)); };
 			const bool merge = c->opt_refill && c->opt_merge_traverse;
@@ -1621,7 +1637,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					}
 					const dim3 ga(std::min(c->grid_anyhit, (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
 					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, b, list_mem[b & 1], &c->d_cnt[0]._pad[0], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
-					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false;
+					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false; rq.valid_in_ray = false;
 					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
 					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
 				}

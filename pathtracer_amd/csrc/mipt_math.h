@@ -66,6 +66,11 @@ MIPT_DEV uint32_t pcg_next(uint64_t& state) {
 	uint32_t rot = (uint32_t)(old >> 59u);
 	return (xs >> rot) | (xs << ((0u - rot) & 31u));
 }
+// the engine after four draws (an LCG: four steps are one multiply-add with M^4 and INC (M^3 + M^2 + M + 1), modulo 2^64)
+MIPT_DEV uint64_t pcg_skip4(uint64_t state) {
+	constexpr uint64_t M = MIPT_PCG_MULT, I = MIPT_PCG_INC, M2 = M * M, M4 = M2 * M2, C4 = I * (M2 * M + M2 + M + 1ULL);
+	return state * M4 + C4;
+}
 // engine()*invmax, invmax = 1.f/engine.max() = 2^-32 (Raytracer.h:28); may return exactly 1.0f
 MIPT_DEV float pcg_uniform(uint64_t& state) { return (float)pcg_next(state) * 2.3283064365386963e-10f; }
 

@@ -125,6 +125,8 @@ struct TravQueue {
 	float* vis;                  // shadow rays: nullptr = add the pending direct term to the path's colour when the light sample is
 	                             // visible (wavefront pipeline); else write 1.f (visible) / 0.f (occluded) to vis[id] (contribution-queue pipeline)
 	bool skip_ghosts;            // shadow rays ignore ghost objects
+	bool valid_in_ray;           // identity queues: a slot without a path is marked by a NaN in its ray origin's .w (MIPT_WF_DEAD_RAY, the wavefront
+	                             // pipeline since round 5) instead of by the VALID bit of its weight word (the contribution-queue pipeline)
 };
 // One queue of one depth: SHADOW = false the closest-hit rays of depth b (Scene::intersection), SHADOW = true the
 // light-sample rays of depth b (Scene::intersection_shadow).  Called by every wave of the grid; returns when the
@@ -204,7 +206,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 					unsigned idx = chunk_next + prefix;
 					unsigned id = identity ? idx : (use_ahead ? id_ahead : list[idx]);
 					bool valid = true;
-					if (identity) valid = (__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID) != 0;
+					if (identity && !tq.valid_in_ray) valid = (__float_as_uint(wf.wgt[id].w) & MIPT_WF_VALID) != 0;
 					if (valid) {
 						MIPT_PROF_COUNT(10)
 						// the stage that created the ray has already visited the analytic objects (mipt_wavefront.h):
@@ -252,8 +254,11 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				ro = mk3(o4.x, o4.y, o4.z); rd = mk3(d4.x, d4.y, d4.z);
 				if (SHADOW) st.dist = o4.w;
 				if (!SHADOW && st.obj == first_mesh) {                                                       // a fresh ray: what the analytic objects left
-					st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
-					if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
+					if (identity && tq.valid_in_ray && o4.w != o4.w) st.cur = MIPT_ST_IDLE;                  // no path in this slot (MIPT_WF_DEAD_RAY)
+					else {
+						st.t = o4.w; st.best = (int)__float_as_uint(d4.w);
+						if (MIPT_HIT_WRITE_THROUGH) wf.hit[st.id] = make_float4(o4.w, 0.f, 0.f, d4.w);
+					}
 				}
 			}
 			if (MIPT_L_NEED) MIPT_PROF_COUNT(6)
@@ -492,8 +497,8 @@ template <int MODE>
 __global__ void __launch_bounds__(MIPT_TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MIPT_EXTEND_WAVES : MIPT_TRAVERSE_WAVES))) k_wf_traverse(const DScene* __restrict__ sc, const float4* __restrict__ nodes, const DTriIsect* __restrict__ tris, DWave wf, int b, unsigned n0, int refill_threshold, int inner_min_flags) {
 	MIPT_DECLARE_LDS_STACK(stk, wf.spill, MIPT_TRAV_BLOCK);
 	unsigned char* leafmap = lds_leafmap_ + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
-	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; return q; };
-	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; return q; };
+	auto extend_q = [&](int bb) { TravQueue q; q.list = wf.list[bb & 1]; q.n_ptr = bb == 0 ? nullptr : &wf.counters[MIPT_CNT_PAIR(bb - 1) + 1]; q.n_imm = n0; q.head = &wf.counters[MIPT_CNT_EXT_HEAD(bb)]; q.identity = bb == 0; q.vis = nullptr; q.skip_ghosts = false; q.valid_in_ray = true; return q; };
+	auto shadow_q = [&](int bb) { TravQueue q; q.list = wf.list_sh; q.n_ptr = &wf.counters[MIPT_CNT_PAIR(bb)]; q.n_imm = 0; q.head = &wf.counters[MIPT_CNT_SH_HEAD(bb)]; q.identity = false; q.vis = nullptr; q.skip_ghosts = false; q.valid_in_ray = false; return q; };
 	if (MODE == 1 || MODE == 2) traverse_queue<true>(sc, nodes, tris, wf, shadow_q(b), refill_threshold, inner_min_flags, stk, leafmap);
 	if (MODE == 0) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b), refill_threshold, inner_min_flags, stk, leafmap);
 	if (MODE == 2) traverse_queue<false>(sc, nodes, tris, wf, extend_q(b + 1), refill_threshold, inner_min_flags, stk, leafmap);

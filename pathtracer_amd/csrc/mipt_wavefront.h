@@ -251,12 +251,15 @@ __device__ __forceinline__ void queue_push2x(unsigned* __restrict__ list_a, unsi
 // bit 31 of wgt.w marks a path slot that holds a live path (slots of 8x8 blocks that stick out of
 // the image never do); depth 0 of a pass uses the identity list, so generation needs no queue.
 #define MIPT_WF_VALID 0x80000000u
+#define MIPT_WF_DEAD_RAY 0xffffffffu      // ray_o.w of a path slot that holds no path at depth 0 (a NaN: the analytic prefix never produces one)
 
-__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt) {
+__global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, DCounters* __restrict__ cnt, int store_jitter) {
 	long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	long long total = (long long)ps.npix_slots * (ps.k1 - ps.k0);
+	// Round 5: what a path starts with is not stored — weight (1, 1, 1), depth nb_bounces, show_lights and the engine after path_begin's four
+	// draws (pcg_skip4) are recomputed by the stages of depth 0 from the path id; a slot that holds no path (pixel outside the image, a
+	// render of depth 0) is marked by a NaN in the .w of its ray origin, which extend(0) and shade(0) load anyway (MIPT_WF_DEAD_RAY).
 	bool valid = false, alive = false;
-	float4 wgt0 = make_float4(0.f, 0.f, 0.f, 0.f);                             // not a live path until proven otherwise (ONE store of the slot's weight word, at the end)
 	if (tid < total) {
 		int kk = (int)(tid / ps.npix_slots);
 		int slot = (int)(tid % ps.npix_slots);
@@ -267,18 +270,16 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_generate(const DScene* __rest
 			PathState p; float dx, dy;
 			path_begin(R, i, j, ps.k0 + kk, p, dx, dy);
 			wf_st(&wf.out.col[tid], make_float4(0.f, 0.f, 0.f, 0.f));
-			wf_st(&wf.out.dxdy[tid], make_float2(dx, dy));
+			if (store_jitter) wf_st(&wf.out.dxdy[tid], make_float2(dx, dy));      // (the column-scan splat recomputes it: MIPT_RESOLVE_RECOMPUTE_JITTER)
 			alive = path_alive(p);
 			if (alive) {
 				float t0; unsigned best0;
 				analytic_prefix_closest(sc, p.ray.o, p.ray.d, t0, best0);       // rides in the unused .w of the ray's two float4s
 				wf_st(&wf.ray_o[tid], make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, t0));
 				wf_st(&wf.ray_d[tid], make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, __uint_as_float(best0)));
-				wgt0 = make_float4(p.weight.x, p.weight.y, p.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)p.depth | (p.show_lights ? 0x10000u : 0u)));
-				wf_st(&wf.rng[tid], make_uint2((unsigned)p.rng, (unsigned)(p.rng >> 32)));
 			}
 		}
-		wf_st(&wf.wgt[tid], wgt0);
+		if (!alive) wf_st(&wf.ray_o[tid], make_float4(0.f, 0.f, 0.f, __uint_as_float(MIPT_WF_DEAD_RAY)));
 	}
 	(void)valid; (void)cnt;     // paths are counted on the host (valid pixels x samples)
 }
@@ -298,8 +299,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 			unsigned idx = base + 64u * u + lane_id();
 			if (idx >= n) continue;
 			unsigned id = b == 0 ? idx : list[idx];
-			if (b == 0 && !(__float_as_uint(wf_ld(&wf.wgt[id]).w) & MIPT_WF_VALID)) continue;
 			float4 o = wf_ld(&wf.ray_o[id]), d = wf_ld(&wf.ray_d[id]);
+			if (b == 0 && o.w != o.w) continue;                           // no path in this slot (MIPT_WF_DEAD_RAY)
 			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
 			Hit h;
 			bool hit = scene_closest(sc, r, h, stk);
@@ -393,12 +394,15 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	// Software pipeline over the sub-chunks of a chunk: the path ids of all sub-chunks are read first, and the state
 	// of sub-chunk u+1 is requested before sub-chunk u is shaded — with 3 waves per SIMD the stage is bound by its
 	// three dependent HBM round trips per vertex (state, shading record, texel), this hides the first one.
+	// depth 0: weight, flags and engine of a path are what path_begin leaves — recomputed, not fetched (k_wf_generate does not store them)
+	const bool initial = b == 0;
 	struct In { float4 w, o, d, hr, col; uint2 rs; };
 	auto fetch = [&](unsigned id, bool ok, In& in) {
 		if (ok) {
-			in.w = wf_ld(&wf.wgt[id]); in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); in.hr = wf_ld(&wf.hit[id]);
+			if (!initial) in.w = wf_ld(&wf.wgt[id]);
+			in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); in.hr = wf_ld(&wf.hit[id]);
 			if (TIER != 1) in.col = wf_ld(&wf.out.col[id]);          // the fast tier touches the colour only when a vertex adds to it
-			in.rs = wf_ld(&wf.rng[id]);
+			if (!initial) in.rs = wf_ld(&wf.rng[id]);
 		}
 	};
 	// tier 4: this wave's request list and its list of continuing path ids (LDS), both wave-uniform counts
@@ -428,13 +432,15 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		lds_u32* const gl = (lds_u32*)(mipt_shade_lds + (GLDS ? (threadIdx.x >> 6) * MIPT_GLDS_WORDS : 0));
 		auto glds_issue = [&](unsigned pid) {
 			if (pid != 0xffffffffu) {
-				__builtin_amdgcn_global_load_lds((gptr_t)&wf.wgt[pid], gl + 0, 16, 0, 2);
+				if (!initial) __builtin_amdgcn_global_load_lds((gptr_t)&wf.wgt[pid], gl + 0, 16, 0, 2);
 				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_o[pid], gl + 256, 16, 0, 2);
 				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_d[pid], gl + 512, 16, 0, 2);
 				__builtin_amdgcn_global_load_lds((gptr_t)&wf.hit[pid], gl + 768, 16, 0, 2);
 				if (TIER != 1) __builtin_amdgcn_global_load_lds((gptr_t)&wf.out.col[pid], gl + 1024, 16, 0, 2);
-				__builtin_amdgcn_global_load_lds((gptr_t)&wf.rng[pid], gl + 1280, 4, 0, 2);
-				__builtin_amdgcn_global_load_lds((gptr_t)((const unsigned*)&wf.rng[pid] + 1), gl + 1344, 4, 0, 2);
+				if (!initial) {
+					__builtin_amdgcn_global_load_lds((gptr_t)&wf.rng[pid], gl + 1280, 4, 0, 2);
+					__builtin_amdgcn_global_load_lds((gptr_t)((const unsigned*)&wf.rng[pid] + 1), gl + 1344, 4, 0, 2);
+				}
 			}
 		};
 		if (GLDS) glds_issue(id_cur);
@@ -453,9 +459,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 					typedef __attribute__((address_space(3))) mipt_v4f lds_f4;
 					const lds_f4* g4 = (const lds_f4*)gl;
 					const mipt_v4f a0 = g4[l], a1 = g4[64 + l], a2 = g4[128 + l], a3 = g4[192 + l];
-					cur.w = make_float4(a0.x, a0.y, a0.z, a0.w); cur.o = make_float4(a1.x, a1.y, a1.z, a1.w); cur.d = make_float4(a2.x, a2.y, a2.z, a2.w); cur.hr = make_float4(a3.x, a3.y, a3.z, a3.w);
+					if (!initial) cur.w = make_float4(a0.x, a0.y, a0.z, a0.w);
+					cur.o = make_float4(a1.x, a1.y, a1.z, a1.w); cur.d = make_float4(a2.x, a2.y, a2.z, a2.w); cur.hr = make_float4(a3.x, a3.y, a3.z, a3.w);
 					if (TIER != 1) { const mipt_v4f a4 = g4[256 + l]; cur.col = make_float4(a4.x, a4.y, a4.z, a4.w); }
-					cur.rs = make_uint2(gl[1280 + l], gl[1344 + l]);
+					if (!initial) cur.rs = make_uint2(gl[1280 + l], gl[1344 + l]);
 				}
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				glds_issue(id_nxt);                                                   // lands while this sub-chunk is shaded
@@ -485,12 +492,17 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 #endif
 			const float4 w = sin.w, o = sin.o, d = sin.d, hr = sin.hr, col = sin.col;
 			const uint2 rs = sin.rs;
-			unsigned fl = __float_as_uint(w.w);
-			if (identity && !(fl & MIPT_WF_VALID)) break;
+			if (initial && o.w != o.w) break;                                 // no path in this slot (MIPT_WF_DEAD_RAY)
+			// pixel of this path (for the per-pixel Cranley-Patterson rotation, and at depth 0 for its engine) and its sample index
+			const int kk = (int)(id / (unsigned)ps.npix_slots), slot = (int)(id % (unsigned)ps.npix_slots);
+			const int blk = slot >> 6, in = slot & 63;
+			const int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
+			const unsigned fl = initial ? (MIPT_WF_VALID | (unsigned)R.nb_bounces | 0x10000u) : __float_as_uint(w.w);       // path_begin: depth nb_bounces, show_lights
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
-			p.weight = mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
-			p.rng = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+			p.weight = initial ? mk3(1.f, 1.f, 1.f) : mk3(w.x, w.y, w.z); p.color = mk3(col.x, col.y, col.z);
+			p.rng = initial ? pcg_skip4(pcg_seed(((uint64_t)pi * (uint64_t)R.W + (uint64_t)pj) * R.seed_stride + (uint64_t)(ps.k0 + kk)))      // the engine behind path_begin's four draws
+			                : ((uint64_t)rs.x | ((uint64_t)rs.y << 32));
 			p.depth = (int)(fl & 0xffffu); p.show_lights = (fl & 0x10000u) != 0;
 			unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
@@ -509,10 +521,6 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				if (MIPT_SHADE_EARLY_DEFER && has_inter && ((sc->merl_mask >> h.obj) & 1u)) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
 			}
 			if (has_inter) hit_material(sc, p.ray, h, P, m);
-			// pixel of this path (for the per-pixel Cranley-Patterson rotation) and its sample index
-			int kk = (int)(id / (unsigned)ps.npix_slots), slot = (int)(id % (unsigned)ps.npix_slots);
-			int blk = slot >> 6, in = slot & 63;
-			int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
 			ShadowRequest sh; f3 wv;
 			bool c;
 			if (TIER == 1) {
