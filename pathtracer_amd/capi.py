@@ -610,7 +610,10 @@ class HostRaytracer:
         self._check(self.host.mh_render_image_nopreviz(self.h), "Raytracer::render_image_nopreviz")
         return self._images()
 
-    def render_image(self):
+    def render_image(self, lookahead=None):
+        """Raytracer::render_image of the host mirror (one publish per sample).  lookahead: publishes rendered per pass (the mirror's default: 8)."""
+        if lookahead is not None:
+            self.host.mh_set_progressive_lookahead(self.h, int(lookahead))
         self._check(self.host.mh_render_image(self.h), "Raytracer::render_image")
         return self._images()
 

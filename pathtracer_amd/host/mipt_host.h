@@ -252,6 +252,7 @@ public:
 	Scene s;
 	volatile int stopped = 0;
 	int current_nb_rays = 0;
+	int progressive_lookahead = 8;     // render_image: one-sample publishes rendered per pass (not a member of the reference: its loop renders them one by one)
 	std::vector<unsigned char> image;
 	std::vector<float> imagedouble;
 	std::vector<float> sample_count;
@@ -334,6 +335,7 @@ int  mh_set_brdf_merl_file(mh_raytracer*, int obj, const char* merl_binary_file)
 const double* mh_merl_data(mh_raytracer*, int obj);      // IsoMERLBRDF::data of the object, or null
 int  mh_prepare(mh_raytracer*, int upload);               // prepare_render; upload=0 skips the device (CPU tests)
 int  mh_render_image(mh_raytracer*);
+void mh_set_progressive_lookahead(mh_raytracer*, int n);
 int  mh_render_image_nopreviz(mh_raytracer*);
 const char* mh_last_error(mh_raytracer*);
 // views

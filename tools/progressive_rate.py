@@ -17,8 +17,9 @@ for spp in (16, 64):
     H.prepare()
     for k, v in opts:
         H.set_option(k, int(v))
-    H.render_image()            # warm-up
-    t0 = time.time(); H.render_image(); wall[spp] = time.time() - t0
+    look = dict(opts).get("progressive_lookahead")
+    H.render_image(look)        # warm-up
+    t0 = time.time(); H.render_image(look); wall[spp] = time.time() - t0
     st = H.stats()
     rays = st["rays_closest"] + st["rays_shadow"]
     print("render_image %d spp: %.1f ms wall, GPU span %.1f ms, %.1f M rays" % (spp, wall[spp] * 1e3, st["render_ms"], rays / 1e6))

@@ -1,5 +1,3 @@
-for w in c2 c3 c4; do for ts in 32 64; do python tools/rank_probe.py $w ranks=1,8 tile_size=$ts 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); r=d.pop('ranks'); print('$w tile', d['tile_size'], 'N', d['nranks'], 't_max', d['t_max_ms'], 'max/mean', d['max_over_mean'], 'rays max/mean', d['rays_max_over_mean'], 'N*mean/t1', d['n_x_mean_over_t1'], 'pred', d['predicted_speedup'], 'resolve/rank', round(sum(x['resolve'] for x in r)/len(r),1))"
-done; done
+timeout 900 python -m pytest tests/test_progressive.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r5_n_tests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_n_tests.txt | tail -3
+python tools/progressive_rate.py 2>&1 | tail -1
+for l in 1 4 8 16; do python tools/progressive_rate.py progressive_lookahead=$l 2>&1 | tail -1; done
