@@ -627,7 +627,8 @@ static void anyhit_study(const o_obj* o, const o_ray* d, float dist_light, int r
 				float t;
 				if (box_invd(qmin, qmax, invd.origin, invd.direction, signs, &t) && t < dist_light) pass[np++] = slot[k];
 			}
-			for (int k = np - 1; k >= 0; k--) stack[sp++] = pass[k];
+			/* (the kernel keeps the first passing slot in a register and pushes the others: depth of the LDS stack = sp - 1 of this walk) */
+			for (int k = np - 1; k >= 0; k--) { stack[sp++] = pass[k]; if (k > 0 && sp - 1 > 16) tl_any_q4[5]++; }
 		}
 		tl_any_q4[0] += wide; tl_any_q4[1] += leaves; tl_any_q4[2] += tris; tl_any_q4[3] += unverified;
 		if (!g->nodes[0].isleaf && found != (ref_result != 0)) tl_any_q4[4]++;

@@ -367,6 +367,7 @@ struct mipt_ctx {
 	const DQuadNode* d_quad_nodes = nullptr;   // four-wide 8-bit nodes of the order-free any-hit traversal (mipt_anyhit.h), one per fat node
 	const float* d_leaf_box = nullptr;         // the float box of every leaf, 32 bytes at its first triangle's index
 	size_t n_quad_nodes = 0;
+	bool anyhit_ordered_because_not_nested = false;   // the uploaded tree has a box outside its parent's: the any-hit stage keeps the ordered kernel
 	bool scene_has_ghost = false;     // a ghost object, a background photo or fog: rendered by the queue kernel (mipt_compositing.h)
 	const float* d_background = nullptr; int backgroundW = 0, backgroundH = 0;
 	struct { float density = 0, absorption = 0, density_decay = 0, absorption_decay = 0, phase_aniso = 0, ground_level = 0; int type = 0, phase_type = 0; } fog;
@@ -983,7 +984,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		}
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
 	}
-	c->d_quad_nodes = nullptr; c->d_leaf_box = nullptr;
+	c->d_quad_nodes = nullptr; c->d_leaf_box = nullptr; c->anyhit_ordered_because_not_nested = false;
 	for (int i = 0; i < s->n_objects; i++) H.obj[i].quad_root = H.obj[i].root_ref;
 	if (H.all_nodes && stg.nfat_total > 0 && stg.nt_total > 0) {
 		// the nodes of the any-hit stage (mipt_anyhit.h), derived on the device from the fat nodes wherever those came from: mark the fat
@@ -995,7 +996,12 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		auto cleanup = [&]() { hipFree(d_mark); hipFree(d_index); hipFree(d_bsum); hipFree(d_changed); };
 		if (hipMalloc((void**)&d_mark, nf * 4) != hipSuccess || hipMalloc((void**)&d_index, nf * 4) != hipSuccess || hipMalloc((void**)&d_bsum, (ntile + 1) * 4) != hipSuccess || hipMalloc((void**)&d_changed, 4) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "hipMalloc of the quad-node marks failed"); }
 		hipMemset(d_mark, 0, nf * 4);
+		hipMemset(d_changed, 0, 4);
+		hipLaunchKernelGGL(k_check_nesting, dim3(gb), dim3(256), 0, 0, H.all_nodes, nf, d_changed);
+		int not_nested = 0;
+		if (hipMemcpy(&not_nested, d_changed, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "checking the boxes of the tree failed: %s", hipGetErrorString(hipGetLastError())); }
 		const uint32_t one = 1;
+		if (not_nested) { cleanup(); c->anyhit_ordered_because_not_nested = true; goto quad_done; }      // a caller's tree whose boxes do not nest: the ordered any-hit kernel
 		for (int i = 0; i < s->n_objects; i++) if (H.obj[i].type == MIPT_OBJ_TRIMESH && !(H.obj[i].root_ref & MIPT_LEAF_BIT)) hipMemcpy(d_mark + H.obj[i].root_ref, &one, 4, hipMemcpyHostToDevice);
 		for (int pass = 0; pass <= MIPT_STACK_DEPTH; pass++) {
 			int changed = 0;
@@ -1028,6 +1034,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		c->d_quad_nodes = (const DQuadNode*)dw; c->d_leaf_box = (const float*)lb;
 		c->n_quad_nodes = nquad;
 	}
+quad_done:
 	for (int i = 0; i < s->n_objects; i++) {
 		DObject& d = H.obj[i];
 		if (d.type != MIPT_OBJ_TRIMESH) continue;

@@ -59,6 +59,25 @@ MIPT_DEV bool box_test_sorted(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mip
 // byte K of a word as a float (the compiler selects v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float quad_byte(uint32_t w) { return (float)((w >> (8 * K)) & 255u); }
 
+// The order-free traversal rests on boxes that NEST: every child's box inside its parent's, which is what TriMesh::build_bvh produces (a
+// node's box is the union of its triangles' boxes, TriangleMesh.cpp:843-858).  A tree handed in through the C ABI is the caller's: this
+// check runs over every inner node at upload; a scene with a box that sticks out of its parent's (or holds a NaN) keeps the ordered kernel.
+__global__ void k_check_nesting(const DFatNode* __restrict__ fat, size_t n, int* __restrict__ bad) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const DFatNode f = fat[i];
+	bool ok = true;
+	for (int side = 0; side < 2; side++) {
+		const uint32_t cref = side ? f.rref : f.lref;
+		const float (*cb)[2] = side ? f.r : f.l;
+		for (int a = 0; a < 3; a++) ok = ok && cb[a][0] <= cb[a][1];
+		if ((cref & MIPT_LEAF_BIT) || cref >= n) continue;
+		const DFatNode c = fat[cref];
+		for (int a = 0; a < 3; a++) ok = ok && c.l[a][0] >= cb[a][0] && c.l[a][1] <= cb[a][1] && c.r[a][0] >= cb[a][0] && c.r[a][1] <= cb[a][1];
+	}
+	if (!ok) *bad = 1;
+}
+
 // Which binary inner nodes become quad nodes: the roots, and from a quad node the inner ones among its (up to four) slots — every second
 // inner level of the tree, shifted wherever a leaf child shortens a side.  One pass marks the slots of the nodes marked so far; a tree of at
 // most MIPT_STACK_DEPTH inner levels needs MIPT_STACK_DEPTH / 2 passes (children follow their parents in the node array, so a pass often

@@ -1,3 +1,4 @@
-timeout 900 python -m pytest tests/test_progressive.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r5_n_tests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_n_tests.txt | tail -3
-python tools/progressive_rate.py 2>&1 | tail -1
-for l in 1 4 8 16; do python tools/progressive_rate.py progressive_lookahead=$l 2>&1 | tail -1; done
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r5_o_gputests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_o_gputests.txt | tail -3
+timeout 600 python tests/tools/fuzz_parity.py 200 7040 2>&1 | tail -1
+python tools/init_time.py c2 2>&1 | tail -2
+python tools/init_time.py c4 2>&1 | tail -2
