@@ -57,3 +57,20 @@ def test_stop_between_two_samples():
     rc, img, cnt, calls, seen = progressive(rt, 4, cancel_after=cfg.spp)      # raised in the last publish: the render is complete
     assert rc == capi.MIPT_OK
     assert_bits(img, full[1], "complete render")
+
+
+def test_publishes_of_the_contribution_queue_pipeline():
+    """A ghost floor over a background photo (pipeline 2: getColor's contribution queue as wavefront stages, its any-hit requests on the
+    order-free kernel): the publishes do not depend on the lookahead either."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import compositing_scene
+    rt = capi.HostRaytracer(device=0)
+    cfg = compositing_scene(rt, "both")
+    rc1, img1, cnt1, calls1, seen1 = progressive(rt, 1)
+    assert rc1 == capi.MIPT_OK and [c[0] for c in calls1] == list(range(1, cfg.spp + 1)) and rt.stats()["pipeline"] == 2
+    rc4, img4, cnt4, calls4, seen4 = progressive(rt, 4)
+    assert rc4 == capi.MIPT_OK and [c[0] for c in calls4] == list(range(1, cfg.spp + 1))
+    for (d1, i1, c1), (d2, i2, c2) in zip(seen1, seen4):
+        assert_bits(i2, i1, f"imagedouble at the publish of sample {d1}")
+    assert_bits(img4, img1, "final imagedouble"); assert_bits(cnt4, cnt1, "final sample_count")
