@@ -1,1 +1,3 @@
-timeout 900 python -m pytest tests/test_progressive.py -m gpu -x -q > gpurun_out/r5_p_tests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_p_tests.txt | tail -3; tail -15 gpurun_out/r5_p_tests.txt | head -12
+bash tools/tail_profile.sh 2>&1 | tail -3
+python tools/tail_profile.py c2 depth=1 2>&1 | tail -10
+python tools/tail_profile.py c2 depth=0 2>&1 | tail -10
