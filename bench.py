@@ -239,7 +239,10 @@ def main():
         # failure instead of falling back to peer copies: a first multi-GPU lease cannot silently measure the copy reduce)
         rt.set_option("reduce", 1)
     rt.apply_config(cfg)
-    rt.set_partition(32, rank, world)
+    # tiles of the partition: 32 x 32 pixels dealt round-robin; a 4K frame is dealt in 64-pixel tiles (a wave of the column-scan splat then lies inside one
+    # tile: all ranks probed on one GPU predict 7.50 instead of 7.29 at 8 GPUs on configs[4], profiles/r5_m_tile_size_32_vs_64_at_8_ranks.txt)
+    tile = 64 if args.width >= 3840 else 32
+    rt.set_partition(tile, rank, world)
     t0 = time.time()
     mesh_obj = rt.add_mesh(mesh)                 # TriMesh::init: axis swap, BVH (on the GPU), triangle soup, tangents
     t_build = time.time() - t0
@@ -341,7 +344,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_text}, {args.width}x{args.height}, {SPS * args.steps} spp timed ({SPS} spp/step), depth {cfg.nb_bounces}",
-                       "parallelism": f"tiles32x{job_gpus}" + (f", one process, mipt_create(n={rt.group_size()}) on devices {in_process}: {rt.group_reduce_kind()}" if in_process else (f", one process per GPU, {world} ranks, {args.backend} all-reduce of the framebuffers" + (" (RCCL)" if args.backend == "nccl" else "") if world > 1 else "")),
+                       "parallelism": f"tiles{tile}x{job_gpus}" + (f", one process, mipt_create(n={rt.group_size()}) on devices {in_process}: {rt.group_reduce_kind()}" if in_process else (f", one process per GPU, {world} ranks, {args.backend} all-reduce of the framebuffers" + (" (RCCL)" if args.backend == "nccl" else "") if world > 1 else "")),
                        "ranks_in_reduce": (rt.group_size() if in_process else world), "reduce": (rt.group_reduce_kind() if in_process else (args.backend + " all_reduce" if world > 1 else "none")),
                        "pipeline": int(pipeline)},
             "mpaths_per_s": paths / elapsed / 1e6, "rays_per_path": rays / max(1.0, paths),

@@ -1,3 +1,4 @@
-bash tools/tail_profile.sh 2>&1 | tail -3
-python tools/tail_profile.py c2 depth=1 2>&1 | tail -10
-python tools/tail_profile.py c2 depth=0 2>&1 | tail -10
+timeout 900 python -m pytest tests/test_bench_contract.py -m gpu -x -q > gpurun_out/r5_r_tests.txt 2>&1; grep -E "passed|failed|error|Error" gpurun_out/r5_r_tests.txt | tail -3; tail -30 gpurun_out/r5_r_tests.txt | grep -v "^$" | tail -12
+python -c "
+import __graft_entry__ as g
+g.smoke()"
