@@ -388,7 +388,15 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "pass_memory_limit" test hook: > 0 = size the pass as if only this many bytes were free (0 = ask the device)
  *   "samples_per_pass" > 0: a pass renders at most this many samples per pixel; with 1 and a progress callback
  *                     mipt_render behaves like the sample loop of Raytracer::render_image (the caller's buffers hold the
- *                     running sums after every sample) without paying an upload and an allocation per sample; 0 = off */
+ *                     running sums after every sample) without paying an upload and an allocation per sample; 0 = off
+ *   "progressive_lookahead" renders with a progress callback: publish groups rendered per pass (default 4, 1 .. 64); the caller still sees
+ *                     exactly the sums through the group it is told about, the snapshots of a pass travel while the next one renders
+ *   "anyhit_wide"     1 = shadow rays go through the order-free any-hit traversal over 8-bit four-wide nodes, with the rays whose answer
+ *                     could depend on the reference's visiting order replayed by the ordered kernel (default),
+ *                     0 = every shadow ray through the ordered kernel (same results).  Scenes whose uploaded tree does not nest use 0
+ *   "anyhit_flag_all" test hook: 1 = every occluded shadow ray is replayed in order
+ *   "device_mesh_as_remote" test hook: 1 = mipt_upload_scene treats a mipt_device_mesh of its own device as another device's
+ *                     (hipMemcpyPeer into its own buffers instead of reading the records in place): what the other members of a group do */
 int mipt_set_option(mipt_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -419,6 +419,7 @@ struct mipt_ctx {
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_anyhit_wide = 1;      // pipeline 1: the shadow stage as the order-free four-wide traversal (mipt_anyhit.h) + ordered replay of the rays it may not decide; 0 = the ordered kernel for every ray
+	int64_t opt_device_mesh_as_remote = 0;  // test hook: a device-resident mesh is treated as another device's (hipMemcpyPeer into this context's own buffers), so a one-GPU box runs what the members of a group run
 	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
 	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
 	unsigned grid_qanyhit = 0;        // ... of k_q_anyhit
@@ -644,6 +645,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_wide")) { c->opt_anyhit_wide = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "device_mesh_as_remote")) { c->opt_device_mesh_as_remote = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_flag_all")) { c->opt_anyhit_flag_all = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
@@ -683,7 +685,7 @@ static int upload_tex_list(mipt_ctx* c, const mipt_texture* list, int n, const D
 struct mipt_device_mesh;
 static int adopt_device_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, struct MeshStaging& stg);
 static int copy_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, DFatNode* dn, DTriIsect* dt, DTriShade* dsh, uint32_t node_base, uint32_t tri_base);
-static bool device_mesh_on(const mipt_device_mesh* dm, int device);
+static bool device_mesh_on(const mipt_device_mesh* dm, const mipt_ctx* c);
 static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFatNode** dn, const DTriIsect** dt, const DTriShade** dsh);
 
 // staging of all meshes' traversal records (one device buffer each)
@@ -959,7 +961,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	}
 	const DTriShade* all_shade = nullptr;
 	int rc;
-	if (stg.chunks.size() == 1 && stg.chunks[0].dev && device_mesh_on(stg.chunks[0].dev, c->device)) {
+	if (stg.chunks.size() == 1 && stg.chunks[0].dev && device_mesh_on(stg.chunks[0].dev, c)) {
 		// the scene's only mesh was built on this device: its records are used where they are (no second copy of 128 bytes per triangle
 		// + 64 per inner node; the scene holds a reference on the handle)
 		int rc2 = share_device_chunk(c, stg.chunks[0].dev, &H.all_nodes, &H.all_tris, &all_shade);

@@ -352,7 +352,7 @@ static int adopt_device_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshSt
 	if (has_uv) {
 		int rc;
 		if ((rc = upload(c, m->uvs, (size_t)m->n_uvs * 3, &d.uvs))) return rc;
-		const bool here = dm->device == c->device;
+		const bool here = dm->device == c->device && !c->opt_device_mesh_as_remote;
 		if (here) { dm->refs.fetch_add(1); c->scene_shared.push_back(dm); }          // the index triples and the tangents are read in place
 		if (here) d.uvidx = dm->d_uvidx;
 		else {
@@ -373,7 +373,7 @@ static int adopt_device_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshSt
 	}
 	return MIPT_OK;
 }
-static bool device_mesh_on(const mipt_device_mesh* dm, int device) { return dm->device == device; }
+static bool device_mesh_on(const mipt_device_mesh* dm, const mipt_ctx* c) { return dm->device == c->device && !c->opt_device_mesh_as_remote; }
 static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFatNode** dn, const DTriIsect** dt, const DTriShade** dsh) {
 	dm->refs.fetch_add(1);
 	c->scene_shared.push_back(dm);
@@ -382,7 +382,7 @@ static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFa
 }
 static int copy_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, DFatNode* dn, DTriIsect* dt, DTriShade* dsh, uint32_t node_base, uint32_t tri_base) {
 	const size_t nfat = (size_t)std::max(dm->nfat, 1), nt = (size_t)dm->ntri;
-	const bool same = dm->device == c->device;
+	const bool same = dm->device == c->device && !c->opt_device_mesh_as_remote;
 	auto copy = [&](void* dst, const void* src, size_t bytes) { return same ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, c->device, src, dm->device, bytes); };
 	HIPCHK(c, copy(dt, dm->d_ti, nt * sizeof(DTriIsect)));
 	HIPCHK(c, copy(dsh, dm->d_ts, nt * sizeof(DTriShade)));

@@ -170,6 +170,31 @@ def test_device_made_records_render_like_host_made_ones(name):
     assert np.array_equal(out[True].view(np.uint32), out[False].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,devices", [("textured", 0), ("cutout", 0), ("merl", 0), ("textured", [0, 0])])
+def test_device_resident_mesh_replicated_with_peer_copies(name, devices):
+    """What the other members of a group do with a mesh that was built on member 0's device: hipMemcpyPeer of the records, the index
+    triples and the tangents into their own buffers (csrc/mipt_mesh_device.h).  A one-GPU box has no other device, so the option
+    device_mesh_as_remote makes a context treat its own device's mesh as a remote one (a peer copy within one device is legal HIP);
+    the scene must render exactly like the one that reads the records in place — alone and as a group of two."""
+    from make_golden import golden_scene
+    out = {}
+    for remote in (0, 1):
+        H = capi.HostRaytracer(device=devices)
+        mesh, cfg, mat = golden_scene(name)
+        H.apply_config(cfg)
+        oid = H.add_mesh(mesh)
+        assert H.mesh_on_device(oid)
+        scenes.install_material(H, oid, mat)
+        H.set_option("device_mesh_as_remote", remote)
+        H.prepare()
+        if isinstance(devices, list):
+            out[remote] = np.concatenate([a.reshape(-1) for a in H.render()])
+        else:
+            pix = np.stack(np.meshgrid(np.arange(0, cfg.H, 3), np.arange(0, cfg.W, 3), indexing="ij"), -1).reshape(-1, 2).astype(np.int32)
+            out[remote] = H.sample_radiance(pix, 0, min(cfg.spp, 4))[0]
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 def test_device_tangents_are_the_host_loop_s():
     """setup_tangents on the device (per-vertex sums in ascending face order, a UV sphere's poles with a thousand incident faces)
     against the host loop, bit for bit, through the lazily downloaded tangentSoup."""
