@@ -11,7 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_model_reproduces_its_committed_output():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traversal_time_model.py")], capture_output=True, text=True, check=True).stdout
     committed = open(os.path.join(ROOT, "profiles", "r5_traversal_time_model.txt")).read()
-    assert out.strip() == committed.strip()
+    # the fit is arithmetic on constants in the tool: verbatim.  The out-of-sample part reads the closing record's counter files, which are
+    # re-taken whenever the library changes (tools/refresh_counters.sh): checked by its numbers below, not by its text
+    cut = "out of sample:"
+    assert out.split(cut)[0].strip() == committed.split(cut)[0].strip() and cut in out and cut in committed
     m = re.search(r"ts = ([\d.]+) ns .* tv = ([\d.]+) ns .* Z = (\d+) ns per step; rms error ([\d.]+) %", out)
     assert m, out.splitlines()[0]
     ts, tv, z, rms = float(m.group(1)), float(m.group(2)), int(m.group(3)), float(m.group(4))
