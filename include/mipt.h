@@ -379,6 +379,8 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     through a fast tier first and the general build takes what it leaves (default), 0 = general build only (same results)
  *   "reduce"          groups only: 0 = RCCL when its communicators exist (default; a reduce that cannot be enqueued falls back to 2 and
  *                     mipt_group_reduce_kind says why), 1 = RCCL or fail, 2 = device copies + adds
+ *   "resolve_packed"  ranks of a tile partition: 1 = a wave of the column-scan splat takes 64 columns that receive something from this rank's
+ *                     pixels (default), 0 = 64 adjacent columns of the frame, of which a rank of 8 owns 32 at most (same results)
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather
  *                     kernel, which is also what filter radii other than 1 and 2 use).  Both add in the reference's order
  *   "invalidate_tables" 1 = the prepare_render tables were modified in place: upload them again

@@ -222,9 +222,14 @@ __global__ void __launch_bounds__(256) k_resolve(DRender R, DPass ps, DSamples i
 template <int FS>
 __global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSamples in, float denom2, int rows, float* __restrict__ accum_out, int zs, float* __restrict__ partial) {
 	const int W = R.W, H = R.H, ftw = 2 * FS + 1;
-	const int j2 = blockIdx.x * blockDim.x + threadIdx.x;
+	int jx = blockIdx.x * blockDim.x + threadIdx.x;
 	const int r0 = blockIdx.y * rows, r1 = min(H, r0 + rows);          // destination rows [r0, r1)
-	if (j2 >= W) return;
+	if (ps.scan_off) {        // a rank of a partition: only the columns of this band that receive anything, packed (with 32-pixel tiles dealt round-robin a wave of 64 adjacent columns would hold one owned tile at most)
+		const int o = ps.scan_off[blockIdx.y], n = ps.scan_off[blockIdx.y + 1] - o;
+		if (jx >= n) return;
+		jx = ps.scan_cols[o + jx];
+	} else if (jx >= W) return;
+	const int j2 = jx;
 	const int nk_all = ps.k1 - ps.k0;
 	const int ka = zs > 1 ? (int)((long long)nk_all * blockIdx.z / zs) : 0, kb = zs > 1 ? (int)((long long)nk_all * (blockIdx.z + 1) / zs) : nk_all;
 	const size_t npx = (size_t)W * H;
@@ -292,6 +297,20 @@ __global__ void __launch_bounds__(64) k_resolve_scan(DRender R, DPass ps, DSampl
 	}
 }
 
+
+// the same sum over the destination pixels of a rank only (the packed column scan writes its partial images there and nowhere else)
+__global__ void __launch_bounds__(256) k_resolve_sum_dest(float* __restrict__ accum, const float* __restrict__ partial, int zs, int W, int H, const int* __restrict__ dest, int ndest) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= ndest) return;
+	const int pid = dest[idx], i2 = pid / W, j2 = pid % W;
+	const size_t npx = (size_t)W * H, d = (size_t)(H - i2 - 1) * W + j2;
+	for (int ch = 0; ch < 4; ch++) {
+		const size_t e = ch < 3 ? 3 * d + ch : 3 * npx + d;
+		float a = accum[e];
+		for (int z = 0; z < zs; z++) a += partial[(size_t)z * 4 * npx + e];
+		accum[e] = a;
+	}
+}
 
 __global__ void __launch_bounds__(256) k_resolve_sum(float* __restrict__ accum, const float* __restrict__ partial, int zs, size_t n) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,8 +426,9 @@ struct mipt_ctx {
 	// cache keys of the uploaded per-render tables / block lists (re-uploaded when any address or
 	// size changes, or after mipt_set_option("invalidate_tables", 1))
 	struct { const void *fi = nullptr, *s2 = nullptr, *rpp = nullptr; int W = 0, H = 0, nrays = 0, fs = -1; float sigma = 0.f; uint64_t fi_hash = 0; } tab_key;
-	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0, fs = -1; } blk_key;
+	struct { int W = 0, H = 0, ts = 0, rk = -1, nr = 0, fs = -1, rows = -1; } blk_key;
 	int blk_ndest = 0;
+	int blk_scan_bands = 0, blk_scan_ncols = 0, blk_scan_max = 0;      // packed column lists of the column-scan splat (ranks of a partition)
 	int blk_nblocks = 0;
 	uint64_t blk_valid_pixels = 0;
 	int64_t opt_pipeline = 1;
@@ -419,6 +439,7 @@ struct mipt_ctx {
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_anyhit_wide = 1;      // pipeline 1: the shadow stage as the order-free four-wide traversal (mipt_anyhit.h) + ordered replay of the rays it may not decide; 0 = the ordered kernel for every ray
+	int64_t opt_resolve_packed = 1;    // ranks of a partition: the column-scan splat visits only the columns that receive something, 64 of them per wave
 	int64_t opt_device_mesh_as_remote = 0;  // test hook: a device-resident mesh is treated as another device's (hipMemcpyPeer into this context's own buffers), so a one-GPU box runs what the members of a group run
 	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
 	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
@@ -645,6 +666,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_wide")) { c->opt_anyhit_wide = value != 0; return MIPT_OK; }
+	if (!strcmp(name, "resolve_packed")) { c->opt_resolve_packed = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "device_mesh_as_remote")) { c->opt_device_mesh_as_remote = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_flag_all")) { c->opt_anyhit_flag_all = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
@@ -1250,7 +1272,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (kb < 0 || ke > p->nrays || kb > ke) return fail(c, MIPT_ERR_INVALID, "sample range outside [0,nrays]");
 	{
 		int ts = p->tile_size > 0 ? p->tile_size : 32, nr = p->tile_nranks > 0 ? p->tile_nranks : 1;
-		const bool cached = c->blk_buf && c->blk_key.W == p->W && c->blk_key.H == p->H && c->blk_key.ts == ts && c->blk_key.rk == p->tile_rank && c->blk_key.nr == nr && c->blk_key.fs == p->filter_size;
+		const int scan_rows = (int)c->opt_resolve_rows;
+		const bool cached = c->blk_buf && c->blk_key.W == p->W && c->blk_key.H == p->H && c->blk_key.ts == ts && c->blk_key.rk == p->tile_rank && c->blk_key.nr == nr && c->blk_key.fs == p->filter_size && c->blk_key.rows == scan_rows;
 		if (!cached) {
 			std::vector<int> blocks, pix2slot;
 			if ((rc = build_blocks(c, p, blocks, pix2slot))) return rc;
@@ -1270,13 +1293,34 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				}
 			}
 			c->blk_ndest = (int)dest.size();
-			size_t blk_bytes = (blocks.size() + pix2slot.size() + dest.size()) * sizeof(int);
+			// the column-scan splat of a rank: per band of `rows` destination rows, the columns that hold a destination pixel
+			std::vector<int> scan_off, scan_cols;
+			c->blk_scan_bands = c->blk_scan_max = 0;
+			if (nr > 1 && scan_rows > 0) {
+				const int W = p->W, H = p->H, nb = (H + scan_rows - 1) / scan_rows;
+				std::vector<unsigned char> has((size_t)nb * W, 0);
+				for (int pid : dest) has[(size_t)(pid / W / scan_rows) * W + pid % W] = 1;
+				scan_off.push_back(0);
+				for (int b = 0; b < nb; b++) {
+					for (int j = 0; j < W; j++) if (has[(size_t)b * W + j]) scan_cols.push_back(j);
+					c->blk_scan_max = std::max(c->blk_scan_max, (int)scan_cols.size() - scan_off.back());
+					scan_off.push_back((int)scan_cols.size());
+				}
+				c->blk_scan_bands = nb;
+			}
+			c->blk_scan_ncols = (int)scan_cols.size();
+			size_t blk_bytes = (blocks.size() + pix2slot.size() + dest.size() + scan_off.size() + scan_cols.size()) * sizeof(int);
 			if ((rc = ensure(c, &c->blk_buf, &c->blk_buf_bytes, blk_bytes))) return rc;
+			if (!scan_off.empty()) {
+				int* sp = (int*)c->blk_buf + blocks.size() + pix2slot.size() + dest.size();
+				HIPCHK(c, hipMemcpyAsync(sp, scan_off.data(), scan_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
+				if (!scan_cols.empty()) HIPCHK(c, hipMemcpyAsync(sp + scan_off.size(), scan_cols.data(), scan_cols.size() * sizeof(int), hipMemcpyHostToDevice, st));
+			}
 			if (!dest.empty()) HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size() + pix2slot.size(), dest.data(), dest.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(c->blk_buf, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			HIPCHK(c, hipMemcpyAsync((int*)c->blk_buf + blocks.size(), pix2slot.data(), pix2slot.size() * sizeof(int), hipMemcpyHostToDevice, st));
 			HIPCHK(c, hipStreamSynchronize(st));
-			c->blk_key.W = p->W; c->blk_key.H = p->H; c->blk_key.ts = ts; c->blk_key.rk = p->tile_rank; c->blk_key.nr = nr; c->blk_key.fs = p->filter_size;
+			c->blk_key.W = p->W; c->blk_key.H = p->H; c->blk_key.ts = ts; c->blk_key.rk = p->tile_rank; c->blk_key.nr = nr; c->blk_key.fs = p->filter_size; c->blk_key.rows = scan_rows;
 		}
 	}
 	const int nblocks = c->blk_nblocks;
@@ -1392,6 +1436,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	DPass P;
 	P.nblocks = nblocks; P.blocks = (const int*)c->blk_buf; P.pix2slot = (const int*)c->blk_buf + 2 * (size_t)nblocks; P.npix_slots = npix_slots;
 	P.ndest = c->blk_ndest; P.dest = c->blk_ndest ? P.pix2slot + (size_t)p->W * p->H : nullptr;
+	P.scan_off = c->blk_scan_bands && P.dest ? P.dest + P.ndest : nullptr;
+	P.scan_cols = P.scan_off ? P.scan_off + c->blk_scan_bands + 1 : nullptr;
 	const long long resolve_threads = P.dest ? (long long)P.ndest : (long long)R.W * R.H;
 	c->kev_kind.clear();
 	unsigned nev = 0;
@@ -1672,11 +1718,14 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 				if (rc2) return rc2;
 				partial = (float*)c->resolve_buf;
 			}
-			const dim3 sgrid((unsigned)((R.W + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)), (unsigned)zs);
+			const bool packed = Pr.scan_off != nullptr && rows > 0 && c->opt_resolve_packed;          // (the lists were made for this `rows`: it is part of their cache key)
+			if (!packed) { Pr.scan_off = nullptr; Pr.scan_cols = nullptr; }
+			const dim3 sgrid((unsigned)(((packed ? std::max(c->blk_scan_max, 1) : R.W) + 63) / 64), (unsigned)((R.H + std::max(rows, 1) - 1) / std::max(rows, 1)), (unsigned)zs);
 			if (rows > 0 && R.filter_size == 1) hipLaunchKernelGGL(k_resolve_scan<1>, sgrid, dim3(64), 0, st, R, Pr, Sr, denom2, rows, d_accum, zs, partial);
 			else if (rows > 0 && R.filter_size == 2) hipLaunchKernelGGL(k_resolve_scan<2>, sgrid, dim3(64), 0, st, R, Pr, Sr, denom2, rows, d_accum, zs, partial);
 			else hipLaunchKernelGGL(k_resolve, dim3((unsigned)((resolve_threads + 255) / 256)), dim3(256), 0, st, R, Pr, Sr, denom2, d_accum);
-			if (zs > 1) { const size_t n4 = 4 * (size_t)R.W * R.H; hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d_accum, (const float*)partial, zs, n4); }
+			if (zs > 1 && packed) hipLaunchKernelGGL(k_resolve_sum_dest, dim3((unsigned)((Pr.ndest + 255) / 256)), dim3(256), 0, st, d_accum, (const float*)partial, zs, R.W, R.H, Pr.dest, Pr.ndest);
+			else if (zs > 1) { const size_t n4 = 4 * (size_t)R.W * R.H; hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d_accum, (const float*)partial, zs, n4); }
 			if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 			return MIPT_OK;
 		};

@@ -142,4 +142,6 @@ struct DPass {
 	int npix_slots;            // nblocks * 64
 	const int* dest;           // pixels that receive a splat from an owned pixel (owned pixels dilated by the
 	int ndest;                 // filter radius), or null = every pixel of the image (single rank)
+	const int* scan_off;       // ranks of a partition, column-scan splat: the destination columns of band b that hold a pixel of `dest` are
+	const int* scan_cols;      // scan_cols[scan_off[b] .. scan_off[b + 1]) (a wave then scans 64 columns WITH work); null = every column
 };

@@ -368,6 +368,26 @@ def test_partition_rank_splat_slices_are_deterministic():
     assert frames[0][0] == frames[0][1]
 
 
+@pytest.mark.parametrize("tile,nranks,slices,rows", [(8, 4, 0, 12), (16, 8, 0, 12), (32, 3, 0, 12), (8, 4, 1, 12), (8, 5, 3, 5), (16, 2, 0, 0)])
+def test_partition_rank_splat_packed_columns_change_nothing(tile, nranks, slices, rows):
+    """Round 5: a wave of a rank's column-scan splat takes 64 columns that receive something from the rank's pixels (option
+    resolve_packed, default) instead of 64 adjacent columns of the frame.  Every destination pixel still gets its terms in the same
+    order from the same slices: the partial frame of every rank is the unpacked kernel's bit for bit — pixels the rank does not reach
+    included (they stay what they were) —, with and without slices, for band heights that do and do not divide the tiles, and
+    with the per-pixel gather kernel (rows = 0), which has no columns to pack."""
+    for rank in range(nranks):
+        out = {}
+        for packed in (1, 0):
+            r = capi.HostRaytracer(device=0)
+            r.set_partition(tile, rank, nranks)
+            setup_scene(r, "blob32")
+            r.set_option("resolve_slices", slices)
+            r.set_option("resolve_rows", rows)
+            r.set_option("resolve_packed", packed)
+            out[packed] = r.render()
+        assert np.array_equal(out[1][0].view(np.uint32), out[0][0].view(np.uint32)) and np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32)), rank
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_object_table_full_and_one_too_many(pipeline):
     """The scene table holds MIPT_MAX_OBJECTS = 31 objects (csrc/mipt_scene.h: the 5 bits a hit record has for the object, minus the
