@@ -359,7 +359,7 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "merge_traverse"  pipeline 1: 1 = the shadow rays of depth b and the closest-hit rays of depth b+1 share one
  *                     launch of the traversal kernel, 0 = one launch per queue (default; measured equal)
  *   "resolve_slices"  ranks of a tile partition: the splat of a pass runs in this many slices along the sample index, summed in slice
- *                     order (0 = default: 1 / owned fraction of the frame, at most 8; 1 = the single-rank kernel form)
+ *                     order (0 = default: 3 / owned fraction of the frame, at most 24 — measured on configs[2] at 4 and 8 ranks; 1 = the single-rank kernel form)
  *   "sort_rays"       pipeline 1: 1 = the closest-hit queue of every depth >= 1 is reordered by direction octant before it is
  *                     traversed (a measured negative, DESIGN.md §4: -11 %; same results), 0 = path-id order (default)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only

@@ -1711,7 +1711,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const int rows = (int)c->opt_resolve_rows;
 			// a rank of a partition: the pass's samples in slices along the sample index (see k_resolve_scan)
 			const int share = (int)std::min<uint64_t>(64, (uint64_t)R.W * (uint64_t)R.H / std::max<uint64_t>(1, c->blk_valid_pixels));     // 1 / (owned fraction of the frame)
-			const int zs = ((share > 1 || c->opt_resolve_slices > 1) && rows > 0 && (R.filter_size == 1 || R.filter_size == 2)) ? std::max(1, std::min((int)c->opt_resolve_slices > 0 ? (int)c->opt_resolve_slices : std::min(share, 8), b - a)) : 1;
+			const int zs = ((share > 1 || c->opt_resolve_slices > 1) && rows > 0 && (R.filter_size == 1 || R.filter_size == 2)) ? std::max(1, std::min((int)c->opt_resolve_slices > 0 ? (int)c->opt_resolve_slices : std::min(3 * share, 24), b - a)) : 1;
 			float* partial = nullptr;
 			if (zs > 1) {
 				int rc2 = ensure(c, &c->resolve_buf, &c->resolve_buf_bytes, (size_t)zs * 4 * (size_t)R.W * R.H * sizeof(float));
