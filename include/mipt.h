@@ -379,10 +379,6 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *                     through a fast tier first and the general build takes what it leaves (default), 0 = general build only (same results)
  *   "reduce"          groups only: 0 = RCCL when its communicators exist (default; a reduce that cannot be enqueued falls back to 2 and
  *                     mipt_group_reduce_kind says why), 1 = RCCL or fail, 2 = device copies + adds
- *   "overlap_anyhit"  pipeline 1: the any-hit launch of depth b runs beside the closest-hit launch of depth b + 1 on a second stream of the
- *                     library (both follow shade(b) and share no data; shade(b + 1) waits for both): -1 = for ranks of a tile
- *                     partition only (default: their launches are an eighth of a frame's and a launch's drain weighs 2 %), 0 = never,
- *                     1 = always (same results; the stage times of mipt_stats then overlap and no longer add up to the render time)
  *   "resolve_packed"  ranks of a tile partition: 1 = a wave of the column-scan splat takes 64 columns that receive something from this rank's
  *                     pixels (default), 0 = 64 adjacent columns of the frame, of which a rank of 8 owns 32 at most (same results)
  *   "resolve_rows"    splat kernel: destination rows per band of the column-scan kernel (default 12; 0 = the per-pixel gather

@@ -439,8 +439,6 @@ struct mipt_ctx {
 	int64_t opt_resolve_slices = 0;   // ranks of a partition: slices of the splat along the sample index (0 = 1 / owned fraction of the frame, at most 8)
 	int64_t opt_sort_rays = 0;        // pipeline 1: the closest-hit queue of depth >= 1 reordered by direction octant (stable counting sort)
 	int64_t opt_anyhit_wide = 1;      // pipeline 1: the shadow stage as the order-free four-wide traversal (mipt_anyhit.h) + ordered replay of the rays it may not decide; 0 = the ordered kernel for every ray
-	int64_t opt_overlap_anyhit = -1;   // pipeline 1: the any-hit launch of depth b runs beside the closest-hit launch of depth b + 1 on a second stream (each fills the other's drain); -1 = for ranks of a partition only (their launches are small), 0 / 1 = never / always
-	hipStream_t aux_stream = nullptr; hipEvent_t ev_shaded = nullptr, ev_anyhit = nullptr;
 	int64_t opt_resolve_packed = 1;    // ranks of a partition: the column-scan splat visits only the columns that receive something, 64 of them per wave
 	int64_t opt_device_mesh_as_remote = 0;  // test hook: a device-resident mesh is treated as another device's (hipMemcpyPeer into this context's own buffers), so a one-GPU box runs what the members of a group run
 	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
@@ -627,9 +625,6 @@ extern "C" void mipt_destroy(mipt_ctx* c) {
 	if (c->resolve_buf) hipFree(c->resolve_buf);
 	if (c->snap_buf) hipFree(c->snap_buf);
 	if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-	if (c->aux_stream) hipStreamDestroy(c->aux_stream);
-	if (c->ev_shaded) hipEventDestroy(c->ev_shaded);
-	if (c->ev_anyhit) hipEventDestroy(c->ev_anyhit);
 	if (c->ev_pub) hipEventDestroy(c->ev_pub);
 	free_scene(c);
 	if (c->pass_buf) hipFree(c->pass_buf);
@@ -671,7 +666,6 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "resolve_slices")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "resolve_slices must be in [0,64]"); c->opt_resolve_slices = value; return MIPT_OK; }
 	if (!strcmp(name, "sort_rays")) { c->opt_sort_rays = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_wide")) { c->opt_anyhit_wide = value != 0; return MIPT_OK; }
-	if (!strcmp(name, "overlap_anyhit")) { if (value < -1 || value > 1) return fail(c, MIPT_ERR_INVALID, "overlap_anyhit must be -1, 0 or 1"); c->opt_overlap_anyhit = value; return MIPT_OK; }
 	if (!strcmp(name, "resolve_packed")) { c->opt_resolve_packed = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "device_mesh_as_remote")) { c->opt_device_mesh_as_remote = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "anyhit_flag_all")) { c->opt_anyhit_flag_all = value != 0; return MIPT_OK; }
@@ -1447,13 +1441,12 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	const long long resolve_threads = P.dest ? (long long)P.ndest : (long long)R.W * R.H;
 	c->kev_kind.clear();
 	unsigned nev = 0;
-	hipStream_t tst = st;              // the stream the timed launches go to (the any-hit launches of an overlapped pass: aux_stream)
 	auto timed_begin = [&](int kind) -> int {
 		while (c->kev.size() < 2 * (size_t)(nev + 1)) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MIPT_ERR_HIP; c->kev.push_back(e); }
 		c->kev_kind.push_back(kind);
-		return hipEventRecord(c->kev[2 * nev], tst) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP;
+		return hipEventRecord(c->kev[2 * nev], st) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP;
 	};
-	auto timed_end = [&]() -> int { int r = hipEventRecord(c->kev[2 * nev + 1], tst) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP; nev++; return r; };
+	auto timed_end = [&]() -> int { int r = hipEventRecord(c->kev[2 * nev + 1], st) == hipSuccess ? MIPT_OK : MIPT_ERR_HIP; nev++; return r; };
 	const unsigned persistent_blocks = (unsigned)c->n_cus * 8u;   // >= resident capacity of every stage kernel
 	// a persistent stage kernel is launched with exactly the blocks that can be resident (its waves take their first
 	// chunk statically: a block that only starts when another one has finished would hold its chunk back until then)
@@ -1661,16 +1654,6 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 			const float4* d_nodes = (const float4*)c->d_all_nodes;
 			const int thr = (int)c->opt_refill_threshold, imin = (int)(c->opt_inner_min & 0xffff) | (c->opt_literal_slab ? 0x10000 : 0) | ((int)(c->opt_lane_limit & 127) << 17);
 			unsigned* const list_mem[2] = {wf.list[0], wf.list[1]};
-			// Overlap: any-hit(b) and extend(b + 1) both follow shade(b) and touch nothing of each other (shadow requests + colours against rays +
-			// hit records; the replay list of any-hit(b) is the consumed queue of depth b, extend(b + 1) reads the other one); shade(b + 1)
-			// rewrites the shadow requests and may add to a colour, so it waits for both.  Each launch's waves fill the other's drain.
-			const bool overlap = !merge && c->opt_refill && p->nb_bounces > 1 && (c->opt_overlap_anyhit == 1 || (c->opt_overlap_anyhit < 0 && p->tile_nranks > 1));
-			if (overlap && !c->aux_stream) {
-				HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-				HIPCHK(c, hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming));
-				HIPCHK(c, hipEventCreateWithFlags(&c->ev_anyhit, hipEventDisableTiming));
-			}
-			bool anyhit_pending = false;
 			for (int b = 0; b < p->nb_bounces; b++) {
 				if (c->opt_sort_rays && !merge && b > 0) {                // reorder the closest-hit queue of this depth (written by shade(b-1))
 					if (timed_begin(0)) return fail(c, MIPT_ERR_HIP, "event record failed");
@@ -1689,7 +1672,6 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
 				}
-				if (anyhit_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_anyhit, 0)); anyhit_pending = false; }
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (c->opt_fast_shade) {
 					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(1), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
@@ -1698,15 +1680,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					else hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(2), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
-				hipStream_t sst = st;          // the stream of this depth's any-hit launches
-				if (overlap && b + 1 < p->nb_bounces) {
-					HIPCHK(c, hipEventRecord(c->ev_shaded, st));
-					HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_shaded, 0));
-					sst = c->aux_stream;
-				}
-				tst = sst;
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, sst, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
+				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);
 				else if (c->opt_refill && c->opt_anyhit_wide && c->d_quad_nodes) {
 					// order-free four-wide traversal, then the ordered kernel over the (normally empty) list of rays it may not decide; the list is
 					// the closest-hit queue of this depth, which shade(b) has consumed
@@ -1716,19 +1691,16 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 						c->grid_anyhit = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
 					}
 					const dim3 ga(std::min(c->grid_anyhit, (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
-					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, sst, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, b, list_mem[b & 1], &c->d_cnt[0]._pad[0], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
+					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, b, list_mem[b & 1], &c->d_cnt[0]._pad[0], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
 					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false; rq.valid_in_ray = false;
 					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
-					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, sst, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
+					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
 				}
-				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, sst, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
-				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, sst, c->d_scene, wf, b);
+				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
+				else hipLaunchKernelGGL(k_wf_shadow, G(7), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, b);
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
-				tst = st;
-				if (sst != st) { HIPCHK(c, hipEventRecord(c->ev_anyhit, sst)); anyhit_pending = true; }
 				wf.list[b & 1] = list_mem[b & 1];
 			}
-			if (anyhit_pending) HIPCHK(c, hipStreamWaitEvent(st, c->ev_anyhit, 0));
 			c->stats.traverse_merged = merge ? 1u : 0u;
 		}
 		// the splat of samples [a, b) of this pass into the accumulators

@@ -368,29 +368,6 @@ def test_partition_rank_splat_slices_are_deterministic():
     assert frames[0][0] == frames[0][1]
 
 
-@pytest.mark.parametrize("name", ["blob32", "glossy", "glass", "textured", "cutout", "merl"])
-def test_anyhit_beside_the_next_depth_s_extend_changes_nothing(name):
-    """Option overlap_anyhit (default: on for ranks of a partition): the any-hit launch of depth b on a second stream beside the closest-hit
-    launch of depth b + 1.  Same frame bit for bit, whole and as ranks, one pass and several, against the reference golden."""
-    g = load_golden(f"scene_{name}.npz")
-    out = {}
-    for ov in (0, 1):
-        r = capi.HostRaytracer(device=0)
-        mesh, cfg, oid = setup_scene(r, name)
-        r.set_option("overlap_anyhit", ov)
-        a = r.render()
-        slots = ((cfg.W + 7) // 8) * ((cfg.H + 7) // 8) * 64
-        r.set_option("pass_memory_limit", int((2.5 * slots * 160 + 240000) / 0.8))          # about two samples per pixel and pass
-        b = r.render()
-        assert r.stats()["passes"] > 1
-        r.set_option("pass_memory_limit", 0)
-        r.set_partition(8, 1, 3)
-        out[ov] = (a, b, r.render())
-    for x, y in zip(out[0], out[1]):
-        assert np.array_equal(x[0].view(np.uint32), y[0].view(np.uint32)) and np.array_equal(x[1].view(np.uint32), y[1].view(np.uint32))
-    assert np.abs(normalised(*out[1][0]) - normalised(g["image"], g["count"])).max() < 1e-5
-
-
 @pytest.mark.parametrize("tile,nranks,slices,rows", [(8, 4, 0, 12), (16, 8, 0, 12), (32, 3, 0, 12), (8, 4, 1, 12), (8, 5, 3, 5), (16, 2, 0, 0)])
 def test_partition_rank_splat_packed_columns_change_nothing(tile, nranks, slices, rows):
     """Round 5: a wave of a rank's column-scan splat takes 64 columns that receive something from the rank's pixels (option
