@@ -239,9 +239,9 @@ def main():
         # failure instead of falling back to peer copies: a first multi-GPU lease cannot silently measure the copy reduce)
         rt.set_option("reduce", 1)
     rt.apply_config(cfg)
-    # tiles of the partition: 32 x 32 pixels dealt round-robin; a 4K frame is dealt in 64-pixel tiles (a wave of the column-scan splat then lies inside one
-    # tile: all ranks probed on one GPU predict 7.50 instead of 7.29 at 8 GPUs on configs[4], profiles/r5_m_tile_size_32_vs_64_at_8_ranks.txt)
-    tile = 64 if args.width >= 3840 else 32
+    # tiles of the partition: 32 x 32 pixels dealt round-robin (the library's default; since the splat of a rank packs the columns it reaches,
+    # larger tiles buy nothing: all ranks probed on one GPU predict 7.69 at 8 GPUs on configs[4], 7.50 with the 64-pixel tiles used before)
+    tile = 32
     rt.set_partition(tile, rank, world)
     t0 = time.time()
     mesh_obj = rt.add_mesh(mesh)                 # TriMesh::init: axis swap, BVH (on the GPU), triangle soup, tangents
