@@ -388,6 +388,37 @@ def test_partition_rank_splat_packed_columns_change_nothing(tile, nranks, slices
         assert np.array_equal(out[1][0].view(np.uint32), out[0][0].view(np.uint32)) and np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32)), rank
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_partition_rank_splat_packed_columns_on_random_partitions(seed):
+    """The same comparison on frames whose sides are not multiples of anything (8-pixel blocks, tiles and bands stick out of the image),
+    both filter radii the column scan is built for (sigma 0.5 -> 1 pixel, sigma 1.0 -> 2 pixels), random tile sizes, rank counts, band
+    heights and slice counts: every rank's partial frame equals the unpacked kernel's bit for bit, and the ranks add up to the whole frame."""
+    rng = np.random.default_rng(100 + seed)
+    W, H = int(rng.integers(33, 150)), int(rng.integers(17, 90))
+    tile, nranks = int(rng.choice([8, 16, 24, 32, 40])), int(rng.integers(2, 9))
+    rows, slices = int(rng.choice([3, 7, 12, 16, 32])), int(rng.choice([0, 0, 1, 2, 5]))
+    cfg = scenes.config_c1(W, H, 6)
+    cfg.sigma_filter = float(rng.choice([0.5, 1.0]))
+    mesh = scenes.blob_mesh(12)
+    one = capi.HostRaytracer(device=0)
+    one.apply_config(cfg); one.add_mesh(mesh); one.prepare()
+    img1, cnt1 = one.render()
+    acc_i, acc_c = np.zeros_like(img1), np.zeros_like(cnt1)
+    for rank in range(nranks):
+        out = {}
+        for packed in (1, 0):
+            r = capi.HostRaytracer(device=0)
+            r.set_partition(tile, rank, nranks)
+            r.apply_config(cfg); r.add_mesh(mesh); r.prepare()
+            r.set_option("resolve_slices", slices); r.set_option("resolve_rows", rows); r.set_option("resolve_packed", packed)
+            out[packed] = r.render()
+        what = (W, H, tile, nranks, rows, slices, cfg.sigma_filter, rank)
+        assert np.array_equal(out[1][0].view(np.uint32), out[0][0].view(np.uint32)) and np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32)), what
+        acc_i += out[1][0]; acc_c += out[1][1]
+    np.testing.assert_allclose(acc_c, cnt1, rtol=1e-5)
+    assert np.abs(normalised(acc_i, acc_c) - normalised(img1, cnt1)).max() < 1e-5
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_object_table_full_and_one_too_many(pipeline):
     """The scene table holds MIPT_MAX_OBJECTS = 31 objects (csrc/mipt_scene.h: the 5 bits a hit record has for the object, minus the
