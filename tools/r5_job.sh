@@ -1,5 +1,5 @@
-S=r5_s
-timeout 1500 python tests/tools/fuzz_parity.py 1000 9101 > gpurun_out/${S}_fuzz_parity_1000_scenes.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_1000_scenes.txt
-timeout 1500 python tests/tools/fuzz_parity.py 500 9102 --queue > gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt
-timeout 1500 python tests/tools/fuzz_parity.py 300 9103 --queue --spheres > gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt
-timeout 1500 python tests/tools/fuzz_parity.py 200 9104 --kind=merl --merl-tiers --spheres > gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt
+S=r5_u
+timeout 1500 python tests/tools/fuzz_parity.py 1000 9201 > gpurun_out/${S}_fuzz_parity_1000_scenes.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_1000_scenes.txt
+timeout 1500 python tests/tools/fuzz_parity.py 500 9202 --queue > gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt
+timeout 1500 python tests/tools/fuzz_parity.py 300 9203 --queue --spheres > gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt
+timeout 1500 python tests/tools/fuzz_parity.py 200 9204 --kind=merl --merl-tiers --spheres > gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt
