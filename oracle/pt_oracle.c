@@ -517,12 +517,21 @@ static int mesh_intersection(const o_obj* o, const o_ray* d, v3* P, float* t, o_
      [18] rays that passed a box with t_box >= 0.998 dist (the only ones whose result can depend on the order)
      [19] of those, rays that found an occluder (they are replayed in the reference's order)
      [20] max stack depth of the four-wide walk  [21] four-wide slot tests  [22] reference box tests  [23] occluded (reference) */
+static _Thread_local uint64_t tl_any_loc[10];   /* local-entry variant (below): [0] rays [1] found in the local walk [2] steps / [3] leaves / [4] triangles of the local walk, [5..7] of the walk from the root that follows a local miss [8] result differs */
+static uint64_t g_any_loc[10];
+static int g_any_loc_height = 6;              /* binary levels between the entry node and the leaf that holds the ray's origin */
 static _Thread_local uint64_t tl_any[24];
 _Thread_local uint64_t tl_any_q4[6];
 static uint64_t g_any_q4[6];
 static uint64_t g_any[24];
 static int g_any_study = 0;
 void o_anyhit_study(int on) { g_any_study = on; if (on) { memset(g_any, 0, sizeof g_any); memset(g_any_q4, 0, sizeof g_any_q4); } }
+void o_anyhit_study_local_height(int h) { g_any_loc_height = h; memset(g_any_loc, 0, sizeof g_any_loc); }
+void o_anyhit_study_get_local(uint64_t* out10) {
+	#pragma omp parallel
+	{ for (int k = 0; k < 10; k++) { __atomic_fetch_add(&g_any_loc[k], tl_any_loc[k], __ATOMIC_RELAXED); tl_any_loc[k] = 0; } }
+	memcpy(out10, g_any_loc, sizeof g_any_loc);
+}
 void o_anyhit_study_get_q4(uint64_t* out6) {
 	#pragma omp parallel
 	{ for (int k = 0; k < 6; k++) { __atomic_fetch_add(&g_any_q4[k], tl_any_q4[k], __ATOMIC_RELAXED); tl_any_q4[k] = 0; } }
@@ -632,6 +641,59 @@ static void anyhit_study(const o_obj* o, const o_ray* d, float dist_light, int r
 		}
 		tl_any_q4[0] += wide; tl_any_q4[1] += leaves; tl_any_q4[2] += tris; tl_any_q4[3] += unverified;
 		if (!g->nodes[0].isleaf && found != (ref_result != 0)) tl_any_q4[4]++;
+	}
+	{          /* four-wide, first passing slot, LOCAL ENTRY: the walk starts at an ancestor of the leaf next to the ray's origin (a shadow ray leaves a
+	              surface of this mesh more often than not, and what shadows a bumpy surface is the next bump); only when that subtree holds no
+	              occluder does the walk start again from the root, skipping the subtree it has seen.  Any reachable occluder decides the ray:
+	              the order-independence argument of the any-hit kernel does not care where the walk enters. */
+		int path[64], depth = 0, cur = 0;
+		while (!g->nodes[cur].isleaf && depth < 63) {
+			path[depth++] = cur;
+			const o_node* a = &g->nodes[g->nodes[cur].fg]; const o_node* b = &g->nodes[g->nodes[cur].fd];
+			float da = 0, db = 0;
+			for (int ax = 0; ax < 3; ax++) {
+				const float x = vget(d->origin, ax);
+				const float ea = fmaxf(fmaxf(vget(a->bmin, ax) - x, x - vget(a->bmax, ax)), 0.f), eb = fmaxf(fmaxf(vget(b->bmin, ax) - x, x - vget(b->bmax, ax)), 0.f);
+				da += ea * ea; db += eb * eb;
+			}
+			cur = da <= db ? g->nodes[cur].fg : g->nodes[cur].fd;
+		}
+		int ed = depth - g_any_loc_height; if (ed < 0) ed = 0; ed &= ~1;      /* wide nodes sit at even binary depths */
+		const int entry = depth > 0 ? path[ed] : 0;
+		int found = 0;
+		tl_any_loc[0]++;
+		for (int phase = 0; phase < 2 && !found; phase++) {
+			if (phase == 1 && entry == 0) break;                   /* the local walk was the whole tree */
+			int sp = 0;
+			uint64_t wide = 0, leaves = 0, tris = 0;
+			stack[sp++] = phase == 0 ? entry : 0;
+			if (g->nodes[0].isleaf) { sp = 0; }
+			while (sp > 0 && !found) {
+				const int c0 = stack[--sp];
+				const o_node* n = &g->nodes[c0];
+				if (n->isleaf) {
+					leaves++;
+					if (study_leaf(o, d, n->fg, n->fd, dist_light, &tris)) { float t; if (box_invd(n->bmin, n->bmax, invd.origin, invd.direction, signs, &t) && t < dist_light) found = 1; }
+					continue;
+				}
+				wide++;
+				int slot[4], ns = 0;
+				const int ch[2] = { n->fg, n->fd };
+				for (int c = 0; c < 2; c++) {
+					const o_node* m = &g->nodes[ch[c]];
+					if (m->isleaf) slot[ns++] = ch[c];
+					else { slot[ns++] = m->fg; slot[ns++] = m->fd; }
+				}
+				for (int k = ns - 1; k >= 0; k--) {
+					float t;
+					if (phase == 1 && slot[k] == entry) continue;        /* seen by the local walk */
+					if (box_invd(g->nodes[slot[k]].bmin, g->nodes[slot[k]].bmax, invd.origin, invd.direction, signs, &t) && t < dist_light) stack[sp++] = slot[k];
+				}
+			}
+			tl_any_loc[2 + 3 * phase] += wide; tl_any_loc[3 + 3 * phase] += leaves; tl_any_loc[4 + 3 * phase] += tris;
+			if (phase == 0 && found) tl_any_loc[1]++;
+		}
+		if (!g->nodes[0].isleaf && found != (ref_result != 0)) tl_any_loc[8]++;
 	}
 	for (int variant = 0; variant < 2; variant++) {          /* four-wide */
 		int sp = 0, found = 0, flagged = 0, maxsp = 0;
