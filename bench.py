@@ -34,13 +34,11 @@ HIP events on the render stream).  Every fraction names its denominator:
                         EXCEEDS 1 (frac_note): most node fetches are served by L1 / L2 / the Infinity Cache and never cross HBM.
   traffic, frac_hbm_measured   HBM bytes per launch from the PMC counters (FETCH_SIZE corrected with the gather factor of
                         tools/fetch_calibration.py, + WRITE_SIZE), and those / duration / 8 TB/s
-  ceilings_measured_in_this_run   fractions against ceilings this run measured on the device itself, each with its "ceiling_source":
-      dependent_gather  the kernel's L2 misses x 128 B / duration against mipt_measure_dependent_gather (dependent random 128-byte
-                        fetches from a table of the scene's size: mostly Infinity Cache, NOT an HBM figure)
-      vmem_issue        vector-memory wave-instructions per CU x the cost of one (mipt_measure_vmem_issue at the kernel's mean
-                        active lanes) / duration: the figure the kernel runs against
-  frac_l1_lookups, latency_model, instruction_issue   TCP line lookups against one per CU and cycle; achieved rays/s against resident
-                        waves x 64 lanes / (dependent fetches per ray x mean vector-memory latency); instruction counts x issue cost
+  issue_model           the ONE account of what the kernel's time follows: busy share of a CU's vector-memory path
+                        (wave-instructions per CU x 11.5 ns) and of a SIMD's vector pipe (instructions x 1.7 ns), constants fitted on seven
+                        profiled builds (profiles/r5_traversal_time_model.txt, tests/test_time_model.py), instruction counts from the PMC run
+  device_rates_measured_in_this_run   raw rates mipt_measure_* takes on this device (ns per vector-memory wave-instruction and CU at the
+                        kernel's lane count; dependent random line fetches per ns): for cross-checking the constants, no fraction is formed
 Per-ray counter values come from the committed PMC run of the same workload (profiles/pmc_counters.json; separate --pmc passes).
 derived_from_pmc_run.same_library_build compares __graft_entry__.source_hash() (csrc/* + include/mipt.h + hipcc flags) with the hash
 that run recorded; when they differ everything derived from the counters is null and derived_from_pmc_run.stale is true.
@@ -385,8 +383,7 @@ def main():
             except Exception:
                 pass
             # ---- the roofline object (task contract / SURVEY 8d): achieved = ALGORITHMIC bytes per launch / launch time, peak = HBM 8 TB/s,
-            # traffic = HBM bytes per launch from the PMC counters.  Everything else names its own denominator: fractions against ceilings
-            # this run measured itself (mipt_measure_*) sit under "ceilings_measured_in_this_run", what is scaled from the committed PMC run
+            # traffic = HBM bytes per launch from the PMC counters.  Everything else names its own denominator; what is scaled from the committed PMC run
             # of the same workload (profiles/pmc_counters.json: per ray of that run x the rays of this one) is dropped to null and
             # flagged stale when this run's library is not the build that was profiled (hash of csrc/* + flags, __graft_entry__.source_hash).
             scene_bytes = int(mesh.ntri) * 64 + int(mesh.ntri) * 64          # ~ one fat node per triangle pair + one record per triangle
@@ -439,22 +436,17 @@ def main():
                                      "active_lanes_per_vector_instruction": pk.get("active_lanes_per_vector_instruction"), "wait_share_of_wave_cycles": pk.get("wait_share_of_wave_cycles")}
                 if pk.get("active_lanes_per_vector_instruction"):
                     lanes_per_instr = int(max(1, min(64, round(pk["active_lanes_per_vector_instruction"]))))
-                if cap_g:
-                    ach = pk["l2_misses_per_ray"] * rays_per_launch * 128.0 / secs / 1e9
-                    ceil["dependent_gather"] = {"frac": ach / (cap_g * 128.0), "achieved_gb_per_s": ach, "peak_gb_per_s": cap_g * 128.0, "glines_per_s": cap_g,
-                                                "ceiling_source": "measured in this run by mipt_measure_dependent_gather: dependent random fetches of 128-byte lines from a table of the scene's size (%d MB)" % (max(64 << 20, scene_bytes) >> 20),
-                                                "achieved_definition": "the kernel's L2 misses x 128 B / launch time (mostly served by the Infinity Cache: not an HBM figure)"}
-                try:   # the CU serves one vector-memory wave-instruction per ~10 ns (measured at the kernel's mean number of active lanes)
-                    ns_instr = rt.measure_vmem_issue(lanes_per_instr, 3000)
-                    ceil["vmem_issue"] = {"frac": pk["vmem_per_ray"] * rays_per_launch / n_cus * ns_instr * 1e-9 / secs,
-                                          "instructions_per_ray": pk["vmem_per_ray"], "ns_per_instruction_and_cu": ns_instr, "at_active_lanes": lanes_per_instr,
-                                          "ceiling_source": "measured in this run by mipt_measure_vmem_issue: cost of a vector-memory wave-instruction per CU at that many active lanes"}
+                try:   # cross-check of the model's first constant on THIS device: the cost of a vector-memory wave-instruction per CU at the kernel's mean number of active lanes
+                    ceil["vmem_ns_per_wave_instruction_and_cu"] = rt.measure_vmem_issue(lanes_per_instr, 3000)
+                    ceil["vmem_measured_at_active_lanes"] = lanes_per_instr
                 except Exception as e:
-                    ceil["vmem_issue_note"] = "%s: %s" % (type(e).__name__, e)
-            elif cap_g:
-                ceil["dependent_gather"] = {"frac": None, "peak_gb_per_s": cap_g * 128.0, "glines_per_s": cap_g,
-                                            "ceiling_source": "measured in this run by mipt_measure_dependent_gather (no current PMC run to take the kernel's L2 misses from)"}
-            rf["ceilings_measured_in_this_run"] = ceil
+                    ceil["vmem_note"] = "%s: %s" % (type(e).__name__, e)
+            if cap_g:
+                ceil["dependent_random_line_fetches_per_ns"] = cap_g
+                ceil["dependent_fetch_table_mb"] = max(64 << 20, scene_bytes) >> 20
+            ceil["source"] = ("measured in this run by mipt_measure_vmem_issue / mipt_measure_dependent_gather (csrc/mipt_measure.h): raw rates of the device, reported for "
+                              "cross-checking the constants of issue_model; no fraction is formed from them (one account of the kernel's time: issue_model)")
+            rf["device_rates_measured_in_this_run"] = ceil
             out["roofline"] = rf
             if pipeline == 1 and sh_launches:
                 sh_alg = rays_s * ob["bytes_shadow"] / (sh_ms * 1e-3) / 1e9
@@ -464,7 +456,6 @@ def main():
                     if not pk: raise KeyError("no current PMC run")
                     pks = json.load(open(pmc_file))[args.workload]["kernels"]["k_wf_anyhit"]
                     secs_s = sh_ms / sh_launches * 1e-3
-                    rs["frac_dependent_gather"] = (pks["l2_misses_per_ray"] * rays_s / sh_launches * 128.0 / secs_s / 1e9) / (cap_g * 128.0) if cap_g else None
                     rs["l2_misses_per_ray"] = pks["l2_misses_per_ray"]
                     rs["vmem_issue_busy"] = pks["vmem_per_ray"] * rays_s / sh_launches / n_cus * TA_NS_PER_VMEM_INSTRUCTION * 1e-9 / secs_s
                     rs["vmem_instructions_per_ray"] = pks["vmem_per_ray"]

@@ -28,7 +28,7 @@ for n in ("c2","c1","c3","c4"):
     try:
         d=json.loads(open(f"gpurun_out/{S}_{n}_bench.json").read().strip().splitlines()[-1])
         r=d.get('roofline',{})
-        print(n, 'Mrays/s %.0f'%d['value'], d.get('stage_ms_per_step'), 'ms/step %.1f'%d['ms_per_step'], 'frac', r.get('frac'), 'hbm', r.get('frac_hbm_measured'), {k:(v.get('frac') if isinstance(v,dict) else v) for k,v in r.get('ceilings_measured_in_this_run',{}).items()}, r.get('derived_from_pmc_run',{}).get('same_library_build'), d.get('cpu_baseline',{}).get('value'), 'init+upload', round(d['host_bvh_build_s']+d['prepare_s'],4))
+        print(n, 'Mrays/s %.0f'%d['value'], d.get('stage_ms_per_step'), 'ms/step %.1f'%d['ms_per_step'], 'frac', r.get('frac'), 'hbm', r.get('frac_hbm_measured'), {k:round(v,3) for k,v in (r.get('issue_model') or {}).items() if k.endswith('_busy')}, r.get('derived_from_pmc_run',{}).get('same_library_build'), d.get('cpu_baseline',{}).get('value'), 'init+upload', round(d['host_bvh_build_s']+d['prepare_s'],4))
     except Exception as e: print(n, "failed", e)
 PY
 head -7 gpurun_out/${S}_kstats.txt
