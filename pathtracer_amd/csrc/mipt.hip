@@ -1673,12 +1673,19 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					if (b == 0 && want_aov) hipLaunchKernelGGL(k_wf_aov, dim3(grid_all), dim3(MIPT_BLOCK), 0, st, c->d_scene, wf, (unsigned)total, aov_n, aov_kd);
 				}
 				if (timed_begin(2)) return fail(c, MIPT_ERR_HIP, "event record failed");
-				if (c->opt_fast_shade) {
-					hipLaunchKernelGGL(k_wf_shade<1>, G(4), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(1), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					if (c->scene_has_merl && c->opt_merl_batch) hipLaunchKernelGGL(k_wf_shade<4>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE4_LDS_BYTES, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					else if (c->scene_has_merl) hipLaunchKernelGGL(k_wf_shade<3>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(3), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-					else hipLaunchKernelGGL(k_wf_shade<2>, G(5), dim3(MIPT_BLOCK), MIPT_SHADE_LDS_BYTES(2), st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
-				} else hipLaunchKernelGGL(k_wf_shade<0>, G(3), dim3(MIPT_BLOCK), 0, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt);
+				{
+					// (depth 0 has its own build of every tier: what a path starts with is recomputed there, not fetched)
+#define MIPT_LAUNCH_SHADE(T, GRID, LDS) do { \
+						if (b == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_shade<T, true>), GRID, dim3(MIPT_BLOCK), LDS, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt); \
+						else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_shade<T, false>), GRID, dim3(MIPT_BLOCK), LDS, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt); } while (0)
+					if (c->opt_fast_shade) {
+						MIPT_LAUNCH_SHADE(1, G(4), MIPT_SHADE_LDS_BYTES(1));
+						if (c->scene_has_merl && c->opt_merl_batch) MIPT_LAUNCH_SHADE(4, G(5), MIPT_SHADE4_LDS_BYTES);
+						else if (c->scene_has_merl) MIPT_LAUNCH_SHADE(3, G(5), MIPT_SHADE_LDS_BYTES(3));
+						else MIPT_LAUNCH_SHADE(2, G(5), MIPT_SHADE_LDS_BYTES(2));
+					} else MIPT_LAUNCH_SHADE(0, G(3), 0);
+#undef MIPT_LAUNCH_SHADE
+				}
 				if (timed_end()) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (timed_begin(merge ? 0 : 1)) return fail(c, MIPT_ERR_HIP, "event record failed");
 				if (merge && b + 1 < p->nb_bounces) hipLaunchKernelGGL(k_wf_traverse<2>, G(2), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, (unsigned)total, thr, imin);

@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #ifndef MIPT_SHADE_WAVES
 #define MIPT_SHADE_WAVES 4
 #endif
+#ifndef MIPT_SHADE_RECOMPUTE_CAMERA
+#define MIPT_SHADE_RECOMPUTE_CAMERA 1   // depth 0: the shade stage recomputes the camera ray instead of fetching it (round 5)
+#endif
 #ifndef MIPT_SHADE_PREFETCH
 #define MIPT_SHADE_PREFETCH 0
 #endif
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #define MIPT_SHADE_LDS_BYTES(TIER) ((TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
 #define MIPT_SHADE4_LDS_BYTES MIPT_SHADE_LDS_BYTES(4)
 extern __shared__ unsigned mipt_shade_lds[];
-template <int TIER>
+template <int TIER, bool INITIAL = false>       // INITIAL: the build for depth 0 (b == 0), where a path's state is recomputed instead of fetched
 __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : (TIER == 4 ? MIPT_SHADE4_WAVES : MIPT_SHADE3_WAVES))))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
 	static_assert(TIER != 4 || MIPT_SHADE_ROLLED, "tier 4 is written into the rolled form of the sub-chunk loop");
 	// (tier 4's code over the WHOLE queue of a depth, no fast tier in front of it, was measured too: configs[4] generate + shade 864 ms
@@ -395,12 +398,16 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	// of sub-chunk u+1 is requested before sub-chunk u is shaded — with 3 waves per SIMD the stage is bound by its
 	// three dependent HBM round trips per vertex (state, shading record, texel), this hides the first one.
 	// depth 0: weight, flags and engine of a path are what path_begin leaves — recomputed, not fetched (k_wf_generate does not store them)
-	const bool initial = b == 0;
+	constexpr bool initial = INITIAL;
+	// ... and neither is the camera ray (MIPT_SHADE_RECOMPUTE_CAMERA): path_begin runs again from the path id — 32 of the ~250 bytes a vertex of
+	// depth 0 moves, in a stage that is bound by them; extend(0) still reads the copy k_wf_generate wrote
+	constexpr bool camera = initial && MIPT_SHADE_RECOMPUTE_CAMERA;
 	struct In { float4 w, o, d, hr, col; uint2 rs; };
 	auto fetch = [&](unsigned id, bool ok, In& in) {
 		if (ok) {
 			if (!initial) in.w = wf_ld(&wf.wgt[id]);
-			in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); in.hr = wf_ld(&wf.hit[id]);
+			if (!camera) { in.o = wf_ld(&wf.ray_o[id]); in.d = wf_ld(&wf.ray_d[id]); }
+			in.hr = wf_ld(&wf.hit[id]);
 			if (TIER != 1) in.col = wf_ld(&wf.out.col[id]);          // the fast tier touches the colour only when a vertex adds to it
 			if (!initial) in.rs = wf_ld(&wf.rng[id]);
 		}
@@ -433,8 +440,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		auto glds_issue = [&](unsigned pid) {
 			if (pid != 0xffffffffu) {
 				if (!initial) __builtin_amdgcn_global_load_lds((gptr_t)&wf.wgt[pid], gl + 0, 16, 0, 2);
-				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_o[pid], gl + 256, 16, 0, 2);
-				__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_d[pid], gl + 512, 16, 0, 2);
+				if (!camera) {
+					__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_o[pid], gl + 256, 16, 0, 2);
+					__builtin_amdgcn_global_load_lds((gptr_t)&wf.ray_d[pid], gl + 512, 16, 0, 2);
+				}
 				__builtin_amdgcn_global_load_lds((gptr_t)&wf.hit[pid], gl + 768, 16, 0, 2);
 				if (TIER != 1) __builtin_amdgcn_global_load_lds((gptr_t)&wf.out.col[pid], gl + 1024, 16, 0, 2);
 				if (!initial) {
@@ -492,11 +501,12 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 #endif
 			const float4 w = sin.w, o = sin.o, d = sin.d, hr = sin.hr, col = sin.col;
 			const uint2 rs = sin.rs;
-			if (initial && o.w != o.w) break;                                 // no path in this slot (MIPT_WF_DEAD_RAY)
+			if (initial && !camera && o.w != o.w) break;                      // no path in this slot (MIPT_WF_DEAD_RAY)
 			// pixel of this path (for the per-pixel Cranley-Patterson rotation, and at depth 0 for its engine) and its sample index
 			const int kk = (int)(id / (unsigned)ps.npix_slots), slot = (int)(id % (unsigned)ps.npix_slots);
 			const int blk = slot >> 6, in = slot & 63;
 			const int pi = ps.blocks[2 * blk] + (in >> 3), pj = ps.blocks[2 * blk + 1] + (in & 7);
+			if (camera && (pi >= R.H || pj >= R.W || R.nb_bounces <= 0)) break;      // the slots k_wf_generate marks dead: outside the image, or a render of depth 0
 			const unsigned fl = initial ? (MIPT_WF_VALID | (unsigned)R.nb_bounces | 0x10000u) : __float_as_uint(w.w);       // path_begin: depth nb_bounces, show_lights
 			PathState p;
 			p.ray.o = mk3(o.x, o.y, o.z); p.ray.d = mk3(d.x, d.y, d.z);
@@ -504,6 +514,11 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			p.rng = initial ? pcg_skip4(pcg_seed(((uint64_t)pi * (uint64_t)R.W + (uint64_t)pj) * R.seed_stride + (uint64_t)(ps.k0 + kk)))      // the engine behind path_begin's four draws
 			                : ((uint64_t)rs.x | ((uint64_t)rs.y << 32));
 			p.depth = (int)(fl & 0xffffu); p.show_lights = (fl & 0x10000u) != 0;
+			if (camera) {                                                      // what k_wf_generate computed for this slot, again: ray, weight (1, 1, 1), engine after its four draws, depth, show_lights
+				float jx, jy;
+				path_begin(R, pi, pj, ps.k0 + kk, p, jx, jy);
+				p.color = mk3(col.x, col.y, col.z);
+			}
 			unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
 			bool has_inter = packed != MIPT_HIT_MISS;
