@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #define MIPT_SHADE_WAVES 4
 #endif
 #ifndef MIPT_SHADE_RECOMPUTE_CAMERA
-#define MIPT_SHADE_RECOMPUTE_CAMERA 1   // depth 0: the shade stage recomputes the camera ray instead of fetching it (round 5)
+#define MIPT_SHADE_RECOMPUTE_CAMERA 0   // 1 = depth 0: the shade stage recomputes the camera ray instead of fetching it.  Measured and off: 32 of ~250 bytes per
+                                        // vertex less, but path_begin costs the fast tier 14 spilled registers: generate + shade 347 against 331 ms on configs[2]
 #endif
 #ifndef MIPT_SHADE_PREFETCH
 #define MIPT_SHADE_PREFETCH 0
@@ -399,8 +400,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	// three dependent HBM round trips per vertex (state, shading record, texel), this hides the first one.
 	// depth 0: weight, flags and engine of a path are what path_begin leaves — recomputed, not fetched (k_wf_generate does not store them)
 	constexpr bool initial = INITIAL;
-	// ... and neither is the camera ray (MIPT_SHADE_RECOMPUTE_CAMERA): path_begin runs again from the path id — 32 of the ~250 bytes a vertex of
-	// depth 0 moves, in a stage that is bound by them; extend(0) still reads the copy k_wf_generate wrote
+	// (MIPT_SHADE_RECOMPUTE_CAMERA: the camera ray too — path_begin run again from the path id; measured slower, off)
 	constexpr bool camera = initial && MIPT_SHADE_RECOMPUTE_CAMERA;
 	struct In { float4 w, o, d, hr, col; uint2 rs; };
 	auto fetch = [&](unsigned id, bool ok, In& in) {
