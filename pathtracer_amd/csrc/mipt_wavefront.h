@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 	const unsigned n = SLOW_LIST ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
 	unsigned* head = &wf.counters[MIPT_CNT((SLOW_LIST ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
 	const unsigned* __restrict__ list = SLOW_LIST ? wf.list_slow : wf.list[b & 1];
-	const bool identity = !SLOW_LIST && b == 0;
+	constexpr bool identity = !SLOW_LIST && INITIAL;
 	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
 	unsigned n_closest = 0, n_shadow = 0;
 	unsigned base;
