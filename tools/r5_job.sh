@@ -1,5 +1,6 @@
-S=r5_u
-timeout 1500 python tests/tools/fuzz_parity.py 1000 9301 > gpurun_out/${S}_fuzz_parity_1000_scenes.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_1000_scenes.txt
-timeout 1500 python tests/tools/fuzz_parity.py 500 9302 --queue > gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_500_scenes_queue.txt
-timeout 1500 python tests/tools/fuzz_parity.py 300 9303 --queue --spheres > gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue_spheres.txt
-timeout 1500 python tests/tools/fuzz_parity.py 200 9304 --kind=merl --merl-tiers --spheres > gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_both_tiers.txt
+for v in "" sw5 "" sw5; do
+  if [ -n "$v" ]; then export MIPT_LIB_OVERRIDE=$PWD/pathtracer_amd/libmipt_$v.so; else unset MIPT_LIB_OVERRIDE; fi
+  for wl in c2 c1; do python bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('variant [$v]', '$wl', 'Mrays/s %.0f'%d['value'], {k:round(v,1) for k,v in d['stage_ms_per_step'].items()})"; done
+done
