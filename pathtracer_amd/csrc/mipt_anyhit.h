@@ -52,9 +52,11 @@ MIPT_DEV bool box_test_sorted(mipt_f2 X, mipt_f2 Y, mipt_f2 Z, mipt_f2 o_xy, mip
 	const mipt_f2 tx = rx * __builtin_shufflevector(i_xy, i_xy, 0, 0), ty = ry * __builtin_shufflevector(i_xy, i_xy, 1, 1), tz = rz * __builtin_shufflevector(oz_iz, oz_iz, 1, 1);
 	const float t_enter = fmaxf(fmaxf(tx.x, ty.x), tz.x);
 	const float t_exit = fminf(fminf(tx.y, ty.y), tz.y);
-	const bool ok = !(t_enter > t_exit) & !(t_exit < 0);
-	t_out = t_enter < 0 ? 0.f : t_enter;
-	return ok;
+	// (BBoxT::intersection_invd's `!(t_enter > t_exit) & !(t_exit < 0)` and `t_enter < 0 ? 0 : t_enter` in one maximum: the two forms agree unless
+	// t_enter is a NaN, which the rays of this kernel cannot produce — an infinite inverse direction goes to the replay list — and where
+	// this form passes MORE boxes, which the order-free walk may always do.  Two vector instructions per box less.)
+	t_out = fmaxf(t_enter, 0.f);
+	return !(t_out > t_exit);
 }
 // byte K of a word as a float (the compiler selects v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float quad_byte(uint32_t w) { return (float)((w >> (8 * K)) & 255u); }
