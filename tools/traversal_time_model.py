@@ -107,6 +107,6 @@ for wl in ("c2", "c1", "c3", "c4"):
         oos.append(t / b["ms"] - 1.0)
         print("%-58s %9.1f %9.1f %+6.1f%%   %.2f" % ("%s, %s (%.0f M rays, %.1f loads per step)" % (kern, wl, rays / 1e6, LOADS_PER_STEP[kern]), t, b["ms"], 100 * (t / b["ms"] - 1), c["TCC_MISS_sum"] / steps))
 print("rms error out of sample: %.1f %% over the mean launches of %d kernel x workload pairs" % (100 * (sum(e * e for e in oos) / len(oos)) ** 0.5, len(oos)))
-print("""reading: the constants carry over to the other workloads within +-11 %, and the error is ordered by the size of the scene (configs[1] 0.13 M triangles:
-  the model is 9 % slow; configs[4] 23.7 M triangles: 11 % fast), as are the L2 misses per step: the term the model lacks is the one it already
-  failed on with the ready list — the cost of a step's fetch beyond the instruction that issues it.  Instruction counts alone place a launch within a tenth.""")
+print("""reading: the constants carry over to the other workloads within an eighth, and the error is ordered by the size of the scene (configs[1] 0.13 M triangles:
+  the model is 8-9 % slow; configs[4] 23.7 M triangles: 12 % fast), as are the L2 misses per step: the term the model lacks is the one it already
+  failed on with the ready list — the cost of a step's fetch beyond the instruction that issues it.  Instruction counts alone place a launch within an eighth.""")
