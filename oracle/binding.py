@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — ctypes bindings of
 
 * oracle/_ref/libptref.so  (class ``Ref``):    the compiled reference (oracle/ref_harness.cpp);
+* oracle/_ref/libptref_mipt.so (class ``RefMipt``): the same reference compiled with the USE_MIPT switch of
+  integration/use_mipt, i.e. with pathtracer_amd/libmipt.so under its own Raytracer / Scene / TriMesh members;
 * oracle/libptoracle.so    (class ``Oracle``): our plain-C restatement (oracle/pt_oracle.c).
 
 Both expose the same methods so a test can run one comparison against either.  Imported only
@@ -15,11 +17,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB_PATH = os.path.join(_HERE, "_ref", "libptref.so")
+REF_MIPT_LIB_PATH = os.path.join(_HERE, "_ref", "libptref_mipt.so")
 ORACLE_LIB_PATH = os.path.join(_HERE, "libptoracle.so")
 
 
 def ref_available() -> bool:
     return os.path.exists(REF_LIB_PATH)
+
+
+def ref_mipt_available() -> bool:
+    return os.path.exists(REF_MIPT_LIB_PATH)
 
 
 def oracle_available() -> bool:
@@ -458,6 +465,70 @@ class Ref(_Base):
         t = self.lib.ref_time_render_image(self.ctx, threads, _p(img, _f), _p(cnt, _f))
         return t, img, cnt
 
+
+    def mesh_bvh_figures(self, obj):
+        """bvh_depth, bvh_avg_depth, bvh_nb_nodes, max_bvh_triangles as TriMesh::build_bvh left them."""
+        o = np.zeros(4, np.float32)
+        self.cdll.ref_mesh_bvh_figures(self.ctx, obj, _p(o, _f))
+        return o
+
+    def add_cylinder(self, A, B, R):
+        return self.cdll.ref_add_cylinder(self.ctx, (_f * 3)(*A), (_f * 3)(*B), _f(R))
+
+
+class RefMipt(Ref):
+    """The reference compiled with -DUSE_MIPT (integration/use_mipt): Raytracer::render_image[_nopreviz], Scene::intersection
+    and TriMesh::build_bvh of the REFERENCE'S OWN classes run on libmipt.so.  Everything `Ref` offers works unchanged; the
+    methods below read the members the binding adds."""
+    PATH = REF_MIPT_LIB_PATH
+
+    def __init__(self):
+        super().__init__()
+        assert self.cdll.ref_mipt_built_with_switch() == 1
+        self.cdll.ref_mipt_error.restype = C.c_char_p
+
+    def upload(self):
+        """Raytracer::mipt_upload(): what render_image does after prepare_render.  Returns the MIPT_* status."""
+        return self.cdll.ref_mipt_upload(self.ctx)
+
+    def status(self):
+        return self.cdll.ref_mipt_status(self.ctx)
+
+    def resident(self):
+        return bool(self.cdll.ref_mipt_resident(self.ctx))
+
+    def error(self):
+        return self.cdll.ref_mipt_error(self.ctx).decode()
+
+    def set_lookahead(self, n):
+        self.cdll.ref_mipt_set_lookahead(self.ctx, int(n))
+
+    def set_dirty(self):
+        self.cdll.ref_mipt_set_dirty(self.ctx)
+
+    def stats(self):
+        o = np.zeros(6, np.uint64)
+        rc = self.cdll.ref_mipt_stats(self.ctx, _p(o, C.c_uint64))
+        if rc != 0:
+            return None
+        return dict(paths=int(o[0]), rays_closest=int(o[1]), rays_shadow=int(o[2]), pipeline=int(o[3]), passes=int(o[4]), replayed=int(o[5]))
+
+    def render_image_stop_at(self, stop_at):
+        img = np.zeros((self.H, self.W, 3), np.float32)
+        cnt = np.zeros((self.H, self.W), np.float32)
+        it = self.cdll.ref_mipt_render_image_stop_at(self.ctx, int(stop_at), _p(img, _f), _p(cnt, _f))
+        return it, img, cnt
+
+    def render_nopreviz_denoiser(self):
+        img, alb, nrm = (np.zeros((self.H, self.W, 3), np.float32) for _ in range(3))
+        cnt = np.zeros((self.H, self.W), np.float32)
+        self.cdll.ref_mipt_render_nopreviz_denoiser(self.ctx, _p(img, _f), _p(cnt, _f), _p(alb, _f), _p(nrm, _f))
+        return img, cnt, alb, nrm
+
+    def image_u8(self):
+        out = np.zeros((self.H, self.W, 3), np.uint8)
+        self.cdll.ref_mipt_get_image_u8(self.ctx, _p(out, C.c_ubyte))
+        return out
 
 
 class Oracle(_Base):

@@ -586,4 +586,74 @@ double ref_time_render_image(RefCtx* c, int threads, float* imagedouble_out, flo
 
 int ref_max_threads() { return ref_thread_cap(); }
 
+// the figures TriMesh::build_bvh leaves for the GUI (mainApp.cpp:974, 1422-1425): max depth, average depth, node count, largest leaf
+void ref_mesh_bvh_figures(RefCtx* c, int obj, float* out4) {
+	TriMesh* g = c->rt->s.castToMesh[obj];
+	out4[0] = (float)g->bvh_depth; out4[1] = g->bvh_avg_depth; out4[2] = (float)g->bvh_nb_nodes; out4[3] = (float)g->max_bvh_triangles;
+}
+
+// an object type outside the hot path (Geometry.h:731-847): a scene holding one makes mipt_upload_scene answer
+// MIPT_ERR_UNSUPPORTED, and the USE_MIPT build of the reference keeps its stock loop for it
+int ref_add_cylinder(RefCtx* c, const float* A, const float* B, float R) {
+	c->rt->s.addObject(new Cylinder(Vector(A[0], A[1], A[2]), Vector(B[0], B[1], B[2]), R));
+	return (int)c->rt->s.objects.size() - 1;
+}
+
+#ifdef USE_MIPT
+// ---- only in oracle/_ref/libptref_mipt.so: the reference compiled with the USE_MIPT switch of integration/use_mipt --------
+// Everything above then runs the reference's own classes with libmipt.so under Raytracer::render_image[_nopreviz],
+// Scene::intersection and TriMesh::build_bvh.  The functions below expose the members the binding adds, so that a test can
+// tell a frame the GPU rendered from one the stock loop rendered.
+int ref_mipt_built_with_switch() { return 1; }
+int ref_mipt_upload(RefCtx* c) { c->rt->mipt_upload(); return c->rt->mipt_status; }     // what render_image does after prepare_render
+int ref_mipt_status(RefCtx* c) { return c->rt->mipt_status; }
+int ref_mipt_resident(RefCtx* c) { return c->rt->s.mipt_resident ? 1 : 0; }
+void ref_mipt_set_lookahead(RefCtx* c, int n) { c->rt->mipt_lookahead = n; }
+void ref_mipt_set_dirty(RefCtx* c) { c->rt->mipt_scene_dirty = true; }
+const char* ref_mipt_error(RefCtx* c) { return c->rt->mipt ? mipt_last_error(c->rt->mipt) : "no context"; }
+int ref_mipt_stats(RefCtx* c, uint64_t* out6) {     // paths, closest-hit rays, shadow rays, pipeline, passes, replayed any-hit rays
+	if (!c->rt->mipt) return MIPT_ERR_NO_SCENE;
+	mipt_stats st; int rc = mipt_get_stats(c->rt->mipt, &st);
+	if (rc != MIPT_OK) return rc;
+	out6[0] = st.paths; out6[1] = st.rays_closest; out6[2] = st.rays_shadow; out6[3] = st.pipeline; out6[4] = st.passes; out6[5] = 0;
+	mipt_debug_anyhit_replayed(c->rt->mipt, &out6[5]);
+	return MIPT_OK;
+}
+// Raytracer::render_image() while another thread — the GUI's, in the reference (mainApp.cpp:913) — calls stopRender() as
+// soon as `stop_at` samples have been published.  Returns realtime_ray_iter as render_image left it.
+}  // extern "C"
+#include <thread>
+#include <atomic>
+#include <unistd.h>
+extern "C" {
+int ref_mipt_render_image_stop_at(RefCtx* c, int stop_at, float* imagedouble_out, float* sample_count_out) {
+	Raytracer* rt = c->rt;
+	rt->clear_image();
+	rt->stopped = false;
+	std::atomic<bool> finished(false);
+	std::thread gui([&]() { while (!finished.load()) { if (rt->realtime_ray_iter >= stop_at) { rt->stopRender(); return; } usleep(20); } });
+	rt->realtime_ray_iter = 0;
+	rt->render_image();
+	finished.store(true);
+	gui.join();
+	memcpy(imagedouble_out, &rt->imagedouble[0], sizeof(float)*(size_t)rt->W*rt->H * 3);
+	memcpy(sample_count_out, &rt->sample_count[0], sizeof(float)*(size_t)rt->W*rt->H);
+	return rt->realtime_ray_iter;
+}
+// render_image_nopreviz() with has_denoiser: the three images the denoiser would read (colour and albedo divided by the
+// count, normals normalised: Raytracer.cpp:1687-1696)
+void ref_mipt_render_nopreviz_denoiser(RefCtx* c, float* imagedouble, float* sample_count, float* albedo, float* normal) {
+	Raytracer* rt = c->rt;
+	rt->clear_image();
+	rt->has_denoiser = true;
+	rt->render_image_nopreviz();
+	rt->has_denoiser = false;
+	const size_t n = (size_t)rt->W * rt->H;
+	memcpy(imagedouble, &rt->imagedouble[0], sizeof(float) * n * 3); memcpy(sample_count, &rt->sample_count[0], sizeof(float) * n);
+	memcpy(albedo, &rt->albedoImage[0], sizeof(float) * n * 3); memcpy(normal, &rt->normalImage[0], sizeof(float) * n * 3);
+}
+// the 8-bit frame of the last render (Raytracer::image)
+void ref_mipt_get_image_u8(RefCtx* c, unsigned char* out) { memcpy(out, &c->rt->image[0], (size_t)c->rt->W * c->rt->H * 3); }
+#endif
+
 }  // extern "C"

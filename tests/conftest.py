@@ -1,5 +1,5 @@
 """pytest configuration: registers the `gpu` marker and builds the test-infrastructure libraries
-(oracle/libptoracle.so always; oracle/_ref/libptref.so only where /root/reference exists)."""
+(oracle/libptoracle.so always; oracle/_ref/libptref.so and libptref_mipt.so only where /root/reference exists)."""
 import os
 import subprocess
 import sys
@@ -13,7 +13,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    subprocess.run(["make", "-s", "-f", os.path.join(ROOT, "oracle", "Makefile"), "oracle", "ref"], check=True, cwd=ROOT)
+    targets = ["oracle", "ref"]
+    if os.path.exists(os.path.join(ROOT, "pathtracer_amd", "libmipt.so")):
+        targets.append("refmipt")     # the reference with the USE_MIPT switch (integration/use_mipt), linked against libmipt.so
+    subprocess.run(["make", "-s", "-f", os.path.join(ROOT, "oracle", "Makefile")] + targets, check=True, cwd=ROOT)
 
 
 @pytest.fixture(scope="session")
