@@ -306,6 +306,10 @@ int mipt_measure_vmem_issue(mipt_ctx* ctx, int active_lanes, int iters, double* 
    0.2 % of the ray's far end (the only ones whose answer can depend on the visiting order of TriMesh::intersection_shadow,
    TriangleMesh.cpp:1239-1319) and rays with an infinite inverse-direction component.  No counterpart in the reference. */
 int mipt_debug_anyhit_replayed(mipt_ctx* ctx, uint64_t* out);
+/* Which any-hit kernel the shadow rays of the resident scene run on: "order-free", or "ordered: <why>" — a tree handed in through
+   mipt_mesh::nodes whose boxes do not nest, are empty or hold a NaN or an infinity keeps the ordered traversal of
+   TriMesh::intersection_shadow for every shadow ray (checked on the device at upload).  No counterpart in the reference. */
+const char* mipt_debug_anyhit_kind(const mipt_ctx* ctx);
 
 /* TriMesh::build_bvh / build_bvh_recur (TriangleMesh.cpp:878-885, 1029-1130) on the GPU: the same nodes at the same
  * positions of the node vector and the same reordering of the triangles as the reference's serial recursion (node boxes

@@ -27,7 +27,7 @@ MIPT_ERR_UNSUPPORTED = 4
 
 # every symbol include/mipt.h declares
 MIPT_SYMBOLS = ["mipt_create", "mipt_destroy", "mipt_last_error", "mipt_abi_version", "mipt_upload_scene", "mipt_render",
-                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_measure_vmem_issue", "mipt_debug_anyhit_replayed", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
+                "mipt_render_device", "mipt_tile_owner", "mipt_measure_stream_read", "mipt_measure_gather_read", "mipt_measure_dependent_gather", "mipt_measure_vmem_issue", "mipt_debug_anyhit_replayed", "mipt_debug_anyhit_kind", "mipt_group_size", "mipt_group_reduce_kind", "mipt_rccl_selftest", "mipt_trace", "mipt_trace_shadow", "mipt_sample_radiance", "mipt_get_stats", "mipt_set_option",
                 "mipt_build_bvh", "mipt_build_bvh_error", "mipt_render_denoiser_inputs", "mipt_sample_denoiser_inputs",
                 "mipt_device_mesh_build", "mipt_device_mesh_download", "mipt_device_mesh_download_tangents", "mipt_device_mesh_free"]
 
@@ -115,6 +115,8 @@ def load():
     mipt.mipt_last_error.argtypes = [C.c_void_p]
     mipt.mipt_build_bvh_error.restype = C.c_char_p
     mipt.mipt_group_reduce_kind.restype = C.c_char_p
+    mipt.mipt_debug_anyhit_kind.restype = C.c_char_p
+    mipt.mipt_debug_anyhit_kind.argtypes = [C.c_void_p]
     mipt.mipt_group_reduce_kind.argtypes = [C.c_void_p]
     mipt.mipt_group_size.argtypes = [C.c_void_p]
     mipt.mipt_rccl_selftest.argtypes = [C.c_void_p]
@@ -593,6 +595,9 @@ class HostRaytracer:
         out = C.c_double(0.0)
         self._check(self.mipt.mipt_measure_vmem_issue(self.ctx, int(active_lanes), int(iters), C.byref(out)), "mipt_measure_vmem_issue")
         return out.value
+
+    def anyhit_kind(self):
+        return self.mipt.mipt_debug_anyhit_kind(self.ctx).decode()
 
     def anyhit_replayed(self):
         """Shadow rays of the last render that the order-free any-hit kernel left to the ordered one (mipt_debug_anyhit_replayed)."""

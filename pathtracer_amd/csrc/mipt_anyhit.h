@@ -63,7 +63,9 @@ template <int K> __device__ __forceinline__ float quad_byte(uint32_t w) { return
 
 // The order-free traversal rests on boxes that NEST: every child's box inside its parent's, which is what TriMesh::build_bvh produces (a
 // node's box is the union of its triangles' boxes, TriangleMesh.cpp:843-858).  A tree handed in through the C ABI is the caller's: this
-// check runs over every inner node at upload; a scene with a box that sticks out of its parent's (or holds a NaN) keeps the ordered kernel.
+// check runs over every inner node at upload; a scene with a box that sticks out of its parent's, holds a NaN or an INFINITE plane keeps the
+// ordered kernel (the 8-bit planes of k_quad_nodes are origin + q * 2^e: an infinite plane has no such cover — the exponent search ends
+// without containing it and the decoded box would reject rays the float box accepts).
 __global__ void k_check_nesting(const DFatNode* __restrict__ fat, size_t n, int* __restrict__ bad) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -72,7 +74,7 @@ __global__ void k_check_nesting(const DFatNode* __restrict__ fat, size_t n, int*
 	for (int side = 0; side < 2; side++) {
 		const uint32_t cref = side ? f.rref : f.lref;
 		const float (*cb)[2] = side ? f.r : f.l;
-		for (int a = 0; a < 3; a++) ok = ok && cb[a][0] <= cb[a][1];
+		for (int a = 0; a < 3; a++) ok = ok && cb[a][0] <= cb[a][1] && fabsf(cb[a][0]) <= 3.402823466e38f && fabsf(cb[a][1]) <= 3.402823466e38f;
 		if ((cref & MIPT_LEAF_BIT) || cref >= n) continue;
 		const DFatNode c = fat[cref];
 		for (int a = 0; a < 3; a++) ok = ok && c.l[a][0] >= cb[a][0] && c.l[a][1] <= cb[a][1] && c.r[a][0] >= cb[a][0] && c.r[a][1] <= cb[a][1];

@@ -147,6 +147,14 @@ extern "C" int mipt_debug_anyhit_replayed(mipt_ctx* c, uint64_t* out) {
 	*out = v;
 	return MIPT_OK;
 }
+// Which any-hit kernel the resident scene's shadow rays run on, and why.
+extern "C" const char* mipt_debug_anyhit_kind(const mipt_ctx* c) {
+	if (!c || !c->d_scene) return "no scene";
+	if (c->anyhit_ordered_because_not_nested) return "ordered: a box of the uploaded tree does not nest in its parent's, is empty, or is not finite";
+	if (!c->d_quad_nodes) return "ordered: the scene has no mesh";
+	if (!c->opt_anyhit_wide) return "ordered: option anyhit_wide = 0";
+	return "order-free";
+}
 extern "C" int mipt_measure_vmem_issue(mipt_ctx* c, int active_lanes, int iters, double* ns_per_instruction_and_cu) {
 	if (!c || !ns_per_instruction_and_cu || active_lanes < 1 || active_lanes > 64 || iters < 1) return fail(c, MIPT_ERR_INVALID, "bad arguments");
 	HIPCHK(c, hipSetDevice(c->device));

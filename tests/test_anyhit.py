@@ -148,3 +148,42 @@ def test_every_pixel_of_a_mid_size_frame():
     rep = G.anyhit_replayed()
     print(f"replayed {rep} of {st['rays_shadow']} shadow rays")
     assert rep <= st["rays_shadow"] // 1000
+
+
+@pytest.mark.parametrize("what", ["infinite inner box", "infinite leaf box", "child outside its parent"])
+def test_tree_handed_in_through_the_abi_that_the_byte_boxes_cannot_cover_keeps_the_ordered_kernel(what):
+    """ADVICE r5: mipt_mesh::nodes is the caller's.  A box with an infinite plane (or one that sticks out of its parent's) has no 8-bit cover;
+    the upload check must send such a scene to the ordered any-hit kernel — results as the reference's traversal of THAT tree gives them,
+    which for a box that only grew are those of the unmodified tree."""
+    import ctypes as C
+    g = load_golden("scene_blob32.npz")
+    capi.set_device_resident(False)            # the mirror then describes the mesh by host arrays: mipt_mesh::nodes
+    try:
+        rt = capi.HostRaytracer(device=0)
+        mesh, cfg, oid = setup_scene(rt, "blob32")
+        assert rt.anyhit_kind() == "order-free"
+        desc = C.cast(rt.scene_desc, C.POINTER(capi.MiptSceneDesc)).contents
+        m = desc.objects[oid].mesh.contents
+        assert m.nodes and not m.device_mesh
+        nodes = np.ctypeslib.as_array(C.cast(m.nodes, C.POINTER(C.c_uint32)), shape=(m.n_nodes, 9)).copy()
+        f = nodes.view(np.float32)
+        isleaf = (nodes[:, 0] & 255) == 1
+        inner = np.flatnonzero(~isleaf)
+        if what == "infinite inner box":
+            f[inner[len(inner) // 2], 3] = -np.inf                    # bbox_min.x of an inner node in the middle of the tree
+        elif what == "infinite leaf box":
+            f[np.flatnonzero(isleaf)[7], 7] = np.inf                  # bbox_max.y of a leaf
+        else:
+            k = inner[3]; child = int(nodes[k, 1])
+            f[child, 6] = f[k, 6] + 1.0                               # the left child's bbox_max.x beyond its parent's
+        m.nodes = C.cast(nodes.ctypes.data, C.POINTER(capi.MiptBvhNode))
+        rc = rt.mipt.mipt_upload_scene(rt.ctx, C.byref(desc))
+        assert rc == capi.MIPT_OK, rt.mipt.mipt_last_error(rt.ctx)
+        assert rt.anyhit_kind().startswith("ordered: a box of the uploaded tree"), rt.anyhit_kind()
+        assert_bits(rt.intersect_shadow(g["rays"], g["shadow_dist"]), g["shadow_occluded"], "occlusion")
+        rt.set_option("pipeline", 1)
+        rgb, _ = rt.sample_radiance(all_pixels(cfg), 0, cfg.spp)
+        assert_bits(rgb, g["sample_rgb"], "per-sample radiance on the ordered any-hit kernel")
+        assert rt.anyhit_replayed() == 0
+    finally:
+        capi.set_device_resident(True)

@@ -84,6 +84,26 @@ def test_live_roofline_names_every_denominator(line):
     assert "sha256" in (d or {"keyed_on": "sha256"})["keyed_on"]
     sh = line["roofline_shade_kernel"]
     assert sh["frac"] == pytest.approx(sh["achieved"] / sh["peak"], rel=1e-9) and "frac_definition" in sh
+    # no fraction that claims to be MEASURED HBM traffic may exceed what this device streams (the line once said 1.16)
+    ceiling = (r["peak_measured_stream_read"] or 8000.0) / 8000.0
+    for obj in (r, line.get("roofline_shadow_kernel") or {}, sh):
+        f = obj.get("frac_hbm_measured")
+        assert f is None or 0.0 < f <= ceiling, (obj.get("kernel"), f, ceiling)
+
+
+def test_committed_counters_charge_every_shade_build_with_its_own_launches():
+    """profiles/pmc_counters.json: the depth-0 builds of the shade tiers are named for what they are and launch once per pass; the stage's bytes
+    per vertex follow from per-build launches (2 passes per step at 1080p: 2 + 2 x (nb_bounces - 1) launches of a tier)."""
+    j = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
+    for wl, depth in (("c2", 4), ("c1", 4), ("c3", 12), ("c4", 4)):
+        ks = j[wl]["kernels"]
+        assert not any("[quad]" in k for k in ks), "the second template argument is INITIAL (depth 0), not a quad build"
+        assert ks["k_wf_shade<1>[depth0]"]["launches_per_step"] == 2 and ks["k_wf_generate"]["launches_per_step"] == 2
+        assert ks["k_wf_shade<1>"]["launches_per_step"] == 2 * (depth - 1)
+        st = j[wl]["stage_generate_shade"]
+        total = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for k, v in ks.items() if k.startswith(("k_wf_shade", "k_wf_generate")))
+        assert st["hbm_bytes_per_step"] == pytest.approx(total, rel=1e-12)
+        assert 100.0 < st["hbm_bytes_per_vertex"] < 1500.0
 
 
 @pytest.mark.gpu

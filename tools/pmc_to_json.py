@@ -16,8 +16,14 @@ f_gather = cal["gather64"]["reported_over_requested"]
 f_stream = cal["stream"]["reported_over_requested"]
 
 
-def canon(k):          # "k_wf_traverse<0, false>" -> "k_wf_traverse<0>"
-    return re.sub(r"<(\d+), (false|true)>", lambda m: "<%s>%s" % (m.group(1), "" if m.group(2) == "false" else "[quad]"), k)
+def canon(k):          # "k_wf_traverse<0, false>" -> "k_wf_traverse<0>"; "k_wf_shade<1, true>" -> "k_wf_shade<1>[depth0]"
+    # the second template argument of k_wf_shade / k_wf_traverse-era kernels is INITIAL (csrc/mipt_wavefront.h: the build that runs at
+    # depth 0 only, where a path's starting state is recomputed instead of fetched) — NOT the "[quad]" of a round-3 experiment, which
+    # this function called it until round 6
+    return re.sub(r"<(\d+), (false|true)>", lambda m: "<%s>%s" % (m.group(1), "" if m.group(2) == "false" else "[depth0]"), k)
+
+
+STEPS_IN_PMC_RUN = 2   # tools/pmc.sh: bench.py --steps 1 --warmup 1 --pmc, every step profiled
 
 
 out = {}
@@ -30,13 +36,15 @@ for arg in sys.argv[2:]:
         if line.startswith("{"):
             bench = json.loads(line)
     ls = bench["launch_stats"]
-    cur, ks = None, {}
+    cur, ks, nd = None, {}, {}
     for line in open(path):
         if not line.startswith(" "):
             cur = canon(line.strip()); ks[cur] = {}
         else:
-            m = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
-            if m: ks[cur][m.group(1)] = float(m.group(2))
+            m = re.match(r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)(?:\s+\((\d+) dispatches\))?", line)
+            if m:
+                ks[cur][m.group(1)] = float(m.group(2))
+                if m.group(3) and m.group(1) == "FETCH_SIZE": nd[cur] = int(m.group(3))
     kernels = {}
     for k, v in ks.items():
         if "FETCH_SIZE" not in v:
@@ -54,6 +62,8 @@ for arg in sys.argv[2:]:
              "mean_vmem_latency_cycles": v.get("TCP_TCP_LATENCY_sum", 0.0) / max(1.0, v.get("TCP_TA_TCP_STATE_READ_sum", 1.0)),
              # mean active lanes of a vector instruction (thread-cycles / instruction-cycles): what bench.py prices a vector-memory instruction at
              "active_lanes_per_vector_instruction": v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, v.get("SQ_ACTIVE_INST_VALU", 1.0))}
+        if k in nd:    # how often a step launches THIS build (bench.py charges every build with its own count, not with the stage's)
+            e["launches_per_step"] = nd[k] / STEPS_IN_PMC_RUN
         if rays:
             e["rays_per_launch"] = rays
             e["tcp_accesses_per_ray"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays
@@ -64,7 +74,11 @@ for arg in sys.argv[2:]:
             e["vmem_per_ray"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / rays
             e["l1_lookups_per_cu_cycle"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * cyc)
         kernels[k] = e
-    out[wl] = {"source": shown + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
+    # the generate + shade stage as a whole: every build charged with its own launches per step, per shade vertex (= closest-hit ray) of the profiled step
+    stage = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 0.0) for k, v in kernels.items() if k.startswith("k_wf_shade") or k.startswith("k_wf_generate"))
+    stage_obj = {"hbm_bytes_per_step": stage, "vertices_per_step": ls["rays_closest"], "hbm_bytes_per_vertex": stage / max(1, ls["rays_closest"]),
+                 "note": "sum over k_wf_generate and every k_wf_shade<tier>[depth0 or not] build of HBM bytes per launch x launches per step of that build; vertices = closest-hit rays of the profiled step"}
+    out[wl] = {"stage_generate_shade": stage_obj, "source": shown + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
                                 "FETCH_SIZE factors from " + sys.argv[1], "kernels": kernels}
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
