@@ -164,8 +164,39 @@ def assert_physical(out):
             raise SystemExit("bench.py: %s.frac_hbm_measured = %.3f is not a physical HBM fraction: refusing to print the line" % (key, f))
 
 
+STAGE = {"name": "start", "reduce": None, "n_gpus": None}      # where a failing run was, for the diagnostic line below
+
+
+def stage(name, **kw):
+    STAGE["name"] = name
+    STAGE.update(kw)
+
+
 def main():
     args = parse()
+    STAGE["n_gpus"] = args.gpus
+    try:
+        run(args)
+    except SystemExit as e:
+        # a refusal or a failed check: the text is the message; still leave ONE JSON line that says where the run stopped, so that a failed
+        # multi-GPU lease tells which of its paths broke (value null: nothing was measured).  Exit code stays non-zero.
+        if e.code not in (0, None) and int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(failure_line(args, str(e.code))))
+        raise
+    except Exception as e:      # noqa: BLE001 — every failure of the product path lands here: library errors (capi.MiptError), RCCL, torch.distributed
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(failure_line(args, "%s: %s" % (type(e).__name__, e))))
+        raise SystemExit("bench.py failed in stage '%s': %s: %s" % (STAGE["name"], type(e).__name__, e))
+
+
+def failure_line(args, text):
+    return {"metric": "Msamples/s (primary+secondary rays) at 1080p\u00d71024spp; 1/2/4/8-GPU scaling", "value": None, "unit": "Mrays/s", "n_gpus": STAGE["n_gpus"],
+            "steps": args.steps, "warmup": args.warmup, "error": text[-1500:], "stage": STAGE["name"], "reduce": STAGE["reduce"],
+            "stages_in_order": ["devices", "process group (torch.distributed / RCCL)", "build", "mipt_create (group: ncclCommInitAll)", "scene: TriMesh::init on the device",
+                                "upload (group: hipMemcpyPeer replication)", "warm-up steps", "timed steps", "framebuffer reduce", "checks"]}
+
+
+def run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -190,6 +221,7 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but --in-process lists {len(in_process)} devices")
         args.gpus = len(in_process)
     # torch.cuda.device_count() does not initialise the GPU
+    stage("devices")
     n_dev = torch.cuda.device_count()
     need = (max(in_process) + 1) if in_process else (local_rank + 1 if launched and not args.share_gpu else 1)
     if n_dev < need:
@@ -199,6 +231,7 @@ def main():
     if in_process:
         local_rank = in_process[0]                       # the caller's accumulator and stream live on the group's first device
     if world > 1:
+        stage("process group (torch.distributed / RCCL)", reduce=args.backend + " all_reduce")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -211,6 +244,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
+    stage("build")
     if rank == 0:
         ge.build()
     if world > 1:
@@ -239,7 +273,10 @@ def main():
     mesh, cfg, mat, wl_text = scenes.workload(args.workload, args.width, args.height, total_spp, args.grid)
     args.width, args.height = cfg.W, cfg.H
 
+    stage("mipt_create (group: ncclCommInitAll)")
     rt = capi.HostRaytracer(device=in_process if in_process else local_rank)
+    if in_process:
+        STAGE["reduce"] = rt.group_reduce_kind()
     if in_process and len(set(in_process)) == len(in_process) and len(in_process) > 1:
         # distinct devices: the group's framebuffer reduce must be RCCL's ncclReduce or the run fails (option reduce = 1 keeps an RCCL
         # failure instead of falling back to peer copies: a first multi-GPU lease cannot silently measure the copy reduce)
@@ -249,11 +286,13 @@ def main():
     # larger tiles buy nothing: all ranks probed on one GPU predict 7.69 at 8 GPUs on configs[4], 7.50 with the 64-pixel tiles used before)
     tile = 32
     rt.set_partition(tile, rank, world)
+    stage("scene: TriMesh::init on the device")
     t0 = time.time()
     mesh_obj = rt.add_mesh(mesh)                 # TriMesh::init: axis swap, BVH (on the GPU), triangle soup, tangents
     t_build = time.time() - t0
     scenes.install_material(rt, mesh_obj, mat)   # material lists, textures, environment map
     bvh_who, bvh_s, bvh_dev_s = rt.mesh_bvh_builder(mesh_obj)
+    stage("upload (group: hipMemcpyPeer replication)")
     t0 = time.time()
     rt.prepare()
     t_prepare = time.time() - t0
@@ -283,9 +322,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    stage("warm-up steps")
     for s in range(args.warmup):
         step(s)
     sync()
+    if in_process:
+        STAGE["reduce"] = rt.group_reduce_kind()
+    stage("timed steps")
     t0 = time.perf_counter()
     rays = paths = 0
     kern_ms = sh_ms = shade_ms = resolve_ms = 0.0
@@ -306,9 +349,11 @@ def main():
             else:
                 host = accum.cpu(); dist.all_reduce(host, op=dist.ReduceOp.SUM); accum.copy_(host)
 
+    stage("framebuffer reduce")
     reduce_frame()
     sync()
     elapsed = time.perf_counter() - t0
+    stage("checks")
     other_line = None
     if OTHER_STEPS:                                      # the other scaling mode, beside the timed region
         o_sps, base = samples_per_step(other), SPS * (args.steps + args.warmup)

@@ -60,8 +60,22 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_trace(const DScene* __restrict__
 	Hit h; f3 P = mk3(0, 0, 0); Mat m;
 	m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
 	bool hit = scene_intersect(sc, r, h, P, m, stk);
+	// triangle_id as Scene::intersection leaves it (Geometry.cpp:589-650): ONE variable for the whole object loop, written by every sphere /
+	// plane the ray hits at any distance (-1, Geometry.h:949-986, 1144-1160) and by a mesh only when it finds something closer than the best so
+	// far — so the winner's triangle survives only if no sphere or plane BEHIND it in the object list is hit by the ray.  (The renderer never
+	// reads it; mouse picking shows it.  Found by the 200-object test of round 6: every scene before had its spheres in front of its meshes.)
+	int reported_tri = hit ? h.tri : -1;
+	if (reported_tri >= 0) {
+		for (int i = h.obj + 1; i < sc->nobj; i++) {
+			const DObject& ob = sc->obj[i];
+			if (ob.type == 0) continue;
+			float tt;
+			const f3 d2 = xf_dir(ob.inv, r.d), o2 = xf_point(ob.inv, r.o);
+			if (ob.type == 1 ? sphere_test(ob, o2, d2, tt) : plane_test(ob, o2, d2, tt)) { reported_tri = -1; break; }
+		}
+	}
 	mipt_hit o;
-	o.has_inter = hit ? 1 : 0; o.object_id = hit ? h.obj : -1; o.triangle_id = hit ? h.tri : -1; o.t = h.t;
+	o.has_inter = hit ? 1 : 0; o.object_id = hit ? h.obj : -1; o.triangle_id = reported_tri; o.t = h.t;
 	o.P[0] = P.x; o.P[1] = P.y; o.P[2] = P.z;
 	o.shadingN[0] = m.shadingN.x; o.shadingN[1] = m.shadingN.y; o.shadingN[2] = m.shadingN.z;
 	o.Kd[0] = m.Kd.x; o.Kd[1] = m.Kd.y; o.Kd[2] = m.Kd.z; o.Ks[0] = m.Ks.x; o.Ks[1] = m.Ks.y; o.Ks[2] = m.Ks.z;
@@ -335,8 +349,7 @@ __global__ void __launch_bounds__(256) k_wf_aov(const DScene* __restrict__ sc, D
 		if (packed != MIPT_HIT_MISS) {
 			Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
-			h.obj = (int)(packed >> 27);
-			h.tri = ((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI);
+			hit_unpack(sc, packed, h.obj, h.tri);
 			f3 P = mk3(0, 0, 0); Mat m;
 			m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
 			hit_material(sc, ray, h, P, m);
@@ -714,7 +727,8 @@ static int share_device_chunk(mipt_ctx* c, const mipt_device_mesh* dm, const DFa
 // (per mesh, not zero-filled and not copied again: the records of a 23.7 M-triangle mesh are 3.5 GB)
 struct MeshChunk { std::unique_ptr<DFatNode[]> fat; size_t nfat = 0; std::unique_ptr<DTriIsect[]> ti; std::unique_ptr<DTriShade[]> ts; size_t nt = 0;
                    const mipt_device_mesh* dev = nullptr; uint32_t node_base = 0, tri_base = 0; };     // dev: the records are on a device already (no host arrays)
-struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0; };
+struct MeshStaging { std::vector<MeshChunk> chunks; size_t nfat_total = 0, nt_total = 0;
+                     std::vector<uint2> fat_leaves; std::mutex fat_mutex; };     // leaves of >= MIPT_LEAF_MAX_TRIS triangles: (scene-wide first triangle, count)
 
 // Re-pack the reference's BVH (36-byte nodes holding their OWN box) into fat nodes holding both
 // CHILDREN's boxes (mipt_scene.h).  Inner nodes keep the reference's depth-first order.
@@ -742,8 +756,9 @@ static int convert_mesh(mipt_ctx* c, const mipt_mesh* m, DObject& d, MeshStaging
 		if (!n.isleaf) { ref = node_base + (uint32_t)fat_index[node]; return MIPT_OK; }
 		int cnt = n.fd - n.fg;
 		if (n.fg < 0 || n.fd > nt || cnt <= 0) return fail(c, MIPT_ERR_INVALID, "BVH leaf range out of bounds");
-		if (cnt > MIPT_LEAF_MAX_TRIS) return fail(c, MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles (max %d)", cnt, MIPT_LEAF_MAX_TRIS);
-		ref = MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (tri_base + (uint32_t)n.fg);
+		// a leaf the count field cannot hold (degenerate splits, TriangleMesh.cpp:1118: unbounded) files its count in the scene's table
+		if (cnt >= MIPT_LEAF_MAX_TRIS) { std::lock_guard<std::mutex> lk(stg.fat_mutex); stg.fat_leaves.push_back(make_uint2(tri_base + (uint32_t)n.fg, (uint32_t)cnt)); }
+		ref = MIPT_LEAF_BIT | ((uint32_t)(std::min(cnt, MIPT_LEAF_MAX_TRIS) - 1) << 26) | (tri_base + (uint32_t)n.fg);
 		return MIPT_OK;
 	};
 	// the traversal stack holds at most one pending far child per inner node on the current root-to-leaf path: refuse
@@ -861,9 +876,13 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	if (s->n_objects < 2 || s->n_objects > MIPT_MAX_OBJECTS) return fail(c, MIPT_ERR_INVALID, "n_objects must be in [2,%d]", MIPT_MAX_OBJECTS);
 	HIPCHK(c, hipSetDevice(c->device));
 	free_scene(c);
-	std::vector<DScene> hs(1);
-	DScene& H = hs[0];
-	memset(&H, 0, sizeof H);
+	// header + n_objects records, one allocation on either side (mipt_scene.h: DScene::obj)
+	const size_t scene_bytes = offsetof(DScene, obj) + (size_t)s->n_objects * sizeof(DObject);
+	std::unique_ptr<void, void (*)(void*)> hs(aligned_alloc(64, (scene_bytes + 63) / 64 * 64), free);
+	if (!hs) return fail(c, MIPT_ERR_INVALID, "out of host memory for %d objects", s->n_objects);
+	memset(hs.get(), 0, scene_bytes);
+	DScene& H = *static_cast<DScene*>(hs.get());
+	DObject* const Hobj = H.obj;
 	H.nobj = s->n_objects;
 	H.first_mesh = s->n_objects;
 	c->n_mesh_objects = 0;
@@ -871,7 +890,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 	MeshStaging stg;
 	for (int i = 0; i < s->n_objects; i++) {
 		const mipt_object& o = s->objects[i];
-		DObject& d = H.obj[i];
+		DObject& d = Hobj[i];
 		if (o.ghost && i < 2) return fail(c, MIPT_ERR_UNSUPPORTED, "the light / environment sphere cannot be a ghost object");
 		if (o.brdf_kind != MIPT_BRDF_PHONG && o.brdf_kind != MIPT_BRDF_MERL) return fail(c, MIPT_ERR_UNSUPPORTED, "object %d: unknown BRDF kind %d", i, o.brdf_kind);
 		if (o.brdf_kind == MIPT_BRDF_MERL && !o.merl_data) return fail(c, MIPT_ERR_INVALID, "object %d: MERL BRDF without a table", i);
@@ -890,7 +909,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 			hipLaunchKernelGGL(k_merl_interleave, dim3((MIPT_MERL_CELLS + 255) / 256), dim3(256), 0, 0, planar, (double*)cells);
 			HIPCHK(c, hipGetLastError());
 			// (the planar copy, 35 MB, stays until the scene is freed: releasing it here costs a device synchronisation and a hipFree, 4-10 ms of the upload)
-			d.merl = (const double*)cells; scene_merl = true; H.merl_mask |= 1u << i;
+			d.merl = (const double*)cells; scene_merl = true; if (i < 32) H.merl_mask |= 1u << i;      // (objects >= 32: object_has_merl reads DObject::brdf_kind)
 		}
 		const mipt_texture* lists[MIPT_TEX_SLOTS]; int counts[MIPT_TEX_SLOTS];
 		lists[MT_KD] = o.textures; counts[MT_KD] = o.n_textures;
@@ -1009,7 +1028,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		H.all_nodes = (const DFatNode*)dn; H.all_tris = (const DTriIsect*)dt; all_shade = (const DTriShade*)dsh;
 	}
 	c->d_quad_nodes = nullptr; c->d_leaf_box = nullptr; c->anyhit_ordered_because_not_nested = false;
-	for (int i = 0; i < s->n_objects; i++) H.obj[i].quad_root = H.obj[i].root_ref;
+	for (int i = 0; i < s->n_objects; i++) Hobj[i].quad_root = Hobj[i].root_ref;
 	if (H.all_nodes && stg.nfat_total > 0 && stg.nt_total > 0) {
 		// the nodes of the any-hit stage (mipt_anyhit.h), derived on the device from the fat nodes wherever those came from: mark the fat
 		// nodes that become quad nodes, number them (exclusive scan), build them densely
@@ -1026,7 +1045,7 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		if (hipMemcpy(&not_nested, d_changed, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "checking the boxes of the tree failed: %s", hipGetErrorString(hipGetLastError())); }
 		const uint32_t one = 1;
 		if (not_nested) { cleanup(); c->anyhit_ordered_because_not_nested = true; goto quad_done; }      // a caller's tree whose boxes do not nest: the ordered any-hit kernel
-		for (int i = 0; i < s->n_objects; i++) if (H.obj[i].type == MIPT_OBJ_TRIMESH && !(H.obj[i].root_ref & MIPT_LEAF_BIT)) hipMemcpy(d_mark + H.obj[i].root_ref, &one, 4, hipMemcpyHostToDevice);
+		for (int i = 0; i < s->n_objects; i++) if (Hobj[i].type == MIPT_OBJ_TRIMESH && !(Hobj[i].root_ref & MIPT_LEAF_BIT)) hipMemcpy(d_mark + Hobj[i].root_ref, &one, 4, hipMemcpyHostToDevice);
 		for (int pass = 0; pass <= MIPT_STACK_DEPTH; pass++) {
 			int changed = 0;
 			hipMemset(d_changed, 0, 4);
@@ -1049,8 +1068,8 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		c->scene_allocs.push_back(lb);
 		hipLaunchKernelGGL(k_leaf_box_init, dim3((unsigned)((8 * stg.nt_total + 255) / 256)), dim3(256), 0, 0, (float*)lb, stg.nt_total);
 		hipLaunchKernelGGL(k_quad_nodes, dim3(gb), dim3(256), 0, 0, H.all_nodes, (const uint32_t*)d_mark, (const uint32_t*)d_index, (DQuadNode*)dw, (float*)lb, nf);
-		for (int i = 0; i < s->n_objects; i++) if (H.obj[i].type == MIPT_OBJ_TRIMESH && !(H.obj[i].root_ref & MIPT_LEAF_BIT)) {
-			if (hipMemcpy(&H.obj[i].quad_root, d_index + H.obj[i].root_ref, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "reading a quad root failed"); }
+		for (int i = 0; i < s->n_objects; i++) if (Hobj[i].type == MIPT_OBJ_TRIMESH && !(Hobj[i].root_ref & MIPT_LEAF_BIT)) {
+			if (hipMemcpy(&Hobj[i].quad_root, d_index + Hobj[i].root_ref, 4, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(c, MIPT_ERR_HIP, "reading a quad root failed"); }
 		}
 		const hipError_t qe = hipDeviceSynchronize();
 		cleanup();
@@ -1059,17 +1078,29 @@ static int upload_scene_one(mipt_ctx* c, const mipt_scene_desc* s) {
 		c->n_quad_nodes = nquad;
 	}
 quad_done:
+	std::vector<uint2> mesh_first;
 	for (int i = 0; i < s->n_objects; i++) {
-		DObject& d = H.obj[i];
+		DObject& d = Hobj[i];
 		if (d.type != MIPT_OBJ_TRIMESH) continue;
 		d.nodes = H.all_nodes; d.tris = H.all_tris; d.shade = all_shade + d.tri_base;
+		if (!mesh_first.empty() && d.tri_base <= mesh_first.back().x) return fail(c, MIPT_ERR_INVALID, "internal: the meshes' triangle ranges are not ascending");
+		mesh_first.push_back(make_uint2(d.tri_base, (unsigned)i));
 	}
+	if (mesh_first.size() == 1 && mesh_first[0].x != 0) return fail(c, MIPT_ERR_INVALID, "internal: the only mesh does not start at triangle 0");   // hit_unpack's short cut
+	// (child_ref files a leaf once per reference to it: a leaf is referenced by exactly one parent, or is the root)
+	std::sort(stg.fat_leaves.begin(), stg.fat_leaves.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+	stg.fat_leaves.erase(std::unique(stg.fat_leaves.begin(), stg.fat_leaves.end(), [](const uint2& a, const uint2& b) { return a.x == b.x; }), stg.fat_leaves.end());
+	H.n_fat_leaves = (int)stg.fat_leaves.size(); H.fat_leaves = nullptr;
+	if (!stg.fat_leaves.empty() && (rc = upload(c, stg.fat_leaves.data(), stg.fat_leaves.size(), &H.fat_leaves))) return rc;
+	for (int i = 0; i < s->n_objects; i++) { Hobj[i].fat_leaves = H.fat_leaves; Hobj[i].n_fat_leaves = H.n_fat_leaves; }
+	H.n_meshes = (int)mesh_first.size(); H.mesh_first = nullptr;
+	if (!mesh_first.empty() && (rc = upload(c, mesh_first.data(), mesh_first.size(), &H.mesh_first))) return rc;
 	if (scene_subs && sphere_extra) scene_inherit = true;      // Ksub inherited like Kd / Ks / Ne: the reference's loop as it runs
 	H.inherit_material = scene_inherit ? 1 : 0;
-	const DScene* dsc = nullptr;
-	rc = upload(c, hs.data(), 1, &dsc);
+	const unsigned char* dsc = nullptr;
+	rc = upload(c, static_cast<const unsigned char*>(hs.get()), scene_bytes, &dsc);
 	if (rc) return rc;
-	c->d_scene = const_cast<DScene*>(dsc);
+	c->d_scene = reinterpret_cast<DScene*>(const_cast<unsigned char*>(dsc));
 	c->d_all_nodes = H.all_nodes; c->d_all_tris = H.all_tris;
 	c->has_scene = true;
 	c->scene_has_merl = scene_merl;

@@ -392,7 +392,8 @@ __device__ __forceinline__ void anyhit_queue(const DScene* __restrict__ sc, cons
 			}
 			if (per_lane) {
 				const lds_f4_ rs = rayslot[lane_id_now()];
-				for (int i = first; i < first + count; i++) {
+				const int last = first + (count < MIPT_LEAF_MAX_TRIS ? count : mipt_leaf_count_scan((uint32_t)first, sc->fat_leaves, sc->n_fat_leaves));
+				for (int i = first; i < last; i++) {
 					float lt, lb, lg;
 					if (tri_test<DERIVE>(tris + i, mk3(o_xy.x, o_xy.y, oz_iz.x), mk3(rs.x, rs.y, rs.z), lt, lb, lg) && lt < rs.w) {
 						const DObject& o = sc->obj[obj];

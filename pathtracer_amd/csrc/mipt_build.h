@@ -659,10 +659,10 @@ __global__ void k_fat_nodes(const ONode* __restrict__ nodes, int total, int ntri
 		if (!ch.isleaf) return irank[c];
 		const int cnt = ch.fd - ch.fg;
 		if (ch.fg < 0 || ch.fd > ntri || cnt <= 0) { atomicOr(&bad[0], 1); return 0u; }
-		if (cnt > MIPT_LEAF_MAX_TRIS) { atomicMax(&bad[1], cnt); return 0u; }
+		if (cnt >= MIPT_LEAF_MAX_TRIS) { atomicMax(&bad[1], cnt); return 0u; }      // (a fat leaf: the mesh goes through the host-side conversion, which files its count)
 		return MIPT_LEAF_BIT | ((uint32_t)(cnt - 1) << 26) | (uint32_t)ch.fg;
 	};
-	if (i == 0) *root_ref = nd.isleaf ? (nd.fd - nd.fg > MIPT_LEAF_MAX_TRIS || nd.fd - nd.fg <= 0 ? ((nd.fd - nd.fg <= 0 ? atomicOr(&bad[0], 1) : atomicMax(&bad[1], nd.fd - nd.fg)), 0u) : (MIPT_LEAF_BIT | ((uint32_t)(nd.fd - nd.fg - 1) << 26) | (uint32_t)nd.fg)) : 0u;
+	if (i == 0) *root_ref = nd.isleaf ? (nd.fd - nd.fg >= MIPT_LEAF_MAX_TRIS || nd.fd - nd.fg <= 0 ? ((nd.fd - nd.fg <= 0 ? atomicOr(&bad[0], 1) : atomicMax(&bad[1], nd.fd - nd.fg)), 0u) : (MIPT_LEAF_BIT | ((uint32_t)(nd.fd - nd.fg - 1) << 26) | (uint32_t)nd.fg)) : 0u;
 	if (nd.isleaf) return;
 	if (nd.fg <= (int)i || nd.fg >= total || nd.fd <= (int)i || nd.fd >= total) { atomicOr(&bad[0], 1); return; }
 	if (depth[i] == 0 || depth[i] > max_levels) atomicOr(&bad[2], 1);

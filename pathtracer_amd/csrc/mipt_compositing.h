@@ -72,7 +72,7 @@ __device__ __attribute__((noinline)) bool mesh_reservoir(const DObject& o, f3 or
 		}
 		if (cur == NONE) break;
 		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
-		int cnt = (int)((cur >> 26) & 31u) + 1;
+		const int cnt = mipt_leaf_count(cur, o.fat_leaves, o.n_fat_leaves);
 		for (int i = first; i < first + cnt; i++) {
 			float lt, lb, lg;
 			if (tri_test(o.tris + i, org, d, lt, lb, lg)) {

@@ -288,7 +288,7 @@ extern "C" int mipt_device_mesh_build(int device_id, const float* vertices, int 
 	BHIP(hipGetLastError());
 	auto drop = [&]() { m->d_fat = nullptr; m->d_ti = nullptr; m->d_ts = nullptr; m->d_uvidx = nullptr; m->d_tangent = nullptr; };     // (still owned by `keep`)
 	if (bad[0]) { drop(); return build_fail(MIPT_ERR_INVALID, "BVH child index out of order / leaf range out of bounds"); }
-	if (bad[1]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles (max %d)", bad[1], MIPT_LEAF_MAX_TRIS); }
+	if (bad[1]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "BVH leaf with %d triangles: meshes with leaves of %d or more triangles are not kept device-resident (upload them through mipt_mesh::nodes)", bad[1], MIPT_LEAF_MAX_TRIS); }
 	if (bad[2]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "BVH with more than %d levels of inner nodes: the traversal stack holds %d", MIPT_STACK_DEPTH, MIPT_STACK_DEPTH); }
 	if (bad[3]) { drop(); return build_fail(MIPT_ERR_UNSUPPORTED, "material group index above 2^30"); }
 	// the handle keeps the reference-layout nodes and the permutation for mipt_device_mesh_download; everything else of the build goes

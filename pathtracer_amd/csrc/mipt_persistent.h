@@ -93,7 +93,7 @@ __device__ __forceinline__ bool visit_object(const DObject& o, int i, f3 ro, f3 
 		float t;
 		bool hit = (o.type == 1) ? sphere_test(o, org, d, t) : plane_test(o, org, d, t);
 		{
-			if (hit && t < st.t) { st.t = t; st.best = (int)(((unsigned)i << 27) | MIPT_HIT_NOTRI); st.beta = 0; st.gamma = 0; }     // (write-through: by the caller)
+			if (hit && t < st.t) { st.t = t; st.best = (int)(MIPT_HIT_ANALYTIC | (unsigned)i); st.beta = 0; st.gamma = 0; }     // (write-through: by the caller)
 		}
 		return false;
 	}
@@ -266,7 +266,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				if (MIPT_L_NEED && st.obj == i) {
 					const float t_before = st.t;
 					const bool enter_mesh = visit_object<SHADOW>(sc->obj[i], i, ro, rd, st, tq.skip_ghosts);
-					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(((unsigned)i << 27) | MIPT_HIT_NOTRI));
+					if (MIPT_HIT_WRITE_THROUGH && !SHADOW && sc->obj[i].type != 0 && st.t < t_before) wf.hit[st.id] = make_float4(st.t, 0.f, 0.f, __uint_as_float(MIPT_HIT_ANALYTIC | (unsigned)i));
 					if (enter_mesh) {}                                   // (st.cur is the mesh's root now)
 					else if (SHADOW && st.best) st.obj = nobj;          // occluded: decided
 					else st.obj = i + 1;
@@ -428,9 +428,9 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						if (win >= 0) {
 							if (!RESV) st.t = cur_t;
 							if (!SHADOW) {
-								const int local = first + win - (int)sc->obj[st.obj].tri_base;
-								if (MIPT_HIT_WRITE_THROUGH && !RESV) wf.hit[st.id] = make_float4(cur_t, wb, wg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
-								else { st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = wb; st.gamma = wg; }
+								// (the scene-wide triangle index identifies the mesh: mipt_trace.h, hit_unpack)
+								if (MIPT_HIT_WRITE_THROUGH && !RESV) wf.hit[st.id] = make_float4(cur_t, wb, wg, __uint_as_float((unsigned)(first + win)));
+								else { st.best = first + win; st.beta = wb; st.gamma = wg; }
 							}
 						}
 						if (SHADOW && decided) { st.best = 1; st.cur = MIPT_NONE; st.sp = 0; }
@@ -440,7 +440,8 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 			}
 			if (per_lane) {
 				bool decided = false;
-				for (int i = first; i < first + count; i++) {
+				const int last = first + (count < MIPT_LEAF_MAX_TRIS ? count : mipt_leaf_count_scan((uint32_t)first, sc->fat_leaves, sc->n_fat_leaves));
+				for (int i = first; i < last; i++) {
 					MIPT_PROF_COUNT(4)
 					float lt, lb, lg;
 					if (tri_test<SHADOW ? (MIPT_DERIVE_SHADOW != 0) : (MIPT_DERIVE_EXTEND != 0)>(tris + i, mk3(st.o_xy.x, st.o_xy.y, st.oz_iz.x), st.d, lt, lb, lg)) {
@@ -454,15 +455,15 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 						if (accept && RESV) {
 							st.count++;
 							const float r1 = pcg_uniform(st.rng);
-							if ((double)r1 < 1. / (double)st.count) { st.dist = lt; st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg; }
+							if ((double)r1 < 1. / (double)st.count) { st.dist = lt; st.best = i; st.beta = lb; st.gamma = lg; }
 						} else if (accept) {
 							st.t = lt;
 							if (SHADOW) {
 								if ((double)lt < (double)st.dist * 0.999) { decided = true; break; }           // TriangleMesh.cpp:1309
 							} else if (MIPT_HIT_WRITE_THROUGH && !RESV) {
-								wf.hit[st.id] = make_float4(lt, lb, lg, __uint_as_float(((unsigned)st.obj << 27) | (unsigned)local));
+								wf.hit[st.id] = make_float4(lt, lb, lg, __uint_as_float((unsigned)i));
 							} else {
-								st.best = (int)(((unsigned)st.obj << 27) | (unsigned)local); st.beta = lb; st.gamma = lg;
+								st.best = i; st.beta = lb; st.gamma = lg;
 							}
 						}
 					}
@@ -477,7 +478,7 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 		if (RESV) {
 			if (st.cur == MIPT_NONE) {
 				st.cur = MIPT_ST_IDLE;
-				const unsigned tri = (unsigned)st.best == MIPT_HIT_MISS ? MIPT_HIT_MISS : ((unsigned)st.best & MIPT_HIT_NOTRI);
+				const unsigned tri = (unsigned)st.best == MIPT_HIT_MISS ? MIPT_HIT_MISS : (unsigned)st.best - sc->obj[st.obj].tri_base;      // the probe's answer: the mesh-local triangle
 				wf.hit[st.id] = make_float4(st.dist, st.beta, st.gamma, __uint_as_float(tri));
 				wf.rng[st.id] = make_uint2((unsigned)st.rng, (unsigned)(st.rng >> 32));
 			}

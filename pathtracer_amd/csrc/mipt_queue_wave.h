@@ -389,9 +389,7 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 			const float4 hr = a1_from_probe ? FRL(12) : QW_LD(&wf.hit[id]);
 			const unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
-			const bool hit = packed != MIPT_HIT_MISS;
-			h.obj = hit ? (int)(packed >> 27) : -1;
-			h.tri = hit ? (((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI)) : -1;
+			const bool hit = hit_unpack(sc, packed, h.obj, h.tri);
 			t_main = h.t;
 			if (hit) hit_material(sc, currentRay, h, P, m);
 			if (hit && nbrebonds == R.nb_bounces && qw.aov_n) {                  // :255-258
@@ -694,10 +692,8 @@ __device__ __forceinline__ int qw_advance(const DScene* __restrict__ sc, const D
 				const bool is_uniform = f11.w != 0.f;
 				const float T = f10.x, proba_t = f10.y, int_ext_partielle = f10.z, phase_func = f10.w;
 				const unsigned packed = __float_as_uint(hr.w);
-				const bool interinter = packed != MIPT_HIT_MISS;
 				Hit ih; ih.t = hr.x; ih.beta = hr.y; ih.gamma = hr.z;
-				ih.obj = interinter ? (int)(packed >> 27) : -1;
-				ih.tri = interinter ? (((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI)) : -1;
+				const bool interinter = hit_unpack(sc, packed, ih.obj, ih.tri);
 				bool visible = true;
 				if (!is_uniform) {
 					const float dl2 = norm2(point_aleatoire - random_P);

@@ -11,7 +11,8 @@
 #pragma once
 #include <stdint.h>
 
-#define MIPT_MAX_OBJECTS 31      // a hit record packs the object into the 5 bits above the 27-bit triangle index; object 31 + "no triangle" is MIPT_HIT_MISS (round 4: 16 -> 31; the reference's std::vector<Object*> is unbounded)
+#define MIPT_MAX_OBJECTS 65536   // a sanity bound on mipt_scene_desc::n_objects, not a layout limit: the object records are a device array of n_objects entries and a
+                                 // hit record names its object by index or by triangle (mipt_trace.h, hit_unpack).  Until round 6: 31 (five bits of the hit word).
 #define MIPT_TEX_SLOTS 8
 // slot ids = the reference's Texture type codes (BRDF.h:256-264) + 7 for the subsurface list
 enum { MT_KD = 0, MT_KS = 1, MT_NORMAL = 2, MT_ALPHA = 3, MT_NE = 4, MT_TRANSP = 5, MT_REFR = 6, MT_KSUB = 7 };
@@ -19,8 +20,11 @@ enum { MT_KD = 0, MT_KS = 1, MT_NORMAL = 2, MT_ALPHA = 3, MT_NE = 4, MT_TRANSP =
 // Child reference of a fat node / traversal stack entry:
 //   ref >= 0           : inner node, index into DMesh::nodes (units of 64 B)
 //   ref <  0 (bit 31)  : leaf, bits 0..25 = first triangle, bits 26..30 = (count-1)
+// A leaf of 32 OR MORE triangles (build_bvh_recur stops splitting when every centre falls on one side, TriangleMesh.cpp:1118: such
+// leaves are unbounded) carries 31 in its count field and its real count in the scene's table of fat leaves (DScene / DObject::fat_leaves,
+// sorted by first triangle; empty for ordinary meshes).  Until round 6 such a mesh was refused.
 #define MIPT_LEAF_BIT 0x80000000u
-#define MIPT_LEAF_MAX_TRIS 32
+#define MIPT_LEAF_MAX_TRIS 32            // count field saturates here: >= this many -> look the count up
 #define MIPT_LEAF_FIRST_MASK 0x03ffffffu
 
 struct DTex {              // Texture (BRDF.h:252-426)
@@ -89,7 +93,26 @@ struct alignas(64) DObject {   // (64-byte aligned and sized: the first 64 bytes
 	int ghost;                 // Object::ghost (Geometry.h:721): only the queue kernel (mipt_compositing.h) renders such scenes
 	const float* uvs;          // Vector[nuvs]
 	const int* uvidx;          // 3 ints per triangle (uvi,uvj,uvk), only when alpha_test
+	const uint2* fat_leaves;   // = DScene::fat_leaves (the per-thread traversals reach the table through their object)
+	int n_fat_leaves;
 };
+// triangles of the leaf a child reference names
+__host__ __device__ inline int mipt_leaf_count(uint32_t ref, const uint2* fat, int nfat) {
+	const int c = (int)((ref >> 26) & 31u) + 1;
+	if (c < MIPT_LEAF_MAX_TRIS) return c;
+	const uint32_t first = ref & MIPT_LEAF_FIRST_MASK;
+	int lo = 0, hi = nfat - 1;
+	while (lo <= hi) { const int mid = (lo + hi) >> 1; const uint32_t f = fat[mid].x; if (f == first) return (int)fat[mid].y; if (f < first) lo = mid + 1; else hi = mid - 1; }
+	return c;                  // (not in the table: cannot happen for a tree this library encoded)
+}
+// The same for the persistent traversal kernels, which have no register to spare (one more live value spilled in the any-hit kernel): a
+// linear walk over the table with wave-uniform (scalar) loads.  The table is empty for ordinary meshes; a mesh needs 32 triangles of
+// one centroid to add an entry.
+__device__ __forceinline__ int mipt_leaf_count_scan(uint32_t first, const uint2* __restrict__ fat, int nfat) {
+	int c = MIPT_LEAF_MAX_TRIS;
+	for (int k = 0; k < nfat; k++) { const uint2 e = fat[k]; if (e.x == first) c = (int)e.y; }
+	return c;
+}
 
 // load_obj_hot() and the group-table branch of query_material() (mipt_trace.h) read these records with raw 16-byte loads at fixed
 // offsets; the host fills them by field name.  A reordered field must fail here, not corrupt every material lookup.
@@ -107,11 +130,19 @@ struct DScene {
 	int first_mesh;              // index of the first TriMesh object (nobj if none): the objects before it are analytic
 	int inherit_material;        // some sphere beyond objects 0 / 1 has no material lists and is not a mirror: Scene::intersection's ONE MaterialValues for all objects
 	                             // of its loop decides what it is shaded with (Geometry.cpp:596); such scenes are rendered by the one-thread-per-sample kernel (mipt_trace.h)
-	unsigned merl_mask;          // bit i: object i carries a measured BRDF (the fast shade tier hands its hits on before it looks at their material)
+	unsigned merl_mask;          // bit i: object i < 32 carries a measured BRDF (the fast shade tier hands its hits on before it looks at their material; objects >= 32: DObject::brdf_kind)
+	int n_meshes;                // TriMesh objects of the scene
 	const DFatNode* all_nodes;   // fat nodes of every mesh, one buffer (wave-uniform base for the persistent traversal)
 	const DTriIsect* all_tris;   // intersection records of every mesh, one buffer
-	DObject obj[MIPT_MAX_OBJECTS];
+	const uint2* fat_leaves;     // (first triangle, count) of every leaf with >= MIPT_LEAF_MAX_TRIS triangles, ascending; usually empty
+	int n_fat_leaves;
+	const uint2* mesh_first;     // n_meshes entries in object order = ascending first triangle: (first triangle of the mesh in all_tris, its object index)
+	DObject obj[];               // nobj records BEHIND the header, in the same allocation (the reference's Scene::objects is an unbounded vector, Geometry.h:1306-1309;
+	                             // until round 6: obj[31]).  Not a pointer to a second buffer: the kernels take the scene as `const DScene* __restrict__`, and only
+	                             // what is reached from THAT pointer by address arithmetic is known not to alias their stores — behind a loaded pointer the
+	                             // object records were re-read after every store (generate + shade +30 % on configs[2], measured)
 };
+static_assert(offsetof(DScene, obj) % 64 == 0, "the object records start on a cache line");
 
 // Per-render constants (kernel argument, by value).
 struct DRender {

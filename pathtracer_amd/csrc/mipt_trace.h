@@ -48,6 +48,33 @@ struct Hit {
 	float beta, gamma;
 };
 
+// The fourth word of a closest-hit record in HBM (wf.hit[].w, and the .w a fresh ray carries in its direction):
+//   MIPT_HIT_MISS                     nothing hit
+//   MIPT_HIT_ANALYTIC | object        a sphere / plane: any object index (Scene::objects is an unbounded vector, Geometry.h:1306-1309)
+//   scene-wide triangle index         a mesh triangle (bit 31 clear; < 2^26): the object is the mesh whose range of the scene's
+//                                     triangle buffer holds it — the only mesh in every BASELINE config (no search, no load),
+//                                     else a binary search over the meshes' first triangles (DScene::mesh_first)
+// Until round 6 the word was object << 27 | mesh-local triangle: 31 objects at most.
+#define MIPT_HIT_MISS 0xffffffffu
+#define MIPT_HIT_ANALYTIC 0x80000000u
+MIPT_DEV bool hit_unpack(const DScene* __restrict__ sc, unsigned packed, int& obj, int& tri) {
+	obj = -1; tri = -1;
+	if (packed == MIPT_HIT_MISS) return false;
+	if (packed & MIPT_HIT_ANALYTIC) { obj = (int)(packed & 0x7fffffffu); return true; }
+	if (sc->n_meshes == 1) { obj = sc->first_mesh; tri = (int)packed; return true; }       // (the scene's first mesh starts at triangle 0)
+	int lo = 0, hi = sc->n_meshes - 1;
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sc->mesh_first[mid].x <= packed) lo = mid; else hi = mid - 1; }
+	const uint2 e = sc->mesh_first[lo];
+	obj = (int)e.y; tri = (int)(packed - e.x);
+	return true;
+}
+MIPT_DEV unsigned hit_pack(const DScene* __restrict__ sc, int obj, int tri) {      // tri: mesh-local, or < 0 for a sphere / plane
+	return tri < 0 ? (MIPT_HIT_ANALYTIC | (unsigned)obj) : (sc->obj[obj].tri_base + (unsigned)tri);
+}
+MIPT_DEV bool object_has_merl(const DScene* __restrict__ sc, int obj) {             // the first 32 objects in a register mask (no load), the rest in their records
+	return obj < 32 ? ((sc->merl_mask >> obj) & 1u) != 0 : sc->obj[obj].brdf_kind == 1;
+}
+
 MIPT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- object transforms (Geometry.h:362-396)
@@ -368,7 +395,7 @@ MIPT_DEV bool mesh_traverse(const DObject& o, f3 org, f3 d, float cur_best_t, fl
 		if (cur == NONE) break;
 		MIPT_PROF_COUNT(2)
 		int first = (int)(cur & MIPT_LEAF_FIRST_MASK);
-		int count = (int)((cur >> 26) & 31u) + 1;
+		const int count = mipt_leaf_count(cur, o.fat_leaves, o.n_fat_leaves);
 		for (int i = first; i < first + count; i++) {
 			float lt, lb, lg;
 			if (tri_test(o.tris + i, org, d, lt, lb, lg)) {

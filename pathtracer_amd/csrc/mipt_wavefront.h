@@ -73,8 +73,7 @@ template <class T> __device__ __forceinline__ void wf_st(T* p, T a) { *p = a; }
 #define MIPT_N_SHADOW(wf, b) ((wf).counters[MIPT_CNT_PAIR(b)])
 #define MIPT_N_EXTEND(wf, b, n0) ((b) == 0 ? (n0) : (wf).counters[MIPT_CNT_PAIR((b) - 1) + 1])
 #define MIPT_WF_COUNTERS (MIPT_WF_NCOUNTERS * MIPT_CNT_STRIDE)
-#define MIPT_HIT_MISS 0xffffffffu
-#define MIPT_HIT_NOTRI 0x07ffffffu
+// (MIPT_HIT_MISS / MIPT_HIT_ANALYTIC and hit_unpack: mipt_trace.h, beside struct Hit)
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -153,7 +152,7 @@ MIPT_DEV void analytic_prefix_closest(const DScene* __restrict__ sc, f3 ro, f3 r
 		f3 org = xf_point(o.inv, ro);
 		float tt;
 		bool hit = (o.type == 1) ? sphere_test(o, org, d, tt) : plane_test(o, org, d, tt);
-		if (hit && tt < t) { t = tt; best = ((unsigned)i << 27) | MIPT_HIT_NOTRI; }
+		if (hit && tt < t) { t = tt; best = MIPT_HIT_ANALYTIC | (unsigned)i; }
 	}
 }
 MIPT_DEV bool analytic_occluded(const DScene* __restrict__ sc, f3 ro, f3 rd, float dist) {
@@ -304,7 +303,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 			Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z);
 			Hit h;
 			bool hit = scene_closest(sc, r, h, stk);
-			unsigned packed = hit ? (((unsigned)h.obj << 27) | (h.tri < 0 ? MIPT_HIT_NOTRI : (unsigned)h.tri)) : MIPT_HIT_MISS;
+			unsigned packed = hit ? hit_pack(sc, h.obj, h.tri) : MIPT_HIT_MISS;
 			wf_st(&wf.hit[id], make_float4(h.t, h.beta, h.gamma, __uint_as_float(packed)));
 		}
 	}
@@ -521,9 +520,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			}
 			unsigned packed = __float_as_uint(hr.w);
 			Hit h; h.t = hr.x; h.beta = hr.y; h.gamma = hr.z;
-			bool has_inter = packed != MIPT_HIT_MISS;
-			h.obj = has_inter ? (int)(packed >> 27) : -1;
-			h.tri = has_inter ? (((packed & MIPT_HIT_NOTRI) == MIPT_HIT_NOTRI) ? -1 : (int)(packed & MIPT_HIT_NOTRI)) : -1;
+			const bool has_inter = hit_unpack(sc, packed, h.obj, h.tri);
 			f3 P = mk3(0, 0, 0); Mat m;
 			m.shadingN = mk3(0, 1, 0); m.Kd = mk3(0.5f, 0.5f, 0.5f); m.Ks = mk3(0, 0, 0); m.Ne = mk3(100, 100, 100); m.Ke = mk3(0, 0, 0); m.transp = false; m.refr_index = 0;
 			if (TIER == 1) {
@@ -533,7 +530,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				// a hit on an object with a measured BRDF is the general tier's whatever its material says: handed on BEFORE the
 				// material is fetched (round 4; until then this tier fetched the material of such a vertex — shading record, group
 				// record, the lot — only to find mat.merl set and defer it, and the general tier fetched it again)
-				if (MIPT_SHADE_EARLY_DEFER && has_inter && ((sc->merl_mask >> h.obj) & 1u)) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
+				if (MIPT_SHADE_EARLY_DEFER && has_inter && object_has_merl(sc, h.obj)) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
 			}
 			if (has_inter) hit_material(sc, p.ray, h, P, m);
 			ShadowRequest sh; f3 wv;

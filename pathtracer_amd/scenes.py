@@ -121,6 +121,30 @@ def fat_leaf_mesh(n: int = 20) -> MeshData:
     return MeshData(m.vertices, m.normals, None, np.ascontiguousarray(fv, np.int32), np.ascontiguousarray(fn, np.int32), None, "fatleaf%d" % n)
 
 
+def huge_leaf_mesh(n: int = 12, fan: int = 100, fans: int = 3) -> MeshData:
+    """Blob plus `fans` bundles of `fan` DIFFERENT triangles whose centroids coincide exactly (integer offsets around a common centre:
+    (A + B + C) / 3 is the same float for all of them): build_bvh_recur cannot split such a bundle (TriangleMesh.cpp:1118), so the tree
+    gets leaves of `fan` triangles — beyond the 32 a leaf reference's count field holds.  Each bundle is a star of thin blades, so rays
+    hit different members of it (and the reference keeps the first in leaf order on a tie)."""
+    m = blob_mesh(n)
+    rng = np.random.default_rng(5)
+    verts, faces = [m.vertices], [m.faces_v]
+    base = m.vertices.shape[0]
+    for b in range(fans):
+        c = np.array([[-1.0, 0.5, 0.75], [0.5, 1.0, -0.5], [0.25, -0.75, 1.0]][b % 3]) * 2.0 + b // 3      # exact in float
+        for k in range(fan):
+            a = rng.integers(-8, 9, 3).astype(np.float64) / 16.0                                          # multiples of 1/16: every sum below is exact
+            d = rng.integers(-8, 9, 3).astype(np.float64) / 16.0
+            if not np.any(np.cross(a, d)):
+                d = d + np.array([0.0625, 0.125, 0.0])
+            tri = np.stack([c + a, c + d, c - a - d])
+            verts.append(tri.astype(np.float32)); faces.append(np.array([[base, base + 1, base + 2]], np.int32)); base += 3
+    v = np.concatenate(verts).astype(np.float32)
+    f = np.ascontiguousarray(np.concatenate(faces), np.int32)
+    nrm = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)
+    return MeshData(v, nrm.astype(np.float32), None, f, f.copy(), None, "hugeleaf%d_%d" % (n, fan))
+
+
 def write_obj(mesh: MeshData, path: str) -> None:
     """OBJ text with ``vn`` and ``f a//a`` (or ``a/t/n``) faces.  SURVEY.md §4 pitfall 1: an OBJ
     without ``vn`` renders black in the reference, so normals are always written."""

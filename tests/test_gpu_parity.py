@@ -419,46 +419,119 @@ def test_partition_rank_splat_packed_columns_on_random_partitions(seed):
     assert np.abs(normalised(acc_i, acc_c) - normalised(img1, cnt1)).max() < 1e-5
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
-def test_object_table_full_and_one_too_many(pipeline):
-    """The scene table holds MIPT_MAX_OBJECTS = 31 objects (csrc/mipt_scene.h: the 5 bits a hit record has for the object, minus the
-    code of a miss; 16 until round 4): light, environment, ground plane, two meshes and 26 spheres of every kind fill it — bit for bit
-    against the oracle, depth 0 (nothing traced) and depth 3 —; a thirty-second object is refused with a message, not truncated."""
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_two_hundred_objects_forty_meshes(pipeline):
+    """Scene::objects is an unbounded vector (Geometry.h:1306-1309).  Until round 6 a hit record had five bits for its object: 31 objects.
+    Now: light, environment, ground plane, 157 spheres of every kind and 40 small meshes (one of them, far beyond object 32, with a measured
+    BRDF; one alpha-tested) — bit for bit against the oracle at depth 3 and depth 0, rays of every mesh by Scene::intersection, and the
+    image through the splat.  A hit names its mesh by the scene-wide triangle index (csrc/mipt_trace.h, hit_unpack)."""
     from oracle.binding import Oracle
 
-    def build(X, extra):
-        cfg = scenes.config_c1(44, 30, 2)
+    def build(X):
+        cfg = scenes.config_c1(64, 40, 2)
         cfg.nb_bounces = 3
         X.apply_config(cfg)
-        rng = np.random.default_rng(7)
-        X.add_mesh(scenes.blob_mesh(10), scale=12.0)
-        for k in range(26 + extra):
-            c = (float(rng.uniform(-30, 30)), float(rng.uniform(-26, 0)), float(rng.uniform(-15, 25)))
-            o = X.add_sphere(c, float(rng.uniform(2, 6)), mirror=(k % 4 == 1))
+        rng = np.random.default_rng(11)
+        meshes = []
+        for k in range(197):
+            c = (float(rng.uniform(-32, 32)), float(rng.uniform(-26, 4)), float(rng.uniform(-20, 28)))
+            if k % 5 == 4 or k == 196:                         # 40 meshes spread over the list (their triangle ranges ascend with the object index)
+                m = scenes.blob_mesh(4 + k % 7, with_uv=(k == 99))
+                sc_ = float(rng.uniform(3, 7))
+                # placed through its vertices (TriMesh::init with center = false keeps them; it swaps the axes (x, y, z) -> (-z, y, x),
+                # TriangleMesh.cpp:742-751: world (x, z) = (-z_in, x_in)); add_mesh then rests the mesh on the ground plane
+                v = m.vertices.astype(np.float64) * sc_ + np.array([c[2], 0.0, -c[0]])
+                m = scenes.MeshData(v.astype(np.float32), m.normals, m.uvs, m.faces_v, m.faces_n, m.faces_t, "blob_%d" % k)
+                o = X.add_mesh(m, scale=1.0, center=False)
+                meshes.append(o)
+                if k == 99:
+                    X.set_group_material(o, 0, (0.8, 0.8, 0.8), (0, 0, 0), (0, 0, 0))
+                    X.set_group_texture(o, 0, 3, scenes.alpha_texture())       # alpha-tested leaves (the per-lane leaf loop)
+                if k == 149:
+                    X.set_brdf_merl(o, scenes.synthetic_merl_table())          # object index > 32: object_has_merl reads the record
+                continue
+            o = X.add_sphere(c, float(rng.uniform(1.5, 4.5)), mirror=(k % 4 == 1))
             if k % 4 == 0: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
             if k % 4 == 2: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0.3, 0.3, 0.3), (40, 40, 40), 1.0, 1.3)
             if k % 4 == 3: X.add_group_material(o, (1, 1, 1), (0, 0, 0), (0, 0, 0), 0.0, 1.4)
-        X.add_mesh(scenes.blob_mesh(8), scale=6.0)
-        return cfg
+        return cfg, meshes
 
     O, G = Oracle(), capi.HostRaytracer(device=0)
     for X in (O, G):
-        cfg = build(X, 0)
+        cfg, meshes = build(X)
         X.prepare()
-    assert G.num_objects() == 31                       # MIPT_MAX_OBJECTS
+    assert G.num_objects() == 200 and len(meshes) == 40
     G.set_option("pipeline", pipeline)
     pix = all_pixels(cfg)
-    assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], O.getcolor_samples(pix, 0, cfg.spp)[0], "31 objects, depth 3")
+    want = O.getcolor_samples(pix, 0, cfg.spp)[0]
+    assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, "200 objects, depth 3")
+    assert (want != 0).any(-1).mean() > 0.3
+    # Scene::intersection: camera-like rays, object and (mesh-local) triangle ids of every kind of object
+    rng = np.random.default_rng(5)
+    rays = np.concatenate([np.tile(np.array(cfg.cam_pos, np.float32), (3000, 1)), rng.normal(size=(3000, 3)).astype(np.float32) * (0.35, 0.25, 0.1) + np.array(cfg.cam_dir, np.float32)], 1).astype(np.float32)
+    gi, gf = G.intersect(rays); oi, of = O.intersect(rays)
+    assert_bits(gi, oi, "hit / object / triangle ids")               # (triangle_id: -1 as soon as a sphere BEHIND the winning mesh in the list is hit, Geometry.cpp:589-650)
+    on_mesh = (oi[:, 0] == 1) & np.isin(oi[:, 1], meshes)
+    assert len(set(oi[on_mesh, 1].tolist())) >= 10 and (oi[on_mesh, 2] >= 0).sum() > 100 and (oi[on_mesh, 2] < 0).sum() > 50, "the rays reach too few meshes for the test to mean anything"
+    assert_bits(gf[oi[:, 0] == 1, :7], of[oi[:, 0] == 1, :7], "t / P / normal")
+    img, cnt = G.render(); oimg, ocnt = O.render_seeded()
+    assert_bits(cnt, ocnt, "splat weights"); assert_bits(img, oimg, "image")
     for X in (O, G):
         X.set_render(cfg.W, cfg.H, cfg.spp, 0)
         X.prepare()
     black = G.getcolor_samples(pix, 0, cfg.spp)[0]
     assert_bits(black, O.getcolor_samples(pix, 0, cfg.spp)[0], "depth 0")
     assert not black.any()
-    G2 = capi.HostRaytracer(device=0)
-    build(G2, 1)
-    with pytest.raises(capi.MiptError, match="n_objects"):
-        G2.prepare()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_leaves_of_a_hundred_triangles(resident):
+    """build_bvh_recur's leaves are unbounded (a bundle of triangles with one centroid cannot be split, TriangleMesh.cpp:1118); a leaf
+    reference here has five bits for the count.  Leaves of 32 and more file their count in the scene's table (csrc/mipt_scene.h,
+    mipt_leaf_count).  Until round 6 such a mesh was refused.  Closest hits, any hits in all three forms of the stage, both pipelines,
+    the contribution-queue kernel's per-thread traversal, a second mesh behind it (the table is scene-wide) — bit for bit against the
+    oracle.  `resident`: the device build declines such a mesh (its records are made by the host-side conversion either way)."""
+    from oracle.binding import Oracle
+    capi.set_device_resident(resident)
+    try:
+        cfg = scenes.config_c1(72, 48, 3)
+        cfg.nb_bounces = 4
+        big, small = scenes.huge_leaf_mesh(), scenes.huge_leaf_mesh(8, 40, 2)
+        O, G = Oracle(), capi.HostRaytracer(device=0)
+        for X in (O, G):
+            X.apply_config(cfg)
+            a = X.add_mesh(small, scale=12.0)
+            b = X.add_mesh(big, scale=30.0)
+            X.prepare()
+        for oid, want_max in ((a, 12), (b, 90)):
+            d = G.mesh_dump(oid)
+            leaves = d["nodes_i"][d["nodes_i"][:, 0] == 1]
+            assert (leaves[:, 2] - leaves[:, 1]).max() >= want_max
+            assert_bits(d["nodes_i"], O.mesh_dump(oid)["nodes_i"], "the reference's tree")
+        pix = all_pixels(cfg)
+        want = O.getcolor_samples(pix, 0, cfg.spp)[0]
+        for opts in ({"pipeline": 1}, {"pipeline": 1, "anyhit_wide": 0}, {"pipeline": 1, "anyhit_flag_all": 1}, {"pipeline": 1, "refill": 0}, {"pipeline": 0}):
+            for k, v in opts.items():
+                G.set_option(k, v)
+            assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, f"per-sample radiance {opts}")
+            G.set_option("anyhit_wide", 1); G.set_option("anyhit_flag_all", 0); G.set_option("refill", 1)
+        G.set_option("pipeline", 1)
+        rng = np.random.default_rng(3)
+        rays = np.concatenate([np.tile(np.array(cfg.cam_pos, np.float32), (4000, 1)), rng.normal(size=(4000, 3)).astype(np.float32) * (0.3, 0.3, 0.1) + np.array(cfg.cam_dir, np.float32)], 1).astype(np.float32)
+        gi, gf = G.intersect(rays); oi, of = O.intersect(rays)
+        assert_bits(gi, oi, "hit / object / triangle ids")
+        dist = rng.uniform(5, 80, 4000).astype(np.float32)
+        assert_bits(G.intersect_shadow(rays, dist), O.intersect_shadow(rays, dist), "occlusion")
+        # fog: the contribution-queue pipeline (its logic stages and, with queue_wavefront = 0, the one-thread-per-sample loop)
+        for X in (O, G):
+            X.set_fog(0.01, 0.002)
+            X.prepare()
+        want = O.getcolor_samples(pix, 0, cfg.spp)[0]
+        for qw in (1, 0):
+            G.set_option("queue_wavefront", qw)
+            assert_bits(G.getcolor_samples(pix, 0, cfg.spp)[0], want, f"fog, queue_wavefront {qw}")
+    finally:
+        capi.set_device_resident(True)
 
 
 @pytest.mark.parametrize("batch", [0, 1])
