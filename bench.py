@@ -539,6 +539,29 @@ def run(args):
                     rsh["traffic_over_algorithmic_bytes"] = per_step * args.steps / (verts * state_bytes)
                 except Exception:
                     pass
+                # Scenes whose shade stage is fp64 arithmetic (the measured-BRDF tiers of configs[4]: glibc's acos / atan2 / sincos restated, 61 correctly rounded
+                # divisions): the bytes above do not describe it.  From the committed counter run of the same build (tools/pmc_fp64.sh -> profiles/fp64_counters.json):
+                # fp64 operations per shade vertex x the vertices of this run / stage time, against the fp64 vector peak.
+                try:
+                    fall = json.load(open(os.path.join(ROOT, "profiles", "fp64_counters.json")))
+                    fj = fall[args.workload]
+                    same64 = fall.get("_build", {}).get("source_sha256_16") == ge.source_hash() and not os.environ.get("MIPT_LIB_OVERRIDE")
+                    st64 = fj["stage_generate_shade"]
+                    if st64["fp64_flop_per_vertex"] > 50.0:       # (a Phong scene has a few fp64 operations per vertex — promotion points of the reference's float code — and stays on the byte roofline)
+                        peak64 = 78.6                              # TFLOP/s: MI355X fp64 vector FMA peak = half the fp32 vector peak of MI355X_MICROARCH.md (157.3)
+                        ach = st64["fp64_flop_per_vertex"] * verts / shade_secs / 1e12 if same64 else None
+                        tier = {k: v for k, v in fj["kernels"].items() if k.startswith("k_wf_shade<4>") or k.startswith("k_wf_shade<3>")}
+                        rsh = {"kernel": rsh["kernel"] + " — measured-BRDF tiers k_wf_shade<3/4>", "bound": "fp64", "unit": "TFLOP/s", "peak": peak64, "achieved": ach, "frac": (ach / peak64) if ach is not None else None,
+                               "frac_definition": "fp64 operations (ADD + MUL + 2 FMA + TRANS wave-instructions x mean active lanes, SQ_INSTS_VALU_*_F64 of the committed counter run) per shade vertex x vertices of this run / stage time / fp64 vector peak 78.6 TFLOP/s",
+                               "fp64_flop_per_vertex": st64["fp64_flop_per_vertex"], "frac_if_every_fp64_instruction_had_64_lanes": (st64["fp64_issue_slot_flop_per_vertex"] * verts / shade_secs / 1e12 / peak64) if same64 else None,
+                               "vertices_per_step": verts / args.steps, "ms_per_step": shade_ms / args.steps,
+                               "measured_brdf_tiers": {k: {q: v[q] for q in ("launches_per_step", "fp64_share_of_vector_instructions", "active_lanes_per_vector_instruction", "vector_instructions_per_simd_and_cycle", "wait_share_of_wave_cycles")} for k, v in tier.items()},
+                               "derived_from_pmc_run": {"file": "profiles/fp64_counters.json", "source": fj["source"], "same_library_build": same64, "stale": not same64},
+                               "why_not_bytes": "the tier evaluates IsoMERLBRDF::eval (BRDF.h:204-246, MERLBRDFRead.cpp:76-206) in fp64 with the host libm's algorithms: about a third of its vector instructions are fp64, "
+                                                "its waves wait (dependent chains at 3 waves per SIMD, 168 registers) for most of their cycles; the byte figures are kept under `hbm`",
+                               "hbm": rsh}
+                except Exception:
+                    pass
                 out["roofline_shade_kernel"] = rsh
             out["stage_ms_per_step"] = {("traverse" if merged else "extend"): kern_ms / args.steps, "shadow": sh_ms / args.steps, "generate+shade": shade_ms / args.steps, "resolve": resolve_ms / args.steps}
             if not args.no_cpu_baseline:

@@ -395,7 +395,7 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "samples_per_pass" > 0: a pass renders at most this many samples per pixel; with 1 and a progress callback
  *                     mipt_render behaves like the sample loop of Raytracer::render_image (the caller's buffers hold the
  *                     running sums after every sample) without paying an upload and an allocation per sample; 0 = off
- *   "progressive_lookahead" renders with a progress callback: publish groups rendered per pass (default 4, 1 .. 64); the caller still sees
+ *   "progressive_lookahead" renders with a progress callback: publish groups rendered per pass (1 .. 64; 0 = default: as many as make a pass hold 64 M paths); the caller still sees
  *                     exactly the sums through the group it is told about, the snapshots of a pass travel while the next one renders
  *   "anyhit_wide"     1 = shadow rays go through the order-free any-hit traversal over 8-bit four-wide nodes, with the rays whose answer
  *                     could depend on the reference's visiting order replayed by the ordered kernel (default),

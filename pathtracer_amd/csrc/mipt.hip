@@ -463,7 +463,7 @@ struct mipt_ctx {
 	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: the running sums are published after every this many samples per pixel (progressive display: 1)
-	int64_t opt_progressive_lookahead = 4;  // progressive display through mipt_render: publish groups rendered per pass (their stages run together; every group is still splatted, published and reported on its own)
+	int64_t opt_progressive_lookahead = 0;  // progressive display through mipt_render: publish groups rendered per pass (their stages run together; every group is still splatted, published and reported on its own); 0 = as many as make a pass hold 64 M paths
 	hipStream_t copy_stream = nullptr;      // downloads of published running sums, beside the compute stream
 	void* snap_buf = nullptr; size_t snap_buf_bytes = 0;   // snapshots of the accumulators, one per publish group of a pass (they are downloaded while the next pass is rendered)
 	hipEvent_t ev_pub = nullptr;
@@ -670,7 +670,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "queue_force_probe_build")) { c->scene_has_subsurface = c->scene_has_subsurface || value != 0; c->grid_qlogic[0] = 0; return MIPT_OK; }   // test hook: the logic stage compiled with the subsurface probe
 	if (!strcmp(name, "resolve_rows")) { if (value < 0 || value > 4096) return fail(c, MIPT_ERR_INVALID, "resolve_rows must be in [0,4096]"); c->opt_resolve_rows = value; return MIPT_OK; }
 	if (!strcmp(name, "pass_memory_limit")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "pass_memory_limit must be >= 0"); c->opt_pass_memory_limit = value; return MIPT_OK; }
-	if (!strcmp(name, "progressive_lookahead")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "progressive_lookahead must be in [1,64]"); c->opt_progressive_lookahead = value; return MIPT_OK; }
+	if (!strcmp(name, "progressive_lookahead")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "progressive_lookahead must be in [0,64]"); c->opt_progressive_lookahead = value; return MIPT_OK; }
 	if (!strcmp(name, "samples_per_pass")) { if (value < 0) return fail(c, MIPT_ERR_INVALID, "samples_per_pass must be >= 0"); c->opt_samples_per_pass = value; return MIPT_OK; }
 	if (!strcmp(name, "refill_threshold")) { if (value < 1 || value > 64) return fail(c, MIPT_ERR_INVALID, "refill_threshold must be in [1,64]"); c->opt_refill_threshold = value; return MIPT_OK; }
 	if (!strcmp(name, "inner_min")) { if (value < 0 || value > 64) return fail(c, MIPT_ERR_INVALID, "inner_min must be in [0,64]"); c->opt_inner_min = value; return MIPT_OK; }
@@ -1172,6 +1172,7 @@ static int ensure(mipt_ctx* c, void** buf, size_t* have, size_t need) {
 static int make_render_consts(mipt_ctx* c, const mipt_render_params* p, DRender& R, float& denom2, hipStream_t st) {
 	if (!p) return fail(c, MIPT_ERR_INVALID, "null render params");
 	if (p->W <= 0 || p->H <= 0 || p->nrays <= 0 || p->nb_bounces < 0) return fail(c, MIPT_ERR_INVALID, "bad image size / sample count / depth");
+	if (p->nb_bounces > 0xffff || (c->scene_has_merl && p->nb_bounces > 0x7fff)) return fail(c, MIPT_ERR_UNSUPPORTED, "nb_bounces %d: a path's state word holds 16 bits of depth (15 on a scene with a measured BRDF)", p->nb_bounces);
 	if (!p->samples2d || !p->randomPerPixel || !p->filter_integral || p->filter_size < 0 || p->filter_size > 8) return fail(c, MIPT_ERR_INVALID, "missing prepare_render tables");
 	if ((double)p->W * p->H > 2.0e9) return fail(c, MIPT_ERR_INVALID, "image too large");
 	memset(&R, 0, sizeof R);
@@ -1368,7 +1369,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	// lane of the chip, thirteen launches that are all ramp and drain.
 	const bool pipelined_publish = hp && cb && !dump && !d_aov;
 	const int publish_group = c->opt_samples_per_pass > 0 ? (int)c->opt_samples_per_pass : 0;     // 0: once per pass
-	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass * (pipelined_publish ? c->opt_progressive_lookahead : 1));
+	// lookahead 0 (default since round 6): as many publish groups as make the pass hold 64 M paths (31 one-sample groups at 1080p, ~35 ms of rendering; at least 4,
+	// at most 64) — below that a pass is mostly the ramp and drain of its ~13 launches (1.7 ms per sample at 4 groups, 1.2 at 16, tools/progressive_rate.py)
+	int64_t lookahead = c->opt_progressive_lookahead;
+	if (lookahead == 0 && c->opt_samples_per_pass > 0) lookahead = std::min<int64_t>(64, std::max<int64_t>(4, (((int64_t)64 << 20) + (int64_t)npix_slots * c->opt_samples_per_pass - 1) / ((int64_t)npix_slots * c->opt_samples_per_pass)));
+	if (c->opt_samples_per_pass > 0) spp_pass = (int)std::min<int64_t>(spp_pass, c->opt_samples_per_pass * (pipelined_publish ? lookahead : 1));
 	spp_pass = std::min(spp_pass, ke - kb);
 	const bool want_aov = d_aov || (dump && dump->out_normal);
 	// 2 = the queue kernel (ghost objects, background photo); the denoiser inputs are a stage of the wavefront pipeline
@@ -1979,8 +1984,8 @@ extern "C" int mipt_render_denoiser_inputs(mipt_ctx* c, const mipt_render_params
 
 #ifdef MIPT_PROFILE_SIMD
 extern "C" int mipt_debug_simd_profile(unsigned long long* out32, int reset) {
-	if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_simd_prof), 256) != hipSuccess) return MIPT_ERR_HIP;
-	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 256) != hipSuccess) return MIPT_ERR_HIP; }
+	if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_simd_prof), 320) != hipSuccess) return MIPT_ERR_HIP;      // (40 counters since round 6: the caller's array must hold them)
+	if (reset) { unsigned long long z[40] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_simd_prof), z, 320) != hipSuccess) return MIPT_ERR_HIP; }
 	return MIPT_OK;
 }
 #endif

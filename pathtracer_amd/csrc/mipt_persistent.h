@@ -36,6 +36,10 @@
 #ifndef MIPT_PREFETCH_IDS
 #define MIPT_PREFETCH_IDS 0
 #endif
+// MIPT_UNIFORM_FETCH: see the inner-node phase of traverse_queue.  Measured: EXPERIMENTS.md (round 6).
+#ifndef MIPT_UNIFORM_FETCH
+#define MIPT_UNIFORM_FETCH 0
+#endif
 #ifndef MIPT_PULL_DIV
 #define MIPT_PULL_DIV 8u                // chunks per wave of the grid when the queue is short
 #endif
@@ -310,7 +314,29 @@ __device__ __forceinline__ void traverse_queue(const DScene* __restrict__ sc, co
 				if (__popcll(mi) < inner_min && __ballot(st.cur >= MIPT_NONE) != 0) break;      // (a leaf, or a ray that has run out of nodes)
 				if (!inner) continue;
 				MIPT_PROF_COUNT(0)
+#ifdef MIPT_PROFILE_SIMD
+				{   // how often the descending lanes of a wave stand on ONE node (the step a scalar fetch could serve)
+					const unsigned c0_ = (unsigned)__builtin_amdgcn_readfirstlane((int)st.cur);
+					const unsigned long long same_ = __ballot(st.cur == c0_);
+					if (same_ == mi) MIPT_PROF_COUNT(32)
+					else if (2 * __popcll(same_) >= __popcll(mi)) MIPT_PROF_COUNT(34)
+				}
+#endif
 				float4 q0, q1, q2, q3;
+#if MIPT_UNIFORM_FETCH
+				// Every descending lane on ONE node (camera rays of an 8 x 8 pixel block at the top of the tree: 23 % of the inner steps of depth 0 on
+				// configs[2], tools/simd_prof.py): the node comes through the scalar cache, one s_load_dwordx16 instead of four vector-memory
+				// instructions — the resource this kernel runs out of.  Same node, same arithmetic: the visit sequence is unchanged.
+				const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cur);
+				if (!SHADOW && !RESV && __builtin_amdgcn_readfirstlane((int)(__ballot(st.cur == cur0) == mi))) {
+					typedef float mipt_f16 __attribute__((ext_vector_type(16)));
+					mipt_f16 nd;
+					const float4* qs = nodes + 4 * (size_t)cur0;
+					asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nd) : "s"(qs) : "memory");
+					q0 = make_float4(nd[0], nd[1], nd[2], nd[3]); q1 = make_float4(nd[4], nd[5], nd[6], nd[7]);
+					q2 = make_float4(nd[8], nd[9], nd[10], nd[11]); q3 = make_float4(nd[12], nd[13], nd[14], nd[15]);
+				} else
+#endif
 				{
 					const float4* q = nodes + 4 * (size_t)st.cur;
 					q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];

@@ -11,7 +11,7 @@
 #pragma once
 #include <stdint.h>
 
-#define MIPT_MAX_OBJECTS 65536   // a sanity bound on mipt_scene_desc::n_objects, not a layout limit: the object records are a device array of n_objects entries and a
+#define MIPT_MAX_OBJECTS 65535   // a sanity bound on mipt_scene_desc::n_objects, not a layout limit: the object records are a device array of n_objects entries and a
                                  // hit record names its object by index or by triangle (mipt_trace.h, hit_unpack).  Until round 6: 31 (five bits of the hit word).
 #define MIPT_TEX_SLOTS 8
 // slot ids = the reference's Texture type codes (BRDF.h:256-264) + 7 for the subsurface list

@@ -286,7 +286,7 @@ __device__ __attribute__((noinline)) bool alpha_rejects(const DObject& o, int i,
 // iteration, 6 object-loop pass, 8 outer iteration, 10 refill; wave cycles: 12 refill + object loop, 13 inner phase, 14 leaf phase
 // shade stage (fast tier): 16 sub-chunk (lanes that hold a vertex), 18 lanes whose vertex is the diffuse one (light sample +
 // continuation), 20 environment hits, 22 misses / light hits, 24 vertices sent to the slow tier
-__device__ unsigned long long g_simd_prof[32];
+__device__ unsigned long long g_simd_prof[40];
 MIPT_DEV unsigned lane_id_() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #define MIPT_PROF_COUNT(slot) { unsigned long long m_ = __ballot(1); if (lane_id_() == (unsigned)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_simd_prof[slot], 1ull); atomicAdd(&g_simd_prof[(slot) + 1], (unsigned long long)__popcll(m_)); } }
 #define MIPT_PROF_CLOCK(var) long long var = clock64()

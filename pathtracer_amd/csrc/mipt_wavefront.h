@@ -547,7 +547,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				bool ra, rb;
 				path_vertex_merl_requests(R, p, P, m, pi * R.W + pj, ps.k0 + kk, sh, ra, req_xa, req_sa, rb, req_xb, req_fb);
 				req_bits = (ra ? 1u : 0u) | (rb ? 2u : 0u);
-				req_meta = ((unsigned)h.obj << 1) | ((unsigned)p.depth << 8);      // p.depth: already the continuation's
+				req_meta = ((unsigned)p.depth << 1) | ((unsigned)h.obj << 16);     // bit 0: the kind; p.depth (15 bits: mipt_render refuses deeper paths on a scene with a
+				                                                                    // measured BRDF): already the continuation's; the object: 16 bits (MIPT_MAX_OBJECTS)
 				c = false;                                                        // (request B decides; see below)
 			} else c = path_vertex<TIER != 2 && !BATCH>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 							const f3 nn = mk3(__uint_as_float(rq[7 * MIPT_MERL_RQ + e]), __uint_as_float(rq[8 * MIPT_MERL_RQ + e]), __uint_as_float(rq[9 * MIPT_MERL_RQ + e]));
 							const f3 w0 = mk3(__uint_as_float(rq[10 * MIPT_MERL_RQ + e]), __uint_as_float(rq[11 * MIPT_MERL_RQ + e]), __uint_as_float(rq[12 * MIPT_MERL_RQ + e]));
 							const unsigned rid = rq[13 * MIPT_MERL_RQ + e], meta = rq[14 * MIPT_MERL_RQ + e];
-							const f3 brdf = merl_eval_inline(sc->obj[(meta >> 1) & 31u].merl, x, wo, nn);
+							const f3 brdf = merl_eval_inline(sc->obj[meta >> 16].merl, x, wo, nn);
 							if (!(meta & 1u)) {                                   // A: Raytracer.cpp:548, then weight * contrib for the shadow stage
 								const f3 contrib = mk3(0, 0, 0) + (mk3(1.f, 1.f, 1.f) * fac) * brdf;
 								const f3 pc = w0 * contrib;
@@ -643,7 +644,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 							} else {                                              // B: :611, then :240-241
 								PathState np;
 								np.weight = ((w0 * mk3(1.f, 1.f, 1.f)) * brdf) * fac;
-								np.depth = (int)((meta >> 8) & 0xffffu);
+								np.depth = (int)((meta >> 1) & 0x7fffu);
 								if (path_alive(np)) {
 									wf_st(&wf.wgt[rid], make_float4(np.weight.x, np.weight.y, np.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)np.depth)));
 									alive_id = rid;

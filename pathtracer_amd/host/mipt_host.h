@@ -252,7 +252,7 @@ public:
 	Scene s;
 	volatile int stopped = 0;
 	int current_nb_rays = 0;
-	int progressive_lookahead = 8;     // render_image: one-sample publishes rendered per pass (not a member of the reference: its loop renders them one by one)
+	int progressive_lookahead = 0;     // render_image: one-sample publishes rendered per pass, 0 = the library's choice (not a member of the reference: its loop renders them one by one)
 	std::vector<unsigned char> image;
 	std::vector<float> imagedouble;
 	std::vector<float> sample_count;

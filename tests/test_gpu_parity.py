@@ -426,6 +426,7 @@ def test_two_hundred_objects_forty_meshes(pipeline):
     BRDF; one alpha-tested) — bit for bit against the oracle at depth 3 and depth 0, rays of every mesh by Scene::intersection, and the
     image through the splat.  A hit names its mesh by the scene-wide triangle index (csrc/mipt_trace.h, hit_unpack)."""
     from oracle.binding import Oracle
+    merl_objs = []
 
     def build(X):
         cfg = scenes.config_c1(64, 40, 2)
@@ -433,6 +434,7 @@ def test_two_hundred_objects_forty_meshes(pipeline):
         X.apply_config(cfg)
         rng = np.random.default_rng(11)
         meshes = []
+        merl_objs.clear()
         for k in range(197):
             c = (float(rng.uniform(-32, 32)), float(rng.uniform(-26, 4)), float(rng.uniform(-20, 28)))
             if k % 5 == 4 or k == 196:                         # 40 meshes spread over the list (their triangle ranges ascend with the object index)
@@ -447,8 +449,9 @@ def test_two_hundred_objects_forty_meshes(pipeline):
                 if k == 99:
                     X.set_group_material(o, 0, (0.8, 0.8, 0.8), (0, 0, 0), (0, 0, 0))
                     X.set_group_texture(o, 0, 3, scenes.alpha_texture())       # alpha-tested leaves (the per-lane leaf loop)
-                if k == 149:
-                    X.set_brdf_merl(o, scenes.synthetic_merl_table())          # object index > 32: object_has_merl reads the record
+                if k in (24, 49, 149, 196):
+                    X.set_brdf_merl(o, scenes.synthetic_merl_table())          # object indices below and above 32 (object_has_merl; the request word of the batched tier)
+                    merl_objs.append(o)
                 continue
             o = X.add_sphere(c, float(rng.uniform(1.5, 4.5)), mirror=(k % 4 == 1))
             if k % 4 == 0: X.add_group_material(o, tuple(rng.uniform(0.1, 1, 3)), (0, 0, 0), (0, 0, 0), 1.0, 1.3)
@@ -472,6 +475,7 @@ def test_two_hundred_objects_forty_meshes(pipeline):
     gi, gf = G.intersect(rays); oi, of = O.intersect(rays)
     assert_bits(gi, oi, "hit / object / triangle ids")               # (triangle_id: -1 as soon as a sphere BEHIND the winning mesh in the list is hit, Geometry.cpp:589-650)
     on_mesh = (oi[:, 0] == 1) & np.isin(oi[:, 1], meshes)
+    assert len(set(oi[on_mesh, 1].tolist()) & set(o for o in merl_objs if o > 32)) >= 1, "no ray reaches a measured-BRDF mesh beyond object 32"
     assert len(set(oi[on_mesh, 1].tolist())) >= 10 and (oi[on_mesh, 2] >= 0).sum() > 100 and (oi[on_mesh, 2] < 0).sum() > 50, "the rays reach too few meshes for the test to mean anything"
     assert_bits(gf[oi[:, 0] == 1, :7], of[oi[:, 0] == 1, :7], "t / P / normal")
     img, cnt = G.render(); oimg, ocnt = O.render_seeded()

@@ -26,7 +26,7 @@ def test_every_publish_holds_the_sums_through_its_sample(name):
     mesh, cfg, oid = setup_scene(rt, name)
     rc1, img1, cnt1, calls1, seen1 = progressive(rt, 1)          # one sample per pass, as the reference's loop
     assert rc1 == capi.MIPT_OK and [c[0] for c in calls1] == list(range(1, cfg.spp + 1))
-    for look in (4, 3, 64):
+    for look in (4, 3, 64, 0):            # 0: the library sizes the pass (default since round 6)
         rc, img, cnt, calls, seen = progressive(rt, look)
         assert rc == capi.MIPT_OK and [c[0] for c in calls] == list(range(1, cfg.spp + 1))
         for (d1, i1, c1), (d2, i2, c2) in zip(seen1, seen):

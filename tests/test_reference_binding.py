@@ -154,7 +154,7 @@ def test_bvh_figures_of_the_device_build():
 
 @needs_lib
 @pytest.mark.gpu
-@pytest.mark.parametrize("lookahead", [1, 8])
+@pytest.mark.parametrize("lookahead", [1, 8, 0])
 def test_stop_render_between_two_samples(lookahead):
     """stopRender() from another thread while render_image() runs: the call returns with exactly the published sums."""
     X, (mesh, cfg, oid) = ref_on_gpu("blob32")
