@@ -458,6 +458,7 @@ struct mipt_ctx {
 	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
 	unsigned grid_qanyhit = 0;        // ... of k_q_anyhit
 	unsigned* q_replay_list = nullptr; // (in the pass buffer)
+	double replay_share = 0.0;         // replayed / shadow rays of the context's last render whose statistics were collected (collect_stats)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
 	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
@@ -1606,7 +1607,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					const dim3 ga(std::max(1u, std::min(c->grid_qanyhit, (nq + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
 					hipLaunchKernelGGL(k_q_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, aq, thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
 					TravQueue rq = tq; rq.list = c->q_replay_list; rq.n_ptr = tq.head + 8; rq.n_imm = 0; rq.head = tq.head + 16; rq.identity = false;
-					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
+					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab || c->replay_share > 0.005;
 					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? g.x : std::min(g.x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
 					return;
 				}
@@ -1736,7 +1737,11 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 					const dim3 ga(std::min(c->grid_anyhit, (unsigned)((total + MIPT_TRAV_BLOCK - 1) / MIPT_TRAV_BLOCK)));
 					hipLaunchKernelGGL(k_wf_anyhit, ga, dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, (const float4*)c->d_quad_nodes, (const float4*)c->d_leaf_box, c->d_all_tris, wf, b, list_mem[b & 1], &c->d_cnt[0]._pad[0], thr, imin | (c->opt_anyhit_flag_all ? (1 << 24) : 0));
 					TravQueue rq; rq.list = list_mem[b & 1]; rq.n_ptr = &wf.counters[MIPT_CNT_REPLAY(b)]; rq.n_imm = 0; rq.head = &wf.counters[MIPT_CNT_REPLAY(b) + 8]; rq.identity = false; rq.vis = nullptr; rq.skip_ghosts = false; rq.valid_in_ray = false;
-					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab;
+					// The replay list is empty on ordinary scenes: 128 blocks start, read a zero and leave.  A scene that does replay (light directions along an
+					// axis: infinite inverse components; occluders within 0.2 % of the far end) replays on every frame: once the last render's statistics show
+					// more than 0.5 % of the shadow rays on the list, the replay gets the whole grid (it ran on 7 % of the chip).  The append itself
+					// costs one atomic per wave-event, not per ray: the compiler aggregates to_replay()'s two atomics over the wave (s_bcnt1 + one leader).
+					const bool all = c->opt_anyhit_flag_all || c->opt_literal_slab || c->replay_share > 0.005;
 					hipLaunchKernelGGL(k_q_traverse<true>, dim3(all ? G(1).x : std::min(G(1).x, 128u)), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, rq, thr, imin);
 				}
 				else if (c->opt_refill) hipLaunchKernelGGL(k_wf_traverse<1>, G(1), dim3(MIPT_TRAV_BLOCK), 0, st, c->d_scene, d_nodes, c->d_all_tris, wf, b, 0u, thr, imin);
@@ -1842,6 +1847,8 @@ static int collect_stats(mipt_ctx* c) {
 	if (c->stats.pipeline == 1 || c->paths_from_host) h.paths = c->host_paths;     // the wavefront stages do not count paths on the device
 	if (c->primary_from_host) h.rays_closest += c->host_paths;
 	c->stats.paths = h.paths; c->stats.rays_closest = h.rays_closest; c->stats.rays_shadow = h.rays_shadow;
+	// how much of the shadow stage went through the ordered replay (hs[0]._pad[0]: mipt_anyhit.h): the next render sizes the replay launches with it
+	c->replay_share = h.rays_shadow ? (double)hs[0]._pad[0] / (double)h.rays_shadow : 0.0;
 	c->stats.mesh_casts_closest = h.rays_closest * (uint64_t)c->n_mesh_objects;
 	c->stats.mesh_casts_shadow = h.rays_shadow * (uint64_t)c->n_mesh_objects;   // upper bound: any-hit stops at the first occluder
 	float ms = 0;

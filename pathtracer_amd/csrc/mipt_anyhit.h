@@ -170,6 +170,10 @@ __global__ void k_leaf_box_init(float* __restrict__ leaf_box, size_t ntri) {
 #endif
 // (the spill columns are the ones of the ordered kernels, read as 4-byte entries: twice as many)
 #define MIPT_ANY_SPILL_STACK (2 * MIPT_SPILL_STACK)
+// Capacity: a quad step pushes at most 3 entries and a tree of MIPT_STACK_DEPTH inner levels has MIPT_STACK_DEPTH / 2 quad levels on any
+// root-to-leaf path; the 4-byte columns overlay the uint2 columns of the ordered kernels, which the host sizes for n_cus * 8 blocks of this size.
+static_assert(MIPT_ANY_LDS_STACK + MIPT_ANY_SPILL_STACK >= 3 * (MIPT_STACK_DEPTH / 2), "LdsStack4 cannot hold the pending slots of the deepest tree the upload accepts");
+static_assert(MIPT_ANY_SPILL_STACK * sizeof(unsigned) <= MIPT_SPILL_STACK * sizeof(uint2), "the any-hit kernel's spill columns must fit the buffer sized for the ordered kernels");
 typedef __attribute__((address_space(3))) unsigned lds_uint1;
 typedef __attribute__((address_space(1))) unsigned glb_uint1;
 // Entry sp of a lane: LDS word (sp * block + thread) for sp < MIPT_ANY_LDS_STACK, else word ((sp - MIPT_ANY_LDS_STACK) * grid threads + global

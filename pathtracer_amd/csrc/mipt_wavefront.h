@@ -143,6 +143,8 @@ __device__ __forceinline__ void queue_push(unsigned* __restrict__ list, unsigned
 //  * shadow ray: occlusion is an OR over the objects (Geometry.cpp:700-741), so every sphere / plane is tested here
 //    whatever its position in the list; an occluded request is dropped, the others only traverse the meshes.
 // Same device functions (xf_dir / xf_point / sphere_test / plane_test) as the in-kernel object loop: bit-identical.
+// t is never a NaN: it starts at +infinity and is only replaced through `tt < t`, which is false for a NaN (degenerate spheres / planes, a NaN camera) —
+// depth 0 marks a slot WITHOUT a path by a NaN in this very word (MIPT_WF_DEAD_RAY), so a live path can never be mistaken for one.
 MIPT_DEV void analytic_prefix_closest(const DScene* __restrict__ sc, f3 ro, f3 rd, float& t, unsigned& best) {
 	t = __int_as_float(0x7f800000); best = MIPT_HIT_MISS;
 	const int n = sc->first_mesh;

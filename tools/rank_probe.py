@@ -52,9 +52,16 @@ for nr in ranks:
     ts = [p["render_ms"] for p in per]
     if nr == 1:
         t1 = ts[0]
-    reduce_ms = 0.0 if nr == 1 else REDUCE_LATENCY_MS + (dims[0] * dims[1] * 16 * (nr - 1) / nr) / (REDUCE_GBPS * 1e6)
+    def reduce_at(gbps):
+        return 0.0 if nr == 1 else REDUCE_LATENCY_MS + (dims[0] * dims[1] * 16 * (nr - 1) / nr) / (gbps * 1e6)
+    reduce_ms = reduce_at(REDUCE_GBPS)
     out = {"workload": wl, "tile_size": tile, "nranks": nr, "t_max_ms": max(ts), "t_mean_ms": round(sum(ts) / nr, 2), "max_over_mean": round(max(ts) / (sum(ts) / nr), 4),
            "rays_max_over_mean": round(max(p["rays"] for p in per) / (sum(p["rays"] for p in per) / nr), 4),
            "n_x_mean_over_t1": round(nr * (sum(ts) / nr) / t1, 4) if t1 else None, "reduce_estimate_ms": round(reduce_ms, 3),
-           "predicted_speedup": round(t1 / (max(ts) + reduce_ms), 3) if t1 else None, "ranks": per}
+           "predicted_speedup": round(t1 / (max(ts) + reduce_ms), 3) if t1 else None,
+           # the reduce is an ASSUMPTION (never measured: no multi-GPU box in this pool; mipt_rccl_selftest has only run on one device) — its constants, and
+           # what the prediction becomes at half and at 5/3 of the assumed rate
+           "reduce_assumption": {"effective_gb_per_s": REDUCE_GBPS, "latency_ms": REDUCE_LATENCY_MS, "bytes": dims[0] * dims[1] * 16, "measured": False},
+           "predicted_speedup_at_45_and_150_gb_per_s": [round(t1 / (max(ts) + reduce_at(45.0)), 3), round(t1 / (max(ts) + reduce_at(150.0)), 3)] if t1 else None,
+           "ranks": per}
     print(json.dumps(out), flush=True)
