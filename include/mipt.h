@@ -367,9 +367,10 @@ int mipt_get_stats(mipt_ctx* ctx, mipt_stats* out);
  *   "sort_rays"       pipeline 1: 1 = the closest-hit queue of every depth >= 1 is reordered by direction octant before it is
  *                     traversed (a measured negative, DESIGN.md §4: -11 %; same results), 0 = path-id order (default)
  *   "fast_shade"      pipeline 1: 1 = two-tier shade stage (default), 0 = general shade kernel only
- *   "merl_batch"      pipeline 1, scenes with a measured BRDF: 1 = the general shade tier files the table evaluations of its vertices and
- *                     runs them 64 to a trip (default: a fifth fewer vector instructions, 0.7 % of the stage's time), 0 = every vertex
- *                     evaluates its own (same results)
+ *   "merl_batch"      pipeline 1, scenes with a measured BRDF: 2 = the general shade tier files the table evaluations of its vertices and a stage
+ *                     of its own evaluates them, the tables of sincos / acos / atan2 in LDS (default since round 6: the stage 14 % faster on
+ *                     configs[4]; 40 bytes more pass state per path), 1 = filed and run 64 to a trip inside the tier, 0 = every vertex
+ *                     evaluates its own (same results in all three)
  *   "refill_threshold", "inner_min"  scheduling parameters of the persistent traversal
  *   "lane_limit"      measurement probe: the persistent traversal hands rays to the first N lanes of a wave only (0 = all 64)
  *   "literal_slab"    test hook: 1 = the persistent traversal evaluates the slab test's early-out chain literally for

@@ -455,13 +455,15 @@ struct mipt_ctx {
 	int64_t opt_resolve_packed = 1;    // ranks of a partition: the column-scan splat visits only the columns that receive something, 64 of them per wave
 	int64_t opt_device_mesh_as_remote = 0;  // test hook: a device-resident mesh is treated as another device's (hipMemcpyPeer into this context's own buffers), so a one-GPU box runs what the members of a group run
 	int64_t opt_anyhit_flag_all = 0;  // test hook: every shadow ray counts as having passed a box near its far end (every occluded ray is replayed in order)
+	unsigned grid_merl[2] = {0, 0};   // resident blocks of k_wf_shade<5> and k_wf_merl_eval (shade tier 5)
 	unsigned grid_anyhit = 0;         // resident blocks of k_wf_anyhit
 	unsigned grid_qanyhit = 0;        // ... of k_q_anyhit
 	unsigned* q_replay_list = nullptr; // (in the pass buffer)
 	double replay_share = 0.0;         // replayed / shadow rays of the context's last render whose statistics were collected (collect_stats)
 	int64_t opt_merge_traverse = 0;   // pipeline 1: shadow(b) and extend(b+1) in one launch of the traversal kernel
 	int64_t opt_fast_shade = 1;       // pipeline 1: two-tier shade stage (fast diffuse tier + general tier)
-	int64_t opt_merl_batch = 1;       // scenes with a measured BRDF: 1 = the general tier files its table evaluations and runs them 64 to a trip (tier 4, mipt_wavefront.h); 0 = tier 3
+	int64_t opt_merl_batch = 2;       // scenes with a measured BRDF: 2 = the general tier files its table evaluations and a stage of its own runs them, libm tables in LDS (tier 5 + k_wf_merl_eval,
+	                                  // default since round 6: configs[4] generate + shade 764 -> 660 ms); 1 = filed and run 64 to a trip inside the tier (tier 4, mipt_wavefront.h); 0 = every vertex evaluates its own (tier 3)
 	int64_t opt_refill = 1;           // pipeline 1: traversal stages with dynamic ray fetch (mipt_persistent.h)
 	int64_t opt_samples_per_pass = 0;       // > 0: the running sums are published after every this many samples per pixel (progressive display: 1)
 	int64_t opt_progressive_lookahead = 0;  // progressive display through mipt_render: publish groups rendered per pass (their stages run together; every group is still splatted, published and reported on its own); 0 = as many as make a pass hold 64 M paths
@@ -685,7 +687,7 @@ extern "C" int mipt_set_option(mipt_ctx* c, const char* name, int64_t value) {
 	if (!strcmp(name, "anyhit_flag_all")) { c->opt_anyhit_flag_all = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "merge_traverse")) { c->opt_merge_traverse = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "fast_shade")) { c->opt_fast_shade = value != 0; return MIPT_OK; }
-	if (!strcmp(name, "merl_batch")) { c->opt_merl_batch = value != 0; c->grid_stage[0] = 0; return MIPT_OK; }
+	if (!strcmp(name, "merl_batch")) { if (value < 0 || value > 2) return fail(c, MIPT_ERR_INVALID, "merl_batch must be 0, 1 or 2"); c->opt_merl_batch = value; c->grid_stage[0] = 0; return MIPT_OK; }
 	if (!strcmp(name, "refill")) { c->opt_refill = value != 0; return MIPT_OK; }
 	if (!strcmp(name, "invalidate_tables")) { c->tab_key.fi = nullptr; c->blk_key.rk = -1; return MIPT_OK; }
 	return fail(c, MIPT_ERR_INVALID, "unknown option %s", name);
@@ -1382,7 +1384,8 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 	if (pipeline == 1 && p->nb_bounces > MIPT_WF_MAX_DEPTH) return fail(c, MIPT_ERR_INVALID, "nb_bounces > %d is not supported by the wavefront pipeline", MIPT_WF_MAX_DEPTH);
 	// Bytes of pass state per path id, and the part that does not depend on the pass size
 	size_t per_path = sizeof(float4) + sizeof(float2), fixed_bytes = 4096;
-	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES + (c->opt_sort_rays ? sizeof(unsigned) : 0); fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned) + MIPT_SORT_BINS * 2048 * sizeof(unsigned) + 64; }
+	const bool merl_split = pipeline == 1 && c->scene_has_merl && c->opt_fast_shade && c->opt_merl_batch == 2;      // shade tier 5 + k_wf_merl_eval
+	if (pipeline == 1) { per_path += MIPT_WF_STATE_BYTES + (c->opt_sort_rays ? sizeof(unsigned) : 0) + (merl_split ? MIPT_WF_MERL_SPLIT_BYTES : 0); fixed_bytes += MIPT_WF_COUNTERS * sizeof(unsigned) + MIPT_SORT_BINS * 2048 * sizeof(unsigned) + 64; }
 	if (want_aov) per_path += 2 * sizeof(float4);
 	if (pipeline == 2 && queue_wave) {   // request / result arrays shared with the traversal kernels, the frame, the lists (the ring itself: per_path_queue)
 		per_path += 5 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(float4) + sizeof(float4) + sizeof(unsigned) + MIPT_QW_FRAME * sizeof(float4) + sizeof(float) + 11 * sizeof(unsigned);
@@ -1429,6 +1432,7 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 		wf.list[0] = (unsigned*)carve(N * sizeof(unsigned)); wf.list[1] = (unsigned*)carve(N * sizeof(unsigned)); wf.list_sh = (unsigned*)carve(N * sizeof(unsigned)); wf.list_slow = (unsigned*)carve(N * sizeof(unsigned));
 		wf.counters = (unsigned*)carve(MIPT_WF_COUNTERS * sizeof(unsigned));
 		if (c->opt_sort_rays) { sort_list = (unsigned*)carve(N * sizeof(unsigned)); sort_hist = (unsigned*)carve(MIPT_SORT_BINS * 2048 * sizeof(unsigned)); }
+		if (merl_split) { wf.mq_a = (float4*)carve(N * sizeof(float4)); wf.mq_b = (float4*)carve(N * sizeof(float4)); wf.list_mrq = (unsigned*)carve(2 * N * sizeof(unsigned)); }
 		wf.out = S;
 		if ((rc = ensure(c, &c->spill_buf, &c->spill_buf_bytes, (size_t)c->n_cus * 8u * (MIPT_BLOCK > MIPT_TRAV_BLOCK ? MIPT_BLOCK : MIPT_TRAV_BLOCK) * MIPT_SPILL_STACK * sizeof(uint2)))) return rc;
 		wf.spill = (uint2*)c->spill_buf;
@@ -1717,7 +1721,18 @@ static int render_impl(mipt_ctx* c, const mipt_render_params* p, float* d_accum,
 						else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_shade<T, false>), GRID, dim3(MIPT_BLOCK), LDS, st, c->d_scene, R, P, wf, b, (unsigned)total, c->d_cnt); } while (0)
 					if (c->opt_fast_shade) {
 						MIPT_LAUNCH_SHADE(1, G(4), MIPT_SHADE_LDS_BYTES(1));
-						if (c->scene_has_merl && c->opt_merl_batch) MIPT_LAUNCH_SHADE(4, G(5), MIPT_SHADE4_LDS_BYTES);
+						if (merl_split) {
+							if (c->grid_merl[0] == 0) {
+								int nb = 0;
+								if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wf_shade<5>, MIPT_BLOCK, MIPT_SHADE_LDS_BYTES(5)) != hipSuccess || nb <= 0) nb = 1;
+								c->grid_merl[0] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
+								if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_wf_merl_eval, MIPT_MERL_EVAL_BLOCK, 0) != hipSuccess || nb <= 0) nb = 1;
+								c->grid_merl[1] = std::min(persistent_blocks, (unsigned)c->n_cus * (unsigned)nb);
+							}
+							MIPT_LAUNCH_SHADE(5, dim3(std::min(c->grid_merl[0], grid_all)), MIPT_SHADE_LDS_BYTES(5));
+							hipLaunchKernelGGL(k_wf_merl_eval, dim3(std::min(c->grid_merl[1], grid_all)), dim3(MIPT_MERL_EVAL_BLOCK), 0, st, (const DScene*)c->d_scene, wf, b);
+						}
+						else if (c->scene_has_merl && c->opt_merl_batch) MIPT_LAUNCH_SHADE(4, G(5), MIPT_SHADE4_LDS_BYTES);
 						else if (c->scene_has_merl) MIPT_LAUNCH_SHADE(3, G(5), MIPT_SHADE_LDS_BYTES(3));
 						else MIPT_LAUNCH_SHADE(2, G(5), MIPT_SHADE_LDS_BYTES(2));
 					} else MIPT_LAUNCH_SHADE(0, G(3), 0);

@@ -175,12 +175,21 @@ MIPT_L64 bool mipt_pow64_main(double x, double y, double& out) {
 #define L64_CS4 (-0x1.5555555555535p-5)
 #define L64_CS6 0x1.6c16bedd9e239p-10
 
+// Where sincos / acos / atan2 read their tables.  Default: the library's constant arrays.  A kernel that spends its time in these functions may hand
+// in copies it made in LDS (k_wf_merl_eval, mipt_wavefront.h: ~60 dependent table reads per BRDF evaluation; every function below is inlined, so the
+// compiler sees the address space and emits ds_read).  Same words, same arithmetic.
+#define MIPT_L64_SINCOS_WORDS 440
+#define MIPT_L64_ASNCS_WORDS 2568
+#define MIPT_L64_INROOT_WORDS 128
+#define MIPT_L64_CIJ_WORDS 1687
+struct L64Tables { const uint64_t *sincos, *asncs, *inroot, *cij; };
+MIPT_L64 L64Tables l64_tables() { L64Tables T; T.sincos = mipt_l64_sincos_tab; T.asncs = mipt_l64_asncs_tab; T.inroot = mipt_l64_inroot_tab; T.cij = mipt_l64_cij_tab; return T; }
 struct L64Tab { double sn, ssn, cs, ccs; };
-MIPT_L64 L64Tab l64_lookup(double u) {
+MIPT_L64 L64Tab l64_lookup(double u, const L64Tables& TB) {
 	const int k = (int)(uint32_t)l64_bits(u) * 4;        // u.i[LOW_HALF] * 4
 	L64Tab t;
-	t.sn = l64_dbl(mipt_l64_sincos_tab[k]); t.ssn = l64_dbl(mipt_l64_sincos_tab[k + 1]);
-	t.cs = l64_dbl(mipt_l64_sincos_tab[k + 2]); t.ccs = l64_dbl(mipt_l64_sincos_tab[k + 3]);
+	t.sn = l64_dbl(TB.sincos[k]); t.ssn = l64_dbl(TB.sincos[k + 1]);
+	t.cs = l64_dbl(TB.sincos[k + 2]); t.ccs = l64_dbl(TB.sincos[k + 3]);
 	return t;
 }
 // ---------------------------------------------------------------- sincos (s_sincos.c)
@@ -189,7 +198,7 @@ MIPT_L64 L64Tab l64_lookup(double u) {
 // 0.855 <= |x| < 2.426 range through a renormalised (a, da) pair for BOTH results, where sin() uses (hp0 - |x|, hp1)
 // directly.  About 2 results in 10 000 differ from those of sin() / cos() in the last bit (tests/native/libm64_check.cpp
 // counts them), so it is sincos that is restated here.
-MIPT_L64 double l64p_do_cos(double x, double dx) {
+MIPT_L64 double l64p_do_cos(double x, double dx, const L64Tables& TB) {
 	if (x < 0) dx = -dx;
 	const double ax = l64_abs(x);
 	const double u = L64_BIG + ax;
@@ -197,11 +206,11 @@ MIPT_L64 double l64p_do_cos(double x, double dx) {
 	const double xx = xr * xr;
 	const double s = xr + (xr * xx) * (L64_SN3 + xx * L64_SN5);
 	const double c = xx * (L64_CS2 + xx * (L64_CS4 + xx * L64_CS6));
-	const L64Tab T = l64_lookup(u);
+	const L64Tab T = l64_lookup(u, TB);
 	const double cor = ((T.ccs - s * T.ssn) - T.cs * c) - T.sn * s;
 	return T.cs + cor;
 }
-MIPT_L64 double l64p_do_sin(double x, double dx) {
+MIPT_L64 double l64p_do_sin(double x, double dx, const L64Tables& TB) {
 	const double xold = x;
 	const double ax = l64_abs(x);
 	if (ax < 0.126) {
@@ -216,7 +225,7 @@ MIPT_L64 double l64p_do_sin(double x, double dx) {
 	const double xx = xr * xr;
 	const double s = xr + (dx + (xr * xx) * (L64_SN3 + xx * L64_SN5));
 	const double c = xr * dx + xx * (L64_CS2 + xx * (L64_CS4 + xx * L64_CS6));
-	const L64Tab T = l64_lookup(u);
+	const L64Tab T = l64_lookup(u, TB);
 	const double cor = ((T.ssn + s * T.ccs) - T.sn * c) + T.cs * s;
 	return l64_copysign(T.sn + cor, xold);
 }
@@ -234,32 +243,33 @@ MIPT_L64 int l64p_reduce(double x, double& a, double& da) {
 	a = b; da = db;
 	return n;
 }
-MIPT_L64 double l64p_do_sincos(double a, double da, int n) {
-	const double r = (n & 1) ? l64p_do_cos(a, da) : l64p_do_sin(a, da);
+MIPT_L64 double l64p_do_sincos(double a, double da, int n, const L64Tables& TB) {
+	const double r = (n & 1) ? l64p_do_cos(a, da, TB) : l64p_do_sin(a, da, TB);
 	return (n & 2) ? -r : r;
 }
 // sincos(x, &s, &c) for |x| < 105414350; false for larger, infinite or NaN arguments
-MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs) {
+MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs, const L64Tables& TB) {
 	const int32_t k = (int32_t)(l64_bits(x) >> 32) & 0x7fffffff;
 	if (k < 0x400368fd) {
 		if (k < 0x3e400000) { sn = x; cs = 1.0; return true; }
-		if (k < 0x3feb6000) { sn = l64p_do_sin(x, 0.0); cs = l64p_do_cos(x, 0.0); return true; }
+		if (k < 0x3feb6000) { sn = l64p_do_sin(x, 0.0, TB); cs = l64p_do_cos(x, 0.0, TB); return true; }
 		const double y = L64_HP0 - l64_abs(x);
 		const double a = y + L64_HP1;
 		const double da = (y - a) + L64_HP1;
-		sn = l64_copysign(l64p_do_cos(a, da), x);
-		cs = l64p_do_sin(a, da);
+		sn = l64_copysign(l64p_do_cos(a, da, TB), x);
+		cs = l64p_do_sin(a, da, TB);
 		return true;
 	}
 	if (k < 0x419921fb) {
 		double a, da;
 		const int n = l64p_reduce(x, a, da);
-		sn = l64p_do_sincos(a, da, n);
-		cs = l64p_do_sincos(a, da, n + 1);
+		sn = l64p_do_sincos(a, da, n, TB);
+		cs = l64p_do_sincos(a, da, n + 1, TB);
 		return true;
 	}
 	return false;
 }
+MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs) { return mipt_sincos64_main(x, sn, cs, l64_tables()); }
 
 // ---------------------------------------------------------------- acos (e_asin.c, IBM Accurate Mathematical Library; glibc 2.35 = after
 // the multi-precision fall-backs were removed: every range returns its first estimate)
@@ -278,9 +288,9 @@ MIPT_L64 bool mipt_sincos64_main(double x, double& sn, double& cs) {
 #define L64_AC_RT3 0x1.4006318d1dab9p-2
 #define L64_PI 0x1.921fb54442d18p+1
 #define L64_PI_LO 0x1.1a62633145c07p-53
-MIPT_L64 double l64_asn(int i) { return l64_dbl(mipt_l64_asncs_tab[i]); }
+#define l64_asn(i) l64_dbl(TB.asncs[i])
 // one piece of [0.125, 0.96875): row n of `stride` doubles = {x0, c1, c2 .. c(stride-5), c_xx, asin(x0) tail, asin(x0)}
-MIPT_L64 double l64_acos_piece(double x, bool positive, int n, int stride) {
+MIPT_L64 double l64_acos_piece(double x, bool positive, int n, int stride, const L64Tables& TB) {
 	const double xx = (positive ? x : -x) - l64_asn(n);
 	double p = l64_asn(n + stride - 5);
 	for (int j = stride - 6; j >= 2; j--) p = l64_fma(xx, p, l64_asn(n + j));
@@ -290,7 +300,7 @@ MIPT_L64 double l64_acos_piece(double x, bool positive, int n, int stride) {
 	if (positive) return (L64_HP1 - t) + (L64_HP0 - y);
 	return (t + L64_HP1) + (y + L64_HP0);
 }
-MIPT_L64 double mipt_acos64(double x) {
+MIPT_L64 double mipt_acos64(double x, const L64Tables& TB) {
 	const uint64_t bits = l64_bits(x);
 	const int32_t m = (int32_t)(bits >> 32);
 	const int32_t k = m & 0x7fffffff;
@@ -316,12 +326,12 @@ MIPT_L64 double mipt_acos64(double x) {
 		else if (k <= 0x3fed7fff) { n = 13 * ((k >> 13) & 0x7f) + 992; stride = 13; }   // < 0.921875
 		else if (k <= 0x3fee7fff) { n = 14 * ((k >> 13) & 0x7f) + 884; stride = 14; }   // < 0.953125
 		else { n = 15 * ((k >> 13) & 0x7f) + 768; stride = 15; }                        // < 0.96875
-		return l64_acos_piece(x, pos, n, stride);
+		return l64_acos_piece(x, pos, n, stride, TB);
 	}
 	if (k <= 0x3fefffff) {                                                  // < 1
 		const double z = (pos ? 1.0 - x : x + 1.0) * 0.5;
 		const uint64_t zb = l64_bits(z);
-		double t = l64_dbl(mipt_l64_inroot_tab[(zb >> 46) & 0x7f]) * l64_dbl((uint64_t)(1023 + (0x1ff - (int)(zb >> 53))) << 52);   // inroot[] * powtwo[]
+		double t = l64_dbl(TB.inroot[(zb >> 46) & 0x7f]) * l64_dbl((uint64_t)(1023 + (0x1ff - (int)(zb >> 53))) << 52);   // inroot[] * powtwo[]
 		const double r = l64_fma(-(t * t), z, 1.0);
 		double q = l64_fma(r, L64_AC_RT3, L64_AC_RT2);
 		q = l64_fma(r, q, L64_AC_RT1); q = l64_fma(r, q, L64_AC_RT0);
@@ -344,6 +354,8 @@ MIPT_L64 double mipt_acos64(double x) {
 	const double u = x - x;                                                 // |x| > 1 (or infinite): invalid
 	return u / u;
 }
+#undef l64_asn
+MIPT_L64 double mipt_acos64(double x) { return mipt_acos64(x, l64_tables()); }
 
 // ---------------------------------------------------------------- atan2 (e_atan2.c, same library, same state: first estimates only)
 // __ieee754_atan2_fma at 0x78060: u = min(|x|,|y|) / max(|x|,|y|) with its rounding error du (one fused multiply), then
@@ -361,16 +373,16 @@ MIPT_L64 double l64_at_poly(double v) {          // d3 + v (d5 + v (d7 + v (d9 +
 	p = l64_fma(v, p, L64_AT_D9); p = l64_fma(v, p, L64_AT_D7); p = l64_fma(v, p, L64_AT_D5);
 	return l64_fma(v, p, L64_AT_D3);
 }
-MIPT_L64 const uint64_t* l64_at_row(double u) {  // i = (TWO52 + 256 u) - TWO52 (round to nearest even), row i - 16
+MIPT_L64 const uint64_t* l64_at_row(double u, const L64Tables& TB) {  // i = (TWO52 + 256 u) - TWO52 (round to nearest even), row i - 16
 	const double r = l64_fma(u, 256.0, 0x1.0p+52) - 0x1.0p+52;
-	return mipt_l64_cij_tab + 7 * ((int)r - 16);
+	return TB.cij + 7 * ((int)r - 16);
 }
 MIPT_L64 double l64_at_tail(const uint64_t* row, double v) {   // c2 + v (c3 + v (c4 + v (c5 + v c6)))
 	double p = l64_fma(v, l64_dbl(row[6]), l64_dbl(row[5]));
 	p = l64_fma(v, p, l64_dbl(row[4])); p = l64_fma(v, p, l64_dbl(row[3]));
 	return l64_fma(v, p, l64_dbl(row[2]));
 }
-MIPT_L64 double mipt_atan264(double y, double x) {
+MIPT_L64 double mipt_atan264(double y, double x, const L64Tables& TB) {
 	const uint64_t xb = l64_bits(x), yb = l64_bits(y);
 	const int32_t ux = (int32_t)(xb >> 32), uy = (int32_t)(yb >> 32);
 	const uint32_t dx = (uint32_t)xb, dy = (uint32_t)yb;
@@ -407,7 +419,7 @@ MIPT_L64 double mipt_atan264(double y, double x) {
 	if (y_smaller && x > 0.0) {                                             // (i) atan(ay / ax)
 		if (small) z = u + l64_fma(u * v2, l64_at_poly(v2), du);
 		else {
-			const uint64_t* row = l64_at_row(u);
+			const uint64_t* row = l64_at_row(u, TB);
 			const double t3 = u - l64_dbl(row[0]);
 			const double w = du + t3;
 			const double dw = (l64_abs(t3) > l64_abs(du)) ? (t3 - w) + du : (du - w) + t3;
@@ -432,10 +444,11 @@ MIPT_L64 double mipt_atan264(double y, double x) {
 		const double cor = (C > l64_abs(u)) ? (C - t2) + q : (q - t2) + C;
 		z = (((cor + C_lo) + (third ? du : -du)) + (third ? zz : -zz)) + t2;
 	} else {
-		const uint64_t* row = l64_at_row(u);
+		const uint64_t* row = l64_at_row(u, TB);
 		const double w = (u - l64_dbl(row[0])) + du;
 		const double zz = l64_fma(third ? w : -w, l64_at_tail(row, w), C_lo);
 		z = (C + (third ? l64_dbl(row[1]) : -l64_dbl(row[1]))) + zz;
 	}
 	return l64_copysign(z, y);
 }
+MIPT_L64 double mipt_atan264(double y, double x) { return mipt_atan264(y, x, l64_tables()); }

@@ -85,10 +85,13 @@ MIPT_DEV void pt_sincosf(float y, float& s, float& c) { mipt_sincosf_pair(y, s, 
 __device__ __attribute__((noinline)) void sincos64_special(double a, double& s, double& c) { s = sin(a); c = cos(a); }
 __device__ __attribute__((noinline)) double pow64_special(double x, double y) { return pow(x, y); }
 MIPT_DEV void pt_sincos64(double a, double& s, double& c) { if (!mipt_sincos64_main(a, s, c)) sincos64_special(a, s, c); }
+MIPT_DEV void pt_sincos64(double a, double& s, double& c, const L64Tables& TB) { if (!mipt_sincos64_main(a, s, c, TB)) sincos64_special(a, s, c); }
 MIPT_DEV double pt_pow64(double x, double y) { double r; if (mipt_pow64_main(x, y, r)) return r; return pow64_special(x, y); }
 MIPT_DEV double pt_exp64(double x) { return mipt_exp64(x); }
 MIPT_DEV double pt_acos64(double x) { return mipt_acos64(x); }
 MIPT_DEV double pt_atan264(double y, double x) { return mipt_atan264(y, x); }
+MIPT_DEV double pt_acos64(double x, const L64Tables& TB) { return mipt_acos64(x, TB); }
+MIPT_DEV double pt_atan264(double y, double x, const L64Tables& TB) { return mipt_atan264(y, x, TB); }
 
 // powf: the host libm's algorithm, bit for bit (mipt_powf.h), for positive finite x and finite non-zero y; the exact
 // special values (pow(x,0) = 1, pow(1,y) = 1, zero / inf / NaN / negative bases) come from the device library.

@@ -92,9 +92,9 @@ MIPT_DEV f3 phong_eval(const Mat& mat, f3 wi, f3 wo, f3 N) {
 // fp64 half/difference-angle transform and table lookup, as the reference.  cos / sin / acos / atan2 are the host libm's
 // sincos(), acos(), atan2() restated (mipt_libm64.h): the angles, and with them the table cells, are the reference's by
 // construction.
-MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, double* out) {   // rotate_vector :49-72
+MIPT_DEV void merl_rotate(const double* v, const double* axis, double angle, double* out, const L64Tables& TB) {   // rotate_vector :49-72
 	double ca, sa;
-	pt_sincos64(angle, sa, ca);
+	pt_sincos64(angle, sa, ca, TB);
 	out[0] = v[0] * ca; out[1] = v[1] * ca; out[2] = v[2] * ca;
 	double temp = axis[0] * v[0] + axis[1] * v[1] + axis[2] * v[2];
 	temp = temp * (1.0 - ca);
@@ -118,7 +118,8 @@ __global__ void k_merl_interleave(const double* __restrict__ planar, double* __r
 	cells[MIPT_MERL_CELL * (size_t)i] = planar[i]; cells[MIPT_MERL_CELL * (size_t)i + 1] = planar[i + MIPT_MERL_CELLS];
 	cells[MIPT_MERL_CELL * (size_t)i + 2] = planar[i + 2 * MIPT_MERL_CELLS]; cells[MIPT_MERL_CELL * (size_t)i + 3] = 0.0;
 }
-MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N) {
+// TB: where the fp64 libm functions read their tables (mipt_libm64.h): the library's arrays, or a kernel's copies in LDS
+MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N, const L64Tables& TB) {
 	f3 t1 = tangent_of(N);
 	f3 t2 = cross(t1, N);
 	f3 wil = mk3(dot(wi, t1), dot(wi, t2), dot(wi, N));
@@ -134,25 +135,25 @@ MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N
 	// std_coords_to_half_diff_coords (:76-127)
 	double theta_in = thetai, fi_in = phii, theta_out = thetao, fi_out = phio;
 	double in_z, pin, cfi, sfi;
-	pt_sincos64(theta_in, pin, in_z);
-	pt_sincos64(fi_in, sfi, cfi);
+	pt_sincos64(theta_in, pin, in_z, TB);
+	pt_sincos64(fi_in, sfi, cfi, TB);
 	double in_x = pin * cfi, in_y = pin * sfi;
 	double in[3] = {in_x, in_y, in_z};
 	{ double len = sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]); in[0] = in[0] / len; in[1] = in[1] / len; in[2] = in[2] / len; }
 	double out_z, pout, cfo, sfo;
-	pt_sincos64(theta_out, pout, out_z);
-	pt_sincos64(fi_out, sfo, cfo);
+	pt_sincos64(theta_out, pout, out_z, TB);
+	pt_sincos64(fi_out, sfo, cfo, TB);
 	double out_x = pout * cfo, out_y = pout * sfo;
 	double half[3] = {(in_x + out_x) / 2.0, (in_y + out_y) / 2.0, (in_z + out_z) / 2.0};
 	{ double len = sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]); half[0] = half[0] / len; half[1] = half[1] / len; half[2] = half[2] / len; }
-	double theta_half = pt_acos64(half[2]);
-	double fi_half = pt_atan264(half[1], half[0]);
+	double theta_half = pt_acos64(half[2], TB);
+	double fi_half = pt_atan264(half[1], half[0], TB);
 	const double bi_normal[3] = {0.0, 1.0, 0.0}, normal[3] = {0.0, 0.0, 1.0};
 	double temp[3], diff[3];
-	merl_rotate(in, normal, -fi_half, temp);
-	merl_rotate(temp, bi_normal, -theta_half, diff);
-	double theta_diff = pt_acos64(diff[2]);
-	double fi_diff = pt_atan264(diff[1], diff[0]);
+	merl_rotate(in, normal, -fi_half, temp, TB);
+	merl_rotate(temp, bi_normal, -theta_half, diff, TB);
+	double theta_diff = pt_acos64(diff[2], TB);
+	double fi_diff = pt_atan264(diff[1], diff[0], TB);
 	// index functions (:134-180)
 	int th_idx;
 	if (theta_half <= 0.0) th_idx = 0;
@@ -180,6 +181,7 @@ MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N
 	double b = bx.x * (1.66 / 1500.0);
 	return mk3((float)r, (float)g, (float)b);
 }
+MIPT_DEV f3 merl_eval_inline(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N, l64_tables()); }
 __device__ __attribute__((noinline)) f3 merl_eval(const double* __restrict__ data, f3 wi, f3 wo, f3 N) { return merl_eval_inline(data, wi, wo, N); }
 
 // ---------------------------------------------------------------- path state

@@ -26,12 +26,18 @@ struct DWave {
 	unsigned* list[2];          // path ids to extend at even / odd depth
 	unsigned* list_sh;          // path ids with a pending shadow ray
 	unsigned* list_slow;        // path ids whose vertex the fast shade tier deferred to the general one
+	// shade tier 5 (round 6): the measured-BRDF evaluations of a depth as a stage of their own (k_wf_merl_eval).  What an evaluation needs beyond the arrays
+	// above waits per path id: hit[] (dead once the vertex has read it) = (wo, the factor of request A), mq_a = (N, the factor of request B), mq_b = (the
+	// path weight at the vertex, continuation depth | object << 16); list_mrq = the requests of the depth: path id | kind << 31 (two per path at most)
+	float4 *mq_a, *mq_b;
+	unsigned* list_mrq;
 	uint2* spill;               // traversal-stack overflow columns (persistent kernels)
 	unsigned* counters;         // queue sizes and heads, one per 128-byte line (MIPT_CNT_* below)
 	DSamples out;
 };
 // bytes of DWave state per path id: 7 float4 + rng + 4 id lists (the pass is sized with it, mipt.hip render_impl)
 #define MIPT_WF_STATE_BYTES (7 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned))
+#define MIPT_WF_MERL_SPLIT_BYTES (2 * sizeof(float4) + 2 * sizeof(unsigned))      // shade tier 5: mq_a, mq_b, two request entries
 // Path state is written once and read once per depth, 10 GB per pass: it is accessed with the non-temporal
 // (streaming) cache policy so that it does not displace the BVH from L2 / Infinity Cache.
 #ifndef MIPT_STREAM_STATE
@@ -56,7 +62,9 @@ template <class T> __device__ __forceinline__ void wf_st(T* p, T a) { *p = a; }
 #define MIPT_WF_CNT_SHADE_HEAD (4 * (MIPT_WF_MAX_DEPTH + 2))
 #define MIPT_WF_CNT_NSLOW (MIPT_WF_CNT_SHADE_HEAD + (MIPT_WF_MAX_DEPTH + 2))
 #define MIPT_WF_CNT_SLOW_HEAD (MIPT_WF_CNT_NSLOW + (MIPT_WF_MAX_DEPTH + 2))
-#define MIPT_WF_NCOUNTERS (MIPT_WF_CNT_SLOW_HEAD + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_CNT_NMRQ (MIPT_WF_CNT_SLOW_HEAD + (MIPT_WF_MAX_DEPTH + 2))      // tier 5: evaluation requests of depth b, then the head of their queue
+#define MIPT_WF_CNT_MRQ_HEAD (MIPT_WF_CNT_NMRQ + (MIPT_WF_MAX_DEPTH + 2))
+#define MIPT_WF_NCOUNTERS (MIPT_WF_CNT_MRQ_HEAD + (MIPT_WF_MAX_DEPTH + 2))
 // every counter sits on its own 128-byte line: atomics on one line are serialised (~11 ns each chip-wide), and a shade
 // launch appends to two queues (shadow requests, continuing paths) once per chunk each
 #ifndef MIPT_CNT_STRIDE
@@ -375,19 +383,22 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #define MIPT_SHADE_GLDS 0
 #endif
 #define MIPT_GLDS_WORDS (5 * 256 + 128)
-#define MIPT_SHADE_LDS_BYTES(TIER) ((TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
+#define MIPT_MRQ_STAGE (2 * 64 * MIPT_WF_UNROLL)       // tier 5: request entries a wave files per chunk at most (staged in LDS: one atomic per chunk)
+#define MIPT_SHADE_LDS_BYTES(TIER) ((TIER) == 5 ? (MIPT_BLOCK / 64) * MIPT_MRQ_STAGE * 4 : (TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
 #define MIPT_SHADE4_LDS_BYTES MIPT_SHADE_LDS_BYTES(4)
 extern __shared__ unsigned mipt_shade_lds[];
 template <int TIER, bool INITIAL = false>       // INITIAL: the build for depth 0 (b == 0), where a path's state is recomputed instead of fetched
-__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 ? MIPT_SHADE2_WAVES : (TIER == 4 ? MIPT_SHADE4_WAVES : MIPT_SHADE3_WAVES))))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
-	static_assert(TIER != 4 || MIPT_SHADE_ROLLED, "tier 4 is written into the rolled form of the sub-chunk loop");
+__global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TIER == 1 ? MIPT_SHADE_WAVES : (TIER == 2 || TIER == 5 ? MIPT_SHADE2_WAVES : (TIER == 4 ? MIPT_SHADE4_WAVES : MIPT_SHADE3_WAVES))))) k_wf_shade(const DScene* __restrict__ sc, DRender R, DPass ps, DWave wf, int b, unsigned n0, DCounters* __restrict__ cnt) {
+	static_assert((TIER != 4 && TIER != 5) || MIPT_SHADE_ROLLED, "tiers 4 and 5 are written into the rolled form of the sub-chunk loop");
 	// (tier 4's code over the WHOLE queue of a depth, no fast tier in front of it, was measured too: configs[4] generate + shade 864 ms
 	// against 771 with the fast tier, and the traversal stages 3 % slower on the queues it leaves)
 	// (a classification pass in front of the fast tier — hits on measured-BRDF objects straight to list_slow, the fast tier over the rest
 	// with all its lanes — was measured as well, git tag r4-classify-experiment: the pass costs 7.3 ms per launch, one atomic per 512
 	// entries IS its time, and the fast tier over a third of the vertices still takes 12.3 ms of its 13.2: configs[4] 875 ms against 787)
 	constexpr bool SLOW_LIST = TIER >= 2;
-	constexpr bool BATCH = TIER == 4;
+	constexpr bool BATCH = TIER == 4;                 // the evaluations in trips of 64 inside this kernel
+	constexpr bool SPLIT = TIER == 5;                 // the evaluations by k_wf_merl_eval, launched behind this kernel: a vertex only files its requests
+	constexpr bool REQ = BATCH || SPLIT;              // a measured-BRDF vertex files requests (path_vertex_merl_requests) instead of evaluating
 	const unsigned n = SLOW_LIST ? wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)] : MIPT_N_EXTEND(wf, b, n0);
 	unsigned* head = &wf.counters[MIPT_CNT((SLOW_LIST ? MIPT_WF_CNT_SLOW_HEAD : MIPT_WF_CNT_SHADE_HEAD) + b)];
 	const unsigned* __restrict__ list = SLOW_LIST ? wf.list_slow : wf.list[b & 1];
@@ -414,6 +425,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		}
 	};
 	// tier 4: this wave's request list and its list of continuing path ids (LDS), both wave-uniform counts
+	unsigned* const mrq_stage = SPLIT ? mipt_shade_lds + (threadIdx.x >> 6) * MIPT_MRQ_STAGE : nullptr;      // tier 5: this wave's request entries of the chunk
+	unsigned n_mrq = 0;
 	unsigned* const rq = BATCH ? mipt_shade_lds + (threadIdx.x >> 6) * MIPT_MERL_LDS_WORDS : nullptr;
 	unsigned* const alive_buf = BATCH ? rq + MIPT_MERL_RQ * MIPT_MERL_RQ_WORDS : nullptr;
 	unsigned rq_count = 0, n_alive = 0;
@@ -542,7 +555,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				if (r == VERTEX_DEFER) { MIPT_PROF_COUNT(24) slow_bits |= 1u << u; break; }
 				if (sh.diffuse) MIPT_PROF_COUNT(18)
 				c = r == VERTEX_CONTINUE;
-			} else if (BATCH && has_inter && h.obj != 0 && h.obj != 1 && !(m.miroir & 1) && !m.transp && m.merl != nullptr) {
+			} else if (REQ && has_inter && h.obj != 0 && h.obj != 1 && !(m.miroir & 1) && !m.transp && m.merl != nullptr) {
 				// exactly the vertices path_vertex takes through the measured BRDF
 				wv = p.weight;
 				req_wo = -p.ray.d; req_n = m.shadingN; req_w = p.weight;
@@ -552,7 +565,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				req_meta = ((unsigned)p.depth << 1) | ((unsigned)h.obj << 16);     // bit 0: the kind; p.depth (15 bits: mipt_render refuses deeper paths on a scene with a
 				                                                                    // measured BRDF): already the continuation's; the object: 16 bits (MIPT_MAX_OBJECTS)
 				c = false;                                                        // (request B decides; see below)
-			} else c = path_vertex<TIER != 2 && !BATCH>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
+			} else c = path_vertex<TIER != 2 && !REQ>(sc, R, p, has_inter, h, P, m, pi * R.W + pj, ps.k0 + kk, sh, wv);
 			n_closest++;
 			// The shadow request of this vertex: an analytic occluder settles it here (never queued); so does a ray that
 			// misses the root box of every mesh — TriMesh::intersection_shadow returns before it visits a node
@@ -565,7 +578,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				sh_queue = true;                                          // measurement probe: no analytic / root tests for the shadow request
 #else
 				if (!analytic_occluded(sc, sh.ray.o, sh.ray.d, sh.dist)) {
-					if (BATCH && (req_bits & 1u)) sh_queue = true;        // its weight * contrib is written by the lane that evaluates request A
+					if (REQ && (req_bits & 1u)) sh_queue = true;          // its weight * contrib is written by the lane that evaluates request A
 					else if (MIPT_SHADE_ROOT_TEST && meshes_missed(sc, sh.ray.o, sh.ray.d, sh.dist)) p.color = p.color + wv * sh.contrib;
 					else sh_queue = true;
 				} else req_bits &= ~1u;                                       // nobody needs the value
@@ -584,10 +597,10 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 				f3 pc = wv * sh.contrib;                              // added by k_wf_shadow if the light sample is visible
 				wf_st(&wf.sh_o[id], make_float4(sh.ray.o.x, sh.ray.o.y, sh.ray.o.z, sh.dist));
 				wf_st(&wf.sh_d[id], make_float4(sh.ray.d.x, sh.ray.d.y, sh.ray.d.z, 0.f));
-				if (!(BATCH && (req_bits & 1u))) wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
+				if (!(REQ && (req_bits & 1u))) wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
 			}
 			c = c && path_alive(p);                                   // Raytracer.cpp:240-241 at the top of the next iteration
-			if (c || (BATCH && (req_bits & 2u))) {
+			if (c || (REQ && (req_bits & 2u))) {
 				float t0; unsigned best0;
 #if MIPT_PERTURB == 2
 				t0 = __int_as_float(0x7f800000); best0 = MIPT_HIT_MISS;         // measurement probe: no analytic prefix for the continuation ray
@@ -606,6 +619,20 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			if (MIPT_SHADE_PREFETCH) cur = nxt;
 			id_cur = id_nxt; id_nxt = id_nn;
 #endif
+			if (SPLIT) {
+				// Tier 5: what the evaluation stage needs of this vertex goes to the per-path arrays, the requests themselves (path id | kind) to the
+				// wave's staging list in LDS; the chunk's entries reach the depth's request queue with ONE atomic at the end of the chunk.
+				if (req_bits) {
+					wf_st(&wf.hit[id], make_float4(req_wo.x, req_wo.y, req_wo.z, req_sa));
+					wf_st(&wf.mq_a[id], make_float4(req_n.x, req_n.y, req_n.z, req_fb));
+					wf_st(&wf.mq_b[id], make_float4(req_w.x, req_w.y, req_w.z, __uint_as_float(req_meta >> 1)));      // depth | object << 15
+				}
+				const unsigned long long ma = __ballot(req_bits & 1u), mb = __ballot(req_bits & 2u);
+				if (req_bits & 1u) mrq_stage[n_mrq + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = id;
+				n_mrq += (unsigned)__popcll(ma);
+				if (req_bits & 2u) mrq_stage[n_mrq + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = id | 0x80000000u;
+				n_mrq += (unsigned)__popcll(mb);
+			}
 			if (BATCH) {
 				// File this sub-chunk's requests (A of all lanes, then B of all lanes), and evaluate the 64 filed last whenever
 				// that many have come together.  A request is complete in itself, so the order of evaluation does not matter.
@@ -664,12 +691,105 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		const unsigned* src = identity ? nullptr : list;
 		if (BATCH) { queue_push2x(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base, alive_buf, n_alive); n_alive = 0; }
 		else queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);
+		if (SPLIT && n_mrq) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			unsigned mbase = 0;
+			if (lane_id() == 0) mbase = atomicAdd(&wf.counters[MIPT_CNT(MIPT_WF_CNT_NMRQ + b)], n_mrq);
+			mbase = __builtin_amdgcn_readfirstlane(mbase);
+			for (unsigned k = lane_id(); k < n_mrq; k += 64u) wf.list_mrq[mbase + k] = mrq_stage[k];
+			__builtin_amdgcn_wave_barrier();
+			n_mrq = 0;
+		}
 		if (TIER == 1) queue_push(wf.list_slow, &wf.counters[MIPT_CNT(MIPT_WF_CNT_NSLOW + b)], slow_bits, src, base);
 		if (BATCH && !got) break;
 	}
 	DCounters* my = MIPT_MY_COUNTERS(cnt);
 	wave_add(&my->rays_closest, n_closest);
 	wave_add(&my->rays_shadow, n_shadow);
+}
+
+// Shade tier 5, second half: the measured-BRDF evaluations of depth b (IsoMERLBRDF::eval, BRDF.h:204-246; MERLBRDFRead.cpp:76-206) as a stage of their
+// own.  Tier 4 runs them in trips of 64 inside the vertex kernel, whose 168 registers (31 values spilled) allow 3 waves per SIMD; its waves wait for
+// 64 % of their cycles and a third of its vector instructions are fp64 chains (profiles/r6_h_c4_fp64_mix_pmc_summary.txt).  Here a lane takes ONE request
+// of the depth's queue (every lane busy, as in a trip), evaluates it and finishes it exactly as the trip's lane does:
+//   A (next-event estimation)  sh_c[id] = w * (0 + ((1,1,1) * sa) * brdf)                                   Raytracer.cpp:548
+//   B (continuation)           weight = ((w * (1,1,1)) * brdf) * fb; path_alive (:240-241) -> wgt[id], the id appended to the next depth's queue   :611
+// Same operations on the same operands as path_vertex: bit-identical; the order of the next depth's queue differs, which no result depends on.
+// The tables of sincos / acos / atan2 (mipt_libm64.h: 38.6 KB together) are copied to LDS when a block starts: an evaluation reads about sixty table words
+// through dependent loads, and from the constant arrays every one of them is a vector-memory round trip.
+#ifndef MIPT_MERL_EVAL_WAVES
+#define MIPT_MERL_EVAL_WAVES 4
+#endif
+#ifndef MIPT_MERL_EVAL_BLOCK
+#define MIPT_MERL_EVAL_BLOCK 512         // two blocks of 8 waves per CU at 4 waves per SIMD: 2 x 38.6 KB of tables
+#endif
+#ifndef MIPT_MERL_LDS_TABLES
+#define MIPT_MERL_LDS_TABLES 1
+#endif
+#define MIPT_MERL_TABLE_WORDS (MIPT_L64_SINCOS_WORDS + MIPT_L64_ASNCS_WORDS + MIPT_L64_INROOT_WORDS + MIPT_L64_CIJ_WORDS + 1)      // (+1: cij rows are 7 words, keep the sum even)
+__global__ void __launch_bounds__(MIPT_MERL_EVAL_BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_MERL_EVAL_WAVES))) k_wf_merl_eval(const DScene* __restrict__ sc, DWave wf, int b) {
+	L64Tables TB = l64_tables();
+#if MIPT_MERL_LDS_TABLES
+	__shared__ uint64_t merl_tables[MIPT_MERL_TABLE_WORDS];
+	{
+		uint64_t* const t_sincos = merl_tables, *const t_asncs = t_sincos + MIPT_L64_SINCOS_WORDS, *const t_inroot = t_asncs + MIPT_L64_ASNCS_WORDS, *const t_cij = t_inroot + MIPT_L64_INROOT_WORDS;
+		for (unsigned k = threadIdx.x; k < MIPT_L64_SINCOS_WORDS; k += MIPT_MERL_EVAL_BLOCK) t_sincos[k] = TB.sincos[k];
+		for (unsigned k = threadIdx.x; k < MIPT_L64_ASNCS_WORDS; k += MIPT_MERL_EVAL_BLOCK) t_asncs[k] = TB.asncs[k];
+		for (unsigned k = threadIdx.x; k < MIPT_L64_INROOT_WORDS; k += MIPT_MERL_EVAL_BLOCK) t_inroot[k] = TB.inroot[k];
+		for (unsigned k = threadIdx.x; k < MIPT_L64_CIJ_WORDS; k += MIPT_MERL_EVAL_BLOCK) t_cij[k] = TB.cij[k];
+		__syncthreads();
+		TB.sincos = t_sincos; TB.asncs = t_asncs; TB.inroot = t_inroot; TB.cij = t_cij;
+	}
+#endif
+	const unsigned n = wf.counters[MIPT_CNT(MIPT_WF_CNT_NMRQ + b)];
+	unsigned* head = &wf.counters[MIPT_CNT(MIPT_WF_CNT_MRQ_HEAD + b)];
+	const unsigned* __restrict__ list = wf.list_mrq;
+	unsigned* __restrict__ next = wf.list[(b + 1) & 1];
+	unsigned base;
+	QueuePuller q; q.init();
+	while (q.pull(head, n, base)) {
+		unsigned alive_bits = 0;
+#pragma unroll 1
+		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
+			const unsigned idx = base + 64u * (unsigned)u + lane_id();
+			if (idx >= n) continue;
+			const unsigned e = list[idx], id = e & 0x7fffffffu;
+			const bool kind_b = (e >> 31) != 0;
+			const float4 h4 = wf_ld(&wf.hit[id]), a4 = wf_ld(&wf.mq_a[id]), b4 = wf_ld(&wf.mq_b[id]);
+			const float4 x4 = kind_b ? wf_ld(&wf.ray_d[id]) : wf_ld(&wf.sh_d[id]);
+			const unsigned meta = __float_as_uint(b4.w);
+			const f3 brdf = merl_eval_inline(sc->obj[meta >> 15].merl, mk3(x4.x, x4.y, x4.z), mk3(h4.x, h4.y, h4.z), mk3(a4.x, a4.y, a4.z), TB);
+			const f3 w0 = mk3(b4.x, b4.y, b4.z);
+			if (!kind_b) {
+				const f3 contrib = mk3(0, 0, 0) + (mk3(1.f, 1.f, 1.f) * h4.w) * brdf;
+				const f3 pc = w0 * contrib;
+				wf_st(&wf.sh_c[id], make_float4(pc.x, pc.y, pc.z, 0.f));
+			} else {
+				PathState np;
+				np.weight = ((w0 * mk3(1.f, 1.f, 1.f)) * brdf) * a4.w;
+				np.depth = (int)(meta & 0x7fffu);
+				if (path_alive(np)) {
+					wf_st(&wf.wgt[id], make_float4(np.weight.x, np.weight.y, np.weight.z, __uint_as_float(MIPT_WF_VALID | (unsigned)np.depth)));
+					alive_bits |= 1u << u;
+				}
+			}
+		}
+		// the continuing paths of this chunk: one atomic on the next depth's count (the high word of the pair shade(b) appends to)
+		unsigned long long m[MIPT_WF_UNROLL];
+		unsigned total = 0;
+#pragma unroll
+		for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) { m[u] = __ballot((alive_bits >> u) & 1u); total += (unsigned)__popcll(m[u]); }
+		if (total) {
+			unsigned nb = 0;
+			if (lane_id() == 0) nb = atomicAdd(&wf.counters[MIPT_CNT_PAIR(b) + 1], total);
+			nb = __builtin_amdgcn_readfirstlane(nb);
+#pragma unroll
+			for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
+				if ((alive_bits >> u) & 1u) next[nb + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u))] = list[base + 64u * (unsigned)u + lane_id()] & 0x7fffffffu;
+				nb += (unsigned)__popcll(m[u]);
+			}
+		}
+	}
 }
 
 // shadow: Scene::intersection_shadow; a visible light sample adds weight*contrib to the path colour

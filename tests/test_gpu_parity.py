@@ -538,7 +538,7 @@ def test_leaves_of_a_hundred_triangles(resident):
         capi.set_device_resident(True)
 
 
-@pytest.mark.parametrize("batch", [0, 1])
+@pytest.mark.parametrize("batch", [0, 1, 2])
 def test_measured_brdf_tiers_against_golden_and_oracle(batch):
     """Scenes with a measured BRDF, general shade tier in both forms: every vertex evaluating its own table entries (`merl_batch` 0)
     and the evaluations filed in LDS and run 64 to a trip (1, the default since round 4).  The golden scene of the compiled reference,

@@ -6,7 +6,7 @@ both media with the three phase functions, subsurface colours), alone and combin
 --spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh.
 --bare-spheres: the same, and a sphere may have no material lists at all (such scenes run on the one-thread-per-sample kernel).
 --kind=<diffuse|glossy|mirror|glass|textured|merl|two|fat>: every scene's mesh gets this material kind (default: drawn per scene).
---merl-tiers: pipeline 1 is checked with both forms of the measured-BRDF tier (`merl_batch` 1 and 0)."""
+--merl-tiers: pipeline 1 is checked with the three forms of the measured-BRDF tier (`merl_batch` 1, 0 and 2)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -109,7 +109,7 @@ for it in range(n_scenes):
     line += " " + "+".join(feats) + (" spheres " + "".join("cmgtdb"[q["kind"]] + ("s" if q["ksub"] else "") for q in sph) if sph else "")
     for pipeline in ((1,) if (feats or any(q["ksub"] for q in sph)) else (1, 0)):
         G.set_option("pipeline", pipeline)
-        for batch in ((1, 0) if (MERL_TIERS and pipeline == 1) else (None,)):
+        for batch in ((1, 0, 2) if (MERL_TIERS and pipeline == 1) else (None,)):
             if batch is not None: G.set_option("merl_batch", batch)
             got = G.getcolor_samples(pix, 0, spp)[0]
             same = bits_equal(got, want).all(-1).mean()
