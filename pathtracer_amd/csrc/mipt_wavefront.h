@@ -383,17 +383,8 @@ __global__ void __launch_bounds__(MIPT_BLOCK) k_wf_extend(const DScene* __restri
 #define MIPT_SHADE_GLDS 0
 #endif
 #define MIPT_GLDS_WORDS (5 * 256 + 128)
-// MIPT_SHADE_SORT_CHUNK (round 6): the fast tier at depth >= 1 ran its vector instructions at 28 of 64 lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU on configs[2]):
-// a sub-chunk of 64 queue entries mixes mesh hits (the long diffuse vertex), hits on the ground plane, and rays that left to the environment or the light.
-// A wave now sorts the 512 path ids of its chunk by the kind of hit (one 4-byte load of the hit word per id, a counting sort through LDS) before it shades
-// them 64 at a time: a sub-chunk is then (almost always) of one kind.  Which lane shades a vertex, and where a path stands in the next depth's queue, is
-// all that changes.
-#ifndef MIPT_SHADE_SORT_CHUNK
-#define MIPT_SHADE_SORT_CHUNK 1
-#endif
-#define MIPT_SHADE_SORTS(TIER) (MIPT_SHADE_SORT_CHUNK && (TIER) == 1)
 #define MIPT_MRQ_STAGE (2 * 64 * MIPT_WF_UNROLL)       // tier 5: request entries a wave files per chunk at most (staged in LDS: one atomic per chunk)
-#define MIPT_SHADE_LDS_BYTES(TIER) (MIPT_SHADE_SORTS(TIER) ? (MIPT_BLOCK / 64) * MIPT_WF_CHUNK * 4 : (TIER) == 5 ? (MIPT_BLOCK / 64) * MIPT_MRQ_STAGE * 4 : (TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
+#define MIPT_SHADE_LDS_BYTES(TIER) ((TIER) == 5 ? (MIPT_BLOCK / 64) * MIPT_MRQ_STAGE * 4 : (TIER) == 4 ? (MIPT_BLOCK / 64) * MIPT_MERL_LDS_WORDS * 4 : ((MIPT_SHADE_GLDS && ((TIER) == 1 || (TIER) == 2 || (TIER) == 3)) ? (MIPT_BLOCK / 64) * MIPT_GLDS_WORDS * 4 : 0))
 #define MIPT_SHADE4_LDS_BYTES MIPT_SHADE_LDS_BYTES(4)
 extern __shared__ unsigned mipt_shade_lds[];
 template <int TIER, bool INITIAL = false>       // INITIAL: the build for depth 0 (b == 0), where a path's state is recomputed instead of fetched
@@ -448,39 +439,7 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 		// The loop over the sub-chunks is NOT unrolled: one copy of the vertex code is ~4 600 instructions (37 KB), four copies
 		// do not fit the 64 KB instruction cache two CUs share.  The path id of sub-chunk u+2 and the state of sub-chunk
 		// u+1 are requested while sub-chunk u is shaded.
-		constexpr bool SORTED = MIPT_SHADE_SORTS(TIER) && !INITIAL;
-		unsigned* const sids = SORTED ? mipt_shade_lds + (threadIdx.x >> 6) * MIPT_WF_CHUNK : nullptr;
-		if (SORTED) {
-			// kinds: 0 a mesh triangle, 1 a sphere / plane other than the light and the environment, 2 light / environment / nothing, 3 no entry (behind the queue's end)
-			unsigned idv[MIPT_WF_UNROLL], kv[MIPT_WF_UNROLL];
-#pragma unroll
-			for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) { const unsigned idx = base + 64u * (unsigned)u + lane_id(); idv[u] = idx < n ? list[idx] : 0xffffffffu; }
-#pragma unroll
-			for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
-				unsigned k = 3u;
-				if (idv[u] != 0xffffffffu) {
-					const unsigned pk = __float_as_uint(__builtin_nontemporal_load(reinterpret_cast<const float*>(&wf.hit[idv[u]]) + 3));
-					k = pk == MIPT_HIT_MISS ? 2u : ((pk & MIPT_HIT_ANALYTIC) ? ((pk & 0x7fffffffu) <= 1u ? 2u : 1u) : 0u);
-				}
-				kv[u] = k;
-			}
-			unsigned start[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-			for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) { start[1] += (unsigned)__popcll(__ballot(kv[u] == 0u)); start[2] += (unsigned)__popcll(__ballot(kv[u] == 1u)); start[3] += (unsigned)__popcll(__ballot(kv[u] == 2u)); }
-			start[3] += start[2] + start[1]; start[2] += start[1]; start[1] += 0u;      // exclusive prefix: kind k starts at start[k]
-#pragma unroll
-			for (int u = 0; u < (int)MIPT_WF_UNROLL; u++) {
-#pragma unroll
-				for (unsigned k = 0; k < 4u; k++) {
-					const unsigned long long m = __ballot(kv[u] == k);
-					if (kv[u] == k) sids[start[k] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idv[u];
-					start[k] += (unsigned)__popcll(m);
-				}
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		}
 		auto load_id = [&](int u) -> unsigned {
-			if (SORTED) return u < (int)MIPT_WF_UNROLL ? sids[64u * (unsigned)u + lane_id()] : 0xffffffffu;
 			const unsigned idx = base + 64u * (unsigned)u + lane_id();
 			return (u < (int)MIPT_WF_UNROLL && idx < n) ? (identity ? idx : list[idx]) : 0xffffffffu;
 		};
@@ -730,11 +689,6 @@ __global__ void __launch_bounds__(MIPT_BLOCK) __attribute__((amdgpu_waves_per_eu
 			}
 		}
 		const unsigned* src = identity ? nullptr : list;
-#if MIPT_SHADE_ROLLED
-		if (SORTED) {          // the chunk's ids as the wave shaded them (every wave's copy is its own; the next chunk overwrites it)
-			src = sids; base = 0;
-		}
-#endif
 		if (BATCH) { queue_push2x(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base, alive_buf, n_alive); n_alive = 0; }
 		else queue_push2(wf.list_sh, next, reinterpret_cast<unsigned long long*>(&wf.counters[MIPT_CNT_PAIR(b)]), cast_bits, cont_bits, src, base);
 		if (SPLIT && n_mrq) {
