@@ -43,4 +43,4 @@ timeout 900 python tests/tools/fuzz_parity.py 500 401 > gpurun_out/${S}_fuzz_par
 timeout 900 python tests/tools/fuzz_parity.py 300 402 --queue > gpurun_out/${S}_fuzz_parity_300_scenes_queue.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_300_scenes_queue.txt
 timeout 900 python tests/tools/fuzz_parity.py 250 403 --queue --spheres > gpurun_out/${S}_fuzz_parity_250_scenes_queue_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_250_scenes_queue_spheres.txt
 timeout 900 python tests/tools/fuzz_parity.py 150 404 --queue --bare-spheres > gpurun_out/${S}_fuzz_parity_150_scenes_queue_bare_spheres.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_150_scenes_queue_bare_spheres.txt
-timeout 900 python tests/tools/fuzz_parity.py 200 405 --merl-tiers > gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_three_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_three_tiers.txt
+timeout 900 python tests/tools/fuzz_parity.py 200 405 --kind=merl --merl-tiers > gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_three_tiers.txt 2>&1; tail -1 gpurun_out/${S}_fuzz_parity_200_scenes_measured_brdf_three_tiers.txt
