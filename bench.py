@@ -550,8 +550,8 @@ def run(args):
                     if st64["fp64_flop_per_vertex"] > 50.0:       # (a Phong scene has a few fp64 operations per vertex — promotion points of the reference's float code — and stays on the byte roofline)
                         peak64 = 78.6                              # TFLOP/s: MI355X fp64 vector FMA peak = half the fp32 vector peak of MI355X_MICROARCH.md (157.3)
                         ach = st64["fp64_flop_per_vertex"] * verts / shade_secs / 1e12 if same64 else None
-                        tier = {k: v for k, v in fj["kernels"].items() if k.startswith("k_wf_shade<4>") or k.startswith("k_wf_shade<3>")}
-                        rsh = {"kernel": rsh["kernel"] + " — measured-BRDF tiers k_wf_shade<3/4>", "bound": "fp64", "unit": "TFLOP/s", "peak": peak64, "achieved": ach, "frac": (ach / peak64) if ach is not None else None,
+                        tier = {k: v for k, v in fj["kernels"].items() if k.startswith(("k_wf_shade<5>", "k_wf_shade<4>", "k_wf_shade<3>", "k_wf_merl_eval"))}
+                        rsh = {"kernel": rsh["kernel"] + " — measured-BRDF tier k_wf_shade<5> + k_wf_merl_eval (k_wf_shade<3/4> with merl_batch 0 / 1)", "bound": "fp64", "unit": "TFLOP/s", "peak": peak64, "achieved": ach, "frac": (ach / peak64) if ach is not None else None,
                                "frac_definition": "fp64 operations (ADD + MUL + 2 FMA + TRANS wave-instructions x mean active lanes, SQ_INSTS_VALU_*_F64 of the committed counter run) per shade vertex x vertices of this run / stage time / fp64 vector peak 78.6 TFLOP/s",
                                "fp64_flop_per_vertex": st64["fp64_flop_per_vertex"], "frac_if_every_fp64_instruction_had_64_lanes": (st64["fp64_issue_slot_flop_per_vertex"] * verts / shade_secs / 1e12 / peak64) if same64 else None,
                                "vertices_per_step": verts / args.steps, "ms_per_step": shade_ms / args.steps,

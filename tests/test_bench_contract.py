@@ -101,7 +101,7 @@ def test_committed_counters_charge_every_shade_build_with_its_own_launches():
         assert ks["k_wf_shade<1>[depth0]"]["launches_per_step"] == 2 and ks["k_wf_generate"]["launches_per_step"] == 2
         assert ks["k_wf_shade<1>"]["launches_per_step"] == 2 * (depth - 1)
         st = j[wl]["stage_generate_shade"]
-        total = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for k, v in ks.items() if k.startswith(("k_wf_shade", "k_wf_generate")))
+        total = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for k, v in ks.items() if k.startswith(("k_wf_shade", "k_wf_generate", "k_wf_merl_eval")))
         assert st["hbm_bytes_per_step"] == pytest.approx(total, rel=1e-12)
         assert 100.0 < st["hbm_bytes_per_vertex"] < 1500.0
 

@@ -31,7 +31,7 @@ for arg in sys.argv[1:]:
                 ks[cur][m.group(1)] = float(m.group(2)); nd[cur] = int(m.group(3))
     kernels, stage_flop, stage_slot_flop = {}, 0.0, 0.0
     for k, v in ks.items():
-        if not (k.startswith("k_wf_shade") or k.startswith("k_wf_generate")) or "SQ_INSTS_VALU" not in v:
+        if not (k.startswith("k_wf_shade") or k.startswith("k_wf_generate") or k.startswith("k_wf_merl_eval")) or "SQ_INSTS_VALU" not in v:     # the stage = generate + shade tiers + (tier 5) the evaluation stage
             continue
         lanes = v["SQ_THREAD_CYCLES_VALU"] / max(1.0, v["SQ_ACTIVE_INST_VALU"])
         f64 = {x: v.get("SQ_INSTS_VALU_%s_F64" % x, 0.0) for x in ("ADD", "MUL", "FMA", "TRANS")}

@@ -75,9 +75,9 @@ for arg in sys.argv[2:]:
             e["l1_lookups_per_cu_cycle"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * cyc)
         kernels[k] = e
     # the generate + shade stage as a whole: every build charged with its own launches per step, per shade vertex (= closest-hit ray) of the profiled step
-    stage = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 0.0) for k, v in kernels.items() if k.startswith("k_wf_shade") or k.startswith("k_wf_generate"))
+    stage = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 0.0) for k, v in kernels.items() if k.startswith("k_wf_shade") or k.startswith("k_wf_generate") or k.startswith("k_wf_merl_eval"))
     stage_obj = {"hbm_bytes_per_step": stage, "vertices_per_step": ls["rays_closest"], "hbm_bytes_per_vertex": stage / max(1, ls["rays_closest"]),
-                 "note": "sum over k_wf_generate and every k_wf_shade<tier>[depth0 or not] build of HBM bytes per launch x launches per step of that build; vertices = closest-hit rays of the profiled step"}
+                 "note": "sum over k_wf_generate, every k_wf_shade<tier>[depth0 or not] build and (measured-BRDF scenes) k_wf_merl_eval of HBM bytes per launch x launches per step of that build; vertices = closest-hit rays of the profiled step"}
     out[wl] = {"stage_generate_shade": stage_obj, "source": shown + " (rocprofv3 --pmc, one counter group per pass, bench.py --steps 1 --warmup 1 --pmc: mean over the launches of both passes); "
                                 "FETCH_SIZE factors from " + sys.argv[1], "kernels": kernels}
 sys.path.insert(0, ROOT)
