@@ -6,6 +6,7 @@ both media with the three phase functions, subsurface colours), alone and combin
 --spheres: every scene also holds 1-3 random spheres (constant, glossy, textured, mirror, glass) before / after the mesh.
 --bare-spheres: the same, and a sphere may have no material lists at all (such scenes run on the one-thread-per-sample kernel).
 --kind=<diffuse|glossy|mirror|glass|textured|merl|two|fat>: every scene's mesh gets this material kind (default: drawn per scene).
+--many: 30-90 spheres and 3-8 more meshes per scene (fat leaves among them).
 --merl-tiers: pipeline 1 is checked with the three forms of the measured-BRDF tier (`merl_batch` 1, 0 and 2)."""
 import os, sys
 import numpy as np
@@ -19,6 +20,7 @@ SPHERES = "--spheres" in sys.argv or "--bare-spheres" in sys.argv
 BARE = "--bare-spheres" in sys.argv      # spheres may also come WITHOUT material lists (kind 5: shaded with the material of the object tested before, Geometry.cpp:596)
 KIND = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--kind=")), None)
 MERL_TIERS = "--merl-tiers" in sys.argv
+MANY = "--many" in sys.argv          # round 6: 30-90 spheres and 3-8 more meshes (one of them sometimes with leaves of 40-100 triangles): object tables far beyond 31 entries, fat leaves
 argv = [a for a in sys.argv if not a.startswith("--")]
 n_scenes = int(argv[1]) if len(argv) > 1 else 20
 rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
@@ -44,13 +46,18 @@ for it in range(n_scenes):
     scale = float(rng.choice([30.0, 5.0, 0.5, 80.0]))
     out = []
     sph = []
-    if SPHERES:
-        for k in range(int(rng.integers(1, 4))):
+    if SPHERES or MANY:
+        for k in range(int(rng.integers(30, 90)) if MANY else int(rng.integers(1, 4))):
             sph.append(dict(c=tuple(float(v) for v in rng.uniform((-35, -25, -25), (35, 25, 30))), r=float(rng.uniform(1, 12)), kind=int(rng.integers(0, 6 if BARE else 5)),
                             first=bool(rng.random() < 0.3), flip=bool(rng.random() < 0.15), Kd=rng.uniform(0.05, 1, 3), Ks=rng.uniform(0, 0.6, 3), Ne=rng.uniform(1, 200, 3)))
     sph_lists = True      # (rounds 1-3: subsurface colours only beside spheres WITH material lists; since round 4 a sphere without — mirror or not — inherits Ksub on the one-thread kernel)
     for q in sph:         # round 4: a sphere with lists may carry a subsurface colour of its own (Sphere::reservoir_sampling_intersection)
         q["ksub"] = tuple(float(v) for v in rng.uniform(0.05, 0.9, 3)) if (QUEUE and q["kind"] in (0, 2, 3) and rng.random() < 0.35) else None
+    extra_meshes = []
+    if MANY:
+        for k in range(int(rng.integers(3, 9))):
+            em = scenes.huge_leaf_mesh(int(rng.integers(6, 12)), int(rng.integers(40, 100)), int(rng.integers(1, 3))) if rng.random() < 0.25 else scenes.blob_mesh(int(rng.integers(4, 14)))
+            extra_meshes.append((em, float(rng.uniform(2, 9)), (float(rng.uniform(-30, 30)), 0.0, float(rng.uniform(-20, 25)))))
     def put_spheres(X, first):
         for q in sph:
             if q["first"] != first: continue
@@ -67,6 +74,10 @@ for it in range(n_scenes):
         put_spheres(X, True)
         oid = X.add_mesh(mesh, scale=scale)
         put_spheres(X, False)
+        if MANY:
+            for (em, es, ec) in extra_meshes:
+                v = em.vertices.astype(np.float64) * es + np.array([ec[2], 0.0, -ec[0]])      # placed through the vertices (world (x, z) = (-z_in, x_in)); add_mesh rests it on the ground
+                X.add_mesh(scenes.MeshData(v.astype(np.float32), em.normals, em.uvs, em.faces_v, em.faces_n, em.faces_t, em.name), scale=1.0, center=False)
         out.append((X, oid))
     # materials must be identical on both sides: draw once, apply twice
     Kd, Ks, Ne = rng.uniform(0, 1, 3), rng.uniform(0, 0.9, 3), rng.uniform(0, 300, 3)
