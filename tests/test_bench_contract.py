@@ -132,6 +132,11 @@ def test_bench_refuses_to_run_without_a_gpu_or_with_fewer_than_asked():
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "refusing to measure fewer GPUs" in (r.stderr + r.stdout)
+    # a run that fails still leaves ONE JSON line: nothing measured (value null), where it stopped, how the framebuffers would have been reduced
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["stage"] == "devices" and "refusing" in d["error"] and d["n_gpus"] == n + 1 and "stages_in_order" in d
 
 
 def test_source_hash_is_stable_and_sees_the_flags():
